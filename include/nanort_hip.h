@@ -1,0 +1,254 @@
+/* include/nanort_hip.h — C ABI of libnanort_hip.so (MI355X / gfx950 backend).
+ *
+ * The drop-in boundary for the hot path of lighttransport/nanort:
+ * BVHAccel<T>::Build() + BVHAccel<T>::Traverse() for the built-in triangle
+ * plugin.  The reference has no FFI of its own — its boundary is a C++
+ * template API in one header — so the entry points below are what the inline
+ * code of include/nanort.h (this repo's API-compatible header) binds when
+ * NANORT_USE_HIP_BACKEND is defined.  Each entry point cites the reference
+ * interface it replaces (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no C++ / torch types;
+ *   - PODs are layout-identical to the reference's (static_asserts below);
+ *   - nrt_status 0 == the reference's `true`; non-zero == `false`, with a
+ *     human-readable reason from nrtLastError() (the reference has no error
+ *     channel beyond bool/assert, nanort.h:1905-1909);
+ *   - "host" entry points take host pointers in/out and own all device
+ *     memory; "Device" entry points take device pointers (HBM-resident
+ *     buffers, e.g. torch tensors) and a hipStream_t passed as void*;
+ *   - one nrt_ctx per BVHAccel object; a context is bound to one GPU and is
+ *     not re-entrant (like BVHAccel::Build, nanort.h:1892); distinct contexts
+ *     may be used from distinct host threads.
+ */
+#ifndef NANORT_HIP_H_
+#define NANORT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRT_API __attribute__((visibility("default")))
+
+typedef int nrt_status;
+enum {
+  NRT_OK = 0,
+  NRT_ERR_INVALID = 1,  /* bad argument / call order                  */
+  NRT_ERR_EMPTY = 2,    /* n == 0: the reference's Build() == false   */
+  NRT_ERR_DEVICE = 3,   /* a HIP call failed (see nrtLastError)       */
+  NRT_ERR_PRECISION = 4 /* _f32 call on an _f64 context or vice versa */
+};
+
+typedef struct nrt_ctx nrt_ctx;
+
+/* ---- PODs: wire formats shared with the reference ----------------------- */
+
+/* nanort::Ray<float> / Ray<double> — nanort.h:474-496. */
+typedef struct {
+  float org[3];
+  float dir[3];
+  float min_t;
+  float max_t;
+  uint32_t type;
+} nrt_ray_f32;
+typedef struct {
+  double org[3];
+  double dir[3];
+  double min_t;
+  double max_t;
+  uint32_t type;
+  uint32_t _pad;
+} nrt_ray_f64;
+
+/* nanort::BVHNode<T> — nanort.h:498-550.
+ * leaf: flag=1, data={count, first slot in indices}; branch: flag=0,
+ * axis in {0,1,2}, data={low-side child, high-side child}. */
+typedef struct {
+  float bmin[3];
+  float bmax[3];
+  int32_t flag;
+  int32_t axis;
+  uint32_t data[2];
+} nrt_node_f32;
+typedef struct {
+  double bmin[3];
+  double bmax[3];
+  int32_t flag;
+  int32_t axis;
+  uint32_t data[2];
+} nrt_node_f64;
+
+/* nanort::TriangleIntersection<T> — nanort.h:996-1005.
+ * The batched entry points write EVERY record: on a miss the record is
+ * {u=0, v=0, t=ray.max_t, prim_id=0xFFFFFFFF} and hit_mask[i]=0 (the
+ * reference leaves the caller's struct untouched on a miss, nanort.h:1206;
+ * include/nanort.h's TraverseBatch restores that behaviour on the host). */
+typedef struct {
+  float u;
+  float v;
+  float t;
+  uint32_t prim_id;
+} nrt_hit_f32;
+typedef struct {
+  double u;
+  double v;
+  double t;
+  uint32_t prim_id;
+  uint32_t _pad;
+} nrt_hit_f64;
+
+/* nanort::BVHBuildOptions<T> — nanort.h:559-583. */
+typedef struct {
+  float cost_t_aabb;
+  uint32_t min_leaf_primitives;
+  uint32_t max_tree_depth;
+  uint32_t bin_size;
+  uint32_t shallow_depth;
+  uint32_t min_primitives_for_parallel_build;
+  uint8_t cache_bbox;
+  uint8_t pad[3];
+} nrt_build_options_f32;
+typedef struct {
+  double cost_t_aabb;
+  uint32_t min_leaf_primitives;
+  uint32_t max_tree_depth;
+  uint32_t bin_size;
+  uint32_t shallow_depth;
+  uint32_t min_primitives_for_parallel_build;
+  uint8_t cache_bbox;
+  uint8_t pad[3];
+} nrt_build_options_f64;
+
+/* nanort::BVHBuildStatistics — nanort.h:586-599.  build_secs IS filled here
+ * (device time of the build; the reference declares it but never writes it). */
+typedef struct {
+  uint32_t max_tree_depth;
+  uint32_t num_leaf_nodes;
+  uint32_t num_branch_nodes;
+  float build_secs;
+} nrt_build_stats;
+
+/* nanort::BVHTraceOptions — nanort.h:604-624. */
+typedef struct {
+  uint32_t prim_ids_range[2]; /* half-open [r0, r1)            nanort.h:1055 */
+  uint32_t skip_prim_id;      /* 0xFFFFFFFF = none             nanort.h:1061 */
+  uint8_t cull_back_face;     /*                               nanort.h:1111 */
+  uint8_t pad[3];
+} nrt_trace_options;
+
+/* Work counters of one batched traversal, in the units SURVEY.md §8(d)
+ * defines the algorithmic bytes on (counted on the reference's traversal
+ * order over the node array actually traversed). */
+typedef struct {
+  uint64_t nodes_visited; /* stack pops == BVHNode fetches + slab tests */
+  uint64_t leaves_tested;
+  uint64_t tris_tested;   /* Intersect() calls                          */
+  uint64_t max_stack;     /* deepest stack (entries) any ray needed     */
+} nrt_trace_counters;
+
+#ifdef __cplusplus
+static_assert(sizeof(nrt_ray_f32) == 36 && sizeof(nrt_ray_f64) == 72, "Ray layout");
+static_assert(sizeof(nrt_node_f32) == 40 && sizeof(nrt_node_f64) == 64, "BVHNode layout");
+static_assert(sizeof(nrt_hit_f32) == 16 && sizeof(nrt_hit_f64) == 32, "TriangleIntersection layout");
+static_assert(sizeof(nrt_build_options_f32) == 28 && sizeof(nrt_build_options_f64) == 32, "BVHBuildOptions layout");
+static_assert(sizeof(nrt_build_stats) == 16 && sizeof(nrt_trace_options) == 16, "stats/options layout");
+#endif
+
+/* ---- context ------------------------------------------------------------ */
+
+/* One context == one nanort::BVHAccel<T> (nanort.h:698-860) living on GPU
+ * `device`.  Precision is fixed by the first nrtSetMesh_* call. */
+NRT_API nrt_status nrtCreate(int device, nrt_ctx **out);
+NRT_API void nrtDestroy(nrt_ctx *ctx);
+/* Reason of the last failure on this context (or of the last failed
+ * nrtCreate when ctx == NULL).  Never NULL. */
+NRT_API const char *nrtLastError(const nrt_ctx *ctx);
+/* Library / device identification, e.g. "libnanort_hip gfx950 ...". */
+NRT_API const char *nrtVersion(void);
+
+/* ---- mesh: replaces the TriangleMesh / TriangleSAHPred / TriangleIntersector
+ * constructors (nanort.h:866-873, 925-930, 1032-1039) ----------------------
+ * vertices are read through `vertex_stride_bytes` exactly like
+ * get_vertex_addr (nanort.h:467-472); faces are tight 3 x u32.  The mesh
+ * carries no vertex count in the reference, so it is derived as
+ * max(faces)+1.  The data is copied to HBM; the caller's arrays are not
+ * referenced after the call returns. */
+NRT_API nrt_status nrtSetMesh_f32(nrt_ctx *ctx, const float *vertices, size_t vertex_stride_bytes,
+                                  const uint32_t *faces, uint32_t num_faces);
+NRT_API nrt_status nrtSetMesh_f64(nrt_ctx *ctx, const double *vertices, size_t vertex_stride_bytes,
+                                  const uint32_t *faces, uint32_t num_faces);
+
+/* ---- build: replaces BVHAccel<T>::Build (nanort.h:716-718, 1892-2149) ----
+ * Binned-SAH construction on the GPU over the mesh set above.  Honours
+ * min_leaf_primitives, max_tree_depth and bin_size; shallow_depth,
+ * min_primitives_for_parallel_build, cache_bbox and cost_t_aabb are CPU
+ * scheduling knobs (or dead, nanort.h:574) and are ignored.  options == NULL
+ * means BVHBuildOptions<T>() defaults.  Emits the reference's node format
+ * and invariants (root = node 0; indices a permutation of [0, n); DFS
+ * pre-order, left child = parent + 1).  NRT_ERR_EMPTY iff num_faces == 0. */
+NRT_API nrt_status nrtBuild_f32(nrt_ctx *ctx, const nrt_build_options_f32 *options,
+                                nrt_build_stats *stats_out, uint64_t *num_nodes_out);
+NRT_API nrt_status nrtBuild_f64(nrt_ctx *ctx, const nrt_build_options_f64 *options,
+                                nrt_build_stats *stats_out, uint64_t *num_nodes_out);
+
+/* Copy the built tree to the host: feeds BVHAccel::nodes_ / indices_ so
+ * GetNodes/GetIndices/BoundingBox/Dump and the per-ray CPU Traverse keep
+ * working (nanort.h:786-806, 2164-2217).  nodes_out holds num_nodes records,
+ * indices_out holds num_faces entries. */
+NRT_API nrt_status nrtGetTree_f32(nrt_ctx *ctx, nrt_node_f32 *nodes_out, uint32_t *indices_out);
+NRT_API nrt_status nrtGetTree_f64(nrt_ctx *ctx, nrt_node_f64 *nodes_out, uint32_t *indices_out);
+NRT_API nrt_status nrtTreeSize(nrt_ctx *ctx, uint64_t *num_nodes_out, uint64_t *num_indices_out);
+
+/* Adopt a tree built elsewhere: BVHAccel<T>::Load (nanort.h:2219-2275) or a
+ * CPU Build().  Validates child / slot bounds and measures the depth. */
+NRT_API nrt_status nrtSetTree_f32(nrt_ctx *ctx, const nrt_node_f32 *nodes, uint64_t num_nodes,
+                                  const uint32_t *indices, uint64_t num_indices);
+NRT_API nrt_status nrtSetTree_f64(nrt_ctx *ctx, const nrt_node_f64 *nodes, uint64_t num_nodes,
+                                  const uint32_t *indices, uint64_t num_indices);
+
+/* ---- traverse: replaces N calls of BVHAccel<T>::Traverse with a
+ * TriangleIntersector (nanort.h:757-759, 2487-2556, 1014-1229) -------------
+ * Closest hit per ray, same arithmetic as the reference (no contraction,
+ * fp64 edge fallback, MaxMult slab test).  options == NULL means
+ * BVHTraceOptions() defaults.  hit_mask_out may be NULL. */
+NRT_API nrt_status nrtTraverseBatch_f32(nrt_ctx *ctx, const nrt_ray_f32 *rays, uint64_t num_rays,
+                                        const nrt_trace_options *options, nrt_hit_f32 *hits_out,
+                                        uint8_t *hit_mask_out);
+NRT_API nrt_status nrtTraverseBatch_f64(nrt_ctx *ctx, const nrt_ray_f64 *rays, uint64_t num_rays,
+                                        const nrt_trace_options *options, nrt_hit_f64 *hits_out,
+                                        uint8_t *hit_mask_out);
+
+/* Same, on HBM-resident buffers, asynchronously on `hip_stream`
+ * (a hipStream_t; NULL = the default stream).  No host synchronisation. */
+NRT_API nrt_status nrtTraverseBatchDevice_f32(nrt_ctx *ctx, const nrt_ray_f32 *d_rays,
+                                              uint64_t num_rays, const nrt_trace_options *options,
+                                              nrt_hit_f32 *d_hits_out, uint8_t *d_hit_mask_out,
+                                              void *hip_stream);
+NRT_API nrt_status nrtTraverseBatchDevice_f64(nrt_ctx *ctx, const nrt_ray_f64 *d_rays,
+                                              uint64_t num_rays, const nrt_trace_options *options,
+                                              nrt_hit_f64 *d_hits_out, uint8_t *d_hit_mask_out,
+                                              void *hip_stream);
+
+/* Measurement aid: run the batch once on HBM-resident rays with the work
+ * counters on (synchronous; results are not written).  Used by bench.py to
+ * turn kernel time into algorithmic bytes per SURVEY.md §8(d). */
+NRT_API nrt_status nrtTraverseCountDevice_f32(nrt_ctx *ctx, const nrt_ray_f32 *d_rays,
+                                              uint64_t num_rays, const nrt_trace_options *options,
+                                              nrt_trace_counters *counters_out);
+NRT_API nrt_status nrtTraverseCountDevice_f64(nrt_ctx *ctx, const nrt_ray_f64 *d_rays,
+                                              uint64_t num_rays, const nrt_trace_options *options,
+                                              nrt_trace_counters *counters_out);
+
+/* Device time (ms, HIP events on the launch stream) of the most recent
+ * traversal launch / build on this context; < 0 if none has completed.
+ * Synchronises with that work. */
+NRT_API float nrtLastTraverseMs(nrt_ctx *ctx);
+NRT_API float nrtLastBuildMs(nrt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANORT_HIP_H_ */

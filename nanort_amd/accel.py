@@ -1,0 +1,217 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+`BVHAccel` here plays the role of nanort::BVHAccel<T> (reference
+nanort.h:698-860) for the built-in triangle plugin, with the same method names
+and argument meaning; every call goes through the C ABI (include/nanort_hip.h)
+into the HIP library.  `TraverseBatch` is the one addition: N rays per call
+instead of the reference's one (`Traverse`, nanort.h:757-759).
+
+    mesh  = TriangleMesh(vertices, faces, stride_bytes)   # nanort.h:925-930
+    accel = BVHAccel(np.float32)
+    accel.Build(mesh.num_faces, mesh, options)            # nanort.h:716-718
+    hits, mask = accel.TraverseBatch(rays, trace_options) # N x Traverse
+
+numpy arrays carry the reference's PODs (nanort_amd.wire).  torch is used only
+by the *Device* variants (HBM-resident tensors, current stream).
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+from .wire import (
+    BUILD_OPTIONS_F32,
+    BUILD_OPTIONS_F64,
+    BUILD_STATS,
+    TRACE_OPTIONS,
+    hit_dtype,
+    node_dtype,
+    ray_dtype,
+    suffix,
+)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class TriangleMesh:
+    """nanort::TriangleMesh<T> (reference nanort.h:922-991): caller-owned flat arrays."""
+
+    def __init__(self, vertices, faces, vertex_stride_bytes=None):
+        self.vertices = np.ascontiguousarray(vertices)
+        if self.vertices.dtype not in (np.float32, np.float64):
+            raise TypeError("vertices must be float32 or float64")
+        self.faces = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+        self.vertex_stride_bytes = (
+            3 * self.vertices.dtype.itemsize if vertex_stride_bytes is None else int(vertex_stride_bytes)
+        )
+        self.num_faces = int(self.faces.shape[0])
+
+    def GetVertices(self):
+        return self.vertices
+
+    def GetFaces(self):
+        return self.faces
+
+    def GetVertexStrideBytes(self):
+        return self.vertex_stride_bytes
+
+
+class BVHAccel:
+    """nanort::BVHAccel<T> on one MI355X (built-in triangle geometry only)."""
+
+    def __init__(self, real=np.float32, device=0):
+        self.real = np.dtype(real)
+        if self.real not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError("real must be float32 or float64")
+        self._s = suffix(self.real)
+        self._L = capi.lib()
+        h = ctypes.c_void_p()
+        st = self._L.nrtCreate(int(device), ctypes.byref(h))
+        if st != capi.NRT_OK:
+            raise capi.NrtError(st, self._L.nrtLastError(None).decode())
+        self._h = h
+        self.device = int(device)
+        self._stats = np.zeros((), dtype=BUILD_STATS)
+        self._mesh = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nrtDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != capi.NRT_OK:
+            raise capi.NrtError(st, self._L.nrtLastError(self._h).decode())
+
+    # -- mesh / build -------------------------------------------------------
+    def SetMesh(self, mesh):
+        if mesh.vertices.dtype != self.real:
+            raise TypeError("mesh precision %s != accel precision %s" % (mesh.vertices.dtype, self.real))
+        self._check(
+            getattr(self._L, "nrtSetMesh_" + self._s)(
+                self._h, _p(mesh.vertices), mesh.vertex_stride_bytes, _p(mesh.faces), mesh.num_faces
+            )
+        )
+        self._mesh = mesh
+
+    def Build(self, num_primitives, mesh, options=None):
+        """BVHAccel::Build (reference nanort.h:1892-2149). Returns False iff n == 0."""
+        if num_primitives != mesh.num_faces:
+            mesh = TriangleMesh(mesh.vertices, mesh.faces[:num_primitives], mesh.vertex_stride_bytes)
+        self.SetMesh(mesh)
+        if options is not None:
+            want = BUILD_OPTIONS_F32 if self.real == np.float32 else BUILD_OPTIONS_F64
+            options = np.asarray(options, dtype=want).reshape(1)
+        nn = ctypes.c_uint64(0)
+        st = getattr(self._L, "nrtBuild_" + self._s)(self._h, _p(options), _p(self._stats.reshape(1)), ctypes.byref(nn))
+        if st == capi.NRT_ERR_EMPTY:
+            return False
+        self._check(st)
+        return True
+
+    def GetStatistics(self):
+        return self._stats.copy()
+
+    def LastBuildMs(self):
+        return float(self._L.nrtLastBuildMs(self._h))
+
+    def LastTraverseMs(self):
+        return float(self._L.nrtLastTraverseMs(self._h))
+
+    def _tree_size(self):
+        nn, ni = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._L.nrtTreeSize(self._h, ctypes.byref(nn), ctypes.byref(ni)))
+        return int(nn.value), int(ni.value)
+
+    def IsValid(self):
+        return self._tree_size()[0] > 0
+
+    def GetTree(self):
+        nn, ni = self._tree_size()
+        nodes = np.zeros((nn,), dtype=node_dtype(self.real))
+        indices = np.zeros((ni,), dtype=np.uint32)
+        if nn:
+            self._check(getattr(self._L, "nrtGetTree_" + self._s)(self._h, _p(nodes), _p(indices)))
+        return nodes, indices
+
+    def GetNodes(self):
+        return self.GetTree()[0]
+
+    def GetIndices(self):
+        return self.GetTree()[1]
+
+    def BoundingBox(self):
+        """BVHAccel::BoundingBox (reference nanort.h:792-804)."""
+        nodes = self.GetNodes()
+        if nodes.shape[0] == 0:
+            m = np.finfo(self.real).max
+            return np.full(3, m, self.real), np.full(3, -m, self.real)
+        return nodes[0]["bmin"].copy(), nodes[0]["bmax"].copy()
+
+    def SetTree(self, nodes, indices):
+        """Adopt a tree built elsewhere (BVHAccel::Load, reference nanort.h:2219-2275)."""
+        nodes = np.ascontiguousarray(nodes, dtype=node_dtype(self.real))
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        self._check(
+            getattr(self._L, "nrtSetTree_" + self._s)(self._h, _p(nodes), nodes.shape[0], _p(indices), indices.shape[0])
+        )
+
+    # -- traverse -----------------------------------------------------------
+    def TraverseBatch(self, rays, options=None):
+        """N x BVHAccel::Traverse (reference nanort.h:2487-2556). Returns (hits, mask)."""
+        rays = np.ascontiguousarray(rays, dtype=ray_dtype(self.real))
+        n = rays.shape[0]
+        hits = np.zeros((n,), dtype=hit_dtype(self.real))
+        mask = np.zeros((n,), dtype=np.uint8)
+        if options is not None:
+            options = np.asarray(options, dtype=TRACE_OPTIONS).reshape(1)
+        self._check(
+            getattr(self._L, "nrtTraverseBatch_" + self._s)(self._h, _p(rays), n, _p(options), _p(hits), _p(mask))
+        )
+        return hits, mask
+
+    def TraverseBatchDevice(self, d_rays, d_hits, d_mask=None, options=None, stream=None):
+        """Same on HBM-resident torch uint8 tensors (raw PODs), async on `stream`
+        (default: torch's current stream)."""
+        import torch
+
+        rsz, hsz = ray_dtype(self.real).itemsize, hit_dtype(self.real).itemsize
+        n = d_rays.numel() * d_rays.element_size() // rsz
+        assert d_hits.numel() * d_hits.element_size() >= n * hsz
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        if options is not None:
+            options = np.asarray(options, dtype=TRACE_OPTIONS).reshape(1)
+        self._check(
+            getattr(self._L, "nrtTraverseBatchDevice_" + self._s)(
+                self._h, d_rays.data_ptr(), n, _p(options), d_hits.data_ptr(),
+                None if d_mask is None else d_mask.data_ptr(), stream,
+            )
+        )
+        return n
+
+    def TraverseCountDevice(self, d_rays, options=None):
+        """Work counters (nodes visited, leaves, triangle tests, max stack) of one batch."""
+        rsz = ray_dtype(self.real).itemsize
+        n = d_rays.numel() * d_rays.element_size() // rsz
+        c = capi.TraceCounters()
+        if options is not None:
+            options = np.asarray(options, dtype=TRACE_OPTIONS).reshape(1)
+        self._check(
+            getattr(self._L, "nrtTraverseCountDevice_" + self._s)(self._h, d_rays.data_ptr(), n, _p(options), ctypes.byref(c))
+        )
+        return {
+            "nodes_visited": int(c.nodes_visited),
+            "leaves_tested": int(c.leaves_tested),
+            "tris_tested": int(c.tris_tested),
+            "max_stack": int(c.max_stack),
+            "num_rays": int(n),
+        }

@@ -1,0 +1,530 @@
+// nanort_amd/csrc/api.hip — the C ABI of libnanort_hip.so (include/nanort_hip.h).
+//
+// One nrt_ctx == one reference BVHAccel<T> (nanort.h:698-860) resident on one
+// MI355X: mesh, node array, index permutation and the leaf-ordered triangle
+// records live in HBM for the lifetime of the context; the host entry points
+// stage rays/hits through grow-only device buffers.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace nrt {
+template <typename T>
+hipError_t launch_traverse(const TraverseArgs<T> &, unsigned grid, bool count, hipStream_t);
+template <typename T>
+hipError_t launch_gather_leaf_tris(const uint32_t *, const uint32_t *, const T *, LeafTri<T> *,
+                                   uint32_t, hipStream_t);
+struct BuildResult {
+  uint64_t num_nodes;
+  uint32_t max_depth, num_leaves, num_branches;
+};
+template <typename T>
+hipError_t gpu_build(int device, hipStream_t s, const T *d_verts, const uint32_t *d_faces,
+                     uint32_t num_faces, uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size,
+                     typename Wire<T>::Node **d_nodes_out, uint32_t **d_indices_out,
+                     BuildResult *res, std::string *err);
+} // namespace nrt
+
+using namespace nrt;
+
+static thread_local std::string g_create_error;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct nrt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr; // internal stream for host entry points / build
+  std::string err;
+  int prec = 0; // 0 unset, 4 = f32, 8 = f64
+  int num_cus = 256;
+
+  // mesh (tight xyz in HBM)
+  void *d_verts = nullptr;
+  uint32_t *d_faces = nullptr;
+  uint32_t num_faces = 0, num_verts = 0;
+
+  // tree
+  void *d_nodes = nullptr;
+  uint32_t *d_indices = nullptr;
+  void *d_tris = nullptr; // LeafTri<T>[num_indices]
+  uint64_t num_nodes = 0, num_indices = 0;
+  uint32_t tree_depth = 0;
+  nrt_build_stats stats = {0, 0, 0, 0.f};
+
+  // traversal scratch
+  uint32_t *d_cursor = nullptr;              // ray cursor
+  unsigned long long *d_counters = nullptr;  // 4 x u64
+  DevBuf spill, st_rays, st_hits, st_mask;
+
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
+  bool have_traverse_time = false, have_build_time = false;
+};
+
+static nrt_status fail(nrt_ctx *c, nrt_status st, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c)
+    c->err = buf;
+  else
+    g_create_error = buf;
+  return st;
+}
+
+#define HIPCHK(c, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail((c), NRT_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+static nrt_status ensure(nrt_ctx *c, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return NRT_OK;
+  if (b.p) HIPCHK(c, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 4;
+  HIPCHK(c, hipMalloc(&b.p, want));
+  b.cap = want;
+  return NRT_OK;
+}
+
+static void free_tree(nrt_ctx *c) {
+  if (c->d_nodes) (void)hipFree(c->d_nodes);
+  if (c->d_indices) (void)hipFree(c->d_indices);
+  if (c->d_tris) (void)hipFree(c->d_tris);
+  c->d_nodes = nullptr;
+  c->d_indices = nullptr;
+  c->d_tris = nullptr;
+  c->num_nodes = c->num_indices = 0;
+  c->tree_depth = 0;
+}
+
+static void free_mesh(nrt_ctx *c) {
+  if (c->d_verts) (void)hipFree(c->d_verts);
+  if (c->d_faces) (void)hipFree(c->d_faces);
+  c->d_verts = nullptr;
+  c->d_faces = nullptr;
+  c->num_faces = c->num_verts = 0;
+}
+
+extern "C" {
+
+const char *nrtVersion(void) { return "libnanort_hip 0.1 (gfx950, HIP)"; }
+
+nrt_status nrtCreate(int device, nrt_ctx **out) {
+  if (!out) return fail(nullptr, NRT_ERR_INVALID, "nrtCreate: out == NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: no HIP device visible (%s)",
+                e == hipSuccess ? "count == 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev)
+    return fail(nullptr, NRT_ERR_INVALID, "nrtCreate: device %d out of range [0,%d)", device, ndev);
+  nrt_ctx *c = new nrt_ctx();
+  c->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&c->ev_t0)) != hipSuccess || (e = hipEventCreate(&c->ev_t1)) != hipSuccess ||
+      (e = hipEventCreate(&c->ev_b0)) != hipSuccess || (e = hipEventCreate(&c->ev_b1)) != hipSuccess ||
+      (e = hipMalloc((void **)&c->d_cursor, 256)) != hipSuccess ||
+      (e = hipMalloc((void **)&c->d_counters, 4 * sizeof(unsigned long long))) != hipSuccess) {
+    fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
+    delete c;
+    return NRT_ERR_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    c->num_cus = prop.multiProcessorCount;
+  *out = c;
+  return NRT_OK;
+}
+
+void nrtDestroy(nrt_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_tree(c);
+  free_mesh(c);
+  DevBuf *bufs[] = {&c->spill, &c->st_rays, &c->st_hits, &c->st_mask};
+  for (DevBuf *b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  if (c->d_cursor) (void)hipFree(c->d_cursor);
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  hipEvent_t evs[] = {c->ev_t0, c->ev_t1, c->ev_b0, c->ev_b1};
+  for (hipEvent_t ev : evs)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *nrtLastError(const nrt_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// mesh
+// ---------------------------------------------------------------------------
+template <typename T>
+static nrt_status set_mesh(nrt_ctx *c, const T *vertices, size_t stride, const uint32_t *faces,
+                           uint32_t num_faces) {
+  if (!c) return NRT_ERR_INVALID;
+  if (c->prec != 0 && c->prec != (int)sizeof(T))
+    return fail(c, NRT_ERR_PRECISION, "nrtSetMesh: context already holds a %s mesh",
+                c->prec == 4 ? "f32" : "f64");
+  if (num_faces && (!vertices || !faces)) return fail(c, NRT_ERR_INVALID, "nrtSetMesh: NULL mesh pointer");
+  if (stride < 3 * sizeof(T) && num_faces)
+    return fail(c, NRT_ERR_INVALID, "nrtSetMesh: vertex stride %zu < %zu", stride, 3 * sizeof(T));
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_tree(c);
+  free_mesh(c);
+  c->prec = (int)sizeof(T);
+  c->num_faces = num_faces;
+  if (num_faces == 0) return NRT_OK;
+  // The reference's mesh carries no vertex count (nanort.h:925-930): derive it.
+  uint32_t maxv = 0;
+  const size_t ni = 3 * (size_t)num_faces;
+  for (size_t i = 0; i < ni; i++) maxv = faces[i] > maxv ? faces[i] : maxv;
+  const uint32_t nv = maxv + 1;
+  c->num_verts = nv;
+  // Compact the strided vertex array (get_vertex_addr, nanort.h:467-472) to tight xyz.
+  const T *src = vertices;
+  std::vector<T> tight;
+  if (stride != 3 * sizeof(T)) {
+    tight.resize(3 * (size_t)nv);
+    const unsigned char *base = reinterpret_cast<const unsigned char *>(vertices);
+    for (uint32_t v = 0; v < nv; v++) {
+      const T *p = reinterpret_cast<const T *>(base + (size_t)v * stride);
+      tight[3 * (size_t)v + 0] = p[0];
+      tight[3 * (size_t)v + 1] = p[1];
+      tight[3 * (size_t)v + 2] = p[2];
+    }
+    src = tight.data();
+  }
+  HIPCHK(c, hipMalloc(&c->d_verts, 3 * (size_t)nv * sizeof(T)));
+  HIPCHK(c, hipMalloc((void **)&c->d_faces, ni * sizeof(uint32_t)));
+  HIPCHK(c, hipMemcpy(c->d_verts, src, 3 * (size_t)nv * sizeof(T), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_faces, faces, ni * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return NRT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// tree adoption / retrieval
+// ---------------------------------------------------------------------------
+template <typename T>
+static nrt_status finish_tree(nrt_ctx *c) {
+  // leaf-ordered triangle records for the traversal kernel
+  if (c->d_tris) HIPCHK(c, hipFree(c->d_tris));
+  c->d_tris = nullptr;
+  HIPCHK(c, hipMalloc(&c->d_tris, std::max<size_t>(1, c->num_indices) * sizeof(LeafTri<T>)));
+  HIPCHK(c, launch_gather_leaf_tris<T>(c->d_indices, c->d_faces, (const T *)c->d_verts,
+                                       (LeafTri<T> *)c->d_tris, (uint32_t)c->num_indices, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NRT_OK;
+}
+
+template <typename T>
+static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint64_t num_nodes,
+                           const uint32_t *indices, uint64_t num_indices) {
+  if (!c) return NRT_ERR_INVALID;
+  if (c->prec != (int)sizeof(T)) return fail(c, NRT_ERR_PRECISION, "nrtSetTree: set a mesh of this precision first");
+  if (!nodes || !indices || num_nodes == 0) return fail(c, NRT_ERR_INVALID, "nrtSetTree: empty tree");
+  if (num_nodes >= 0xFFFFFFFFull || num_indices >= 0xFFFFFFFFull)
+    return fail(c, NRT_ERR_INVALID, "nrtSetTree: tree too large");
+  // Validate what the traversal loop relies on and measure depth.
+  for (uint64_t i = 0; i < num_indices; i++)
+    if (indices[i] >= c->num_faces)
+      return fail(c, NRT_ERR_INVALID, "nrtSetTree: indices[%llu]=%u >= num_faces %u",
+                  (unsigned long long)i, indices[i], c->num_faces);
+  uint32_t depth = 0;
+  {
+    std::vector<std::pair<uint32_t, uint32_t> > st;
+    std::vector<uint8_t> seen(num_nodes, 0);
+    st.push_back(std::make_pair(0u, 0u));
+    while (!st.empty()) {
+      std::pair<uint32_t, uint32_t> e = st.back();
+      st.pop_back();
+      const typename Wire<T>::Node &n = nodes[e.first];
+      if (seen[e.first]) return fail(c, NRT_ERR_INVALID, "nrtSetTree: node %u reachable twice", e.first);
+      seen[e.first] = 1;
+      depth = std::max(depth, e.second);
+      if (n.flag == 0) {
+        if (n.data[0] >= num_nodes || n.data[1] >= num_nodes)
+          return fail(c, NRT_ERR_INVALID, "nrtSetTree: node %u child out of range", e.first);
+        if (n.axis < 0 || n.axis > 2) return fail(c, NRT_ERR_INVALID, "nrtSetTree: node %u axis %d", e.first, n.axis);
+        st.push_back(std::make_pair(n.data[1], e.second + 1));
+        st.push_back(std::make_pair(n.data[0], e.second + 1));
+      } else {
+        if ((uint64_t)n.data[1] + n.data[0] > num_indices)
+          return fail(c, NRT_ERR_INVALID, "nrtSetTree: leaf %u slots out of range", e.first);
+      }
+    }
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_tree(c);
+  c->num_nodes = num_nodes;
+  c->num_indices = num_indices;
+  c->tree_depth = depth;
+  HIPCHK(c, hipMalloc(&c->d_nodes, num_nodes * sizeof(typename Wire<T>::Node)));
+  HIPCHK(c, hipMalloc((void **)&c->d_indices, std::max<uint64_t>(1, num_indices) * sizeof(uint32_t)));
+  HIPCHK(c, hipMemcpy(c->d_nodes, nodes, num_nodes * sizeof(typename Wire<T>::Node), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_indices, indices, num_indices * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return finish_tree<T>(c);
+}
+
+template <typename T>
+static nrt_status get_tree(nrt_ctx *c, typename Wire<T>::Node *nodes_out, uint32_t *indices_out) {
+  if (!c) return NRT_ERR_INVALID;
+  if (c->prec != (int)sizeof(T)) return fail(c, NRT_ERR_PRECISION, "nrtGetTree: precision mismatch");
+  if (!c->d_nodes) return fail(c, NRT_ERR_INVALID, "nrtGetTree: no tree");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (nodes_out)
+    HIPCHK(c, hipMemcpy(nodes_out, c->d_nodes, c->num_nodes * sizeof(typename Wire<T>::Node), hipMemcpyDeviceToHost));
+  if (indices_out)
+    HIPCHK(c, hipMemcpy(indices_out, c->d_indices, c->num_indices * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return NRT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// build
+// ---------------------------------------------------------------------------
+template <typename T>
+static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, nrt_build_stats *stats_out,
+                        uint64_t *num_nodes_out) {
+  if (!c) return NRT_ERR_INVALID;
+  if (c->prec != (int)sizeof(T)) return fail(c, NRT_ERR_PRECISION, "nrtBuild: set a mesh of this precision first");
+  if (c->num_faces == 0) return fail(c, NRT_ERR_EMPTY, "nrtBuild: no primitives (reference Build() returns false)");
+  uint32_t min_leaf = 4, max_depth = 256, bin_size = 64; // BVHBuildOptions() defaults, nanort.h:574-582
+  if (opt) {
+    min_leaf = opt->min_leaf_primitives;
+    max_depth = opt->max_tree_depth;
+    bin_size = opt->bin_size;
+  }
+  if (bin_size < 2) return fail(c, NRT_ERR_INVALID, "nrtBuild: bin_size must be > 1 (nanort.h:1905)");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_tree(c);
+  typename Wire<T>::Node *d_nodes = nullptr;
+  uint32_t *d_indices = nullptr;
+  BuildResult res;
+  std::string err;
+  HIPCHK(c, hipEventRecord(c->ev_b0, c->stream));
+  hipError_t e = gpu_build<T>(c->device, c->stream, (const T *)c->d_verts, c->d_faces, c->num_faces, min_leaf,
+                              max_depth, bin_size, &d_nodes, &d_indices, &res, &err);
+  if (e != hipSuccess) return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s (%s)", err.c_str(), hipGetErrorString(e));
+  if (!err.empty()) return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s", err.c_str());
+  HIPCHK(c, hipEventRecord(c->ev_b1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev_b1));
+  c->have_build_time = true;
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev_b0, c->ev_b1));
+  c->d_nodes = d_nodes;
+  c->d_indices = d_indices;
+  c->num_nodes = res.num_nodes;
+  c->num_indices = c->num_faces;
+  c->tree_depth = res.max_depth;
+  c->stats.max_tree_depth = res.max_depth;
+  c->stats.num_leaf_nodes = res.num_leaves;
+  c->stats.num_branch_nodes = res.num_branches;
+  c->stats.build_secs = ms * 1e-3f;
+  if (stats_out) *stats_out = c->stats;
+  if (num_nodes_out) *num_nodes_out = c->num_nodes;
+  return finish_tree<T>(c);
+}
+
+// ---------------------------------------------------------------------------
+// traverse
+// ---------------------------------------------------------------------------
+static const nrt_trace_options kDefaultTrace = {{0u, 0x7FFFFFFFu}, 0xFFFFFFFFu, 0, {0, 0, 0}}; // nanort.h:617-623
+
+template <typename T>
+static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_rays, uint64_t n,
+                                  const nrt_trace_options *opt, typename Wire<T>::Hit *d_hits, uint8_t *d_mask,
+                                  hipStream_t s, bool count, bool timed) {
+  if (c->prec != (int)sizeof(T)) return fail(c, NRT_ERR_PRECISION, "nrtTraverseBatch: precision mismatch");
+  if (!c->d_nodes) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatch: no tree (call nrtBuild or nrtSetTree)");
+  if (n == 0) return NRT_OK;
+  if (!d_rays) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatch: NULL rays");
+  if (n > 0x7FFFFFFFull) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatch: more than 2^31-1 rays in one call");
+  if (!opt) opt = &kDefaultTrace;
+  HIPCHK(c, hipSetDevice(c->device));
+
+  // persistent grid: every block resident (LDS stack 32 KiB/block -> 5 blocks per CU)
+  const unsigned blocks_per_cu = 5;
+  uint64_t need_blocks = (n + kTraverseBlock - 1) / kTraverseBlock;
+  unsigned grid = (unsigned)std::min<uint64_t>(need_blocks, (uint64_t)c->num_cus * blocks_per_cu);
+  const uint32_t total_threads = grid * kTraverseBlock;
+  const uint32_t levels = c->tree_depth + 2 > (uint32_t)kLdsStack ? c->tree_depth + 2 - kLdsStack : 0;
+  if (levels) {
+    nrt_status st = ensure(c, c->spill, (size_t)levels * total_threads * sizeof(uint32_t));
+    if (st) return st;
+  }
+
+  TraverseArgs<T> a;
+  a.nodes = (const typename Wire<T>::Node *)c->d_nodes;
+  a.tris = (const LeafTri<T> *)c->d_tris;
+  a.rays = d_rays;
+  a.hits = d_hits;
+  a.mask = d_mask;
+  a.num_rays = (uint32_t)n;
+  a.range0 = opt->prim_ids_range[0];
+  a.range1 = opt->prim_ids_range[1];
+  a.skip_prim = opt->skip_prim_id;
+  a.cull_back_face = opt->cull_back_face ? 1u : 0u;
+  a.spill = (uint32_t *)c->spill.p;
+  a.spill_stride = total_threads;
+  a.spill_levels = levels;
+  a.ray_cursor = c->d_cursor;
+  a.counters = c->d_counters;
+  a.chunk = 256;
+
+  HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, sizeof(uint32_t), s));
+  if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), s));
+  if (timed) HIPCHK(c, hipEventRecord(c->ev_t0, s));
+  HIPCHK(c, launch_traverse<T>(a, grid, count, s));
+  if (timed) {
+    HIPCHK(c, hipEventRecord(c->ev_t1, s));
+    c->have_traverse_time = true;
+  }
+  return NRT_OK;
+}
+
+template <typename T>
+static nrt_status traverse_host(nrt_ctx *c, const typename Wire<T>::Ray *rays, uint64_t n,
+                                const nrt_trace_options *opt, typename Wire<T>::Hit *hits, uint8_t *mask) {
+  if (!c) return NRT_ERR_INVALID;
+  if (n == 0) return NRT_OK;
+  if (!rays || !hits) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatch: NULL rays/hits");
+  typedef typename Wire<T>::Ray Ray;
+  typedef typename Wire<T>::Hit Hit;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t kMaxChunk = 1ull << 26; // rays per launch (keeps staging bounded)
+  for (uint64_t off = 0; off < n; off += kMaxChunk) {
+    const uint64_t m = std::min(kMaxChunk, n - off);
+    nrt_status st;
+    if ((st = ensure(c, c->st_rays, m * sizeof(Ray)))) return st;
+    if ((st = ensure(c, c->st_hits, m * sizeof(Hit)))) return st;
+    if ((st = ensure(c, c->st_mask, m))) return st;
+    HIPCHK(c, hipMemcpyAsync(c->st_rays.p, rays + off, m * sizeof(Ray), hipMemcpyHostToDevice, c->stream));
+    st = traverse_device<T>(c, (const Ray *)c->st_rays.p, m, opt, (Hit *)c->st_hits.p, (uint8_t *)c->st_mask.p,
+                            c->stream, false, true);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(hits + off, c->st_hits.p, m * sizeof(Hit), hipMemcpyDeviceToHost, c->stream));
+    if (mask) HIPCHK(c, hipMemcpyAsync(mask + off, c->st_mask.p, m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return NRT_OK;
+}
+
+template <typename T>
+static nrt_status traverse_count(nrt_ctx *c, const typename Wire<T>::Ray *d_rays, uint64_t n,
+                                 const nrt_trace_options *opt, nrt_trace_counters *out) {
+  if (!c || !out) return NRT_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  nrt_status st = traverse_device<T>(c, d_rays, n, opt, nullptr, nullptr, c->stream, true, false);
+  if (st) return st;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  unsigned long long h[4];
+  HIPCHK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  out->nodes_visited = h[0];
+  out->leaves_tested = h[1];
+  out->tris_tested = h[2];
+  out->max_stack = h[3];
+  return NRT_OK;
+}
+
+extern "C" {
+
+nrt_status nrtSetMesh_f32(nrt_ctx *c, const float *v, size_t stride, const uint32_t *f, uint32_t nf) {
+  return set_mesh<float>(c, v, stride, f, nf);
+}
+nrt_status nrtSetMesh_f64(nrt_ctx *c, const double *v, size_t stride, const uint32_t *f, uint32_t nf) {
+  return set_mesh<double>(c, v, stride, f, nf);
+}
+
+nrt_status nrtBuild_f32(nrt_ctx *c, const nrt_build_options_f32 *o, nrt_build_stats *st, uint64_t *nn) {
+  return build<float>(c, o, st, nn);
+}
+nrt_status nrtBuild_f64(nrt_ctx *c, const nrt_build_options_f64 *o, nrt_build_stats *st, uint64_t *nn) {
+  return build<double>(c, o, st, nn);
+}
+
+nrt_status nrtGetTree_f32(nrt_ctx *c, nrt_node_f32 *n, uint32_t *i) { return get_tree<float>(c, n, i); }
+nrt_status nrtGetTree_f64(nrt_ctx *c, nrt_node_f64 *n, uint32_t *i) { return get_tree<double>(c, n, i); }
+
+nrt_status nrtTreeSize(nrt_ctx *c, uint64_t *nn, uint64_t *ni) {
+  if (!c) return NRT_ERR_INVALID;
+  if (nn) *nn = c->num_nodes;
+  if (ni) *ni = c->num_indices;
+  return NRT_OK;
+}
+
+nrt_status nrtSetTree_f32(nrt_ctx *c, const nrt_node_f32 *n, uint64_t nn, const uint32_t *i, uint64_t ni) {
+  return set_tree<float>(c, n, nn, i, ni);
+}
+nrt_status nrtSetTree_f64(nrt_ctx *c, const nrt_node_f64 *n, uint64_t nn, const uint32_t *i, uint64_t ni) {
+  return set_tree<double>(c, n, nn, i, ni);
+}
+
+nrt_status nrtTraverseBatch_f32(nrt_ctx *c, const nrt_ray_f32 *r, uint64_t n, const nrt_trace_options *o,
+                                nrt_hit_f32 *h, uint8_t *m) {
+  return traverse_host<float>(c, r, n, o, h, m);
+}
+nrt_status nrtTraverseBatch_f64(nrt_ctx *c, const nrt_ray_f64 *r, uint64_t n, const nrt_trace_options *o,
+                                nrt_hit_f64 *h, uint8_t *m) {
+  return traverse_host<double>(c, r, n, o, h, m);
+}
+
+nrt_status nrtTraverseBatchDevice_f32(nrt_ctx *c, const nrt_ray_f32 *r, uint64_t n, const nrt_trace_options *o,
+                                      nrt_hit_f32 *h, uint8_t *m, void *s) {
+  if (!c) return NRT_ERR_INVALID;
+  if (n && !h) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchDevice: NULL hits");
+  return traverse_device<float>(c, r, n, o, h, m, (hipStream_t)s, false, true);
+}
+nrt_status nrtTraverseBatchDevice_f64(nrt_ctx *c, const nrt_ray_f64 *r, uint64_t n, const nrt_trace_options *o,
+                                      nrt_hit_f64 *h, uint8_t *m, void *s) {
+  if (!c) return NRT_ERR_INVALID;
+  if (n && !h) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchDevice: NULL hits");
+  return traverse_device<double>(c, r, n, o, h, m, (hipStream_t)s, false, true);
+}
+
+nrt_status nrtTraverseCountDevice_f32(nrt_ctx *c, const nrt_ray_f32 *r, uint64_t n, const nrt_trace_options *o,
+                                      nrt_trace_counters *out) {
+  return traverse_count<float>(c, r, n, o, out);
+}
+nrt_status nrtTraverseCountDevice_f64(nrt_ctx *c, const nrt_ray_f64 *r, uint64_t n, const nrt_trace_options *o,
+                                      nrt_trace_counters *out) {
+  return traverse_count<double>(c, r, n, o, out);
+}
+
+float nrtLastTraverseMs(nrt_ctx *c) {
+  if (!c || !c->have_traverse_time) return -1.f;
+  if (hipEventSynchronize(c->ev_t1) != hipSuccess) return -1.f;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) != hipSuccess) return -1.f;
+  return ms;
+}
+
+float nrtLastBuildMs(nrt_ctx *c) {
+  if (!c || !c->have_build_time) return -1.f;
+  return c->stats.build_secs * 1e3f;
+}
+
+} // extern "C"

@@ -1,0 +1,70 @@
+// nanort_amd/csrc/common.h — device-side PODs and launch-argument blocks shared
+// by the gfx950 kernels (traverse.hip, build.hip) and the C ABI (api.hip).
+//
+// The node / ray / hit records are the reference's wire formats
+// (include/nanort_hip.h; reference nanort.h:474-550, 996-1005).  Everything
+// else in this file is private device layout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nanort_hip.h"
+
+namespace nrt {
+
+constexpr int kWave = 64;           // gfx950 wavefront
+constexpr int kTraverseBlock = 256; // 4 waves, one per SIMD
+constexpr int kLdsStack = 32;       // per-lane stack entries kept in LDS (32 KiB / block)
+constexpr unsigned kInvalid = 0xFFFFFFFFu;
+
+template <typename T>
+struct Wire;
+template <>
+struct Wire<float> {
+  typedef nrt_ray_f32 Ray;
+  typedef nrt_node_f32 Node;
+  typedef nrt_hit_f32 Hit;
+  typedef nrt_build_options_f32 BuildOptions;
+};
+template <>
+struct Wire<double> {
+  typedef nrt_ray_f64 Ray;
+  typedef nrt_node_f64 Node;
+  typedef nrt_hit_f64 Hit;
+  typedef nrt_build_options_f64 BuildOptions;
+};
+
+// Leaf-ordered triangle record: slot s of the index permutation holds the three
+// vertices of primitive indices[s] plus its id, so a leaf {count, first} reads
+// `count` consecutive records instead of chasing indices -> faces -> vertices.
+// Same values as the reference's gather (nanort.h:1065-1071), pre-resolved.
+template <typename T>
+struct alignas(8) LeafTri {
+  T p0[3];
+  T p1[3];
+  T p2[3];
+  uint32_t prim_id;
+};
+static_assert(sizeof(LeafTri<float>) == 40, "LeafTri<float>");
+static_assert(sizeof(LeafTri<double>) == 80, "LeafTri<double>");
+
+template <typename T>
+struct TraverseArgs {
+  const typename Wire<T>::Node *nodes;
+  const LeafTri<T> *tris;
+  const typename Wire<T>::Ray *rays;
+  typename Wire<T>::Hit *hits; // may be null (counting pass)
+  uint8_t *mask;               // may be null
+  uint32_t num_rays;
+  uint32_t range0, range1, skip_prim; // BVHTraceOptions
+  uint32_t cull_back_face;
+  uint32_t *spill;        // [spill_levels][spill_stride] overflow stack, may be null
+  uint32_t spill_stride;  // == total threads of the launch
+  uint32_t spill_levels;
+  uint32_t *ray_cursor;              // persistent-thread work counter (zeroed per launch)
+  unsigned long long *counters;      // 4 x u64 when counting
+  uint32_t chunk;                    // rays claimed per atomic
+};
+
+} // namespace nrt
