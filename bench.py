@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""bench.py — the headline measurement of the hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Metric (BASELINE.json): Mrays/s (primary + 1-bounce) at 1920x1080 on the
+1M-triangle mesh; BVH build ms.  Workload = config C3 of SURVEY.md §8(d):
+Plane(1000,500) (exactly 1 000 000 triangles), fp32, objrender camera.
+
+One "step" = one pass of the hot path over one batch: wave 1 (W*H primary
+rays) + wave 2 (one cosine-weighted bounce ray per wave-1 hit), both already
+resident in HBM, traced by the batched traversal kernel through the C ABI
+(nrtTraverseBatchDevice_f32) on torch's current stream.  The BVH is built on
+the GPU (nrtBuild_f32) before the timed region; its device time is reported
+as `build_ms` (median of several builds).
+
+N > 1 (weak scaling): the image grows to 1920 x (1080*N) and rank r traces the
+interleaved rows y = r (mod N), i.e. 1920x1080 rays per GPU, over its own
+replica of the BVH (deterministic build, no broadcast).  The wave-1 hit
+records are gathered to every rank with one RCCL all-gather per step, issued
+asynchronously so it overlaps wave 2.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel k_traverse<float>: ALGORITHMIC bytes per launch
+                (52 + 40*nodes_visited + 52*tris_tested per ray, SURVEY.md §8d,
+                counted on the tree actually traversed by the kernel's own
+                counting pass) / mean launch duration measured live with HIP
+                events on the launch stream; peak = 8 TB/s HBM3E.
+  cpu_baseline  the UNMODIFIED reference (oracle/_ref, OpenMP, all host cores)
+                on a bounded sample of the same ray buffers; falls back to the
+                single-thread C port (oracle/liboracle.so) when _ref is absent.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+WIDTH, HEIGHT = 1920, 1080
+
+
+def algorithmic_bytes(counters, real_bytes=4):
+    """per ray sizeof(Ray)+sizeof(Hit) + 40 B per node visit + 52 B per triangle test (fp32)."""
+    if real_bytes == 4:
+        return 52 * counters["num_rays"] + 40 * counters["nodes_visited"] + 52 * counters["tris_tested"]
+    return 104 * counters["num_rays"] + 64 * counters["nodes_visited"] + 88 * counters["tris_tested"]
+
+
+def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, budget_s=12.0):
+    """Reference (or port) timed on the host cores over a bounded sample of the same buffers."""
+    from oracle import bindings as ob
+
+    total = rays1.shape[0] + rays2.shape[0]
+    if ob.reference_available():
+        R = ob.Reference(verts, faces)
+        cores = R.max_threads()
+        ok, st = R.build(parallel=True)
+        build_ms = st["build_secs"] * 1e3
+        # probe rate on a few rows, then size the sample to the budget
+        probe = rays1[: WIDTH * 8]
+        _, _, secs = R.traverse(probe, chunk=WIDTH)
+        rate = probe.shape[0] / max(secs, 1e-9)
+        frac = min(1.0, budget_s * rate / total)
+        rows1 = max(8, int(rays1.shape[0] // WIDTH * frac))
+        step = max(1, (rays1.shape[0] // WIDTH) // rows1)
+        s1 = rays1.reshape(-1, WIDTH)[::step].reshape(-1)
+        s2 = rays2[:: max(1, step)]
+        best = 1e30
+        for _ in range(2):
+            _, _, t1 = R.traverse(s1, chunk=WIDTH)
+            _, _, t2 = R.traverse(s2, chunk=WIDTH)
+            best = min(best, t1 + t2)
+        value = (s1.shape[0] + s2.shape[0]) / best / 1e6
+        out = {
+            "value": round(value, 4), "unit": "Mrays/s", "cores": int(cores), "kind": "reference",
+            "sample": "unmodified nanort.h (g++ -O3 -fopenmp, own parallel Build: %d nodes, depth %d), "
+                      "every %d-th row of wave 1 (%d rays) + every %d-th wave-2 ray (%d rays), "
+                      "omp dynamic row loop, best of 2" % (
+                          st["num_leaf_nodes"] + st["num_branch_nodes"], st["max_tree_depth"], step,
+                          s1.shape[0], step, s2.shape[0]),
+            "build_ms": round(build_ms, 1),
+        }
+        # same traversal code over the GPU-built node array: separates "better tree" from "faster traversal"
+        if R.load_tree(gpu_nodes, gpu_indices):
+            _, _, t1 = R.traverse(rays1, chunk=WIDTH)
+            _, _, t2 = R.traverse(rays2, chunk=WIDTH)
+            out["value_on_gpu_built_tree"] = round(total / (t1 + t2) / 1e6, 4)
+        return out
+    O = ob.Oracle()
+    t0 = time.time()
+    nodes, idx, _ = O.build(verts, faces)
+    build_ms = (time.time() - t0) * 1e3
+    s1 = rays1.reshape(-1, WIDTH)[::54].reshape(-1)
+    t0 = time.time()
+    O.traverse(nodes, idx, verts, faces, s1)
+    dt = time.time() - t0
+    return {"value": round(s1.shape[0] / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": "liboracle.so single thread, every 54th row of wave 1 (%d rays)" % s1.shape[0],
+            "build_ms": round(build_ms, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--builds", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+
+    from nanort_amd import BVHAccel, TriangleMesh, scenes
+    from nanort_amd.wire import HIT_F32, RAY_F32
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    # ---- mesh + BVH (replicated per rank, deterministic) ----------------------
+    verts, faces = scenes.plane(1000, 500)
+    mesh = TriangleMesh(verts, faces)
+    accel = BVHAccel(np.float32, device=local_rank)
+    build_ms = []
+    for _ in range(max(1, args.builds)):
+        assert accel.Build(mesh.num_faces, mesh)
+        build_ms.append(accel.LastBuildMs())
+    stats = accel.GetStatistics()
+
+    # ---- rays: wave 1 (this rank's interleaved rows), wave 2 from its hits --------
+    H_glob = HEIGHT * world
+    rays1 = scenes.camera_rays_rows(WIDTH, H_glob, rank, world, HEIGHT)
+    n1 = rays1.shape[0]
+    d_rays1 = torch.from_numpy(rays1.view(np.uint8)).cuda()
+    d_hits1 = torch.empty(n1 * HIT_F32.itemsize, dtype=torch.uint8, device="cuda")
+    d_mask1 = torch.empty(n1, dtype=torch.uint8, device="cuda")
+    accel.TraverseBatchDevice(d_rays1, d_hits1, d_mask1)
+    torch.cuda.synchronize()
+    hits1 = d_hits1.cpu().numpy().view(HIT_F32)
+    mask1 = d_mask1.cpu().numpy()
+    # pixel index of ray i in the global image: row (rank + world * (i // W)), column i % W
+    rays2 = scenes.secondary_rays("bounce", verts, faces, rays1, hits1, mask1, pixel_base=rank * n1)
+    n2 = rays2.shape[0]
+    d_rays2 = torch.from_numpy(rays2.view(np.uint8)).cuda()
+    d_hits2 = torch.empty(max(1, n2) * HIT_F32.itemsize, dtype=torch.uint8, device="cuda")
+    d_mask2 = torch.empty(max(1, n2), dtype=torch.uint8, device="cuda")
+    gathered = None
+    if world > 1:
+        gathered = torch.empty(world * n1 * HIT_F32.itemsize, dtype=torch.uint8, device="cuda")
+
+    # ---- work counters -> algorithmic bytes per launch ---------------------------
+    c1 = accel.TraverseCountDevice(d_rays1)
+    c2 = accel.TraverseCountDevice(d_rays2)
+    bytes1, bytes2 = algorithmic_bytes(c1), algorithmic_bytes(c2)
+
+    def step(ev=None):
+        work = None
+        if ev is not None:
+            ev[0].record()
+        accel.TraverseBatchDevice(d_rays1, d_hits1, d_mask1)
+        if ev is not None:
+            ev[1].record()
+        if world > 1:
+            work = dist.all_gather_into_tensor(gathered, d_hits1, async_op=True)  # overlaps wave 2
+        if ev is not None:
+            ev[2].record()
+        accel.TraverseBatchDevice(d_rays2, d_hits2, d_mask2)
+        if ev is not None:
+            ev[3].record()
+        if work is not None:
+            work.wait()
+
+    for _ in range(args.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+
+    k_ms1 = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    k_ms2 = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
+    rays_per_step = n1 + n2
+    if world > 1:
+        t = torch.tensor([dt, float(rays_per_step), float(bytes1 + bytes2), k_ms1 + k_ms2], dtype=torch.float64,
+                         device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        total_rays = float(tsum[1])
+    else:
+        total_rays = float(rays_per_step)
+
+    if rank == 0:
+        value = total_rays * args.steps / dt / 1e6
+        achieved = (bytes1 + bytes2) / ((k_ms1 + k_ms2) * 1e-3) / 1e9  # GB/s, this rank's two launches
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_c3.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (primary + 1-bounce) at 1920x1080, 1M-tri mesh; BVH build ms",
+            "value": round(value, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "C3: Plane(1000,500) = 1,000,000 triangles fp32; %dx%d objrender-camera primaries "
+                            "+ 1 cosine bounce per hit (%d + %d rays per GPU per step)" % (WIDTH, HEIGHT, n1, n2),
+                "parallelism": "replicated BVH, interleaved image rows per GPU%s" % (
+                    ", RCCL all-gather of wave-1 hit records overlapped with wave 2" if world > 1 else ""),
+                "rays_per_step": int(total_rays),
+            },
+            "build_ms": round(float(np.median(build_ms)), 4),
+            "bvh": {"nodes": int(stats["num_leaf_nodes"] + stats["num_branch_nodes"]),
+                    "max_depth": int(stats["max_tree_depth"])},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "nrt::k_traverse<float,false>",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": int((bytes1 + bytes2) // 2),
+                "launch_ms": round((k_ms1 + k_ms2) / 2, 4),
+                "per_wave": {
+                    "primary": {"ms": round(k_ms1, 4), "rays": n1, "nodes_per_ray": round(c1["nodes_visited"] / n1, 2),
+                                "tris_per_ray": round(c1["tris_tested"] / n1, 2), "bytes": int(bytes1)},
+                    "bounce": {"ms": round(k_ms2, 4), "rays": n2,
+                               "nodes_per_ray": round(c2["nodes_visited"] / max(1, n2), 2),
+                               "tris_per_ray": round(c2["tris_tested"] / max(1, n2), 2), "bytes": int(bytes2)},
+                },
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            nodes, indices = accel.GetTree()
+            out["cpu_baseline"] = cpu_baseline(verts, faces, rays1, rays2, nodes, indices)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

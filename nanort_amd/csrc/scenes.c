@@ -131,11 +131,25 @@ void nrt_scene_sphere(uint32_t nu, uint32_t nv, float *verts, uint32_t *faces) {
  * float3::normalize (multiply by 1/len when len > 1e-6, main.cc:190-198),
  * min_t=0, max_t=1e30; row-major.  Rows [y0, y1) of a W x H image are written
  * (a tile for the multi-GPU split); out must hold (y1-y0)*W rays. */
+static void camera_rows(uint32_t W, uint32_t H, uint32_t y0, uint32_t y_step, uint32_t rows, ray_f32 *out);
+
 void nrt_rays_camera(uint32_t W, uint32_t H, uint32_t y0, uint32_t y1, ray_f32 *out) {
-  uint32_t x, y;
-  for (y = y0; y < y1; y++) {
+  camera_rows(W, H, y0, 1, y1 - y0, out);
+}
+
+/* Interleaved row split for the multi-GPU tile partition: rows y0, y0+y_step,
+ * ... (`rows` of them) of the same W x H image. */
+void nrt_rays_camera_rows(uint32_t W, uint32_t H, uint32_t y0, uint32_t y_step, uint32_t rows,
+                          ray_f32 *out) {
+  camera_rows(W, H, y0, y_step, rows, out);
+}
+
+static void camera_rows(uint32_t W, uint32_t H, uint32_t y0, uint32_t y_step, uint32_t rows, ray_f32 *out) {
+  uint32_t x, j;
+  for (j = 0; j < rows; j++) {
+    const uint32_t y = y0 + j * y_step;
     for (x = 0; x < W; x++) {
-      ray_f32 *r = &out[(size_t)(y - y0) * W + x];
+      ray_f32 *r = &out[(size_t)j * W + x];
       float dx = ((float)x / (float)W) - 0.5f;
       float dy = ((float)y / (float)H) - 0.5f;
       float dz = -1.0f;

@@ -30,6 +30,8 @@ def _lib():
         L.nrt_scene_sphere.restype = None
         L.nrt_rays_camera.argtypes = [u32, u32, u32, u32, vp]
         L.nrt_rays_camera.restype = None
+        L.nrt_rays_camera_rows.argtypes = [u32, u32, u32, u32, u32, vp]
+        L.nrt_rays_camera_rows.restype = None
         L.nrt_rays_secondary.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, u64, u64, vp]
         L.nrt_rays_secondary.restype = u64
         _LIB = L
@@ -62,6 +64,13 @@ def camera_rays(width, height, y0=0, y1=None):
         y1 = height
     rays = np.empty(((y1 - y0) * width,), dtype=RAY_F32)
     _lib().nrt_rays_camera(width, height, y0, y1, _p(rays))
+    return rays
+
+
+def camera_rays_rows(width, height, y0, y_step, rows):
+    """Rows y0, y0+y_step, ... of the width x height camera image (multi-GPU interleaved tiles)."""
+    rays = np.empty((rows * width,), dtype=RAY_F32)
+    _lib().nrt_rays_camera_rows(width, height, y0, y_step, rows, _p(rays))
     return rays
 
 

@@ -1,0 +1,61 @@
+"""Shared test helpers (CPU side): tie-aware hit comparison, option builders."""
+import numpy as np
+
+from nanort_amd.wire import default_trace_options
+
+
+def trace_options(range_=None, skip=None, cull=None):
+    o = default_trace_options()
+    if range_ is not None:
+        o["prim_ids_range"] = range_
+    if skip is not None:
+        o["skip_prim_id"] = skip
+    if cull is not None:
+        o["cull_back_face"] = 1 if cull else 0
+    return o
+
+
+def _fields_equal(a, b):
+    """Bitwise equality of the four meaningful fields (fp64 records carry 4 padding bytes)."""
+    return all(np.ascontiguousarray(a[k]).tobytes() == np.ascontiguousarray(b[k]).tobytes() for k in ("t", "u", "v", "prim_id"))
+
+
+def assert_hits_identical(a_hits, a_mask, b_hits, b_mask):
+    """Bit-for-bit equality of hit records (same tree => same tie breaks)."""
+    assert np.array_equal(a_mask, b_mask), "hit masks differ at %s" % np.nonzero(a_mask != b_mask)[0][:8]
+    if not _fields_equal(a_hits, b_hits):
+        bad = np.nonzero(
+            (a_hits["t"] != b_hits["t"]) | (a_hits["prim_id"] != b_hits["prim_id"])
+            | (a_hits["u"] != b_hits["u"]) | (a_hits["v"] != b_hits["v"])
+        )[0]
+        raise AssertionError("hit records differ at %d rays, first %s:\n%s\n%s" % (
+            bad.size, bad[:4], a_hits[bad[:4]], b_hits[bad[:4]]))
+
+
+def assert_hits_match(ref_hits, ref_mask, hits, mask, oracle, onodes, oindices, verts, faces, rays,
+                      base_opts=None, max_ties=None):
+    """Parity across DIFFERENT trees: hit flags and t bit-equal
+    everywhere; u, v, prim_id bit-equal except at true ties — two primitives at
+    exactly the same t along the ray (shared edges/vertices), where the
+    reference itself keeps whichever it tested last (nanort.h:1133 accepts
+    equality).  Every such ray is verified: the oracle restricted to the
+    reported primitive must reproduce the reported record bit-for-bit.
+    Returns the number of ties."""
+    assert np.array_equal(ref_mask, mask), "hit masks differ at %s" % np.nonzero(ref_mask != mask)[0][:8]
+    assert np.ascontiguousarray(ref_hits["t"]).tobytes() == np.ascontiguousarray(hits["t"]).tobytes(), "t differs at %s" % np.nonzero(ref_hits["t"] != hits["t"])[0][:8]
+    diff = np.nonzero(ref_hits["prim_id"] != hits["prim_id"])[0]
+    same = ref_hits["prim_id"] == hits["prim_id"]
+    assert np.array_equal(ref_hits["u"][same], hits["u"][same]) and np.array_equal(ref_hits["v"][same], hits["v"][same]), \
+        "u/v differ on rays that report the same primitive"
+    if max_ties is not None:
+        assert diff.size <= max_ties, "%d prim_id mismatches" % diff.size
+    for i in diff:
+        o = default_trace_options() if base_opts is None else base_opts.copy()
+        p = int(hits["prim_id"][i])
+        lo = max(p, int(o["prim_ids_range"][0]))
+        hi = min(p + 1, int(o["prim_ids_range"][1]))
+        o["prim_ids_range"] = (lo, hi)
+        h1, m1 = oracle.traverse(onodes, oindices, verts, faces, rays[i:i + 1], o)
+        assert m1[0] == 1 and _fields_equal(h1, hits[i:i + 1]), \
+            "ray %d: reported prim %d is not an exact tie of the reference's prim %d" % (i, p, ref_hits["prim_id"][i])
+    return int(diff.size)

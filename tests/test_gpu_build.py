@@ -1,0 +1,194 @@
+"""GPU parity, build: nrtBuild emits a valid reference-format tree (structural validator), the
+reference's CPU traversal over that tree and the GPU traversal over it agree bit-for-bit, and the
+hit records equal the reference's own (reference-built tree) up to verified exact ties."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from bvh_check import sah_cost, validate_bvh
+from helpers import assert_hits_identical, assert_hits_match
+from nanort_amd import BVHAccel, TriangleMesh, scenes
+from nanort_amd.wire import default_build_options, widen_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def build(real, v, f, **opt):
+    a = BVHAccel(real)
+    o = default_build_options(real)
+    for k, val in opt.items():
+        o[k] = val
+    assert a.Build(f.shape[0], TriangleMesh(v, f), o)
+    nodes, idx = a.GetTree()
+    return a, nodes, idx
+
+
+def test_c1_build_valid_and_parity(oracle, c1_mesh, golden_dir):
+    v, f = c1_mesh
+    a, nodes, idx = build(np.float32, v, f)
+    m = validate_bvh(nodes, idx, v, f, stats=a.GetStatistics())
+    g = np.load(os.path.join(golden_dir, "c1_ref.npz"))
+    assert m["sah_cost"] <= sah_cost(g["nodes_f32"]), "GPU tree must not be worse than the reference's (SAH)"
+    rays = scenes.camera_rays(256, 256)
+    h, mk = a.TraverseBatch(rays)
+    # (ii) CPU restatement of the reference traversal over the GPU-built array: identical bits
+    oh, om = oracle.traverse(nodes, idx, v, f, rays)
+    assert_hits_identical(oh, om, h, mk)
+    # (iii) vs the reference's own records (its own tree): equal up to verified ties
+    ties = assert_hits_match(g["hits_256_f32"], g["mask_256_f32"], h, mk, oracle, g["nodes_f32"], g["indices_f32"], v, f, rays)
+    assert ties <= 64
+    bmin, bmax = a.BoundingBox()
+    assert np.array_equal(bmin, g["nodes_f32"][0]["bmin"]) and np.array_equal(bmax, g["nodes_f32"][0]["bmax"])
+    assert a.LastBuildMs() > 0 and a.GetStatistics()["build_secs"] > 0
+
+
+@pytest.mark.parametrize("opt", [
+    dict(min_leaf_primitives=1), dict(min_leaf_primitives=8), dict(min_leaf_primitives=16, bin_size=8),
+    dict(bin_size=2), dict(bin_size=1024), dict(max_tree_depth=6), dict(max_tree_depth=0), dict(max_tree_depth=1),
+])
+def test_build_options_are_honoured(oracle, opt):
+    v, f = scenes.plane(60, 40)  # 4800 triangles: top phase + subtree phase
+    a, nodes, idx = build(np.float32, v, f, **opt)
+    validate_bvh(nodes, idx, v, f, min_leaf=opt.get("min_leaf_primitives", 4),
+                 max_depth=opt.get("max_tree_depth", 256), stats=a.GetStatistics())
+    rays = scenes.camera_rays(160, 90)
+    h, mk = a.TraverseBatch(rays)
+    oh, om = oracle.traverse(nodes, idx, v, f, rays)
+    assert_hits_identical(oh, om, h, mk)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 9, 255, 256, 257, 513])
+def test_tiny_and_boundary_primitive_counts(oracle, n):
+    v, f = scenes.plane(40, 20)
+    f = f[:n]
+    a, nodes, idx = build(np.float32, v, f)
+    validate_bvh(nodes, idx, v, f, stats=a.GetStatistics())
+    rays = scenes.camera_rays(64, 36)
+    h, mk = a.TraverseBatch(rays)
+    oh, om = oracle.traverse(nodes, idx, v, f, rays)
+    assert_hits_identical(oh, om, h, mk)
+
+
+def test_empty_build_returns_false_like_the_reference(c1_mesh):
+    v, f = c1_mesh
+    a = BVHAccel(np.float32)
+    assert a.Build(0, TriangleMesh(v, f[:0])) is False  # nanort.h:1907-1909
+    assert not a.IsValid()
+    bmin, bmax = a.BoundingBox()
+    assert bmin[0] == np.finfo(np.float32).max and bmax[0] == -np.finfo(np.float32).max  # nanort.h:792-796
+
+
+def test_coincident_centroids_use_the_median_fallback(oracle):
+    """1000 copies of one triangle + a few others: no centroid separates them (nanort.h:1845-1850)."""
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [5, 5, 5], [6, 5, 5], [5, 6, 5]], dtype=np.float32)
+    f = np.array([[0, 1, 2]] * 1000 + [[3, 4, 5]] * 3, dtype=np.uint32)
+    a, nodes, idx = build(np.float32, v, f)
+    validate_bvh(nodes, idx, v, f, stats=a.GetStatistics())
+    rays = scenes.camera_rays(32, 32)
+    rays["org"] = (0.25, 0.25, 3.0)
+    rays["dir"] = (0.0, 0.0, -1.0)
+    h, mk = a.TraverseBatch(rays)
+    oh, om = oracle.traverse(nodes, idx, v, f, rays)
+    assert_hits_identical(oh, om, h, mk)
+    assert mk.all() and (h["t"] == 3.0).all()
+
+
+def test_build_is_deterministic(c1_mesh):
+    v, f = scenes.sphere(96, 48)
+    _, n1, i1 = build(np.float32, v, f)
+    _, n2, i2 = build(np.float32, v, f)
+    assert n1.tobytes() == n2.tobytes() and np.array_equal(i1, i2)
+
+
+def test_fp64_build(oracle, c1_mesh):
+    v, f = c1_mesh
+    v64 = v.astype(np.float64)
+    a, nodes, idx = build(np.float64, v64, f)
+    validate_bvh(nodes, idx, v64, f, stats=a.GetStatistics())
+    rays = widen_rays(scenes.camera_rays(256, 256))
+    h, mk = a.TraverseBatch(rays)
+    oh, om = oracle.traverse(nodes, idx, v64, f, rays)
+    assert_hits_identical(oh, om, h, mk)
+
+
+def test_strided_vertices(oracle):
+    rng = np.random.default_rng(3)
+    vb = rng.uniform(-1, 1, size=(400, 7)).astype(np.float32)
+    f = rng.integers(0, 400, size=(1500, 3), dtype=np.uint32)
+    a = BVHAccel(np.float32)
+    assert a.Build(1500, TriangleMesh(vb, f, 28))
+    nodes, idx = a.GetTree()
+    tight = np.ascontiguousarray(vb[:, :3])
+    validate_bvh(nodes, idx, tight, f, stats=a.GetStatistics())
+
+
+# ---- full-size configs of BASELINE.json ---------------------------------------------------------
+
+def test_c2_sphere_full_frame_vs_reference_sample(oracle, golden_dir):
+    v, f = scenes.sphere()
+    a, nodes, idx = build(np.float32, v, f)
+    validate_bvh(nodes, idx, v, f, stats=a.GetStatistics())
+    rays = scenes.camera_rays(1920, 1080)
+    h, mk = a.TraverseBatch(rays)
+    s = np.load(os.path.join(golden_dir, "sphere_sample.npz"))
+    st = int(s["stride"])
+    onodes, oidx, _ = oracle.build(v, f)
+    assert_hits_match(s["hits"], s["mask"], h[::st], mk[::st], oracle, onodes, oidx, v, f, rays[::st], max_ties=200)
+
+
+def test_c3_plane_1m_full_frame(oracle, golden_dir):
+    """Config C3 at BASELINE.json's full size: 1 000 000 triangles, 1920x1080 primaries + bounce."""
+    v, f = scenes.plane(1000, 500)
+    a, nodes, idx = build(np.float32, v, f)
+    m = validate_bvh(nodes, idx, v, f, stats=a.GetStatistics())
+    assert m["max_depth"] < 64
+    rays = scenes.camera_rays(1920, 1080)
+    h, mk = a.TraverseBatch(rays)
+    ka = json.load(open(os.path.join(golden_dir, "known_answers.json")))["KA4"]["wave_1920x1080"]
+    # size-independent checksums against the reference's full frame: hit count and sum of t
+    # (t is tie-independent, so the sums must agree exactly in double accumulation)
+    assert int(mk.sum()) == ka["num_hits"] == 2055142
+    assert float(h["t"][mk == 1].astype(np.float64).sum()) == ka["sum_t"]
+    s = np.load(os.path.join(golden_dir, "c3_sample.npz"))
+    st = int(s["stride"])
+    onodes, oidx, _ = oracle.build(v, f)
+    ties = assert_hits_match(s["hits"], s["mask"], h[::st], mk[::st], oracle, onodes, oidx, v, f, rays[::st], max_ties=2000)
+    # the GPU traversal and the CPU restatement agree bit-for-bit on the GPU-built tree (subsample)
+    sub = rays[::97]
+    oh, om = oracle.traverse(nodes, idx, v, f, sub)
+    assert_hits_identical(oh, om, h[::97], mk[::97])
+    # properties: permuting the rays permutes the hits; tracing twice is idempotent
+    perm = np.random.default_rng(0).permutation(rays.shape[0])
+    hp, mp = a.TraverseBatch(rays[perm])
+    assert hp.tobytes() == h[perm].tobytes() and np.array_equal(mp, mk[perm])
+    # bounce wave from these hits: round trip through the wave-2 generator, CPU restatement on a subsample
+    r2 = scenes.secondary_rays("bounce", v, f, rays, h, mk)
+    h2, m2 = a.TraverseBatch(r2)
+    oh2, om2 = oracle.traverse(nodes, idx, v, f, r2[::101])
+    assert_hits_identical(oh2, om2, h2[::101], m2[::101])
+    print("C3: %d ties on the %d-ray sample" % (ties, s["hits"].shape[0]))
+
+
+def test_scale_by_two_doubles_t_exactly():
+    """Linearity: scaling the mesh and the ray origins by 2 (a power of two) scales every t by exactly 2
+    and leaves u, v, prim_id and the hit mask unchanged."""
+    v, f = scenes.sphere(128, 64)
+    rays = scenes.camera_rays(320, 180)
+    a, _, _ = build(np.float32, v, f)
+    h, m = a.TraverseBatch(rays)
+    r2 = rays.copy()
+    r2["org"] *= 2
+    b, _, _ = build(np.float32, v * 2, f)
+    h2, m2 = b.TraverseBatch(r2)
+    assert np.array_equal(m, m2)
+    hit = m == 1
+    assert np.array_equal(h["t"][hit] * 2, h2["t"][hit]) and np.array_equal(h["prim_id"], h2["prim_id"])
+    assert np.array_equal(h["u"][hit], h2["u"][hit]) and np.array_equal(h["v"][hit], h2["v"][hit])
+
+
+def test_smoke_entry_point():
+    import __graft_entry__
+
+    __graft_entry__.smoke()

@@ -1,0 +1,171 @@
+"""GPU parity, traversal: the HIP kernel through the C ABI vs the CPU oracle, SAME node array
+=> every hit record bit-identical (t, u, v, prim_id, hit flag), fp32 and fp64."""
+import numpy as np
+import pytest
+
+from helpers import assert_hits_identical, trace_options
+from nanort_amd import BVHAccel, TriangleMesh, scenes
+from nanort_amd.wire import ray_dtype, widen_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_on_tree(real, v, f, nodes, idx, stride=None):
+    a = BVHAccel(real)
+    a.SetMesh(TriangleMesh(v, f, stride))
+    a.SetTree(nodes, idx)
+    return a
+
+
+@pytest.fixture(scope="module")
+def c1(oracle, c1_mesh):
+    v, f = c1_mesh
+    nodes, idx, _ = oracle.build(v, f)
+    return v, f, nodes, idx, gpu_on_tree(np.float32, v, f, nodes, idx)
+
+
+def test_c1_256_bit_exact_and_counters(oracle, c1):
+    v, f, nodes, idx, a = c1
+    rays = scenes.camera_rays(256, 256)
+    oh, om, cnt = oracle.traverse(nodes, idx, v, f, rays, count=True)
+    h, m = a.TraverseBatch(rays)
+    assert_hits_identical(oh, om, h, m)
+    import torch
+
+    c = a.TraverseCountDevice(torch.from_numpy(rays.view(np.uint8)).cuda())
+    assert (c["nodes_visited"], c["leaves_tested"], c["tris_tested"], c["max_stack"]) == tuple(int(x) for x in cnt)
+
+
+@pytest.mark.parametrize("opts", [dict(cull=True), dict(skip=7), dict(range_=(12, 500)), dict(range_=(3, 3))])
+def test_trace_options(oracle, c1, opts):
+    v, f, nodes, idx, a = c1
+    rays = scenes.camera_rays(256, 256)
+    o = trace_options(**opts)
+    oh, om = oracle.traverse(nodes, idx, v, f, rays, o)
+    h, m = a.TraverseBatch(rays, o)
+    assert_hits_identical(oh, om, h, m)
+
+
+def test_golden_fixture_without_the_oracle(c1, golden_dir):
+    """Straight against the reference's own output committed under tests/golden/."""
+    import os
+
+    v, f, nodes, idx, a = c1
+    g = np.load(os.path.join(golden_dir, "c1_ref.npz"))
+    a2 = gpu_on_tree(np.float32, v, f, g["nodes_f32"], g["indices_f32"])
+    h, m = a2.TraverseBatch(scenes.camera_rays(256, 256))
+    assert_hits_identical(g["hits_256_f32"], g["mask_256_f32"], h, m)
+    rw = scenes.camera_rays(256, 256)
+    rw["min_t"] = 19.0
+    rw["max_t"] = 24.5914974
+    h, m = a2.TraverseBatch(rw)
+    assert_hits_identical(g["hits_256_window"], g["mask_256_window"], h, m)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 257, 1000, 4099])
+def test_ragged_batch_sizes(oracle, c1, n):
+    v, f, nodes, idx, a = c1
+    rays = scenes.camera_rays(128, 128)[5000:5000 + n]
+    h, m = a.TraverseBatch(rays)
+    assert h.shape[0] == n
+    if n:
+        oh, om = oracle.traverse(nodes, idx, v, f, rays)
+        assert_hits_identical(oh, om, h, m)
+
+
+def test_fp64(oracle, c1_mesh):
+    v, f = c1_mesh
+    v64 = v.astype(np.float64)
+    nodes, idx, _ = oracle.build(v64, f)
+    a = gpu_on_tree(np.float64, v64, f, nodes, idx)
+    rays = widen_rays(scenes.camera_rays(256, 256))
+    oh, om = oracle.traverse(nodes, idx, v64, f, rays)
+    h, m = a.TraverseBatch(rays)
+    assert_hits_identical(oh, om, h, m)
+
+
+def test_deep_reference_tree_spills_past_the_lds_stack(oracle):
+    """The reference's own tree on a grid mesh is deep (X-only binning): the per-lane stack
+    overflows its 32 LDS entries and must continue in the global spill buffer."""
+    v, f = scenes.plane(300, 150)
+    nodes, idx, st = oracle.build(v, f)
+    assert st["max_tree_depth"] > 40
+    a = gpu_on_tree(np.float32, v, f, nodes, idx)
+    rays = scenes.camera_rays(640, 360)
+    oh, om, cnt = oracle.traverse(nodes, idx, v, f, rays, count=True)
+    assert cnt[3] > 33, "fixture no longer exercises the spill path"
+    h, m = a.TraverseBatch(rays)
+    assert_hits_identical(oh, om, h, m)
+
+
+@pytest.mark.parametrize("real", [np.float32, np.float64])
+def test_random_soup_and_hostile_rays(oracle, real):
+    """Random triangle soup (degenerate triangles included), strided vertices, rays with zero
+    direction components / axis-aligned / tiny windows: NaN-discarding slab test, vsafe_inverse,
+    fp64 edge fallback."""
+    rng = np.random.default_rng(7)
+    nv, nf, se = 1500, 5000, 4
+    vbuf = rng.uniform(-1, 1, size=(nv, se)).astype(real)
+    vbuf[:50, :3] = np.round(vbuf[:50, :3] * 4) / 4  # lattice points: exact edge hits
+    faces = rng.integers(0, nv, size=(nf, 3), dtype=np.uint32)
+    faces[:20, 1] = faces[:20, 0]  # degenerate
+    stride = se * vbuf.dtype.itemsize
+    nodes, idx, _ = oracle.build(vbuf, faces, stride=stride)
+    a = gpu_on_tree(real, vbuf, faces, nodes, idx, stride)
+    n = 20000
+    rays = np.zeros((n,), dtype=ray_dtype(real))
+    rays["org"] = rng.uniform(-2, 2, size=(n, 3))
+    rays["org"][:3000] = np.round(rays["org"][:3000] * 4) / 4
+    d = rng.normal(size=(n, 3))
+    d[:1000, 0] = 0.0
+    d[1000:2000, 1] = 0.0
+    d[2000:2500, :2] = 0.0
+    d[2500:3000] = np.round(d[2500:3000])
+    d[np.all(d == 0, axis=1)] = (0, 0, 1)
+    d[3000:3200, 2] = 1e-9
+    rays["dir"] = d
+    rays["max_t"] = rng.choice([1e30, 0.5, 3.0], size=n)
+    rays["min_t"] = rng.choice([0.0, 1e-3, 0.4], size=n)
+    for o in (None, trace_options(cull=True)):
+        oh, om = oracle.traverse(nodes, idx, vbuf, faces, rays, o, stride=stride)
+        h, m = a.TraverseBatch(rays, o)
+        assert_hits_identical(oh, om, h, m)
+
+
+def test_device_resident_entry_point_matches_host_entry_point(c1):
+    import torch
+
+    from nanort_amd.wire import HIT_F32
+
+    v, f, nodes, idx, a = c1
+    rays = scenes.camera_rays(200, 100)
+    h, m = a.TraverseBatch(rays)
+    d_rays = torch.from_numpy(rays.view(np.uint8)).cuda()
+    d_hits = torch.zeros(rays.shape[0] * 16, dtype=torch.uint8, device="cuda")
+    d_mask = torch.zeros(rays.shape[0], dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        a.TraverseBatchDevice(d_rays, d_hits, d_mask)
+    s.synchronize()
+    assert d_hits.cpu().numpy().view(HIT_F32).tobytes() == h.tobytes()
+    assert np.array_equal(d_mask.cpu().numpy(), m)
+    assert a.LastTraverseMs() > 0
+
+
+def test_error_paths(c1_mesh):
+    from nanort_amd import NrtError
+
+    v, f = c1_mesh
+    a = BVHAccel(np.float32)
+    with pytest.raises(NrtError):  # no tree yet
+        a.SetMesh(TriangleMesh(v, f))
+        a.TraverseBatch(scenes.camera_rays(8, 8))
+    with pytest.raises(TypeError):  # precision mismatch caught on the host side
+        a.SetMesh(TriangleMesh(v.astype(np.float64), f))
+    from nanort_amd.wire import NODE_F32
+
+    bad = np.zeros((1,), dtype=NODE_F32)
+    bad["flag"] = 0
+    bad["data"] = (5, 6)
+    with pytest.raises(NrtError):  # child index out of range
+        a.SetTree(bad, np.arange(f.shape[0], dtype=np.uint32))
