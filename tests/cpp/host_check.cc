@@ -1,0 +1,131 @@
+// tests/cpp/host_check.cc — drives include/nanort.h the way the reference's examples do.
+//
+//   host_check regress30 [x]          the scenario of the reference's
+//                                     test/regression/possible-accuracy-problem-30 (fp64, one triangle)
+//   host_check trace MESH RAYS OUT    Build + per-ray Traverse (and, with the HIP backend compiled in,
+//                                     TraverseBatch) over a raw mesh / ray file; hit records to OUT
+//
+// Built twice by tests/test_host_header.py: plain (generic host path) and with
+// -DNANORT_USE_HIP_BACKEND -lnanort_hip (GPU Build + TraverseBatch).
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "nanort.h"
+
+static int regress30(bool tiny) {
+  typedef double real;
+  real vertices[9] = {1.0, 2.0, -3.0, -1.0, 2.0, -3.0, 1.0, 2.0, 3.0};
+  unsigned int triangles[3] = {0, 1, 2};
+  real d[3] = {tiny ? -5.30287619e-17 : 0.0, -8.66025404e-01, -0.5};
+  nanort::BVHBuildOptions<real> build_options;
+  build_options.cache_bbox = true;
+  nanort::TriangleMesh<real> mesh(vertices, triangles, sizeof(real) * 3);
+  nanort::TriangleSAHPred<real> pred(vertices, triangles, sizeof(real) * 3);
+  nanort::BVHAccel<real> accel;
+  if (!accel.Build(1, mesh, pred, build_options)) return 2;
+  nanort::Ray<real> ray;
+  ray.org[0] = -0.36;
+  ray.org[1] = 7.93890843;
+  ray.org[2] = 1.2160368;
+  const real len = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  for (int k = 0; k < 3; k++) ray.dir[k] = d[k] / len;
+  ray.min_t = 0.0;
+  ray.max_t = 1.0e+30;
+  nanort::TriangleIntersector<real, nanort::TriangleIntersection<real> > isector(vertices, triangles, sizeof(real) * 3);
+  nanort::TriangleIntersection<real> isect;
+  const bool hit = accel.Traverse(ray, isector, &isect);
+  if (!hit) {
+    printf("No intersection detected\n");
+    return 1;
+  }
+  printf("isect.u =%g v = %g t = %.17g\n", isect.u, isect.v, isect.t);
+  return 0;
+}
+
+template <typename T>
+static int trace(const char *mesh_path, const char *rays_path, const char *out_path) {
+  // mesh: u32 nv, u32 nf, T xyz[nv], u32 ijk[nf]; rays: u64 n, Ray<T>[n]
+  FILE *fp = fopen(mesh_path, "rb");
+  if (!fp) return 2;
+  uint32_t nv = 0, nf = 0;
+  if (fread(&nv, 4, 1, fp) != 1 || fread(&nf, 4, 1, fp) != 1) return 2;
+  std::vector<T> verts(3 * (size_t)nv);
+  std::vector<unsigned int> faces(3 * (size_t)nf);
+  if (fread(verts.data(), sizeof(T), verts.size(), fp) != verts.size()) return 2;
+  if (fread(faces.data(), 4, faces.size(), fp) != faces.size()) return 2;
+  fclose(fp);
+  fp = fopen(rays_path, "rb");
+  if (!fp) return 2;
+  uint64_t n = 0;
+  if (fread(&n, 8, 1, fp) != 1) return 2;
+  std::vector<nanort::Ray<T> > rays(n);
+  if (fread(rays.data(), sizeof(nanort::Ray<T>), n, fp) != n) return 2;
+  fclose(fp);
+
+  nanort::TriangleMesh<T> mesh(verts.data(), faces.data(), sizeof(T) * 3);
+  nanort::TriangleSAHPred<T> pred(verts.data(), faces.data(), sizeof(T) * 3);
+  nanort::BVHAccel<T> accel;
+  if (!accel.Build(nf, mesh, pred)) {
+    fprintf(stderr, "Build failed\n");
+    return 3;
+  }
+  nanort::BVHBuildStatistics st = accel.GetStatistics();
+  printf("nodes %zu leaf %u branch %u depth %u build_secs %g\n", accel.GetNodes().size(), st.num_leaf_nodes, st.num_branch_nodes,
+         st.max_tree_depth, (double)st.build_secs);
+
+  // per-ray path, exactly like the reference's render loops
+  std::vector<nanort::TriangleIntersection<T> > hits(n);
+  std::vector<unsigned char> mask(n, 0);
+  for (uint64_t i = 0; i < n; i++) {
+    nanort::TriangleIntersector<T> isector(verts.data(), faces.data(), sizeof(T) * 3);
+    memset(&hits[i], 0, sizeof(hits[i]));
+    hits[i].t = rays[i].max_t;
+    hits[i].prim_id = 0xFFFFFFFFu;
+    mask[i] = accel.Traverse(rays[i], isector, &hits[i]) ? 1 : 0;
+  }
+#ifdef NANORT_USE_HIP_BACKEND
+  // batched GPU path over the same (GPU-built) node array: must agree bit for bit
+  std::vector<nanort::TriangleIntersection<T> > bhits(n);
+  std::vector<unsigned char> bmask(n, 0);
+  for (uint64_t i = 0; i < n; i++) {
+    memset(&bhits[i], 0, sizeof(bhits[i]));
+    bhits[i].t = rays[i].max_t;
+    bhits[i].prim_id = 0xFFFFFFFFu;
+  }
+  if (!accel.TraverseBatch(rays.data(), n, bhits.data(), bmask.data())) {
+    fprintf(stderr, "TraverseBatch failed: %s\n", accel.LastBackendError().c_str());
+    return 4;
+  }
+  uint64_t bad = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    if (bmask[i] != mask[i] || bhits[i].t != hits[i].t || bhits[i].u != hits[i].u || bhits[i].v != hits[i].v ||
+        bhits[i].prim_id != hits[i].prim_id)
+      bad++;
+  }
+  printf("batch_vs_per_ray_mismatches %llu\n", (unsigned long long)bad);
+  if (bad) return 5;
+#endif
+  fp = fopen(out_path, "wb");
+  if (!fp) return 2;
+  fwrite(hits.data(), sizeof(hits[0]), n, fp);
+  fwrite(mask.data(), 1, n, fp);
+  // the tree, so the caller can validate it
+  uint64_t nn = accel.GetNodes().size();
+  fwrite(&nn, 8, 1, fp);
+  fwrite(accel.GetNodes().data(), sizeof(nanort::BVHNode<T>), nn, fp);
+  fwrite(accel.GetIndices().data(), 4, nf, fp);
+  fclose(fp);
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc >= 2 && !strcmp(argv[1], "regress30")) return regress30(argc > 2);
+  if (argc == 6 && !strcmp(argv[1], "trace")) {
+    return !strcmp(argv[2], "f64") ? trace<double>(argv[3], argv[4], argv[5]) : trace<float>(argv[3], argv[4], argv[5]);
+  }
+  fprintf(stderr, "usage: host_check regress30 [x] | trace f32|f64 MESH RAYS OUT\n");
+  return 64;
+}

@@ -1,0 +1,157 @@
+"""include/nanort.h — the header-only host side: compiles stand-alone under every macro set the
+reference supports, compiles the reference's own examples UNCHANGED (where the reference tree is
+present), and its generic host path gives reference-identical hit records."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from bvh_check import validate_bvh
+from helpers import assert_hits_match
+from nanort_amd import scenes
+from nanort_amd.wire import HIT_F32, HIT_F64, NODE_F32, NODE_F64, widen_rays
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+REFERENCE = os.environ.get("REFERENCE", "/root/reference")
+LIBDIR = os.path.join(ROOT, "nanort_amd", "lib")
+
+
+def cxx(args, **kw):
+    r = subprocess.run(["g++"] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, **kw)
+    assert r.returncode == 0, "g++ %s failed:\n%s" % (" ".join(args), r.stdout[-3000:])
+    return r.stdout
+
+
+@pytest.mark.parametrize("flags", [
+    [], ["-DNANORT_USE_CPP11_FEATURE", "-pthread"], ["-fopenmp", "-DNANORT_ENABLE_PARALLEL_BUILD"],
+    ["-DNANORT_ENABLE_SERIALIZATION"], ["-DNANORT_USE_HIP_BACKEND", "-DNANORT_ENABLE_SERIALIZATION"],
+])
+def test_header_compiles_standalone(tmp_path, flags):
+    """The reference's CI check: `${CXX} -std=c++11 -c nanort.cc` (.travis.yml:3-34)."""
+    tu = tmp_path / "nanort.cc"
+    tu.write_text('#include "nanort.h"\n')
+    cxx(["-std=c++11", "-O2", "-Wall", "-Wextra", "-Werror", "-I", INC, "-c", str(tu), "-o", str(tmp_path / "o.o")] + flags)
+
+
+@pytest.fixture(scope="module")
+def host_check(tmp_path_factory):
+    d = tmp_path_factory.mktemp("hostcheck")
+    exe = d / "host_check"
+    cxx(["-std=c++11", "-O2", "-Wall", "-Wextra", "-I", INC, os.path.join(ROOT, "tests", "cpp", "host_check.cc"), "-o", str(exe)])
+    return str(exe), d
+
+
+def test_regression_30_known_answer(host_check):
+    exe, _ = host_check
+    for extra in ([], ["x"]):
+        out = subprocess.run([exe, "regress30"] + extra, stdout=subprocess.PIPE, text=True)
+        assert out.returncode == 0, out.stdout
+        assert "isect.u =0.68 v = 0.131201" in out.stdout  # SURVEY.md §8c KA1, both argv modes
+
+
+def write_inputs(d, v, f, rays):
+    mesh, rp = os.path.join(d, "mesh.bin"), os.path.join(d, "rays.bin")
+    with open(mesh, "wb") as fp:
+        fp.write(np.array([v.shape[0], f.shape[0]], dtype=np.uint32).tobytes())
+        fp.write(np.ascontiguousarray(v).tobytes())
+        fp.write(np.ascontiguousarray(f, dtype=np.uint32).tobytes())
+    with open(rp, "wb") as fp:
+        fp.write(np.array([rays.shape[0]], dtype=np.uint64).tobytes())
+        fp.write(rays.tobytes())
+    return mesh, rp
+
+
+def read_output(path, n, nf, f64):
+    hd, nd = (HIT_F64, NODE_F64) if f64 else (HIT_F32, NODE_F32)
+    raw = open(path, "rb").read()
+    o = 0
+    hits = np.frombuffer(raw, dtype=hd, count=n, offset=o)
+    o += n * hd.itemsize
+    mask = np.frombuffer(raw, dtype=np.uint8, count=n, offset=o)
+    o += n
+    nn = int(np.frombuffer(raw, dtype=np.uint64, count=1, offset=o)[0])
+    o += 8
+    nodes = np.frombuffer(raw, dtype=nd, count=nn, offset=o)
+    o += nn * nd.itemsize
+    idx = np.frombuffer(raw, dtype=np.uint32, count=nf, offset=o)
+    return hits, mask, nodes, idx
+
+
+@pytest.mark.parametrize("f64", [False, True])
+def test_generic_host_path_matches_the_oracle(host_check, oracle, c1_mesh, f64):
+    """Host builder (all three axes binned) + per-ray Traverse of include/nanort.h on C1: a valid tree and the
+    reference's hit records (up to verified exact ties, since the tree differs)."""
+    exe, d = host_check
+    v, f = c1_mesh
+    rays = scenes.camera_rays(128, 128)
+    if f64:
+        v, rays = v.astype(np.float64), widen_rays(rays)
+    mesh, rp = write_inputs(str(d), v, f, rays)
+    out = os.path.join(str(d), "out.bin")
+    r = subprocess.run([exe, "trace", "f64" if f64 else "f32", mesh, rp, out], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stdout
+    hits, mask, nodes, idx = read_output(out, rays.shape[0], f.shape[0], f64)
+    validate_bvh(nodes, idx, v, f)
+    onodes, oidx, _ = oracle.build(v, f)
+    oh, om = oracle.traverse(onodes, oidx, v, f, rays)
+    assert_hits_match(oh, om, hits, mask, oracle, onodes, oidx, v, f, rays, max_ties=32)
+
+
+REF_PROGRAMS = [
+    ("examples/path_tracer/main.cc", ["-DNANORT_USE_CPP11_FEATURE", "-pthread", "-Iexamples/path_tracer", "-Iexamples/common"]),
+    ("examples/path_tracer/main.cc", ["-fopenmp", "-Iexamples/path_tracer", "-Iexamples/common"]),
+    ("examples/objrender/main.cc", ["-fopenmp", "-Iexamples/objrender", "-Iexamples/common"]),
+    ("examples/double_precision/main.cc", ["-fopenmp", "-Iexamples/double_precision", "-Iexamples/common"]),
+    ("test/regression/possible-accuracy-problem-30/main.cc", []),
+    ("examples/particle_primitive/main.cc", ["-Iexamples/particle_primitive", "-Iexamples/common"]),
+    ("examples/cylinder_primitive/main.cc", ["-Iexamples/cylinder_primitive", "-Iexamples/common"]),
+    ("examples/bidir_path_tracer/main.cc", ["-fopenmp", "-Iexamples/bidir_path_tracer", "-Iexamples/common"]),
+]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")), reason="reference tree not present")
+@pytest.mark.parametrize("backend", [[], ["-DNANORT_USE_HIP_BACKEND"]])
+@pytest.mark.parametrize("src,flags", REF_PROGRAMS)
+def test_reference_programs_compile_unchanged(src, flags, backend):
+    """Drop-in: the reference's own sources, read where they lie, type-check against THIS header
+    (include path order puts include/ first, so `#include "nanort.h"` resolves here)."""
+    fl = [x if not x.startswith("-Iexamples") else "-I" + os.path.join(REFERENCE, x[2:]) for x in flags]
+    cxx(["-std=c++11", "-fsyntax-only", "-w", "-I", INC] + fl + backend + [os.path.join(REFERENCE, src)])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")), reason="reference tree not present")
+def test_reference_regression_program_runs_against_this_header(tmp_path):
+    exe = tmp_path / "regress"
+    cxx(["-std=c++11", "-O0", "-I", INC, os.path.join(REFERENCE, "test/regression/possible-accuracy-problem-30/main.cc"), "-o", str(exe)])
+    for extra in ([], ["x"]):
+        out = subprocess.run([str(exe)] + extra, stdout=subprocess.PIPE, text=True).stdout
+        assert "We have the expected result" in out and "isect.u =0.68 v = 0.131201" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("f64", [False, True])
+def test_hip_backend_build_and_traverse_batch(tmp_path, oracle, f64):
+    """-DNANORT_USE_HIP_BACKEND: Build() runs on the GPU through the C ABI, GetNodes() returns a valid
+    reference-format tree, per-ray host Traverse() over it == TraverseBatch() on the GPU, bit for bit, and both
+    equal the reference's records up to verified ties."""
+    exe = tmp_path / "host_check_hip"
+    cxx(["-std=c++11", "-O2", "-Wall", "-Wextra", "-DNANORT_USE_HIP_BACKEND", "-I", INC,
+         os.path.join(ROOT, "tests", "cpp", "host_check.cc"), "-o", str(exe),
+         "-L", LIBDIR, "-lnanort_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    v, f = scenes.sphere(128, 64)
+    rays = scenes.camera_rays(320, 180)
+    if f64:
+        v, rays = v.astype(np.float64), widen_rays(rays)
+    mesh, rp = write_inputs(str(tmp_path), v, f, rays)
+    out = os.path.join(str(tmp_path), "out.bin")
+    r = subprocess.run([str(exe), "trace", "f64" if f64 else "f32", mesh, rp, out], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "batch_vs_per_ray_mismatches 0" in r.stdout
+    hits, mask, nodes, idx = read_output(out, rays.shape[0], f.shape[0], f64)
+    validate_bvh(nodes, idx, v, f)
+    onodes, oidx, _ = oracle.build(v, f)
+    oh, om = oracle.traverse(onodes, oidx, v, f, rays)
+    assert_hits_match(oh, om, hits, mask, oracle, onodes, oidx, v, f, rays, max_ties=200)
