@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -17,7 +18,15 @@
 
 namespace nrt {
 template <typename T>
-hipError_t launch_traverse(const TraverseArgs<T> &, unsigned grid, bool count, hipStream_t);
+hipError_t launch_traverse(const TraverseArgs<T> &, unsigned grid, bool count, int lds_stack, hipStream_t);
+template <typename T>
+int traverse_blocks_per_cu(int lds_stack);
+template <typename T>
+hipError_t launch_traverse_wide(const TraverseArgs<T> &, unsigned grid, int lds_stack, hipStream_t);
+template <typename T>
+int traverse_wide_blocks_per_cu(int lds_stack);
+template <typename T>
+hipError_t launch_make_wide(const typename Wire<T>::Node *, uint32_t, WideNode<T> *, hipStream_t);
 template <typename T>
 hipError_t launch_gather_leaf_tris(const uint32_t *, const uint32_t *, const T *, LeafTri<T> *,
                                    uint32_t, hipStream_t);
@@ -57,6 +66,7 @@ struct nrt_ctx {
   void *d_nodes = nullptr;
   uint32_t *d_indices = nullptr;
   void *d_tris = nullptr; // LeafTri<T>[num_indices]
+  void *d_wide = nullptr; // WideNode<T>[num_nodes]
   uint64_t num_nodes = 0, num_indices = 0;
   uint32_t tree_depth = 0;
   nrt_build_stats stats = {0, 0, 0, 0.f};
@@ -65,6 +75,13 @@ struct nrt_ctx {
   uint32_t *d_cursor = nullptr;              // ray cursor
   unsigned long long *d_counters = nullptr;  // 4 x u64
   DevBuf spill, st_rays, st_hits, st_mask;
+
+  // traversal tuning (env NRT_LDS_STACK / NRT_REFILL_MIN / NRT_TRAV_MIN / NRT_CHUNK override)
+  int lds_stack = kLdsStackDefault;
+  unsigned blocks_per_cu = 0, chunk = 256, refill_min = 48, trav_min = 8;
+  int wide = 1, wide_stack = 10; // production path: WideNode kernel (env NRT_WIDE=0 selects the binary kernel)
+  unsigned wide_blocks_per_cu = 0;
+  DevBuf spill_tmin;
 
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
   bool have_traverse_time = false, have_build_time = false;
@@ -106,6 +123,8 @@ static void free_tree(nrt_ctx *c) {
   if (c->d_nodes) (void)hipFree(c->d_nodes);
   if (c->d_indices) (void)hipFree(c->d_indices);
   if (c->d_tris) (void)hipFree(c->d_tris);
+  if (c->d_wide) (void)hipFree(c->d_wide);
+  c->d_wide = nullptr;
   c->d_nodes = nullptr;
   c->d_indices = nullptr;
   c->d_tris = nullptr;
@@ -150,6 +169,18 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     c->num_cus = prop.multiProcessorCount;
+  if (const char *e = getenv("NRT_LDS_STACK")) {
+    int v = atoi(e);
+    if (v == 16 || v == 24 || v == 32) c->lds_stack = v;
+  }
+  if (const char *e = getenv("NRT_REFILL_MIN")) c->refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
+  if (const char *e = getenv("NRT_TRAV_MIN")) c->trav_min = (unsigned)std::min(64, std::max(1, atoi(e)));
+  if (const char *e = getenv("NRT_CHUNK")) c->chunk = (unsigned)std::max(64, atoi(e));
+  if (const char *e = getenv("NRT_WIDE")) c->wide = atoi(e) != 0;
+  if (const char *e = getenv("NRT_WIDE_STACK")) {
+    int v = atoi(e);
+    if (v == 8 || v == 10 || v == 12 || v == 16) c->wide_stack = v;
+  }
   *out = c;
   return NRT_OK;
 }
@@ -160,7 +191,7 @@ void nrtDestroy(nrt_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_tree(c);
   free_mesh(c);
-  DevBuf *bufs[] = {&c->spill, &c->st_rays, &c->st_hits, &c->st_mask};
+  DevBuf *bufs[] = {&c->spill, &c->spill_tmin, &c->st_rays, &c->st_hits, &c->st_mask};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->d_cursor) (void)hipFree(c->d_cursor);
@@ -234,6 +265,11 @@ static nrt_status finish_tree(nrt_ctx *c) {
   HIPCHK(c, hipMalloc(&c->d_tris, std::max<size_t>(1, c->num_indices) * sizeof(LeafTri<T>)));
   HIPCHK(c, launch_gather_leaf_tris<T>(c->d_indices, c->d_faces, (const T *)c->d_verts,
                                        (LeafTri<T> *)c->d_tris, (uint32_t)c->num_indices, c->stream));
+  if (c->d_wide) HIPCHK(c, hipFree(c->d_wide));
+  c->d_wide = nullptr;
+  HIPCHK(c, hipMalloc(&c->d_wide, std::max<size_t>(1, c->num_nodes) * sizeof(WideNode<T>)));
+  HIPCHK(c, launch_make_wide<T>((const typename Wire<T>::Node *)c->d_nodes, (uint32_t)c->num_nodes,
+                                (WideNode<T> *)c->d_wide, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return NRT_OK;
 }
@@ -366,20 +402,30 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   if (!opt) opt = &kDefaultTrace;
   HIPCHK(c, hipSetDevice(c->device));
 
-  // persistent grid: every block resident (LDS stack 32 KiB/block -> 5 blocks per CU)
-  const unsigned blocks_per_cu = 5;
+  // persistent grid: every block resident (occupancy of the chosen variant)
+  const bool use_wide = c->wide && !count && c->d_wide;
+  if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
+  if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack);
+  const unsigned blocks_per_cu = use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu;
+  const int stack_entries = use_wide ? c->wide_stack : c->lds_stack;
   uint64_t need_blocks = (n + kTraverseBlock - 1) / kTraverseBlock;
   unsigned grid = (unsigned)std::min<uint64_t>(need_blocks, (uint64_t)c->num_cus * blocks_per_cu);
   const uint32_t total_threads = grid * kTraverseBlock;
-  const uint32_t levels = c->tree_depth + 2 > (uint32_t)kLdsStack ? c->tree_depth + 2 - kLdsStack : 0;
+  const uint32_t levels = c->tree_depth + 2 > (uint32_t)stack_entries ? c->tree_depth + 2 - stack_entries : 0;
   if (levels) {
     nrt_status st = ensure(c, c->spill, (size_t)levels * total_threads * sizeof(uint32_t));
     if (st) return st;
+    if (use_wide) {
+      st = ensure(c, c->spill_tmin, (size_t)levels * total_threads * sizeof(T));
+      if (st) return st;
+    }
   }
 
   TraverseArgs<T> a;
   a.nodes = (const typename Wire<T>::Node *)c->d_nodes;
   a.tris = (const LeafTri<T> *)c->d_tris;
+  a.wide = (const WideNode<T> *)c->d_wide;
+  a.spill_tmin = (T *)c->spill_tmin.p;
   a.rays = d_rays;
   a.hits = d_hits;
   a.mask = d_mask;
@@ -393,12 +439,17 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.spill_levels = levels;
   a.ray_cursor = c->d_cursor;
   a.counters = c->d_counters;
-  a.chunk = 256;
+  a.chunk = c->chunk;
+  a.refill_min = c->refill_min;
+  a.trav_min = c->trav_min;
 
   HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, sizeof(uint32_t), s));
   if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), s));
   if (timed) HIPCHK(c, hipEventRecord(c->ev_t0, s));
-  HIPCHK(c, launch_traverse<T>(a, grid, count, s));
+  if (use_wide)
+    HIPCHK(c, launch_traverse_wide<T>(a, grid, c->wide_stack, s));
+  else
+    HIPCHK(c, launch_traverse<T>(a, grid, count, c->lds_stack, s));
   if (timed) {
     HIPCHK(c, hipEventRecord(c->ev_t1, s));
     c->have_traverse_time = true;

@@ -15,7 +15,7 @@ namespace nrt {
 
 constexpr int kWave = 64;           // gfx950 wavefront
 constexpr int kTraverseBlock = 256; // 4 waves, one per SIMD
-constexpr int kLdsStack = 32;       // per-lane stack entries kept in LDS (32 KiB / block)
+constexpr int kLdsStackDefault = 32; // per-lane stack entries kept in LDS (32 -> 32 KiB / block)
 constexpr unsigned kInvalid = 0xFFFFFFFFu;
 
 template <typename T>
@@ -49,10 +49,28 @@ struct alignas(8) LeafTri {
 static_assert(sizeof(LeafTri<float>) == 40, "LeafTri<float>");
 static_assert(sizeof(LeafTri<double>) == 80, "LeafTri<double>");
 
+// Private traversal layout: one record per BRANCH node holding BOTH children's boxes, so a
+// step fetches one record and tests two boxes (the child boxes are copied bit-for-bit from
+// the BVHNode array; slot i corresponds to BVHNode i, leaf slots are unused).
+// Child reference: bit 31 set -> leaf, low 31 bits = BVHNode index of that leaf;
+// otherwise the BVHNode / WideNode index of the inner child.
+template <typename T>
+struct alignas(16) WideNode {
+  T box0[6]; // child data[0]: bmin, bmax
+  T box1[6]; // child data[1]
+  uint32_t c0, c1;
+  int32_t axis;
+  uint32_t pad;
+};
+static_assert(sizeof(WideNode<float>) == 64, "WideNode<float>");
+static_assert(sizeof(WideNode<double>) == 112, "WideNode<double>");
+constexpr uint32_t kLeafBit = 0x80000000u;
+
 template <typename T>
 struct TraverseArgs {
   const typename Wire<T>::Node *nodes;
   const LeafTri<T> *tris;
+  const WideNode<T> *wide; // may be null (binary kernel only)
   const typename Wire<T>::Ray *rays;
   typename Wire<T>::Hit *hits; // may be null (counting pass)
   uint8_t *mask;               // may be null
@@ -60,11 +78,14 @@ struct TraverseArgs {
   uint32_t range0, range1, skip_prim; // BVHTraceOptions
   uint32_t cull_back_face;
   uint32_t *spill;        // [spill_levels][spill_stride] overflow stack, may be null
+  T *spill_tmin;          // same shape, entry t_min (wide kernel)
   uint32_t spill_stride;  // == total threads of the launch
   uint32_t spill_levels;
   uint32_t *ray_cursor;              // persistent-thread work counter (zeroed per launch)
   unsigned long long *counters;      // 4 x u64 when counting
   uint32_t chunk;                    // rays claimed per atomic
+  uint32_t refill_min;               // refill idle lanes once this many are idle (1..64)
+  uint32_t trav_min;                 // leave the inner-node loop when fewer lanes than this are walking
 };
 
 } // namespace nrt

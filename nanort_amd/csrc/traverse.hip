@@ -60,7 +60,7 @@ struct Lane {
   T u, v;
   uint32_t prim;
   int kx, ky, kz;
-  int sign[3];
+  int sign0, sign1, sign2; // dir < 0 per axis (scalars: no runtime-indexed array)
 };
 
 template <typename T>
@@ -103,9 +103,9 @@ __device__ __forceinline__ void lane_init(Lane<T> &L, const typename Wire<T>::Ra
   L.Sy = sel3(d0, d1, d2, ky) / dz;
   L.Sz = T(1.0) / dz;
   // Traverse prologue (nanort.h:2505-2516)
-  L.sign[0] = d0 < T(0) ? 1 : 0;
-  L.sign[1] = d1 < T(0) ? 1 : 0;
-  L.sign[2] = d2 < T(0) ? 1 : 0;
+  L.sign0 = d0 < T(0) ? 1 : 0;
+  L.sign1 = d1 < T(0) ? 1 : 0;
+  L.sign2 = d2 < T(0) ? 1 : 0;
   L.inv[0] = safe_inverse<T>(d0);
   L.inv[1] = safe_inverse<T>(d1);
   L.inv[2] = safe_inverse<T>(d2);
@@ -118,8 +118,9 @@ __device__ __forceinline__ bool slab_test(const Lane<T> &L, const T bmin[3], con
   T tmin = L.min_t, tmax = L.hit_t;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const T lo = L.sign[k] ? bmax[k] : bmin[k];
-    const T hi = L.sign[k] ? bmin[k] : bmax[k];
+    const int sg = k == 0 ? L.sign0 : (k == 1 ? L.sign1 : L.sign2);
+    const T lo = sg ? bmax[k] : bmin[k];
+    const T hi = sg ? bmin[k] : bmax[k];
     const T t0 = (lo - L.org[k]) * L.inv[k];
     const T t1 = (hi - L.org[k]) * L.inv[k] * mm;
     tmin = (t0 > tmin) ? t0 : tmin; // safemax(t0, tmin)
@@ -177,10 +178,13 @@ __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
-template <typename T, bool COUNT>
+// Lane states of the while-while loop.
+enum : int { LANE_IDLE = 0, LANE_TRAV = 1, LANE_LEAF = 2 };
+
+template <typename T, bool COUNT, int STACK>
 __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<T> a) {
   // [depth][thread]: a wave's 64 lanes hit 64 consecutive dwords -> conflict-free.
-  __shared__ uint32_t s_stack[kLdsStack][kTraverseBlock];
+  __shared__ uint32_t s_stack[STACK][kTraverseBlock];
 
   typedef typename Wire<T>::Node Node;
   typedef typename Wire<T>::Ray Ray;
@@ -193,8 +197,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<
 
   Lane<T> L;
   uint32_t rid = kInvalid; // ray this lane is working on
-  uint32_t cur = 0;        // node to visit next
-  int sp = 0;              // entries on this lane's stack
+  uint32_t cur = 0;        // node to visit next (LANE_TRAV)
+  uint32_t leaf_first = 0, leaf_cnt = 0; // pending leaf (LANE_LEAF)
+  int state = LANE_IDLE;
+  int sp = 0; // entries on this lane's stack
 
   // wave-uniform claimed range [chunk_next, chunk_end)
   uint32_t chunk_next = 0, chunk_end = 0;
@@ -202,15 +208,50 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<
 
   unsigned long long c_nodes = 0, c_leaves = 0, c_tris = 0, c_stack = 0;
 
+  // Pop the next node, or finish the ray when the stack is empty:
+  // PostTraversal (nanort.h:1205-1211) with the strict final predicate (:2552).
+  // (A macro with select-style updates: every state variable is assigned on both
+  // paths, which keeps them all in registers.)
+#define NRT_POP_OR_FINISH()                                                              \
+  do {                                                                                   \
+    const bool fin_ = (sp == 0);                                                         \
+    if (fin_) {                                                                          \
+      const bool hit_ = L.hit_t < L.max_t;                                               \
+      if (a.hits) {                                                                      \
+        Hit h_;                                                                          \
+        h_.u = hit_ ? L.u : T(0);                                                        \
+        h_.v = hit_ ? L.v : T(0);                                                        \
+        h_.t = hit_ ? L.hit_t : L.max_t;                                                 \
+        h_.prim_id = hit_ ? L.prim : kInvalid;                                           \
+        a.hits[rid] = h_;                                                                \
+      }                                                                                  \
+      if (a.mask) a.mask[rid] = hit_ ? 1 : 0;                                            \
+    }                                                                                    \
+    uint32_t popped_ = cur;                                                              \
+    if (!fin_) {                                                                         \
+      const int sp1_ = sp - 1;                                                           \
+      if (sp1_ < STACK) {                                                                \
+        popped_ = s_stack[sp1_][tid];                                                    \
+      } else {                                                                           \
+        popped_ = a.spill[(size_t)(sp1_ - STACK) * a.spill_stride + gslot];              \
+      }                                                                                  \
+    }                                                                                    \
+    cur = popped_;                                                                       \
+    sp = fin_ ? sp : sp - 1;                                                             \
+    rid = fin_ ? kInvalid : rid;                                                         \
+    state = fin_ ? LANE_IDLE : LANE_TRAV;                                                \
+  } while (0)
+
   for (;;) {
     // ---- hand new rays to idle lanes (ballot rank inside the wave's chunk) ----
-    unsigned long long idle = __ballot(rid == kInvalid);
-    if (idle != 0ull) {
+    unsigned long long idle = __ballot(state == LANE_IDLE);
+    if (!exhausted && (unsigned)__builtin_popcountll(idle) >= a.refill_min) {
       while (idle != 0ull && !exhausted) {
         if (chunk_next == chunk_end) {
+          const int leader = __builtin_ctzll(idle);
           uint32_t base = 0;
-          if (lane == (unsigned)__builtin_ctzll(idle)) base = atomicAdd(a.ray_cursor, a.chunk);
-          base = __builtin_amdgcn_readfirstlane(__shfl(base, __builtin_ctzll(idle)));
+          if (lane == (unsigned)leader) base = atomicAdd(a.ray_cursor, a.chunk);
+          base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
           if (base >= a.num_rays) {
             exhausted = true;
             break;
@@ -222,75 +263,69 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<
         const unsigned avail = chunk_end - chunk_next;
         const unsigned take = want < avail ? want : avail;
         const unsigned rank = (unsigned)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
-        if (rid == kInvalid && rank < take) {
+        if (state == LANE_IDLE && rank < take) {
           rid = chunk_next + rank;
           const Ray r = a.rays[rid];
           lane_init<T>(L, r);
           cur = 0;
           sp = 0;
+          state = LANE_TRAV;
+          if (COUNT) c_stack = c_stack > 1ull ? c_stack : 1ull;
         }
         chunk_next += take;
-        idle = __ballot(rid == kInvalid);
+        idle = __ballot(state == LANE_IDLE);
       }
-      if (exhausted && idle == ~0ull) break; // nothing left anywhere in this wave
+    }
+    if (idle == ~0ull) {
+      if (exhausted) break; // nothing left anywhere in this wave
+      continue;             // (cannot happen: refill_min <= 64)
     }
 
-    // ---- one traversal step for every live lane --------------------------------
-    if (rid != kInvalid) {
+    // ---- phase 1: inner nodes, until this lane reaches a leaf or finishes -----------
+    while (state == LANE_TRAV) {
       const Node nd = a.nodes[cur];
       if (COUNT) c_nodes++;
-      bool descend = false;
       if (slab_test<T>(L, nd.bmin, nd.bmax)) {
         if (nd.flag == 0) {
-          const int near = sel3(L.sign[0], L.sign[1], L.sign[2], nd.axis);
+          const int near = sel3(L.sign0, L.sign1, L.sign2, nd.axis);
           const uint32_t far_child = near ? nd.data[0] : nd.data[1];
           cur = near ? nd.data[1] : nd.data[0];
           // push far; near stays in `cur` (it would be popped next anyway: nanort.h:2542-2543)
-          if (sp < kLdsStack) {
+          if (sp < STACK) {
             s_stack[sp][tid] = far_child;
           } else {
-            a.spill[(size_t)(sp - kLdsStack) * a.spill_stride + gslot] = far_child;
+            a.spill[(size_t)(sp - STACK) * a.spill_stride + gslot] = far_child;
           }
           sp++;
           if (COUNT) {
             // the reference holds near+far on its stack at this point
-            unsigned long long need = (unsigned long long)sp + 1ull;
+            const unsigned long long need = (unsigned long long)sp + 1ull;
             c_stack = need > c_stack ? need : c_stack;
           }
-          descend = true;
         } else {
-          const uint32_t cnt = nd.data[0], first = nd.data[1];
+          leaf_cnt = nd.data[0];
+          leaf_first = nd.data[1];
+          state = LANE_LEAF;
           if (COUNT) c_leaves++;
-          for (uint32_t i = 0; i < cnt; i++) {
-            const LeafTri<T> tri = a.tris[first + i];
-            if (COUNT) c_tris++;
-            tri_test<T>(L, tri, a.range0, a.range1, a.skip_prim, cull);
-          }
+        }
+      } else {
+        NRT_POP_OR_FINISH();
+      }
+      // leave early when too few lanes are still walking inner nodes
+      if ((unsigned)__builtin_popcountll(__ballot(state == LANE_TRAV)) < a.trav_min) break;
+    }
+
+    // ---- phase 2: lanes holding a leaf test its triangles together ------------------
+    if (__ballot(state == LANE_LEAF) != 0ull) {
+      const uint32_t cnt = state == LANE_LEAF ? leaf_cnt : 0u;
+      for (uint32_t i = 0; __ballot(i < cnt) != 0ull; i++) {
+        if (i < cnt) {
+          const LeafTri<T> tri = a.tris[leaf_first + i];
+          if (COUNT) c_tris++;
+          tri_test<T>(L, tri, a.range0, a.range1, a.skip_prim, cull);
         }
       }
-      if (!descend) {
-        if (sp == 0) {
-          // PostTraversal (nanort.h:1205-1211) with the strict final predicate (:2552)
-          const bool hit = L.hit_t < L.max_t;
-          if (a.hits) {
-            Hit h;
-            h.u = hit ? L.u : T(0);
-            h.v = hit ? L.v : T(0);
-            h.t = hit ? L.hit_t : L.max_t;
-            h.prim_id = hit ? L.prim : kInvalid;
-            a.hits[rid] = h;
-          }
-          if (a.mask) a.mask[rid] = hit ? 1 : 0;
-          rid = kInvalid;
-        } else {
-          sp--;
-          if (sp < kLdsStack) {
-            cur = s_stack[sp][tid];
-          } else {
-            cur = a.spill[(size_t)(sp - kLdsStack) * a.spill_stride + gslot];
-          }
-        }
-      }
+      if (state == LANE_LEAF) NRT_POP_OR_FINISH();
     }
   }
 
@@ -310,6 +345,207 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<
       atomicMax(&a.counters[3], c_stack);
     }
   }
+#undef NRT_POP_OR_FINISH
+}
+
+// ---------------------------------------------------------------------------
+// Production kernel: same traversal ORDER and same culling decisions as the
+// binary loop above (hence the same hit records, ties included), but each step
+// fetches one WideNode and tests both children.  A child that passes its slab
+// test is entered at once (near first) or pushed with its t_min; a popped entry
+// is entered iff t_min <= hit_t, which is exactly the reference's test at pop
+// time, because its slab test factors into (t_min <= t_max of the planes) — which
+// does not depend on hit_t and was established at push time — and
+// (t_min <= hit_t) (nanort.h:2315-2318: hit_t is the innermost operand of the
+// safemin chain).
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ bool slab_test_tmin(const Lane<T> &L, const T box[6], T &tmin_out) {
+  const T mm = Const<T>::maxmult();
+  T tmin = L.min_t, tmax = L.hit_t;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int sg = k == 0 ? L.sign0 : (k == 1 ? L.sign1 : L.sign2);
+    const T lo = sg ? box[3 + k] : box[k];
+    const T hi = sg ? box[k] : box[3 + k];
+    const T t0 = (lo - L.org[k]) * L.inv[k];
+    const T t1 = (hi - L.org[k]) * L.inv[k] * mm;
+    tmin = (t0 > tmin) ? t0 : tmin;
+    tmax = (t1 < tmax) ? t1 : tmax;
+  }
+  tmin_out = tmin;
+  return tmin <= tmax;
+}
+
+enum : int { W_IDLE = 0, W_TRAV = 1, W_LEAF = 2, W_POP = 3 };
+
+template <typename T, int STACK>
+__global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const TraverseArgs<T> a) {
+  __shared__ uint32_t s_ref[STACK][kTraverseBlock];
+  __shared__ T s_tmin[STACK][kTraverseBlock];
+
+  typedef typename Wire<T>::Node Node;
+  typedef typename Wire<T>::Ray Ray;
+  typedef typename Wire<T>::Hit Hit;
+
+  const unsigned tid = threadIdx.x;
+  const unsigned lane = lane_id();
+  const unsigned gslot = blockIdx.x * kTraverseBlock + tid;
+  const bool cull = a.cull_back_face != 0;
+
+  Lane<T> L;
+  uint32_t rid = kInvalid;
+  uint32_t cur = 0; // W_TRAV: WideNode index; W_LEAF: BVHNode index of the leaf
+  int state = W_IDLE;
+  int sp = 0;
+  uint32_t chunk_next = 0, chunk_end = 0;
+  bool exhausted = false;
+
+  for (;;) {
+    // ---- refill idle lanes ---------------------------------------------------------
+    unsigned long long idle = __ballot(state == W_IDLE);
+    if (!exhausted && (unsigned)__builtin_popcountll(idle) >= a.refill_min) {
+      while (idle != 0ull && !exhausted) {
+        if (chunk_next == chunk_end) {
+          const int leader = __builtin_ctzll(idle);
+          uint32_t base = 0;
+          if (lane == (unsigned)leader) base = atomicAdd(a.ray_cursor, a.chunk);
+          base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
+          if (base >= a.num_rays) {
+            exhausted = true;
+            break;
+          }
+          chunk_next = base;
+          chunk_end = (a.num_rays - base < a.chunk) ? a.num_rays : base + a.chunk;
+        }
+        const unsigned want = (unsigned)__builtin_popcountll(idle);
+        const unsigned avail = chunk_end - chunk_next;
+        const unsigned take = want < avail ? want : avail;
+        const unsigned rank = (unsigned)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+        if (state == W_IDLE && rank < take) {
+          rid = chunk_next + rank;
+          const Ray r = a.rays[rid];
+          lane_init<T>(L, r);
+          sp = 0;
+          // the reference pops and tests the root first (nanort.h:2526-2533)
+          const Node root = a.nodes[0];
+          const bool root_hit = slab_test<T>(L, root.bmin, root.bmax);
+          cur = 0;
+          state = root_hit ? (root.flag == 0 ? W_TRAV : W_LEAF) : W_POP; // W_POP with sp == 0 finishes the ray
+        }
+        chunk_next += take;
+        idle = __ballot(state == W_IDLE);
+      }
+    }
+    if (idle == ~0ull) {
+      if (exhausted) break;
+      continue;
+    }
+
+    // ---- phase 1: inner nodes / stack pops ---------------------------------------------
+    while (state == W_TRAV || state == W_POP) {
+      if (state == W_TRAV) {
+        const WideNode<T> w = a.wide[cur];
+        T tm0, tm1;
+        const bool h0 = slab_test_tmin<T>(L, w.box0, tm0);
+        const bool h1 = slab_test_tmin<T>(L, w.box1, tm1);
+        const int near = sel3(L.sign0, L.sign1, L.sign2, w.axis); // near child = data[dir_sign[axis]] (nanort.h:2538)
+        const uint32_t rn = near ? w.c1 : w.c0, rf = near ? w.c0 : w.c1;
+        const bool hn = near ? h1 : h0, hf = near ? h0 : h1;
+        const T tf = near ? tm0 : tm1;
+        if (hn && hf) { // far child waits with its t_min
+          if (sp < STACK) {
+            s_ref[sp][tid] = rf;
+            s_tmin[sp][tid] = tf;
+          } else {
+            const size_t o = (size_t)(sp - STACK) * a.spill_stride + gslot;
+            a.spill[o] = rf;
+            a.spill_tmin[o] = tf;
+          }
+          sp++;
+        }
+        const uint32_t next = hn ? rn : rf;
+        if (hn || hf) {
+          cur = next & ~kLeafBit;
+          state = (next & kLeafBit) ? W_LEAF : W_TRAV;
+        } else {
+          state = W_POP;
+        }
+      } else { // W_POP
+        const bool fin = (sp == 0);
+        if (fin) { // PostTraversal (nanort.h:1205-1211), strict final predicate (:2552)
+          const bool hit = L.hit_t < L.max_t;
+          Hit h;
+          h.u = hit ? L.u : T(0);
+          h.v = hit ? L.v : T(0);
+          h.t = hit ? L.hit_t : L.max_t;
+          h.prim_id = hit ? L.prim : kInvalid;
+          a.hits[rid] = h;
+          if (a.mask) a.mask[rid] = hit ? 1 : 0;
+        }
+        uint32_t ref = 0;
+        T tm = T(0);
+        if (!fin) {
+          const int s1 = sp - 1;
+          if (s1 < STACK) {
+            ref = s_ref[s1][tid];
+            tm = s_tmin[s1][tid];
+          } else {
+            const size_t o = (size_t)(s1 - STACK) * a.spill_stride + gslot;
+            ref = a.spill[o];
+            tm = a.spill_tmin[o];
+          }
+        }
+        const bool enter = !fin && (tm <= L.hit_t); // the reference's slab test at pop time
+        sp = fin ? sp : sp - 1;
+        cur = enter ? (ref & ~kLeafBit) : cur;
+        state = fin ? W_IDLE : (enter ? ((ref & kLeafBit) ? W_LEAF : W_TRAV) : W_POP);
+        rid = fin ? kInvalid : rid;
+      }
+      if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < a.trav_min) break;
+    }
+
+    // ---- phase 2: leaves ------------------------------------------------------------------
+    if (__ballot(state == W_LEAF) != 0ull) {
+      uint32_t cnt = 0, first = 0;
+      if (state == W_LEAF) {
+        const Node *nd = a.nodes + cur;
+        cnt = nd->data[0];
+        first = nd->data[1];
+      }
+      for (uint32_t i = 0; __ballot(i < cnt) != 0ull; i++) {
+        if (i < cnt) {
+          const LeafTri<T> tri = a.tris[first + i];
+          tri_test<T>(L, tri, a.range0, a.range1, a.skip_prim, cull);
+        }
+      }
+      state = (state == W_LEAF) ? W_POP : state;
+    }
+  }
+}
+
+// BVHNode[] -> WideNode[] (slot i <- branch node i; leaf slots untouched).
+template <typename T>
+__global__ __launch_bounds__(256) void k_make_wide(const typename Wire<T>::Node *__restrict__ nodes, uint32_t n,
+                                                   WideNode<T> *__restrict__ wide) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const typename Wire<T>::Node nd = nodes[i];
+  if (nd.flag != 0) return;
+  const typename Wire<T>::Node a = nodes[nd.data[0]], b = nodes[nd.data[1]];
+  WideNode<T> w;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    w.box0[k] = a.bmin[k];
+    w.box0[3 + k] = a.bmax[k];
+    w.box1[k] = b.bmin[k];
+    w.box1[3 + k] = b.bmax[k];
+  }
+  w.c0 = nd.data[0] | (a.flag != 0 ? kLeafBit : 0u);
+  w.c1 = nd.data[1] | (b.flag != 0 ? kLeafBit : 0u);
+  w.axis = nd.axis;
+  w.pad = 0;
+  wide[i] = w;
 }
 
 // Leaf-ordered triangle records from (indices, faces, tight vertices).
@@ -336,13 +572,68 @@ __global__ __launch_bounds__(256) void k_gather_leaf_tris(const uint32_t *__rest
 
 // ---- host-side launchers (called from api.hip) ------------------------------
 
-template <typename T>
-hipError_t launch_traverse(const TraverseArgs<T> &args, unsigned grid, bool count, hipStream_t s) {
+template <typename T, int STACK>
+static hipError_t launch_traverse_s(const TraverseArgs<T> &args, unsigned grid, bool count, hipStream_t s) {
   if (count) {
-    hipLaunchKernelGGL((k_traverse<T, true>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+    hipLaunchKernelGGL((k_traverse<T, true, STACK>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
   } else {
-    hipLaunchKernelGGL((k_traverse<T, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+    hipLaunchKernelGGL((k_traverse<T, false, STACK>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
   }
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_traverse(const TraverseArgs<T> &args, unsigned grid, bool count, int lds_stack, hipStream_t s) {
+  switch (lds_stack) {
+    case 16: return launch_traverse_s<T, 16>(args, grid, count, s);
+    case 24: return launch_traverse_s<T, 24>(args, grid, count, s);
+    default: return launch_traverse_s<T, 32>(args, grid, count, s);
+  }
+}
+
+// Resident blocks per CU of the (non-counting) traversal kernel for a given LDS stack depth.
+template <typename T>
+int traverse_blocks_per_cu(int lds_stack) {
+  int n = 0;
+  hipError_t e;
+  switch (lds_stack) {
+    case 16: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<T, false, 16>, kTraverseBlock, 0); break;
+    case 24: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<T, false, 24>, kTraverseBlock, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<T, false, 32>, kTraverseBlock, 0); break;
+  }
+  if (e != hipSuccess || n < 1) n = 4;
+  return n > 8 ? 8 : n;
+}
+
+template <typename T>
+hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int lds_stack, hipStream_t s) {
+  switch (lds_stack) {
+    case 8: hipLaunchKernelGGL((k_traverse_wide<T, 8>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
+    case 10: hipLaunchKernelGGL((k_traverse_wide<T, 10>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
+    case 12: hipLaunchKernelGGL((k_traverse_wide<T, 12>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
+    default: hipLaunchKernelGGL((k_traverse_wide<T, 16>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+int traverse_wide_blocks_per_cu(int lds_stack) {
+  int n = 0;
+  hipError_t e;
+  switch (lds_stack) {
+    case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 8>, kTraverseBlock, 0); break;
+    case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10>, kTraverseBlock, 0); break;
+    case 12: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 12>, kTraverseBlock, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 16>, kTraverseBlock, 0); break;
+  }
+  if (e != hipSuccess || n < 1) n = 4;
+  return n > 8 ? 8 : n;
+}
+
+template <typename T>
+hipError_t launch_make_wide(const typename Wire<T>::Node *nodes, uint32_t n, WideNode<T> *wide, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((k_make_wide<T>), dim3((n + 255u) / 256u), dim3(256), 0, s, nodes, n, wide);
   return hipGetLastError();
 }
 
@@ -355,8 +646,16 @@ hipError_t launch_gather_leaf_tris(const uint32_t *indices, const uint32_t *face
   return hipGetLastError();
 }
 
-template hipError_t launch_traverse<float>(const TraverseArgs<float> &, unsigned, bool, hipStream_t);
-template hipError_t launch_traverse<double>(const TraverseArgs<double> &, unsigned, bool, hipStream_t);
+template hipError_t launch_traverse<float>(const TraverseArgs<float> &, unsigned, bool, int, hipStream_t);
+template hipError_t launch_traverse<double>(const TraverseArgs<double> &, unsigned, bool, int, hipStream_t);
+template hipError_t launch_traverse_wide<float>(const TraverseArgs<float> &, unsigned, int, hipStream_t);
+template hipError_t launch_traverse_wide<double>(const TraverseArgs<double> &, unsigned, int, hipStream_t);
+template int traverse_wide_blocks_per_cu<float>(int);
+template int traverse_wide_blocks_per_cu<double>(int);
+template hipError_t launch_make_wide<float>(const nrt_node_f32 *, uint32_t, WideNode<float> *, hipStream_t);
+template hipError_t launch_make_wide<double>(const nrt_node_f64 *, uint32_t, WideNode<double> *, hipStream_t);
+template int traverse_blocks_per_cu<float>(int);
+template int traverse_blocks_per_cu<double>(int);
 template hipError_t launch_gather_leaf_tris<float>(const uint32_t *, const uint32_t *, const float *,
                                                    LeafTri<float> *, uint32_t, hipStream_t);
 template hipError_t launch_gather_leaf_tris<double>(const uint32_t *, const uint32_t *,
