@@ -26,13 +26,14 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &, unsigned grid, int lds_
 template <typename T>
 int traverse_wide_blocks_per_cu(int lds_stack);
 template <typename T>
-hipError_t launch_make_wide(const typename Wire<T>::Node *, uint32_t, WideNode<T> *, hipStream_t);
+hipError_t launch_make_wide(const typename Wire<T>::Node *, uint32_t, uint32_t packed, uint32_t *scratch, WideNode<T> *,
+                            hipStream_t);
 template <typename T>
 hipError_t launch_gather_leaf_tris(const uint32_t *, const uint32_t *, const T *, LeafTri<T> *,
                                    uint32_t, hipStream_t);
 struct BuildResult {
   uint64_t num_nodes;
-  uint32_t max_depth, num_leaves, num_branches;
+  uint32_t max_depth, num_leaves, num_branches, max_leaf_count;
 };
 template <typename T>
 hipError_t gpu_build(int device, hipStream_t s, const T *d_verts, const uint32_t *d_faces,
@@ -69,6 +70,8 @@ struct nrt_ctx {
   void *d_wide = nullptr; // WideNode<T>[num_nodes]
   uint64_t num_nodes = 0, num_indices = 0;
   uint32_t tree_depth = 0;
+  uint32_t max_leaf_count = 0, min_leaf_count = 0; // over the leaves of the current tree
+  uint32_t packed_leaves = 0;
   nrt_build_stats stats = {0, 0, 0, 0.f};
 
   // traversal scratch
@@ -78,7 +81,8 @@ struct nrt_ctx {
 
   // traversal tuning (env NRT_LDS_STACK / NRT_REFILL_MIN / NRT_TRAV_MIN / NRT_CHUNK override)
   int lds_stack = kLdsStackDefault;
-  unsigned blocks_per_cu = 0, chunk = 256, refill_min = 48, trav_min = 8;
+  unsigned blocks_per_cu = 0, chunk = 128, refill_min = 48, trav_min = 8;
+  unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
   int wide = 1, wide_stack = 10; // production path: WideNode kernel (env NRT_WIDE=0 selects the binary kernel)
   unsigned wide_blocks_per_cu = 0;
   DevBuf spill_tmin;
@@ -160,7 +164,7 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
       (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&c->ev_t0)) != hipSuccess || (e = hipEventCreate(&c->ev_t1)) != hipSuccess ||
       (e = hipEventCreate(&c->ev_b0)) != hipSuccess || (e = hipEventCreate(&c->ev_b1)) != hipSuccess ||
-      (e = hipMalloc((void **)&c->d_cursor, 256)) != hipSuccess ||
+      (e = hipMalloc((void **)&c->d_cursor, 64 * 16)) != hipSuccess ||
       (e = hipMalloc((void **)&c->d_counters, 4 * sizeof(unsigned long long))) != hipSuccess) {
     fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
     delete c;
@@ -175,7 +179,8 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   }
   if (const char *e = getenv("NRT_REFILL_MIN")) c->refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
   if (const char *e = getenv("NRT_TRAV_MIN")) c->trav_min = (unsigned)std::min(64, std::max(1, atoi(e)));
-  if (const char *e = getenv("NRT_CHUNK")) c->chunk = (unsigned)std::max(64, atoi(e));
+  if (const char *e = getenv("NRT_CHUNK")) c->chunk = (unsigned)std::max(16, atoi(e));
+  if (const char *e = getenv("NRT_PARTS")) c->num_parts = (unsigned)std::min(16, std::max(1, atoi(e)));
   if (const char *e = getenv("NRT_WIDE")) c->wide = atoi(e) != 0;
   if (const char *e = getenv("NRT_WIDE_STACK")) {
     int v = atoi(e);
@@ -267,10 +272,20 @@ static nrt_status finish_tree(nrt_ctx *c) {
                                        (LeafTri<T> *)c->d_tris, (uint32_t)c->num_indices, c->stream));
   if (c->d_wide) HIPCHK(c, hipFree(c->d_wide));
   c->d_wide = nullptr;
-  HIPCHK(c, hipMalloc(&c->d_wide, std::max<size_t>(1, c->num_nodes) * sizeof(WideNode<T>)));
-  HIPCHK(c, launch_make_wide<T>((const typename Wire<T>::Node *)c->d_nodes, (uint32_t)c->num_nodes,
-                                (WideNode<T> *)c->d_wide, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // one WideNode per branch; a binary tree has (num_nodes - 1) / 2 of them
+  HIPCHK(c, hipMalloc(&c->d_wide, std::max<size_t>(1, c->num_nodes / 2 + 1) * sizeof(WideNode<T>)));
+  c->packed_leaves = (c->min_leaf_count >= 1 && c->max_leaf_count <= kPackedMaxCount &&
+                      c->num_indices <= (uint64_t)kPackedFirstMask) ? 1u : 0u;
+  {
+    const size_t tiles = (c->num_nodes + 1023) / 1024;
+    uint32_t *scratch = nullptr;
+    HIPCHK(c, hipMalloc((void **)&scratch, (tiles + c->num_nodes + 1) * sizeof(uint32_t)));
+    hipError_t e = launch_make_wide<T>((const typename Wire<T>::Node *)c->d_nodes, (uint32_t)c->num_nodes,
+                                       c->packed_leaves, scratch, (WideNode<T> *)c->d_wide, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(scratch);
+    HIPCHK(c, e);
+  }
   return NRT_OK;
 }
 
@@ -287,7 +302,7 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
     if (indices[i] >= c->num_faces)
       return fail(c, NRT_ERR_INVALID, "nrtSetTree: indices[%llu]=%u >= num_faces %u",
                   (unsigned long long)i, indices[i], c->num_faces);
-  uint32_t depth = 0;
+  uint32_t depth = 0, max_leaf = 0, min_leaf = 0xFFFFFFFFu;
   {
     std::vector<std::pair<uint32_t, uint32_t> > st;
     std::vector<uint8_t> seen(num_nodes, 0);
@@ -308,6 +323,8 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
       } else {
         if ((uint64_t)n.data[1] + n.data[0] > num_indices)
           return fail(c, NRT_ERR_INVALID, "nrtSetTree: leaf %u slots out of range", e.first);
+        max_leaf = std::max(max_leaf, n.data[0]);
+        min_leaf = std::min(min_leaf, n.data[0]);
       }
     }
   }
@@ -317,6 +334,8 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
   c->num_nodes = num_nodes;
   c->num_indices = num_indices;
   c->tree_depth = depth;
+  c->max_leaf_count = max_leaf;
+  c->min_leaf_count = min_leaf;
   HIPCHK(c, hipMalloc(&c->d_nodes, num_nodes * sizeof(typename Wire<T>::Node)));
   HIPCHK(c, hipMalloc((void **)&c->d_indices, std::max<uint64_t>(1, num_indices) * sizeof(uint32_t)));
   HIPCHK(c, hipMemcpy(c->d_nodes, nodes, num_nodes * sizeof(typename Wire<T>::Node), hipMemcpyHostToDevice));
@@ -376,6 +395,8 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   c->num_nodes = res.num_nodes;
   c->num_indices = c->num_faces;
   c->tree_depth = res.max_depth;
+  c->max_leaf_count = res.max_leaf_count;
+  c->min_leaf_count = 1; // the GPU builder never emits an empty leaf
   c->stats.max_tree_depth = res.max_depth;
   c->stats.num_leaf_nodes = res.num_leaves;
   c->stats.num_branch_nodes = res.num_branches;
@@ -425,6 +446,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.nodes = (const typename Wire<T>::Node *)c->d_nodes;
   a.tris = (const LeafTri<T> *)c->d_tris;
   a.wide = (const WideNode<T> *)c->d_wide;
+  a.packed_leaves = c->packed_leaves;
   a.spill_tmin = (T *)c->spill_tmin.p;
   a.rays = d_rays;
   a.hits = d_hits;
@@ -438,12 +460,13 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.spill_stride = total_threads;
   a.spill_levels = levels;
   a.ray_cursor = c->d_cursor;
+  a.num_parts = c->num_parts;
   a.counters = c->d_counters;
   a.chunk = c->chunk;
   a.refill_min = c->refill_min;
   a.trav_min = c->trav_min;
 
-  HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, sizeof(uint32_t), s));
+  HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 64 * 16, s));
   if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), s));
   if (timed) HIPCHK(c, hipEventRecord(c->ev_t0, s));
   if (use_wide)

@@ -42,7 +42,7 @@ namespace nrt {
 
 struct BuildResult {
   uint64_t num_nodes;
-  uint32_t max_depth, num_leaves, num_branches;
+  uint32_t max_depth, num_leaves, num_branches, max_leaf_count;
 };
 
 constexpr int kSmall = 256;     // nodes at or below this many primitives go to the subtree phase
@@ -153,7 +153,8 @@ struct LevelInfo {
   uint32_t max_depth;   // stats
   uint32_t num_leaves;
   uint32_t num_branches;
-  uint32_t pad[2];
+  uint32_t max_leaf_count;
+  uint32_t pad;
 };
 
 template <typename T>
@@ -250,6 +251,7 @@ __global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info) {
     info->max_depth = 0;
     info->num_leaves = 0;
     info->num_branches = 0;
+    info->max_leaf_count = 0;
   }
 }
 
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
     s_perm[0][i] = (uint16_t)i;
   }
   Node *out = scratch_nodes + 2 * (size_t)L;
-  uint32_t node_count = 0, leaves = 0, deepest = 0;
+  uint32_t node_count = 0, leaves = 0, deepest = 0, biggest_leaf = 0;
   int sp = 0;
   if (lane == 0) {
     s_stack[0].lo = 0;
@@ -847,6 +849,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
       if (lane == 0) out[me] = nd;
       for (uint32_t i = lo + lane; i < hi; i += 64u) indices[L + i] = s_rec[s_perm[0][i]].prim;
       leaves++;
+      biggest_leaf = n > biggest_leaf ? n : biggest_leaf;
       continue;
     }
 
@@ -960,6 +963,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
     atomicAdd(&info->num_leaves, leaves);
     atomicAdd(&info->num_branches, node_count - leaves);
     atomicMax(&info->max_depth, deepest);
+    atomicMax(&info->max_leaf_count, biggest_leaf);
   }
 }
 
@@ -999,6 +1003,7 @@ __global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, const uint32_t
     if (t.kind == KIND_LEAF) {
       leaves++;
       deepest = t.depth > deepest ? t.depth : deepest;
+      atomicMax(&info->max_leaf_count, t.r - t.l);
     }
   }
   if (leaves) atomicAdd(&info->num_leaves, leaves);
@@ -1221,6 +1226,7 @@ hipError_t gpu_build(int device, hipStream_t s, const T *d_verts, const uint32_t
   res->max_depth = h.max_depth;
   res->num_leaves = h.num_leaves;
   res->num_branches = h.num_branches;
+  res->max_leaf_count = h.max_leaf_count;
   *d_nodes_out = nodes;
   *d_indices_out = indices;
   cleanup();

@@ -50,10 +50,13 @@ static_assert(sizeof(LeafTri<float>) == 40, "LeafTri<float>");
 static_assert(sizeof(LeafTri<double>) == 80, "LeafTri<double>");
 
 // Private traversal layout: one record per BRANCH node holding BOTH children's boxes, so a
-// step fetches one record and tests two boxes (the child boxes are copied bit-for-bit from
-// the BVHNode array; slot i corresponds to BVHNode i, leaf slots are unused).
-// Child reference: bit 31 set -> leaf, low 31 bits = BVHNode index of that leaf;
-// otherwise the BVHNode / WideNode index of the inner child.
+// step fetches one record and tests two boxes.  Records are dense, in the pre-order of the
+// branch nodes (record j <-> the j-th branch of the BVHNode array); the child boxes are copied
+// bit-for-bit from the BVHNode array.
+// Child reference (32 bits): bit 31 clear -> inner child, value = its WideNode index;
+// bit 31 set -> leaf: either PACKED {count-1 : 4 bits [30:27], first slot : 27 bits} when every
+// leaf of the tree has 1..16 primitives and the index array has < 2^27 slots, or INDIRECT
+// {BVHNode index of the leaf : 31 bits} (count/first are then read from that node).
 template <typename T>
 struct alignas(16) WideNode {
   T box0[6]; // child data[0]: bmin, bmax
@@ -65,12 +68,16 @@ struct alignas(16) WideNode {
 static_assert(sizeof(WideNode<float>) == 64, "WideNode<float>");
 static_assert(sizeof(WideNode<double>) == 112, "WideNode<double>");
 constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kPackedFirstBits = 27;
+constexpr uint32_t kPackedFirstMask = (1u << kPackedFirstBits) - 1u;
+constexpr uint32_t kPackedMaxCount = 16;
 
 template <typename T>
 struct TraverseArgs {
   const typename Wire<T>::Node *nodes;
   const LeafTri<T> *tris;
   const WideNode<T> *wide; // may be null (binary kernel only)
+  uint32_t packed_leaves;  // leaf references of `wide` are PACKED (see WideNode)
   const typename Wire<T>::Ray *rays;
   typename Wire<T>::Hit *hits; // may be null (counting pass)
   uint8_t *mask;               // may be null
@@ -81,7 +88,8 @@ struct TraverseArgs {
   T *spill_tmin;          // same shape, entry t_min (wide kernel)
   uint32_t spill_stride;  // == total threads of the launch
   uint32_t spill_levels;
-  uint32_t *ray_cursor;              // persistent-thread work counter (zeroed per launch)
+  uint32_t *ray_cursor;              // persistent-thread work counters, one per ray partition, 64 B apart (zeroed per launch)
+  uint32_t num_parts;                // ray partitions (== XCDs): contiguous ranges of the ray array, one home range per XCD
   unsigned long long *counters;      // 4 x u64 when counting
   uint32_t chunk;                    // rays claimed per atomic
   uint32_t refill_min;               // refill idle lanes once this many are idle (1..64)

@@ -178,6 +178,65 @@ __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// Work distribution of the persistent kernels.  The ray array is cut into `num_parts`
+// contiguous ranges (one per XCD); a wave first drains its home range (blockIdx % num_parts —
+// the dispatcher places block b on XCD b % 8, used for L2 affinity only, never for
+// correctness) and then steals from the others.  One atomicAdd per `chunk` rays.
+struct Claim {
+  uint32_t next, end; // claimed, not yet handed out: [next, end)
+  uint32_t part, tried;
+  bool exhausted;
+};
+
+template <typename T>
+__device__ __forceinline__ void claim_init(const TraverseArgs<T> &a, Claim &c) {
+  c.next = c.end = 0;
+  c.part = blockIdx.x % a.num_parts;
+  c.tried = 0;
+  c.exhausted = false;
+}
+
+// All lanes of the wave call this (uniform control flow); `leader` is any active lane index.
+template <typename T>
+__device__ __forceinline__ bool claim_chunk(const TraverseArgs<T> &a, Claim &c, unsigned lane, int leader) {
+  while (c.tried < a.num_parts) {
+    const uint32_t lo = (uint32_t)(((unsigned long long)a.num_rays * c.part) / a.num_parts);
+    const uint32_t hi = (uint32_t)(((unsigned long long)a.num_rays * (c.part + 1)) / a.num_parts);
+    uint32_t base = 0;
+    if (lane == (unsigned)leader) base = atomicAdd(a.ray_cursor + 16u * c.part, a.chunk);
+    base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
+    if (base < hi - lo) {
+      c.next = lo + base;
+      c.end = (hi - c.next < a.chunk) ? hi : c.next + a.chunk;
+      return true;
+    }
+    c.part = (c.part + 1 == a.num_parts) ? 0 : c.part + 1;
+    c.tried++;
+  }
+  c.exhausted = true;
+  return false;
+}
+
+// Streaming accesses (each ray is read once, each hit written once): keep them out of the
+// way of the tree data in L2 with the non-temporal hint.
+template <typename T>
+__device__ __forceinline__ typename Wire<T>::Ray load_ray_nt(const typename Wire<T>::Ray *p) {
+  typename Wire<T>::Ray r;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(p);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(r) / 4; k++) dst[k] = __builtin_nontemporal_load(src + k);
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void store_hit_nt(typename Wire<T>::Hit *p, const typename Wire<T>::Hit &h) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 *src = reinterpret_cast<const u32x4 *>(&h);
+  u32x4 *dst = reinterpret_cast<u32x4 *>(p);
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(h) / 16; k++) __builtin_nontemporal_store(src[k], dst + k);
+}
+
 // Lane states of the while-while loop.
 enum : int { LANE_IDLE = 0, LANE_TRAV = 1, LANE_LEAF = 2 };
 
@@ -202,9 +261,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<
   int state = LANE_IDLE;
   int sp = 0; // entries on this lane's stack
 
-  // wave-uniform claimed range [chunk_next, chunk_end)
-  uint32_t chunk_next = 0, chunk_end = 0;
-  bool exhausted = false;
+  Claim ck; // wave-uniform claimed range
+  claim_init<T>(a, ck);
 
   unsigned long long c_nodes = 0, c_leaves = 0, c_tris = 0, c_stack = 0;
 
@@ -223,7 +281,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<
         h_.v = hit_ ? L.v : T(0);                                                        \
         h_.t = hit_ ? L.hit_t : L.max_t;                                                 \
         h_.prim_id = hit_ ? L.prim : kInvalid;                                           \
-        a.hits[rid] = h_;                                                                \
+        store_hit_nt<T>(a.hits + rid, h_);                                               \
       }                                                                                  \
       if (a.mask) a.mask[rid] = hit_ ? 1 : 0;                                            \
     }                                                                                    \
@@ -245,39 +303,28 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<
   for (;;) {
     // ---- hand new rays to idle lanes (ballot rank inside the wave's chunk) ----
     unsigned long long idle = __ballot(state == LANE_IDLE);
-    if (!exhausted && (unsigned)__builtin_popcountll(idle) >= a.refill_min) {
-      while (idle != 0ull && !exhausted) {
-        if (chunk_next == chunk_end) {
-          const int leader = __builtin_ctzll(idle);
-          uint32_t base = 0;
-          if (lane == (unsigned)leader) base = atomicAdd(a.ray_cursor, a.chunk);
-          base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
-          if (base >= a.num_rays) {
-            exhausted = true;
-            break;
-          }
-          chunk_next = base;
-          chunk_end = (a.num_rays - base < a.chunk) ? a.num_rays : base + a.chunk;
-        }
+    if (!ck.exhausted && (unsigned)__builtin_popcountll(idle) >= a.refill_min) {
+      while (idle != 0ull && !ck.exhausted) {
+        if (ck.next == ck.end && !claim_chunk<T>(a, ck, lane, __builtin_ctzll(idle))) break;
         const unsigned want = (unsigned)__builtin_popcountll(idle);
-        const unsigned avail = chunk_end - chunk_next;
+        const unsigned avail = ck.end - ck.next;
         const unsigned take = want < avail ? want : avail;
         const unsigned rank = (unsigned)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
         if (state == LANE_IDLE && rank < take) {
-          rid = chunk_next + rank;
-          const Ray r = a.rays[rid];
+          rid = ck.next + rank;
+          const Ray r = load_ray_nt<T>(a.rays + rid);
           lane_init<T>(L, r);
           cur = 0;
           sp = 0;
           state = LANE_TRAV;
           if (COUNT) c_stack = c_stack > 1ull ? c_stack : 1ull;
         }
-        chunk_next += take;
+        ck.next += take;
         idle = __ballot(state == LANE_IDLE);
       }
     }
     if (idle == ~0ull) {
-      if (exhausted) break; // nothing left anywhere in this wave
+      if (ck.exhausted) break; // nothing left anywhere in this wave
       continue;             // (cannot happen: refill_min <= 64)
     }
 
@@ -398,47 +445,38 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
   uint32_t cur = 0; // W_TRAV: WideNode index; W_LEAF: BVHNode index of the leaf
   int state = W_IDLE;
   int sp = 0;
-  uint32_t chunk_next = 0, chunk_end = 0;
-  bool exhausted = false;
+  Claim ck;
+  claim_init<T>(a, ck);
 
   for (;;) {
     // ---- refill idle lanes ---------------------------------------------------------
     unsigned long long idle = __ballot(state == W_IDLE);
-    if (!exhausted && (unsigned)__builtin_popcountll(idle) >= a.refill_min) {
-      while (idle != 0ull && !exhausted) {
-        if (chunk_next == chunk_end) {
-          const int leader = __builtin_ctzll(idle);
-          uint32_t base = 0;
-          if (lane == (unsigned)leader) base = atomicAdd(a.ray_cursor, a.chunk);
-          base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
-          if (base >= a.num_rays) {
-            exhausted = true;
-            break;
-          }
-          chunk_next = base;
-          chunk_end = (a.num_rays - base < a.chunk) ? a.num_rays : base + a.chunk;
-        }
+    if (!ck.exhausted && (unsigned)__builtin_popcountll(idle) >= a.refill_min) {
+      while (idle != 0ull && !ck.exhausted) {
+        if (ck.next == ck.end && !claim_chunk<T>(a, ck, lane, __builtin_ctzll(idle))) break;
         const unsigned want = (unsigned)__builtin_popcountll(idle);
-        const unsigned avail = chunk_end - chunk_next;
+        const unsigned avail = ck.end - ck.next;
         const unsigned take = want < avail ? want : avail;
         const unsigned rank = (unsigned)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
         if (state == W_IDLE && rank < take) {
-          rid = chunk_next + rank;
-          const Ray r = a.rays[rid];
+          rid = ck.next + rank;
+          const Ray r = load_ray_nt<T>(a.rays + rid);
           lane_init<T>(L, r);
           sp = 0;
           // the reference pops and tests the root first (nanort.h:2526-2533)
           const Node root = a.nodes[0];
           const bool root_hit = slab_test<T>(L, root.bmin, root.bmax);
-          cur = 0;
+          // root branch -> WideNode 0; root leaf -> its leaf reference
+          cur = (root.flag == 0) ? 0u
+                                 : (a.packed_leaves ? (((root.data[0] - 1u) << kPackedFirstBits) | root.data[1]) : 0u);
           state = root_hit ? (root.flag == 0 ? W_TRAV : W_LEAF) : W_POP; // W_POP with sp == 0 finishes the ray
         }
-        chunk_next += take;
+        ck.next += take;
         idle = __ballot(state == W_IDLE);
       }
     }
     if (idle == ~0ull) {
-      if (exhausted) break;
+      if (ck.exhausted) break;
       continue;
     }
 
@@ -480,7 +518,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           h.v = hit ? L.v : T(0);
           h.t = hit ? L.hit_t : L.max_t;
           h.prim_id = hit ? L.prim : kInvalid;
-          a.hits[rid] = h;
+          store_hit_nt<T>(a.hits + rid, h);
           if (a.mask) a.mask[rid] = hit ? 1 : 0;
         }
         uint32_t ref = 0;
@@ -509,9 +547,14 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
     if (__ballot(state == W_LEAF) != 0ull) {
       uint32_t cnt = 0, first = 0;
       if (state == W_LEAF) {
-        const Node *nd = a.nodes + cur;
-        cnt = nd->data[0];
-        first = nd->data[1];
+        if (a.packed_leaves) {
+          cnt = (cur >> kPackedFirstBits) + 1u;
+          first = cur & kPackedFirstMask;
+        } else {
+          const Node *nd = a.nodes + cur;
+          cnt = nd->data[0];
+          first = nd->data[1];
+        }
       }
       for (uint32_t i = 0; __ballot(i < cnt) != 0ull; i++) {
         if (i < cnt) {
@@ -524,9 +567,75 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
   }
 }
 
-// BVHNode[] -> WideNode[] (slot i <- branch node i; leaf slots untouched).
+// BVHNode[] -> dense WideNode[]: (1) branches per 1024-node tile, (2) exclusive scan of the
+// tile counts, (3) dense index of every branch node, (4) the records.
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+  const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= (unsigned)off) inc += t;
+  }
+  if (lane == 63) s_wave[w] = inc;
+  __syncthreads();
+  uint32_t pre = 0;
+  total = 0;
+  for (unsigned j = 0; j < 4; j++) {
+    if (j < w) pre += s_wave[j];
+    total += s_wave[j];
+  }
+  __syncthreads();
+  return pre + inc - v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wide_count(const typename Wire<T>::Node *__restrict__ nodes, uint32_t n,
+                                                    uint32_t *__restrict__ tile_count) {
+  __shared__ uint32_t s_wave[4];
+  uint32_t c = 0;
+  const uint32_t base = blockIdx.x * 1024u + threadIdx.x * 4u;
+  for (uint32_t k = 0; k < 4; k++)
+    if (base + k < n && nodes[base + k].flag == 0) c++;
+  uint32_t total;
+  (void)block_exclusive_scan_256(c, s_wave, total);
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void k_wide_scan_tiles(uint32_t *tile_count, uint32_t num_tiles) {
+  __shared__ uint32_t s_wave[4];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < num_tiles; base += 256u) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < num_tiles ? tile_count[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan_256(v, s_wave, total);
+    if (i < num_tiles) tile_count[i] = carry + ex;
+    carry += total;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wide_index(const typename Wire<T>::Node *__restrict__ nodes, uint32_t n,
+                                                    const uint32_t *__restrict__ tile_base,
+                                                    uint32_t *__restrict__ dense_of) {
+  __shared__ uint32_t s_wave[4];
+  const uint32_t base = blockIdx.x * 1024u + threadIdx.x * 4u;
+  uint32_t flags[4], c = 0;
+  for (uint32_t k = 0; k < 4; k++) {
+    flags[k] = (base + k < n && nodes[base + k].flag == 0) ? 1u : 0u;
+    c += flags[k];
+  }
+  uint32_t total;
+  uint32_t ex = tile_base[blockIdx.x] + block_exclusive_scan_256(c, s_wave, total);
+  for (uint32_t k = 0; k < 4; k++) {
+    if (base + k < n) dense_of[base + k] = ex;
+    ex += flags[k];
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_make_wide(const typename Wire<T>::Node *__restrict__ nodes, uint32_t n,
+                                                   const uint32_t *__restrict__ dense_of, uint32_t packed,
                                                    WideNode<T> *__restrict__ wide) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
@@ -541,11 +650,13 @@ __global__ __launch_bounds__(256) void k_make_wide(const typename Wire<T>::Node 
     w.box1[k] = b.bmin[k];
     w.box1[3 + k] = b.bmax[k];
   }
-  w.c0 = nd.data[0] | (a.flag != 0 ? kLeafBit : 0u);
-  w.c1 = nd.data[1] | (b.flag != 0 ? kLeafBit : 0u);
+  const uint32_t la = packed ? (((a.data[0] - 1u) << kPackedFirstBits) | a.data[1]) : nd.data[0];
+  const uint32_t lb = packed ? (((b.data[0] - 1u) << kPackedFirstBits) | b.data[1]) : nd.data[1];
+  w.c0 = a.flag != 0 ? (kLeafBit | la) : dense_of[nd.data[0]];
+  w.c1 = b.flag != 0 ? (kLeafBit | lb) : dense_of[nd.data[1]];
   w.axis = nd.axis;
   w.pad = 0;
-  wide[i] = w;
+  wide[dense_of[i]] = w;
 }
 
 // Leaf-ordered triangle records from (indices, faces, tight vertices).
@@ -630,10 +741,17 @@ int traverse_wide_blocks_per_cu(int lds_stack) {
   return n > 8 ? 8 : n;
 }
 
+// scratch: tile counts (ceil(n/1024) u32) followed by dense_of (n u32)
 template <typename T>
-hipError_t launch_make_wide(const typename Wire<T>::Node *nodes, uint32_t n, WideNode<T> *wide, hipStream_t s) {
+hipError_t launch_make_wide(const typename Wire<T>::Node *nodes, uint32_t n, uint32_t packed, uint32_t *scratch,
+                            WideNode<T> *wide, hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL((k_make_wide<T>), dim3((n + 255u) / 256u), dim3(256), 0, s, nodes, n, wide);
+  const uint32_t tiles = (n + 1023u) / 1024u;
+  uint32_t *tile_count = scratch, *dense_of = scratch + tiles;
+  hipLaunchKernelGGL((k_wide_count<T>), dim3(tiles), dim3(256), 0, s, nodes, n, tile_count);
+  hipLaunchKernelGGL(k_wide_scan_tiles, dim3(1), dim3(256), 0, s, tile_count, tiles);
+  hipLaunchKernelGGL((k_wide_index<T>), dim3(tiles), dim3(256), 0, s, nodes, n, tile_count, dense_of);
+  hipLaunchKernelGGL((k_make_wide<T>), dim3((n + 255u) / 256u), dim3(256), 0, s, nodes, n, dense_of, packed, wide);
   return hipGetLastError();
 }
 
@@ -652,8 +770,10 @@ template hipError_t launch_traverse_wide<float>(const TraverseArgs<float> &, uns
 template hipError_t launch_traverse_wide<double>(const TraverseArgs<double> &, unsigned, int, hipStream_t);
 template int traverse_wide_blocks_per_cu<float>(int);
 template int traverse_wide_blocks_per_cu<double>(int);
-template hipError_t launch_make_wide<float>(const nrt_node_f32 *, uint32_t, WideNode<float> *, hipStream_t);
-template hipError_t launch_make_wide<double>(const nrt_node_f64 *, uint32_t, WideNode<double> *, hipStream_t);
+template hipError_t launch_make_wide<float>(const nrt_node_f32 *, uint32_t, uint32_t, uint32_t *, WideNode<float> *,
+                                            hipStream_t);
+template hipError_t launch_make_wide<double>(const nrt_node_f64 *, uint32_t, uint32_t, uint32_t *, WideNode<double> *,
+                                             hipStream_t);
 template int traverse_blocks_per_cu<float>(int);
 template int traverse_blocks_per_cu<double>(int);
 template hipError_t launch_gather_leaf_tris<float>(const uint32_t *, const uint32_t *, const float *,
