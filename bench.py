@@ -252,7 +252,7 @@ def main():
                     "max_depth": int(stats["max_tree_depth"])},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "nrt::k_traverse<float,false>",
+                "kernel": "nrt::k_traverse_wide<float,10>",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -81,8 +81,11 @@ struct nrt_ctx {
 
   // traversal tuning (env NRT_LDS_STACK / NRT_REFILL_MIN / NRT_TRAV_MIN / NRT_CHUNK override)
   int lds_stack = kLdsStackDefault;
-  unsigned blocks_per_cu = 0, chunk = 128, refill_min = 48, trav_min = 8;
+  unsigned blocks_per_cu = 0, chunk = 64, refill_min = 48, trav_min = 8;
   unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
+  unsigned debug_flags = 0;
+  unsigned static_pct = 75; // share of a batch handed out statically, percent (env NRT_STATIC_PCT)
+  unsigned max_blocks_per_cu = 0; // env NRT_BLOCKS_PER_CU caps the persistent grid
   int wide = 1, wide_stack = 10; // production path: WideNode kernel (env NRT_WIDE=0 selects the binary kernel)
   unsigned wide_blocks_per_cu = 0;
   DevBuf spill_tmin;
@@ -164,7 +167,7 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
       (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&c->ev_t0)) != hipSuccess || (e = hipEventCreate(&c->ev_t1)) != hipSuccess ||
       (e = hipEventCreate(&c->ev_b0)) != hipSuccess || (e = hipEventCreate(&c->ev_b1)) != hipSuccess ||
-      (e = hipMalloc((void **)&c->d_cursor, 64 * 16)) != hipSuccess ||
+      (e = hipMalloc((void **)&c->d_cursor, kCursorStrideWords * 4 * kMaxParts)) != hipSuccess ||
       (e = hipMalloc((void **)&c->d_counters, 4 * sizeof(unsigned long long))) != hipSuccess) {
     fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
     delete c;
@@ -180,7 +183,10 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   if (const char *e = getenv("NRT_REFILL_MIN")) c->refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
   if (const char *e = getenv("NRT_TRAV_MIN")) c->trav_min = (unsigned)std::min(64, std::max(1, atoi(e)));
   if (const char *e = getenv("NRT_CHUNK")) c->chunk = (unsigned)std::max(16, atoi(e));
-  if (const char *e = getenv("NRT_PARTS")) c->num_parts = (unsigned)std::min(16, std::max(1, atoi(e)));
+  if (const char *e = getenv("NRT_PARTS")) c->num_parts = (unsigned)std::min((int)kMaxParts, std::max(1, atoi(e)));
+  if (const char *e = getenv("NRT_DEBUG")) c->debug_flags = (unsigned)atoi(e);
+  if (const char *e = getenv("NRT_STATIC_PCT")) c->static_pct = (unsigned)std::min(100, std::max(0, atoi(e)));
+  if (const char *e = getenv("NRT_BLOCKS_PER_CU")) c->max_blocks_per_cu = (unsigned)std::max(0, atoi(e));
   if (const char *e = getenv("NRT_WIDE")) c->wide = atoi(e) != 0;
   if (const char *e = getenv("NRT_WIDE_STACK")) {
     int v = atoi(e);
@@ -427,11 +433,17 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   const bool use_wide = c->wide && !count && c->d_wide;
   if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
   if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack);
-  const unsigned blocks_per_cu = use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu;
+  unsigned blocks_per_cu = use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu;
+  if (c->max_blocks_per_cu && blocks_per_cu > c->max_blocks_per_cu) blocks_per_cu = c->max_blocks_per_cu;
   const int stack_entries = use_wide ? c->wide_stack : c->lds_stack;
   uint64_t need_blocks = (n + kTraverseBlock - 1) / kTraverseBlock;
   unsigned grid = (unsigned)std::min<uint64_t>(need_blocks, (uint64_t)c->num_cus * blocks_per_cu);
+  const unsigned parts = std::max(1u, std::min(c->num_parts, grid));
+  grid = ((grid + parts - 1) / parts) * parts; // whole blocks per partition (ranks are partition-major)
   const uint32_t total_threads = grid * kTraverseBlock;
+  const uint32_t total_waves = grid * (kTraverseBlock / kWave);
+  // static share: a multiple of 64 rays per wave, c->static_pct percent of the batch in total
+  const uint32_t static_per_wave = (uint32_t)(((uint64_t)n * c->static_pct / 100) / total_waves / 64) * 64;
   const uint32_t levels = c->tree_depth + 2 > (uint32_t)stack_entries ? c->tree_depth + 2 - stack_entries : 0;
   if (levels) {
     nrt_status st = ensure(c, c->spill, (size_t)levels * total_threads * sizeof(uint32_t));
@@ -447,6 +459,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.tris = (const LeafTri<T> *)c->d_tris;
   a.wide = (const WideNode<T> *)c->d_wide;
   a.packed_leaves = c->packed_leaves;
+  a.debug_flags = c->debug_flags;
   a.spill_tmin = (T *)c->spill_tmin.p;
   a.rays = d_rays;
   a.hits = d_hits;
@@ -460,13 +473,16 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.spill_stride = total_threads;
   a.spill_levels = levels;
   a.ray_cursor = c->d_cursor;
-  a.num_parts = c->num_parts;
+  a.num_parts = parts;
+  a.static_per_wave = static_per_wave;
+  a.dyn_begin = static_per_wave * total_waves;
+  a.blocks_per_part = grid / parts;
   a.counters = c->d_counters;
   a.chunk = c->chunk;
   a.refill_min = c->refill_min;
   a.trav_min = c->trav_min;
 
-  HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, 64 * 16, s));
+  HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, kCursorStrideWords * 4 * c->num_parts, s));
   if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), s));
   if (timed) HIPCHK(c, hipEventRecord(c->ev_t0, s));
   if (use_wide)

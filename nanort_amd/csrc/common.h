@@ -17,6 +17,8 @@ constexpr int kWave = 64;           // gfx950 wavefront
 constexpr int kTraverseBlock = 256; // 4 waves, one per SIMD
 constexpr int kLdsStackDefault = 32; // per-lane stack entries kept in LDS (32 -> 32 KiB / block)
 constexpr unsigned kInvalid = 0xFFFFFFFFu;
+constexpr unsigned kCursorStrideWords = 1024; // per-partition work cursors 4 KiB apart (separate memory channels)
+constexpr unsigned kMaxParts = 16;
 
 template <typename T>
 struct Wire;
@@ -78,6 +80,7 @@ struct TraverseArgs {
   const LeafTri<T> *tris;
   const WideNode<T> *wide; // may be null (binary kernel only)
   uint32_t packed_leaves;  // leaf references of `wide` are PACKED (see WideNode)
+  uint32_t debug_flags;    // profiling only (env NRT_DEBUG): 1 = skip triangle tests, 2 = skip traversal
   const typename Wire<T>::Ray *rays;
   typename Wire<T>::Hit *hits; // may be null (counting pass)
   uint8_t *mask;               // may be null
@@ -90,6 +93,9 @@ struct TraverseArgs {
   uint32_t spill_levels;
   uint32_t *ray_cursor;              // persistent-thread work counters, one per ray partition, 64 B apart (zeroed per launch)
   uint32_t num_parts;                // ray partitions (== XCDs): contiguous ranges of the ray array, one home range per XCD
+  uint32_t static_per_wave;          // rays [rank*static_per_wave, +static_per_wave) belong to wave `rank` without any atomic
+  uint32_t dyn_begin;                // rays [dyn_begin, num_rays) are claimed dynamically (per-partition cursors)
+  uint32_t blocks_per_part;          // gridDim.x / num_parts
   unsigned long long *counters;      // 4 x u64 when counting
   uint32_t chunk;                    // rays claimed per atomic
   uint32_t refill_min;               // refill idle lanes once this many are idle (1..64)

@@ -26,6 +26,8 @@ struct Const<float> {
   static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
   static __device__ __forceinline__ float maxmult() { return 1.00000024f; }
   static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
+  static __device__ __forceinline__ float fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+  static __device__ __forceinline__ float fmin(float a, float b) { return __builtin_fminf(a, b); }
 };
 template <>
 struct Const<double> {
@@ -33,6 +35,8 @@ struct Const<double> {
   static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
   static __device__ __forceinline__ double maxmult() { return 1.0000000000000004; }
   static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
+  static __device__ __forceinline__ double fmax(double a, double b) { return __builtin_fmax(a, b); }
+  static __device__ __forceinline__ double fmin(double a, double b) { return __builtin_fmin(a, b); }
 };
 
 template <typename T>
@@ -123,8 +127,11 @@ __device__ __forceinline__ bool slab_test(const Lane<T> &L, const T bmin[3], con
     const T hi = sg ? bmin[k] : bmax[k];
     const T t0 = (lo - L.org[k]) * L.inv[k];
     const T t1 = (hi - L.org[k]) * L.inv[k] * mm;
-    tmin = (t0 > tmin) ? t0 : tmin; // safemax(t0, tmin)
-    tmax = (t1 < tmax) ? t1 : tmax; // safemin(t1, tmax)
+    // safemax(t0, tmin) / safemin(t1, tmax) (nanort.h:1236-1243): a NaN first operand is dropped and the
+    // running value is never NaN, which is exactly maxNum/minNum (v_max_f32 / v_min_f32); the only
+    // difference, the sign of a zero result, cannot change `tmin <= tmax`.
+    tmin = Const<T>::fmax(t0, tmin);
+    tmax = Const<T>::fmin(t1, tmax);
   }
   return tmin <= tmax;
 }
@@ -178,10 +185,15 @@ __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
-// Work distribution of the persistent kernels.  The ray array is cut into `num_parts`
-// contiguous ranges (one per XCD); a wave first drains its home range (blockIdx % num_parts —
-// the dispatcher places block b on XCD b % 8, used for L2 affinity only, never for
-// correctness) and then steals from the others.  One atomicAdd per `chunk` rays.
+// Work distribution of the persistent kernels.
+//  * A static share of the rays needs no atomics at all: wave `rank` owns
+//    [rank * static_per_wave, +static_per_wave).  Ranks are XCD-major (the dispatcher places
+//    block b on XCD b % 8 — used for L2 affinity only, never for correctness), so each XCD
+//    walks one contiguous band of the ray array and its L2 keeps one part of the tree.
+//  * The rest, [dyn_begin, num_rays), is cut into `num_parts` ranges with one cursor each
+//    (4 KiB apart); a wave drains its home range first and then steals from the others,
+//    `chunk` rays per atomicAdd.  Device-scope atomics on one word saturate near 100 per
+//    microsecond on this part, hence the static share and the modest chunk count.
 struct Claim {
   uint32_t next, end; // claimed, not yet handed out: [next, end)
   uint32_t part, tried;
@@ -190,8 +202,11 @@ struct Claim {
 
 template <typename T>
 __device__ __forceinline__ void claim_init(const TraverseArgs<T> &a, Claim &c) {
-  c.next = c.end = 0;
-  c.part = blockIdx.x % a.num_parts;
+  const uint32_t part = blockIdx.x % a.num_parts;
+  const uint32_t rank = (part * a.blocks_per_part + blockIdx.x / a.num_parts) * (kTraverseBlock / kWave) + threadIdx.x / kWave;
+  c.next = rank * a.static_per_wave;
+  c.end = c.next + a.static_per_wave;
+  c.part = part;
   c.tried = 0;
   c.exhausted = false;
 }
@@ -199,15 +214,17 @@ __device__ __forceinline__ void claim_init(const TraverseArgs<T> &a, Claim &c) {
 // All lanes of the wave call this (uniform control flow); `leader` is any active lane index.
 template <typename T>
 __device__ __forceinline__ bool claim_chunk(const TraverseArgs<T> &a, Claim &c, unsigned lane, int leader) {
+  const uint32_t dyn = a.num_rays - a.dyn_begin;
+  const uint32_t per = dyn / a.num_parts, extra = dyn % a.num_parts; // first `extra` parts hold one more ray
   while (c.tried < a.num_parts) {
-    const uint32_t lo = (uint32_t)(((unsigned long long)a.num_rays * c.part) / a.num_parts);
-    const uint32_t hi = (uint32_t)(((unsigned long long)a.num_rays * (c.part + 1)) / a.num_parts);
+    const uint32_t lo = a.dyn_begin + c.part * per + (c.part < extra ? c.part : extra);
+    const uint32_t len = per + (c.part < extra ? 1u : 0u);
     uint32_t base = 0;
-    if (lane == (unsigned)leader) base = atomicAdd(a.ray_cursor + 16u * c.part, a.chunk);
+    if (lane == (unsigned)leader) base = atomicAdd(a.ray_cursor + kCursorStrideWords * c.part, a.chunk);
     base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
-    if (base < hi - lo) {
+    if (base < len) {
       c.next = lo + base;
-      c.end = (hi - c.next < a.chunk) ? hi : c.next + a.chunk;
+      c.end = (len - base < a.chunk) ? lo + len : c.next + a.chunk;
       return true;
     }
     c.part = (c.part + 1 == a.num_parts) ? 0 : c.part + 1;
@@ -312,7 +329,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<
         const unsigned rank = (unsigned)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
         if (state == LANE_IDLE && rank < take) {
           rid = ck.next + rank;
-          const Ray r = load_ray_nt<T>(a.rays + rid);
+          const Ray r = (a.debug_flags & 4u) ? a.rays[rid] : load_ray_nt<T>(a.rays + rid);
           lane_init<T>(L, r);
           cur = 0;
           sp = 0;
@@ -417,8 +434,8 @@ __device__ __forceinline__ bool slab_test_tmin(const Lane<T> &L, const T box[6],
     const T hi = sg ? box[k] : box[3 + k];
     const T t0 = (lo - L.org[k]) * L.inv[k];
     const T t1 = (hi - L.org[k]) * L.inv[k] * mm;
-    tmin = (t0 > tmin) ? t0 : tmin;
-    tmax = (t1 < tmax) ? t1 : tmax;
+    tmin = Const<T>::fmax(t0, tmin); // see slab_test
+    tmax = Const<T>::fmin(t1, tmax);
   }
   tmin_out = tmin;
   return tmin <= tmax;
@@ -460,7 +477,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
         const unsigned rank = (unsigned)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
         if (state == W_IDLE && rank < take) {
           rid = ck.next + rank;
-          const Ray r = load_ray_nt<T>(a.rays + rid);
+          const Ray r = (a.debug_flags & 4u) ? a.rays[rid] : load_ray_nt<T>(a.rays + rid);
           lane_init<T>(L, r);
           sp = 0;
           // the reference pops and tests the root first (nanort.h:2526-2533)
@@ -470,6 +487,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           cur = (root.flag == 0) ? 0u
                                  : (a.packed_leaves ? (((root.data[0] - 1u) << kPackedFirstBits) | root.data[1]) : 0u);
           state = root_hit ? (root.flag == 0 ? W_TRAV : W_LEAF) : W_POP; // W_POP with sp == 0 finishes the ray
+          if (a.debug_flags & 2u) state = W_POP;
         }
         ck.next += take;
         idle = __ballot(state == W_IDLE);
@@ -556,6 +574,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           first = nd->data[1];
         }
       }
+      if (a.debug_flags & 1u) cnt = 0;
       for (uint32_t i = 0; __ballot(i < cnt) != 0ull; i++) {
         if (i < cnt) {
           const LeafTri<T> tri = a.tris[first + i];
