@@ -36,20 +36,14 @@ struct BuildResult {
   uint32_t max_depth, num_leaves, num_branches, max_leaf_count;
 };
 template <typename T>
-hipError_t gpu_build(int device, hipStream_t s, const T *d_verts, const uint32_t *d_faces,
-                     uint32_t num_faces, uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size,
-                     typename Wire<T>::Node **d_nodes_out, uint32_t **d_indices_out,
-                     BuildResult *res, std::string *err);
+hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, uint32_t num_faces,
+                     uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, DevBuf *workspace,
+                     DevBuf *nodes_buf, DevBuf *indices_buf, BuildResult *res, std::string *err);
 } // namespace nrt
 
 using namespace nrt;
 
 static thread_local std::string g_create_error;
-
-struct DevBuf {
-  void *p = nullptr;
-  size_t cap = 0;
-};
 
 struct nrt_ctx {
   int device = 0;
@@ -63,11 +57,12 @@ struct nrt_ctx {
   uint32_t *d_faces = nullptr;
   uint32_t num_faces = 0, num_verts = 0;
 
-  // tree
-  void *d_nodes = nullptr;
-  uint32_t *d_indices = nullptr;
-  void *d_tris = nullptr; // LeafTri<T>[num_indices]
-  void *d_wide = nullptr; // WideNode<T>[num_nodes]
+  // tree (grow-only buffers: a per-frame rebuild allocates nothing in the steady state)
+  DevBuf b_nodes, b_indices, b_tris, b_wide, b_wide_scratch, b_build_ws;
+  void *d_nodes = nullptr;       // == b_nodes.p while a tree is present
+  uint32_t *d_indices = nullptr; // == b_indices.p
+  void *d_tris = nullptr;        // LeafTri<T>[num_indices] == b_tris.p
+  void *d_wide = nullptr;        // WideNode<T>[branches]   == b_wide.p
   uint64_t num_nodes = 0, num_indices = 0;
   uint32_t tree_depth = 0;
   uint32_t max_leaf_count = 0, min_leaf_count = 0; // over the leaves of the current tree
@@ -116,21 +111,12 @@ static nrt_status fail(nrt_ctx *c, nrt_status st, const char *fmt, ...) {
   } while (0)
 
 static nrt_status ensure(nrt_ctx *c, DevBuf &b, size_t bytes) {
-  if (bytes <= b.cap) return NRT_OK;
-  if (b.p) HIPCHK(c, hipFree(b.p));
-  b.p = nullptr;
-  b.cap = 0;
-  size_t want = bytes + bytes / 4;
-  HIPCHK(c, hipMalloc(&b.p, want));
-  b.cap = want;
+  HIPCHK(c, devbuf_ensure(&b, bytes));
   return NRT_OK;
 }
 
+// Forget the current tree (the buffers stay allocated for the next one).
 static void free_tree(nrt_ctx *c) {
-  if (c->d_nodes) (void)hipFree(c->d_nodes);
-  if (c->d_indices) (void)hipFree(c->d_indices);
-  if (c->d_tris) (void)hipFree(c->d_tris);
-  if (c->d_wide) (void)hipFree(c->d_wide);
   c->d_wide = nullptr;
   c->d_nodes = nullptr;
   c->d_indices = nullptr;
@@ -202,7 +188,8 @@ void nrtDestroy(nrt_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   free_tree(c);
   free_mesh(c);
-  DevBuf *bufs[] = {&c->spill, &c->spill_tmin, &c->st_rays, &c->st_hits, &c->st_mask};
+  DevBuf *bufs[] = {&c->spill,   &c->spill_tmin, &c->st_rays, &c->st_hits,         &c->st_mask,    &c->b_nodes,
+                    &c->b_indices, &c->b_tris,     &c->b_wide,  &c->b_wide_scratch, &c->b_build_ws};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->d_cursor) (void)hipFree(c->d_cursor);
@@ -270,28 +257,21 @@ static nrt_status set_mesh(nrt_ctx *c, const T *vertices, size_t stride, const u
 // ---------------------------------------------------------------------------
 template <typename T>
 static nrt_status finish_tree(nrt_ctx *c) {
+  nrt_status st;
   // leaf-ordered triangle records for the traversal kernel
-  if (c->d_tris) HIPCHK(c, hipFree(c->d_tris));
-  c->d_tris = nullptr;
-  HIPCHK(c, hipMalloc(&c->d_tris, std::max<size_t>(1, c->num_indices) * sizeof(LeafTri<T>)));
+  if ((st = ensure(c, c->b_tris, std::max<size_t>(1, c->num_indices) * sizeof(LeafTri<T>)))) return st;
+  c->d_tris = c->b_tris.p;
   HIPCHK(c, launch_gather_leaf_tris<T>(c->d_indices, c->d_faces, (const T *)c->d_verts,
                                        (LeafTri<T> *)c->d_tris, (uint32_t)c->num_indices, c->stream));
-  if (c->d_wide) HIPCHK(c, hipFree(c->d_wide));
-  c->d_wide = nullptr;
   // one WideNode per branch; a binary tree has (num_nodes - 1) / 2 of them
-  HIPCHK(c, hipMalloc(&c->d_wide, std::max<size_t>(1, c->num_nodes / 2 + 1) * sizeof(WideNode<T>)));
+  if ((st = ensure(c, c->b_wide, std::max<size_t>(1, c->num_nodes / 2 + 1) * sizeof(WideNode<T>)))) return st;
+  c->d_wide = c->b_wide.p;
   c->packed_leaves = (c->min_leaf_count >= 1 && c->max_leaf_count <= kPackedMaxCount &&
                       c->num_indices <= (uint64_t)kPackedFirstMask) ? 1u : 0u;
-  {
-    const size_t tiles = (c->num_nodes + 1023) / 1024;
-    uint32_t *scratch = nullptr;
-    HIPCHK(c, hipMalloc((void **)&scratch, (tiles + c->num_nodes + 1) * sizeof(uint32_t)));
-    hipError_t e = launch_make_wide<T>((const typename Wire<T>::Node *)c->d_nodes, (uint32_t)c->num_nodes,
-                                       c->packed_leaves, scratch, (WideNode<T> *)c->d_wide, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(scratch);
-    HIPCHK(c, e);
-  }
+  const size_t tiles = (c->num_nodes + 1023) / 1024;
+  if ((st = ensure(c, c->b_wide_scratch, (tiles + c->num_nodes + 1) * sizeof(uint32_t)))) return st;
+  HIPCHK(c, launch_make_wide<T>((const typename Wire<T>::Node *)c->d_nodes, (uint32_t)c->num_nodes, c->packed_leaves,
+                                (uint32_t *)c->b_wide_scratch.p, (WideNode<T> *)c->d_wide, c->stream));
   return NRT_OK;
 }
 
@@ -342,11 +322,16 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
   c->tree_depth = depth;
   c->max_leaf_count = max_leaf;
   c->min_leaf_count = min_leaf;
-  HIPCHK(c, hipMalloc(&c->d_nodes, num_nodes * sizeof(typename Wire<T>::Node)));
-  HIPCHK(c, hipMalloc((void **)&c->d_indices, std::max<uint64_t>(1, num_indices) * sizeof(uint32_t)));
+  nrt_status st;
+  if ((st = ensure(c, c->b_nodes, num_nodes * sizeof(typename Wire<T>::Node)))) return st;
+  if ((st = ensure(c, c->b_indices, std::max<uint64_t>(1, num_indices) * sizeof(uint32_t)))) return st;
+  c->d_nodes = c->b_nodes.p;
+  c->d_indices = (uint32_t *)c->b_indices.p;
   HIPCHK(c, hipMemcpy(c->d_nodes, nodes, num_nodes * sizeof(typename Wire<T>::Node), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_indices, indices, num_indices * sizeof(uint32_t), hipMemcpyHostToDevice));
-  return finish_tree<T>(c);
+  if ((st = finish_tree<T>(c))) return st;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NRT_OK;
 }
 
 template <typename T>
@@ -382,34 +367,33 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   free_tree(c);
-  typename Wire<T>::Node *d_nodes = nullptr;
-  uint32_t *d_indices = nullptr;
   BuildResult res;
   std::string err;
   HIPCHK(c, hipEventRecord(c->ev_b0, c->stream));
-  hipError_t e = gpu_build<T>(c->device, c->stream, (const T *)c->d_verts, c->d_faces, c->num_faces, min_leaf,
-                              max_depth, bin_size, &d_nodes, &d_indices, &res, &err);
+  hipError_t e = gpu_build<T>(c->stream, (const T *)c->d_verts, c->d_faces, c->num_faces, min_leaf, max_depth,
+                              bin_size, &c->b_build_ws, &c->b_nodes, &c->b_indices, &res, &err);
   if (e != hipSuccess) return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s (%s)", err.c_str(), hipGetErrorString(e));
-  if (!err.empty()) return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s", err.c_str());
-  HIPCHK(c, hipEventRecord(c->ev_b1, c->stream));
-  HIPCHK(c, hipEventSynchronize(c->ev_b1));
-  c->have_build_time = true;
-  float ms = 0.f;
-  HIPCHK(c, hipEventElapsedTime(&ms, c->ev_b0, c->ev_b1));
-  c->d_nodes = d_nodes;
-  c->d_indices = d_indices;
+  c->d_nodes = c->b_nodes.p;
+  c->d_indices = (uint32_t *)c->b_indices.p;
   c->num_nodes = res.num_nodes;
   c->num_indices = c->num_faces;
   c->tree_depth = res.max_depth;
   c->max_leaf_count = res.max_leaf_count;
   c->min_leaf_count = 1; // the GPU builder never emits an empty leaf
+  nrt_status fst = finish_tree<T>(c); // leaf-ordered triangles + WideNode array: part of the build
+  if (fst) return fst;
+  HIPCHK(c, hipEventRecord(c->ev_b1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev_b1));
+  c->have_build_time = true;
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev_b0, c->ev_b1));
   c->stats.max_tree_depth = res.max_depth;
   c->stats.num_leaf_nodes = res.num_leaves;
   c->stats.num_branch_nodes = res.num_branches;
   c->stats.build_secs = ms * 1e-3f;
   if (stats_out) *stats_out = c->stats;
   if (num_nodes_out) *num_nodes_out = c->num_nodes;
-  return finish_tree<T>(c);
+  return NRT_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -33,6 +33,9 @@
 //   * the partition is stable and the whole build is deterministic.
 // Hit records do not depend on tree topology, which is what
 // parity is judged on.
+#include <stddef.h>
+
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -50,6 +53,8 @@ constexpr int kTile = 2048;     // primitives per top-phase chunk (256 threads x
 constexpr int kMaxBins = 64;    // top phase: lane == bin
 constexpr int kSmallBins = 16;  // subtree phase: 3 x 15 candidates == 45 lanes
 constexpr uint32_t kMedian = 0xFFFFFFFFu;
+constexpr int kSubStack = 48;     // pending high-side children per subtree wave (LDS)
+constexpr int kSubStackSafe = 36; // above this many, splits are forced to the object median (depth <= log2 n more)
 
 enum : uint32_t { KIND_SPLIT = 0, KIND_SMALL = 1, KIND_LEAF = 2 };
 
@@ -146,15 +151,25 @@ struct BoundsAcc { // integer-ordered images: bmin[3] bmax[3] cmin[3] cmax[3]
   typename Ord<T>::U v[12];
 };
 
+constexpr int kMaxTopLevels = 120; // top-phase levels recorded for the relayout
+
+// Device-resident state of the top phase: the host launches level after level with
+// upper-bound grids and reads this back only to decide when to stop.
 struct LevelInfo {
-  uint32_t num_active;
+  uint32_t num_active;  // SPLIT nodes of the level being processed
   uint32_t num_chunks;
   uint32_t num_small;   // running count of subtree tasks (all levels)
   uint32_t max_depth;   // stats
   uint32_t num_leaves;
   uint32_t num_branches;
   uint32_t max_leaf_count;
-  uint32_t pad;
+  uint32_t error;       // 1: top array capacity exceeded
+  uint32_t cand_begin, cand_end; // top nodes created by the previous level (candidates for this one)
+  uint32_t top_count;   // top nodes allocated so far
+  uint32_t child_base;  // first top index of the children created by the level being processed
+  uint32_t top_cap;
+  uint32_t num_levels;  // levels recorded in level_begin
+  uint32_t level_begin[kMaxTopLevels + 2];
 };
 
 template <typename T>
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256) void k_prim_records(const T *__restrict__ vert
 }
 
 template <typename T>
-__global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info) {
+__global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info, uint32_t top_cap) {
   if (threadIdx.x < 12) scene->v[threadIdx.x] = (threadIdx.x % 6 < 3) ? Ord<T>::highest() : Ord<T>::lowest();
   if (threadIdx.x == 0) {
     info->num_active = 0;
@@ -252,6 +267,15 @@ __global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info) {
     info->num_leaves = 0;
     info->num_branches = 0;
     info->max_leaf_count = 0;
+    info->error = 0;
+    info->cand_begin = 0;
+    info->cand_end = 1;
+    info->top_count = 1;
+    info->child_base = 1;
+    info->top_cap = top_cap;
+    info->num_levels = 1;
+    info->level_begin[0] = 0;
+    info->level_begin[1] = 1;
   }
 }
 
@@ -298,8 +322,9 @@ __global__ void k_make_root(const BoundsAcc<T> *scene, uint32_t n, uint32_t max_
 // One block: compacts the SPLIT nodes among top[cand_begin, cand_end) into the
 // active list (in order) and assigns each its chunks.
 template <typename T>
-__global__ __launch_bounds__(1024) void k_level_setup(TopNode<T> *top, uint32_t cand_begin, uint32_t cand_end,
-                                                       uint32_t *active, uint32_t *chunk_base, LevelInfo *info) {
+__global__ __launch_bounds__(1024) void k_level_setup(TopNode<T> *top, uint32_t *active, uint32_t *chunk_base,
+                                                       LevelInfo *info) {
+  const uint32_t cand_begin = info->cand_begin, cand_end = info->cand_end;
   __shared__ uint32_t s_wave[2][16];
   __shared__ uint32_t s_carry[2];
   const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -345,8 +370,22 @@ __global__ __launch_bounds__(1024) void k_level_setup(TopNode<T> *top, uint32_t 
     __syncthreads();
   }
   if (tid == 0) {
-    info->num_active = s_carry[0];
-    info->num_chunks = s_carry[1];
+    uint32_t A = s_carry[0];
+    const uint32_t tc = info->top_count;
+    if (A && ((unsigned long long)tc + 2ull * A > info->top_cap || info->num_levels >= (uint32_t)kMaxTopLevels)) {
+      info->error = 1; // the host retries with a larger top array
+      A = 0;
+    }
+    info->num_active = A;
+    info->num_chunks = A ? s_carry[1] : 0;
+    info->child_base = tc;
+    info->cand_begin = tc;
+    info->cand_end = tc + 2 * A;
+    info->top_count = tc + 2 * A;
+    if (A) {
+      info->num_levels += 1;
+      info->level_begin[info->num_levels] = tc + 2 * A;
+    }
   }
 }
 
@@ -358,10 +397,10 @@ struct GBins { // per active node, integer-ordered, accumulated with global atom
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_init_level(GBins<T> *gbins, BoundsAcc<T> *child_acc, uint32_t num_active) {
+__global__ __launch_bounds__(256) void k_init_level(GBins<T> *gbins, BoundsAcc<T> *child_acc, const LevelInfo *info) {
   typedef typename Ord<T>::U U;
   const uint32_t a = blockIdx.x;
-  if (a >= num_active) return;
+  if (a >= info->num_active) return;
   GBins<T> *g = &gbins[a];
   for (int i = threadIdx.x; i < 3 * kMaxBins; i += 256) {
     const int k = i / kMaxBins, b = i % kMaxBins;
@@ -394,9 +433,11 @@ __device__ __forceinline__ uint32_t find_task(const uint32_t *chunk_base, uint32
 // per-bin counts kept for the stable partition's offsets.
 template <typename T>
 __global__ __launch_bounds__(256) void k_bin(const TopNode<T> *__restrict__ top, const uint32_t *__restrict__ active,
-                                             const uint32_t *__restrict__ chunk_base, uint32_t num_active,
+                                             const uint32_t *__restrict__ chunk_base, const LevelInfo *info,
                                              const PrimRec<T> *__restrict__ recs, int K, GBins<T> *gbins,
                                              uint32_t *__restrict__ chunk_hist) {
+  if (blockIdx.x >= info->num_chunks) return; // grids are upper bounds
+  const uint32_t num_active = info->num_active;
   typedef typename Ord<T>::U U;
   __shared__ uint32_t s_cnt[3][kMaxBins];
   __shared__ U s_min[3][kMaxBins][3];
@@ -465,8 +506,10 @@ template <typename T>
 __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *__restrict__ active,
                                               const GBins<T> *__restrict__ gbins, int K,
                                               const uint32_t *__restrict__ chunk_hist, uint32_t *chunk_left_base,
-                                              uint32_t next_top_base) {
+                                              const LevelInfo *info) {
   const uint32_t a = blockIdx.x;
+  if (a >= info->num_active) return;
+  const uint32_t next_top_base = info->child_base;
   const unsigned lane = threadIdx.x;
   TopNode<T> &nd = top[active[a]];
   const GBins<T> &g = gbins[a];
@@ -600,7 +643,7 @@ __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *_
 template <typename T>
 __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict__ top,
                                                    const uint32_t *__restrict__ active,
-                                                   const uint32_t *__restrict__ chunk_base, uint32_t num_active,
+                                                   const uint32_t *__restrict__ chunk_base, const LevelInfo *info,
                                                    const uint32_t *__restrict__ chunk_left_base,
                                                    const PrimRec<T> *__restrict__ src, PrimRec<T> *__restrict__ dst,
                                                    int K, BoundsAcc<T> *child_acc) {
@@ -610,6 +653,8 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
   __shared__ U s_acc[2][12];
   const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const uint32_t chunk = blockIdx.x;
+  if (chunk >= info->num_chunks) return; // grids are upper bounds
+  const uint32_t num_active = info->num_active;
   if (tid == 0) s_task = find_task(chunk_base, num_active, chunk);
   if (tid < 24) s_acc[tid / 12][tid % 12] = ((tid % 12) % 6 < 3) ? (U)Ord<T>::highest() : (U)Ord<T>::lowest();
   __syncthreads();
@@ -725,11 +770,11 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_children(TopNode<T> *top, const uint32_t *__restrict__ active,
-                                                  uint32_t num_active, const BoundsAcc<T> *__restrict__ child_acc,
+                                                  const BoundsAcc<T> *__restrict__ child_acc,
                                                   uint32_t max_depth, uint32_t dst_buf, uint32_t *small_list,
                                                   LevelInfo *info) {
   const uint32_t a = blockIdx.x * 256u + threadIdx.x;
-  if (a >= num_active) return;
+  if (a >= info->num_active) return;
   const TopNode<T> p = top[active[a]];
   for (uint32_t c = 0; c < 2; c++) {
     TopNode<T> t;
@@ -763,11 +808,20 @@ __global__ __launch_bounds__(256) void k_children(TopNode<T> *top, const uint32_
 // ---------------------------------------------------------------------------
 // subtree phase: one wave builds everything below a node of <= kSmall prims
 // ---------------------------------------------------------------------------
-struct SubStack {
-  uint16_t lo, hi, parent, depth_right; // depth_right: bit15 = is right child, low 15 bits unused
+// Pending high-side child of the per-wave subtree builder.
+template <typename T>
+struct SubPending {
+  T bmin[3], bmax[3]; // its AABB, known from the parent's bins
+  uint16_t lo, hi, parent;
+  uint16_t flags;     // bit 0: AABB is not known (median split) and must be reduced
   uint32_t depth;
 };
 
+// One wave per node of <= kSmall primitives: records in LDS, a 16-bit permutation that is
+// partitioned in place, LDS bin reduction (3 axes x K <= 16 bins, ds_min/ds_max on
+// integer-ordered keys), lane == (axis, bin) prefix/suffix sweeps inside 16-lane groups.
+// The low-side child is processed next (so it is numbered parent + 1, pre-order); the
+// high-side child waits on an LDS stack together with its AABB.
 template <typename T>
 __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t *__restrict__ small_list,
                                                 const PrimRec<T> *__restrict__ recs0,
@@ -775,11 +829,16 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
                                                 uint32_t max_depth, typename Wire<T>::Node *scratch_nodes,
                                                 uint32_t *indices, LevelInfo *info) {
   typedef typename Wire<T>::Node Node;
+  typedef typename Ord<T>::U U;
   __shared__ PrimRec<T> s_rec[kSmall];
   __shared__ uint16_t s_perm[2][kSmall];
-  __shared__ SubStack s_stack[kSmall + 2];
+  __shared__ SubPending<T> s_stack[kSubStack];
+  __shared__ uint32_t s_cnt[3][kSmallBins];
+  __shared__ U s_bmin[3][kSmallBins][3];
+  __shared__ U s_bmax[3][kSmallBins][3];
 
   const unsigned lane = threadIdx.x;
+  if (blockIdx.x >= info->num_small) return; // grid is an upper bound
   TopNode<T> &task = top[small_list[blockIdx.x]];
   const uint32_t L = task.l, n_all = task.r - task.l;
   const PrimRec<T> *src = (task.buf ? recs1 : recs0) + L;
@@ -790,49 +849,64 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
   Node *out = scratch_nodes + 2 * (size_t)L;
   uint32_t node_count = 0, leaves = 0, deepest = 0, biggest_leaf = 0;
   int sp = 0;
-  if (lane == 0) {
-    s_stack[0].lo = 0;
-    s_stack[0].hi = (uint16_t)n_all;
-    s_stack[0].parent = 0xFFFF;
-    s_stack[0].depth_right = 0;
-    s_stack[0].depth = task.depth;
+
+  // current node (wave-uniform)
+  uint32_t lo = 0, hi = n_all, depth = task.depth, parent = 0xFFFFu;
+  bool is_high = false, need_box = false;
+  T mn[3], mx[3];
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    mn[d] = task.bmin[d];
+    mx[d] = task.bmax[d];
   }
-  sp = 1;
   __syncthreads();
 
-  while (sp > 0) {
-    sp--;
-    const SubStack e = s_stack[sp];
-    const uint32_t lo = e.lo, hi = e.hi, n = hi - lo, depth = e.depth;
+  for (;;) {
+    const uint32_t n = hi - lo;
     const uint32_t me = node_count++;
     deepest = depth > deepest ? depth : deepest;
-    if (e.parent != 0xFFFF && (e.depth_right & 0x8000) && lane == 0) out[e.parent].data[1] = me;
+    if (is_high && lane == 0) out[parent].data[1] = me;
 
-    // node AABB + centroid bounds
-    T mn[3], mx[3], cmn[3], cmx[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-      mn[d] = cmn[d] = Lim<T>::max();
-      mx[d] = cmx[d] = -Lim<T>::max();
-    }
-    for (uint32_t i = lo + lane; i < hi; i += 64u) {
-      const PrimRec<T> &r = s_rec[s_perm[0][i]];
+    const bool leaf = n <= (min_leaf > 1u ? min_leaf : 1u) || depth >= max_depth; // nanort.h:1781-1783
+    // centroid bounds (and the AABB after a median split): one pass + wave reduction
+    T cmn[3], cmx[3];
+    if (!leaf || need_box) {
+      T amn[3], amx[3];
 #pragma unroll
       for (int d = 0; d < 3; d++) {
-        mn[d] = tmin(mn[d], r.bmin[d]);
-        mx[d] = tmax(mx[d], r.bmax[d]);
-        cmn[d] = tmin(cmn[d], r.c[d]);
-        cmx[d] = tmax(cmx[d], r.c[d]);
+        cmn[d] = amn[d] = Lim<T>::max();
+        cmx[d] = amx[d] = -Lim<T>::max();
+      }
+      for (uint32_t i = lo + lane; i < hi; i += 64u) {
+        const PrimRec<T> &r = s_rec[s_perm[0][i]];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          cmn[d] = tmin(cmn[d], r.c[d]);
+          cmx[d] = tmax(cmx[d], r.c[d]);
+          if (need_box) {
+            amn[d] = tmin(amn[d], r.bmin[d]);
+            amx[d] = tmax(amx[d], r.bmax[d]);
+          }
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 3; d++)
+        for (int off = 32; off > 0; off >>= 1) {
+          cmn[d] = tmin(cmn[d], __shfl_xor(cmn[d], off));
+          cmx[d] = tmax(cmx[d], __shfl_xor(cmx[d], off));
+          if (need_box) {
+            amn[d] = tmin(amn[d], __shfl_xor(amn[d], off));
+            amx[d] = tmax(amx[d], __shfl_xor(amx[d], off));
+          }
+        }
+      if (need_box) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          mn[d] = amn[d];
+          mx[d] = amx[d];
+        }
       }
     }
-#pragma unroll
-    for (int d = 0; d < 3; d++)
-      for (int off = 32; off > 0; off >>= 1) {
-        mn[d] = tmin(mn[d], __shfl_xor(mn[d], off));
-        mx[d] = tmax(mx[d], __shfl_xor(mx[d], off));
-        cmn[d] = tmin(cmn[d], __shfl_xor(cmn[d], off));
-        cmx[d] = tmax(cmx[d], __shfl_xor(cmx[d], off));
-      }
 
     Node nd;
 #pragma unroll
@@ -841,7 +915,8 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
       nd.bmax[d] = mx[d];
     }
 
-    if (n <= (min_leaf > 1u ? min_leaf : 1u) || depth >= max_depth) { // leaf rule: nanort.h:1781-1783 (a 1-prim node cannot split)
+    bool descend = false;
+    if (leaf) {
       nd.flag = 1;
       nd.axis = 0;
       nd.data[0] = n;
@@ -850,113 +925,217 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
       for (uint32_t i = lo + lane; i < hi; i += 64u) indices[L + i] = s_rec[s_perm[0][i]].prim;
       leaves++;
       biggest_leaf = n > biggest_leaf ? n : biggest_leaf;
-      continue;
-    }
-
-    // lane == candidate (axis ca, split s in 1..K-1): sweep all primitives
-    const int ncand = 3 * (K - 1);
-    const int ca = (int)lane / (K - 1), cs = (int)lane % (K - 1) + 1;
-    T cost = Lim<T>::inf();
-    uint32_t nl = 0;
-    if ((int)lane < ncand) {
-      const T clo = ca == 0 ? cmn[0] : (ca == 1 ? cmn[1] : cmn[2]);
-      const T chi = ca == 0 ? cmx[0] : (ca == 1 ? cmx[1] : cmx[2]);
-      const T sc = bin_scale<T>(clo, chi, K);
-      T lmn[3], lmx[3], rmn[3], rmx[3];
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        lmn[d] = rmn[d] = Lim<T>::max();
-        lmx[d] = rmx[d] = -Lim<T>::max();
-      }
-      for (uint32_t i = lo; i < hi; i++) {
-        const PrimRec<T> &r = s_rec[s_perm[0][i]];
-        const T c = ca == 0 ? r.c[0] : (ca == 1 ? r.c[1] : r.c[2]);
-        const bool left = bin_of<T>(c, clo, sc, K) < cs;
-        nl += left ? 1u : 0u;
+    } else {
+      // ---- LDS bin reduction ------------------------------------------------------------------
+      for (int i = lane; i < 3 * kSmallBins; i += 64) {
+        const int k = i / kSmallBins, b = i % kSmallBins;
+        s_cnt[k][b] = 0;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          const T b0 = r.bmin[d], b1 = r.bmax[d];
-          lmn[d] = left ? tmin(lmn[d], b0) : lmn[d];
-          lmx[d] = left ? tmax(lmx[d], b1) : lmx[d];
-          rmn[d] = left ? rmn[d] : tmin(rmn[d], b0);
-          rmx[d] = left ? rmx[d] : tmax(rmx[d], b1);
+          s_bmin[k][b][d] = Ord<T>::highest();
+          s_bmax[k][b][d] = Ord<T>::lowest();
         }
       }
-      if (nl > 0 && nl < n) cost = T(nl) * half_area<T>(lmn, lmx) + T(n - nl) * half_area<T>(rmn, rmx);
-    }
-    T bc = cost;
-    unsigned who = lane; // candidate order == (axis, bin): ties -> lowest axis, then lowest bin
-    for (int off = 32; off > 0; off >>= 1) {
-      const T oc = __shfl_xor(bc, off);
-      const unsigned ow = __shfl_xor(who, off);
-      if (oc < bc || (oc == bc && ow < who)) {
-        bc = oc;
-        who = ow;
-      }
-    }
-    int axis = 0;
-    uint32_t split_bin = kMedian, nleft = n >> 1;
-    if (bc < Lim<T>::inf()) {
-      axis = (int)who / (K - 1);
-      split_bin = who % (K - 1) + 1;
-      nleft = __shfl(nl, who);
-    }
-
-    // stable partition of s_perm[0][lo, hi) through s_perm[1]
-    {
-      const T clo = axis == 0 ? cmn[0] : (axis == 1 ? cmn[1] : cmn[2]);
-      const T chi = axis == 0 ? cmx[0] : (axis == 1 ? cmx[1] : cmx[2]);
-      const T sc = bin_scale<T>(clo, chi, K);
-      uint32_t run_l = 0, run_r = 0;
-      for (uint32_t i0 = lo; i0 < hi; i0 += 64u) {
-        const uint32_t i = i0 + lane;
-        const bool valid = i < hi;
-        uint16_t id = 0;
-        bool left = false;
-        if (valid) {
-          id = s_perm[0][i];
-          if (split_bin == kMedian) {
-            left = (i - lo) < nleft;
-          } else {
-            const PrimRec<T> &r = s_rec[id];
-            const T c = axis == 0 ? r.c[0] : (axis == 1 ? r.c[1] : r.c[2]);
-            left = (uint32_t)bin_of<T>(c, clo, sc, K) < split_bin;
+      T sc[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) sc[k] = bin_scale<T>(cmn[k], cmx[k], K);
+      __syncthreads();
+      for (uint32_t i = lo + lane; i < hi; i += 64u) {
+        const PrimRec<T> &r = s_rec[s_perm[0][i]];
+        U emin[3], emax[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          emin[d] = Ord<T>::enc(r.bmin[d]);
+          emax[d] = Ord<T>::enc(r.bmax[d]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int b = bin_of<T>(r.c[k], cmn[k], sc[k], K);
+          atomicAdd(&s_cnt[k][b], 1u);
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            atomicMin(&s_bmin[k][b][d], emin[d]);
+            atomicMax(&s_bmax[k][b][d], emax[d]);
           }
         }
-        const unsigned long long bl = __ballot(valid && left), br = __ballot(valid && !left);
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        if (valid) {
-          const uint32_t d = left ? lo + run_l + (uint32_t)__builtin_popcountll(bl & lt)
-                                  : lo + nleft + run_r + (uint32_t)__builtin_popcountll(br & lt);
-          s_perm[1][d] = id;
-        }
-        run_l += (uint32_t)__builtin_popcountll(bl);
-        run_r += (uint32_t)__builtin_popcountll(br);
       }
       __syncthreads();
-      for (uint32_t i = lo + lane; i < hi; i += 64u) s_perm[0][i] = s_perm[1][i];
-    }
 
-    nd.flag = 0;
-    nd.axis = axis;
-    nd.data[0] = me + 1; // low-side child follows its parent (pre-order)
-    nd.data[1] = 0;      // patched when the high-side child is emitted
-    if (lane == 0) {
-      out[me] = nd;
-      // push high side first so the low side is processed (and numbered) next
-      s_stack[sp].lo = (uint16_t)(lo + nleft);
-      s_stack[sp].hi = (uint16_t)hi;
-      s_stack[sp].parent = (uint16_t)me;
-      s_stack[sp].depth_right = 0x8000;
-      s_stack[sp].depth = depth + 1;
-      s_stack[sp + 1].lo = (uint16_t)lo;
-      s_stack[sp + 1].hi = (uint16_t)(lo + nleft);
-      s_stack[sp + 1].parent = (uint16_t)me;
-      s_stack[sp + 1].depth_right = 0;
-      s_stack[sp + 1].depth = depth + 1;
+      // ---- lane == (axis, bin): sweeps inside 16-lane groups ----------------------------------------
+      const int ax = (int)lane >> 4, bn = (int)lane & 15;
+      uint32_t cnt = 0;
+      T bmn[3], bmx[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        bmn[d] = Lim<T>::max();
+        bmx[d] = -Lim<T>::max();
+      }
+      if (ax < 3 && bn < K) {
+        cnt = s_cnt[ax][bn];
+        if (cnt) {
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            bmn[d] = Ord<T>::dec(s_bmin[ax][bn][d]);
+            bmx[d] = Ord<T>::dec(s_bmax[ax][bn][d]);
+          }
+        }
+      }
+      uint32_t pc = cnt, sc_n = cnt; // inclusive prefix / suffix inside the 16-lane group
+      T pmn[3] = {bmn[0], bmn[1], bmn[2]}, pmx[3] = {bmx[0], bmx[1], bmx[2]};
+      T smn[3] = {bmn[0], bmn[1], bmn[2]}, smx[3] = {bmx[0], bmx[1], bmx[2]};
+      for (int off = 1; off < 16; off <<= 1) {
+        const uint32_t tc = __shfl_up(pc, off, 16), uc = __shfl_down(sc_n, off, 16);
+        T t0[3], t1[3], u0[3], u1[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          t0[d] = __shfl_up(pmn[d], off, 16);
+          t1[d] = __shfl_up(pmx[d], off, 16);
+          u0[d] = __shfl_down(smn[d], off, 16);
+          u1[d] = __shfl_down(smx[d], off, 16);
+        }
+        if (bn >= off) {
+          pc += tc;
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            pmn[d] = tmin(pmn[d], t0[d]);
+            pmx[d] = tmax(pmx[d], t1[d]);
+          }
+        }
+        if (bn + off < 16) {
+          sc_n += uc;
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            smn[d] = tmin(smn[d], u0[d]);
+            smx[d] = tmax(smx[d], u1[d]);
+          }
+        }
+      }
+      // candidate (ax, s = bn), s in 1..K-1: low side = bins [0, s), high side = bins [s, K)
+      const uint32_t nl = __shfl_up(pc, 1, 16);
+      T lmn[3], lmx[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        lmn[d] = __shfl_up(pmn[d], 1, 16);
+        lmx[d] = __shfl_up(pmx[d], 1, 16);
+      }
+      T cost = Lim<T>::inf();
+      if (ax < 3 && bn >= 1 && bn < K && nl > 0 && sc_n > 0)
+        cost = T(nl) * half_area<T>(lmn, lmx) + T(sc_n) * half_area<T>(smn, smx);
+      T bc = cost;
+      unsigned who = lane; // lane order == (axis, bin): ties -> lowest axis, then lowest bin
+      for (int off = 32; off > 0; off >>= 1) {
+        const T oc = __shfl_xor(bc, off);
+        const unsigned ow = __shfl_xor(who, off);
+        if (oc < bc || (oc == bc && ow < who)) {
+          bc = oc;
+          who = ow;
+        }
+      }
+      int axis = 0;
+      uint32_t split_bin = kMedian, nleft = n >> 1;
+      T cl[3], ch[3], rl[3], rh[3]; // children AABBs (valid unless median)
+      // a pathological chain of lopsided SAH splits could outgrow the LDS stack: past kSubStackSafe
+      // pending nodes fall back to balanced object-median splits (at most log2(kSmall) more levels)
+      if (bc < Lim<T>::inf() && sp < kSubStackSafe) {
+        axis = (int)who >> 4;
+        split_bin = who & 15u;
+        nleft = __shfl(nl, who);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          cl[d] = __shfl(lmn[d], who);
+          ch[d] = __shfl(lmx[d], who);
+          rl[d] = __shfl(smn[d], who);
+          rh[d] = __shfl(smx[d], who);
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < 3; d++) cl[d] = ch[d] = rl[d] = rh[d] = T(0);
+      }
+      const bool median = split_bin == kMedian;
+
+      // ---- stable partition of s_perm[0][lo, hi) through s_perm[1] -----------------------------------
+      {
+        const T clo = axis == 0 ? cmn[0] : (axis == 1 ? cmn[1] : cmn[2]);
+        const T scl = axis == 0 ? sc[0] : (axis == 1 ? sc[1] : sc[2]);
+        uint32_t run_l = 0, run_r = 0;
+        for (uint32_t i0 = lo; i0 < hi; i0 += 64u) {
+          const uint32_t i = i0 + lane;
+          const bool valid = i < hi;
+          uint16_t id = 0;
+          bool left = false;
+          if (valid) {
+            id = s_perm[0][i];
+            if (median) {
+              left = (i - lo) < nleft;
+            } else {
+              const PrimRec<T> &r = s_rec[id];
+              const T c = axis == 0 ? r.c[0] : (axis == 1 ? r.c[1] : r.c[2]);
+              left = (uint32_t)bin_of<T>(c, clo, scl, K) < split_bin;
+            }
+          }
+          const unsigned long long bl = __ballot(valid && left), br = __ballot(valid && !left);
+          const unsigned long long lt = (1ull << lane) - 1ull;
+          if (valid) {
+            const uint32_t d = left ? lo + run_l + (uint32_t)__builtin_popcountll(bl & lt)
+                                    : lo + nleft + run_r + (uint32_t)__builtin_popcountll(br & lt);
+            s_perm[1][d] = id;
+          }
+          run_l += (uint32_t)__builtin_popcountll(bl);
+          run_r += (uint32_t)__builtin_popcountll(br);
+        }
+        __syncthreads();
+        for (uint32_t i = lo + lane; i < hi; i += 64u) s_perm[0][i] = s_perm[1][i];
+      }
+
+      nd.flag = 0;
+      nd.axis = axis;
+      nd.data[0] = me + 1; // low-side child follows its parent (pre-order)
+      nd.data[1] = 0;      // patched when the high-side child is emitted
+      if (lane == 0) {
+        out[me] = nd;
+        SubPending<T> &e = s_stack[sp];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          e.bmin[d] = rl[d];
+          e.bmax[d] = rh[d];
+        }
+        e.lo = (uint16_t)(lo + nleft);
+        e.hi = (uint16_t)hi;
+        e.parent = (uint16_t)me;
+        e.flags = median ? 1 : 0;
+        e.depth = depth + 1;
+      }
+      sp++;
+      // continue with the low side
+      hi = lo + nleft;
+      depth = depth + 1;
+      parent = me;
+      is_high = false;
+      need_box = median;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        mn[d] = cl[d];
+        mx[d] = ch[d];
+      }
+      descend = true;
+      __syncthreads();
     }
-    sp += 2;
-    __syncthreads();
+    if (!descend) {
+      if (sp == 0) break;
+      sp--;
+      const SubPending<T> &e = s_stack[sp];
+      lo = e.lo;
+      hi = e.hi;
+      depth = e.depth;
+      parent = e.parent;
+      is_high = true;
+      need_box = (e.flags & 1) != 0;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        mn[d] = e.bmin[d];
+        mx[d] = e.bmax[d];
+      }
+    }
   }
   if (lane == 0) {
     task.size = node_count;
@@ -972,8 +1151,9 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
 // small top array), then emission / splice
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, const uint32_t *__restrict__ level_begin,
-                                                  int num_levels, LevelInfo *info) {
+__global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, LevelInfo *info) {
+  const uint32_t *level_begin = info->level_begin;
+  const int num_levels = (int)info->num_levels;
   // level_begin[0..num_levels]: top nodes of level L are [level_begin[L], level_begin[L+1])
   for (int L = num_levels - 1; L >= 0; L--) {
     for (uint32_t i = level_begin[L] + threadIdx.x; i < level_begin[L + 1]; i += 1024u) {
@@ -1012,12 +1192,12 @@ __global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, const uint32_t
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_emit_top(const TopNode<T> *__restrict__ top, uint32_t num_top,
+__global__ __launch_bounds__(256) void k_emit_top(const TopNode<T> *__restrict__ top, const LevelInfo *info,
                                                   const PrimRec<T> *__restrict__ recs0,
                                                   const PrimRec<T> *__restrict__ recs1,
                                                   typename Wire<T>::Node *nodes, uint32_t *indices) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= num_top) return;
+  if (i >= info->top_count) return;
   const TopNode<T> &t = top[i];
   if (t.kind == KIND_SMALL) return;
   typename Wire<T>::Node nd;
@@ -1048,7 +1228,8 @@ template <typename T>
 __global__ __launch_bounds__(64) void k_emit_small(const TopNode<T> *__restrict__ top,
                                                    const uint32_t *__restrict__ small_list,
                                                    const typename Wire<T>::Node *__restrict__ scratch_nodes,
-                                                   typename Wire<T>::Node *nodes) {
+                                                   typename Wire<T>::Node *nodes, const LevelInfo *info) {
+  if (blockIdx.x >= info->num_small) return;
   const TopNode<T> &t = top[small_list[blockIdx.x]];
   const typename Wire<T>::Node *src = scratch_nodes + 2 * (size_t)t.l;
   for (uint32_t i = threadIdx.x; i < t.size; i += 64u) {
@@ -1064,179 +1245,155 @@ __global__ __launch_bounds__(64) void k_emit_small(const TopNode<T> *__restrict_
 // ---------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------
-#define BCHK(call)                                                                          \
-  do {                                                                                      \
-    hipError_t e_ = (call);                                                                 \
-    if (e_ != hipSuccess) {                                                                 \
-      *err = std::string(#call) + ": " + hipGetErrorString(e_);                             \
-      cleanup();                                                                            \
-      return e_;                                                                            \
-    }                                                                                       \
-  } while (0)
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 template <typename T>
-hipError_t gpu_build(int device, hipStream_t s, const T *d_verts, const uint32_t *d_faces, uint32_t n,
-                     uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, typename Wire<T>::Node **d_nodes_out,
-                     uint32_t **d_indices_out, BuildResult *res, std::string *err) {
+struct BuildPlan { // carve-up of the build workspace for n primitives
+  size_t max_top, max_active, max_chunks;
+  size_t off_recs0, off_recs1, off_scratch, off_top, off_child_acc, off_active, off_chunk_base, off_gbins,
+      off_chunk_hist, off_chunk_left, off_small, off_scene, off_info, total;
+  BuildPlan(uint32_t n, size_t top_scale) {
+    typedef typename Wire<T>::Node Node;
+    max_active = (size_t)n / kSmall + 2;
+    max_chunks = (size_t)n / kTile + max_active + 1;
+    max_top = top_scale * (4 * ((size_t)n / kSmall + 1) + 64);
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+      const size_t at = o;
+      o = align_up(o + bytes, 256);
+      return at;
+    };
+    off_recs0 = take((size_t)n * sizeof(PrimRec<T>));
+    off_recs1 = take((size_t)n * sizeof(PrimRec<T>));
+    off_scratch = take(2 * (size_t)n * sizeof(Node));
+    off_top = take(max_top * sizeof(TopNode<T>));
+    off_child_acc = take(2 * max_active * sizeof(BoundsAcc<T>));
+    off_active = take(max_active * sizeof(uint32_t));
+    off_chunk_base = take(max_active * sizeof(uint32_t));
+    off_gbins = take(max_active * sizeof(GBins<T>));
+    off_chunk_hist = take(max_chunks * 3 * kMaxBins * sizeof(uint32_t));
+    off_chunk_left = take(max_chunks * sizeof(uint32_t));
+    off_small = take((max_top + 1) * sizeof(uint32_t));
+    off_scene = take(sizeof(BoundsAcc<T>));
+    off_info = take(sizeof(LevelInfo));
+    total = o;
+  }
+};
+
+#define BCHK(call)                                                      \
+  do {                                                                  \
+    hipError_t e_ = (call);                                             \
+    if (e_ != hipSuccess) {                                             \
+      *err = std::string(#call) + ": " + hipGetErrorString(e_);         \
+      return e_;                                                        \
+    }                                                                   \
+  } while (0)
+
+// Builds into caller-owned grow-only buffers (no allocation in the steady state of a
+// per-frame rebuild).  Host synchronisations: one or two to learn that the top phase has
+// run out of large nodes, one to size the node array.
+template <typename T>
+hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, uint32_t n, uint32_t min_leaf,
+                     uint32_t max_depth, uint32_t bin_size, DevBuf *workspace, DevBuf *nodes_buf, DevBuf *indices_buf,
+                     BuildResult *res, std::string *err) {
   typedef typename Wire<T>::Node Node;
-  (void)device;
   const int K = (int)(bin_size < 2 ? 2 : (bin_size > (uint32_t)kMaxBins ? (uint32_t)kMaxBins : bin_size));
   const int Ks = K < kSmallBins ? K : kSmallBins;
 
-  PrimRec<T> *recs[2] = {nullptr, nullptr};
-  TopNode<T> *top = nullptr;
-  BoundsAcc<T> *scene = nullptr, *child_acc = nullptr;
-  LevelInfo *info = nullptr;
-  uint32_t *active = nullptr, *chunk_base = nullptr, *chunk_hist = nullptr, *chunk_left = nullptr,
-           *small_list = nullptr, *level_begin_d = nullptr, *indices = nullptr;
-  GBins<T> *gbins = nullptr;
-  Node *scratch = nullptr, *nodes = nullptr;
-  size_t gbins_cap = 0, chunk_cap = 0;
+  for (size_t top_scale = 1;; top_scale *= 8) {
+    const BuildPlan<T> plan(n, top_scale);
+    BCHK(devbuf_ensure(workspace, plan.total));
+    BCHK(devbuf_ensure(indices_buf, (size_t)n * sizeof(uint32_t)));
+    char *base = (char *)workspace->p;
+    PrimRec<T> *recs[2] = {(PrimRec<T> *)(base + plan.off_recs0), (PrimRec<T> *)(base + plan.off_recs1)};
+    Node *scratch = (Node *)(base + plan.off_scratch);
+    TopNode<T> *top = (TopNode<T> *)(base + plan.off_top);
+    BoundsAcc<T> *child_acc = (BoundsAcc<T> *)(base + plan.off_child_acc);
+    uint32_t *active = (uint32_t *)(base + plan.off_active);
+    uint32_t *chunk_base = (uint32_t *)(base + plan.off_chunk_base);
+    GBins<T> *gbins = (GBins<T> *)(base + plan.off_gbins);
+    uint32_t *chunk_hist = (uint32_t *)(base + plan.off_chunk_hist);
+    uint32_t *chunk_left = (uint32_t *)(base + plan.off_chunk_left);
+    uint32_t *small_list = (uint32_t *)(base + plan.off_small);
+    BoundsAcc<T> *scene = (BoundsAcc<T> *)(base + plan.off_scene);
+    LevelInfo *info = (LevelInfo *)(base + plan.off_info);
+    uint32_t *indices = (uint32_t *)indices_buf->p;
 
-  bool success = false;
-  auto cleanup = [&]() {
-    void *ptrs[] = {recs[0], recs[1], top, scene, child_acc, info, active, chunk_base, chunk_hist,
-                    chunk_left, small_list, level_begin_d, gbins, scratch};
-    for (void *p : ptrs)
-      if (p) (void)hipFree(p);
-    if (!success) {
-      if (nodes) (void)hipFree(nodes);
-      if (indices) (void)hipFree(indices);
+    hipLaunchKernelGGL((k_init_scene<T>), dim3(1), dim3(64), 0, s, scene, info, (uint32_t)plan.max_top);
+    {
+      unsigned grid = (unsigned)std::min<size_t>(((size_t)n + 255) / 256, 2048);
+      hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, n, recs[0], scene);
     }
-  };
-
-  size_t max_top = 4 * ((size_t)n / kSmall + 1) + 64; // grows on demand (unbalanced SAH splits)
-  const size_t max_active = (size_t)n / kSmall + 2;
-  BCHK(hipMalloc((void **)&recs[0], (size_t)n * sizeof(PrimRec<T>)));
-  BCHK(hipMalloc((void **)&recs[1], (size_t)n * sizeof(PrimRec<T>)));
-  BCHK(hipMalloc((void **)&top, max_top * sizeof(TopNode<T>)));
-  BCHK(hipMalloc((void **)&scene, sizeof(BoundsAcc<T>)));
-  BCHK(hipMalloc((void **)&child_acc, 2 * max_active * sizeof(BoundsAcc<T>)));
-  BCHK(hipMalloc((void **)&info, sizeof(LevelInfo)));
-  BCHK(hipMalloc((void **)&active, max_active * sizeof(uint32_t)));
-  BCHK(hipMalloc((void **)&chunk_base, max_active * sizeof(uint32_t)));
-  BCHK(hipMalloc((void **)&small_list, (max_top + 1) * sizeof(uint32_t)));
-  BCHK(hipMalloc((void **)&indices, (size_t)n * sizeof(uint32_t)));
-  BCHK(hipMalloc((void **)&scratch, 2 * (size_t)n * sizeof(Node)));
-
-  hipLaunchKernelGGL((k_init_scene<T>), dim3(1), dim3(64), 0, s, scene, info);
-  {
-    unsigned grid = (unsigned)std::min<size_t>(((size_t)n + 255) / 256, 2048);
-    hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, n, recs[0], scene);
-  }
-  hipLaunchKernelGGL((k_make_root<T>), dim3(1), dim3(64), 0, s, scene, n, max_depth, top, small_list, info);
-  BCHK(hipGetLastError());
-
-  // ---- top phase ----
-  std::vector<uint32_t> level_begin;
-  level_begin.push_back(0);
-  level_begin.push_back(1);
-  uint32_t cand_begin = 0, cand_end = 1, top_count = 1;
-  int cur = 0; // buffer holding the ranges of the nodes being split
-  LevelInfo h;
-  for (;;) {
-    hipLaunchKernelGGL((k_level_setup<T>), dim3(1), dim3(1024), 0, s, top, cand_begin, cand_end, active, chunk_base,
-                       info);
+    hipLaunchKernelGGL((k_make_root<T>), dim3(1), dim3(64), 0, s, scene, n, max_depth, top, small_list, info);
     BCHK(hipGetLastError());
-    BCHK(hipMemcpyAsync(&h, info, sizeof(h), hipMemcpyDeviceToHost, s));
+
+    // ---- top phase: level after level, grids sized by upper bounds ----------------------------
+    LevelInfo h;
+    int cur = 0; // buffer holding the ranges of the nodes being split
+    int expect = 0;
+    for (size_t m = (size_t)n / kSmall; m > 0; m >>= 1) expect++;
+    int next_check = (n <= (uint32_t)kSmall) ? 0 : expect + 2;
+    bool overflow = false;
+    for (int level = 0;; level++) {
+      hipLaunchKernelGGL((k_level_setup<T>), dim3(1), dim3(1024), 0, s, top, active, chunk_base, info);
+      if (level >= next_check) {
+        BCHK(hipMemcpyAsync(&h, info, offsetof(LevelInfo, level_begin), hipMemcpyDeviceToHost, s));
+        BCHK(hipStreamSynchronize(s));
+        if (h.error) {
+          overflow = true;
+          break;
+        }
+        if (h.num_active == 0) break;
+        next_check = level + 3;
+      }
+      const size_t a_max = level < 31 ? std::min<size_t>((size_t)1 << level, plan.max_active) : plan.max_active;
+      const size_t c_max = std::min<size_t>((size_t)n / kTile + a_max + 1, plan.max_chunks);
+      hipLaunchKernelGGL((k_init_level<T>), dim3((unsigned)a_max), dim3(256), 0, s, gbins, child_acc, info);
+      hipLaunchKernelGGL((k_bin<T>), dim3((unsigned)c_max), dim3(256), 0, s, top, active, chunk_base, info, recs[cur],
+                         K, gbins, chunk_hist);
+      hipLaunchKernelGGL((k_split<T>), dim3((unsigned)a_max), dim3(64), 0, s, top, active, gbins, K, chunk_hist,
+                         chunk_left, info);
+      hipLaunchKernelGGL((k_partition<T>), dim3((unsigned)c_max), dim3(256), 0, s, top, active, chunk_base, info,
+                         chunk_left, recs[cur], recs[1 - cur], K, child_acc);
+      hipLaunchKernelGGL((k_children<T>), dim3((unsigned)((a_max + 255) / 256)), dim3(256), 0, s, top, active,
+                         child_acc, max_depth, (uint32_t)(1 - cur), small_list, info);
+      BCHK(hipGetLastError());
+      cur = 1 - cur;
+    }
+    if (overflow) continue; // lopsided splits outgrew the top array: retry with a larger one
+
+    // ---- subtree phase + relayout ----------------------------------------------------------------
+    const uint32_t num_small = h.num_small;
+    if (num_small) {
+      hipLaunchKernelGGL((k_subtree<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
+                         min_leaf, max_depth, scratch, indices, info);
+    }
+    hipLaunchKernelGGL((k_layout<T>), dim3(1), dim3(1024), 0, s, top, info);
+    BCHK(hipGetLastError());
+    TopNode<T> root;
+    BCHK(hipMemcpyAsync(&root, top, sizeof(root), hipMemcpyDeviceToHost, s));
+    BCHK(hipMemcpyAsync(&h, info, offsetof(LevelInfo, level_begin), hipMemcpyDeviceToHost, s));
     BCHK(hipStreamSynchronize(s));
-    const uint32_t A = h.num_active, C = h.num_chunks;
-    if (A == 0) break;
-    if (A > max_active) {
-      *err = "internal: top-phase capacity exceeded";
-      cleanup();
-      return hipErrorUnknown;
-    }
-    if (top_count + 2 * (size_t)A > max_top) { // grow the top array and the task list, keeping contents
-      const size_t new_cap = 2 * (top_count + 2 * (size_t)A) + 64;
-      TopNode<T> *ntop = nullptr;
-      uint32_t *nsmall = nullptr;
-      BCHK(hipMalloc((void **)&ntop, new_cap * sizeof(TopNode<T>)));
-      BCHK(hipMemcpyAsync(ntop, top, top_count * sizeof(TopNode<T>), hipMemcpyDeviceToDevice, s));
-      BCHK(hipMalloc((void **)&nsmall, (new_cap + 1) * sizeof(uint32_t)));
-      BCHK(hipMemcpyAsync(nsmall, small_list, (max_top + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-      BCHK(hipStreamSynchronize(s));
-      (void)hipFree(top);
-      (void)hipFree(small_list);
-      top = ntop;
-      small_list = nsmall;
-      max_top = new_cap;
-    }
-    if (A > gbins_cap) {
-      if (gbins) BCHK(hipFree(gbins));
-      gbins = nullptr;
-      gbins_cap = (size_t)A + A / 2 + 16;
-      BCHK(hipMalloc((void **)&gbins, gbins_cap * sizeof(GBins<T>)));
-    }
-    if (C > chunk_cap) {
-      if (chunk_hist) BCHK(hipFree(chunk_hist));
-      if (chunk_left) BCHK(hipFree(chunk_left));
-      chunk_hist = chunk_left = nullptr;
-      chunk_cap = (size_t)C + C / 2 + 16;
-      BCHK(hipMalloc((void **)&chunk_hist, chunk_cap * 3 * kMaxBins * sizeof(uint32_t)));
-      BCHK(hipMalloc((void **)&chunk_left, chunk_cap * sizeof(uint32_t)));
-    }
-    hipLaunchKernelGGL((k_init_level<T>), dim3(A), dim3(256), 0, s, gbins, child_acc, A);
-    hipLaunchKernelGGL((k_bin<T>), dim3(C), dim3(256), 0, s, top, active, chunk_base, A, recs[cur], K, gbins,
-                       chunk_hist);
-    hipLaunchKernelGGL((k_split<T>), dim3(A), dim3(64), 0, s, top, active, gbins, K, chunk_hist, chunk_left,
-                       top_count);
-    hipLaunchKernelGGL((k_partition<T>), dim3(C), dim3(256), 0, s, top, active, chunk_base, A, chunk_left,
-                       recs[cur], recs[1 - cur], K, child_acc);
-    hipLaunchKernelGGL((k_children<T>), dim3((A + 255) / 256), dim3(256), 0, s, top, active, A, child_acc,
-                       max_depth, (uint32_t)(1 - cur), small_list, info);
+    const uint64_t num_nodes = root.size;
+    BCHK(devbuf_ensure(nodes_buf, num_nodes * sizeof(Node)));
+    Node *nodes = (Node *)nodes_buf->p;
+    hipLaunchKernelGGL((k_emit_top<T>), dim3((h.top_count + 255) / 256), dim3(256), 0, s, top, info, recs[0], recs[1],
+                       nodes, indices);
+    if (num_small)
+      hipLaunchKernelGGL((k_emit_small<T>), dim3(num_small), dim3(64), 0, s, top, small_list, scratch, nodes, info);
     BCHK(hipGetLastError());
-    cand_begin = top_count;
-    cand_end = top_count + 2 * A;
-    top_count = cand_end;
-    level_begin.push_back(top_count);
-    cur = 1 - cur;
+    res->num_nodes = num_nodes;
+    res->max_depth = h.max_depth;
+    res->num_leaves = h.num_leaves;
+    res->num_branches = h.num_branches;
+    res->max_leaf_count = h.max_leaf_count;
+    return hipSuccess;
   }
-  // level_begin currently has one entry more than levels created only if the loop added it; normalise
-  const int num_levels = (int)level_begin.size() - 1;
-
-  // ---- subtree phase ----
-  const uint32_t num_small = h.num_small;
-  if (num_small) {
-    hipLaunchKernelGGL((k_subtree<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
-                       min_leaf, max_depth, scratch, indices, info);
-    BCHK(hipGetLastError());
-  }
-
-  // ---- relayout ----
-  BCHK(hipMalloc((void **)&level_begin_d, level_begin.size() * sizeof(uint32_t)));
-  BCHK(hipMemcpyAsync(level_begin_d, level_begin.data(), level_begin.size() * sizeof(uint32_t),
-                      hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL((k_layout<T>), dim3(1), dim3(1024), 0, s, top, level_begin_d, num_levels, info);
-  BCHK(hipGetLastError());
-  TopNode<T> root;
-  BCHK(hipMemcpyAsync(&root, top, sizeof(root), hipMemcpyDeviceToHost, s));
-  BCHK(hipMemcpyAsync(&h, info, sizeof(h), hipMemcpyDeviceToHost, s));
-  BCHK(hipStreamSynchronize(s));
-  const uint64_t num_nodes = root.size;
-  BCHK(hipMalloc((void **)&nodes, num_nodes * sizeof(Node)));
-  hipLaunchKernelGGL((k_emit_top<T>), dim3((top_count + 255) / 256), dim3(256), 0, s, top, top_count, recs[0],
-                     recs[1], nodes, indices);
-  if (num_small)
-    hipLaunchKernelGGL((k_emit_small<T>), dim3(num_small), dim3(64), 0, s, top, small_list, scratch, nodes);
-  BCHK(hipGetLastError());
-  BCHK(hipStreamSynchronize(s));
-  success = true;
-  res->num_nodes = num_nodes;
-  res->max_depth = h.max_depth;
-  res->num_leaves = h.num_leaves;
-  res->num_branches = h.num_branches;
-  res->max_leaf_count = h.max_leaf_count;
-  *d_nodes_out = nodes;
-  *d_indices_out = indices;
-  cleanup();
-  return hipSuccess;
 }
 
-template hipError_t gpu_build<float>(int, hipStream_t, const float *, const uint32_t *, uint32_t, uint32_t, uint32_t,
-                                     uint32_t, nrt_node_f32 **, uint32_t **, BuildResult *, std::string *);
-template hipError_t gpu_build<double>(int, hipStream_t, const double *, const uint32_t *, uint32_t, uint32_t,
-                                      uint32_t, uint32_t, nrt_node_f64 **, uint32_t **, BuildResult *,
-                                      std::string *);
+template hipError_t gpu_build<float>(hipStream_t, const float *, const uint32_t *, uint32_t, uint32_t, uint32_t,
+                                     uint32_t, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
+template hipError_t gpu_build<double>(hipStream_t, const double *, const uint32_t *, uint32_t, uint32_t, uint32_t,
+                                      uint32_t, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
 
 } // namespace nrt

@@ -7,6 +7,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/nanort_hip.h"
@@ -19,6 +20,29 @@ constexpr int kLdsStackDefault = 32; // per-lane stack entries kept in LDS (32 -
 constexpr unsigned kInvalid = 0xFFFFFFFFu;
 constexpr unsigned kCursorStrideWords = 1024; // per-partition work cursors 4 KiB apart (separate memory channels)
 constexpr unsigned kMaxParts = 16;
+
+// Grow-only device buffer owned by a context.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+inline hipError_t devbuf_ensure(DevBuf *b, size_t bytes) {
+  if (bytes <= b->cap) return hipSuccess;
+  if (b->p) {
+    hipError_t e = hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+    if (e != hipSuccess) return e;
+  }
+  const size_t want = bytes + bytes / 4 + 256;
+  hipError_t e = hipMalloc(&b->p, want);
+  if (e != hipSuccess) {
+    b->p = nullptr;
+    return e;
+  }
+  b->cap = want;
+  return hipSuccess;
+}
 
 template <typename T>
 struct Wire;
