@@ -149,7 +149,7 @@ class Reference:
                 getattr(L, "ref_create_" + s).argtypes = [vp, sz, vp, u32]
                 getattr(L, "ref_create_" + s).restype = vp
                 getattr(L, "ref_destroy_" + s).argtypes = [vp]
-                getattr(L, "ref_build_" + s).argtypes = [vp, vp, vp]
+                getattr(L, "ref_build_" + s).argtypes = [vp, vp, vp, ctypes.c_int]
                 getattr(L, "ref_build_" + s).restype = ctypes.c_int
                 getattr(L, "ref_num_nodes_" + s).argtypes = [vp]
                 getattr(L, "ref_num_nodes_" + s).restype = u64
@@ -181,13 +181,13 @@ class Reference:
         except Exception:
             pass
 
-    def build(self, parallel=False, min_leaf=4, max_depth=256, bin_size=64, cache_bbox=False):
+    def build(self, parallel=False, min_leaf=4, max_depth=256, bin_size=64, cache_bbox=False, threads=0):
         """Reference Build(). parallel=False forces the serial arm (nanort.h:2129)."""
         o = _ShimBuildOptions(
             min_leaf, max_depth, bin_size, 4, (1024 * 8) if parallel else 0xFFFFFFFF, 1 if cache_bbox else 0
         )
         st = _ShimStats()
-        ok = getattr(self.L, "ref_build_" + self.s)(self.h, ctypes.byref(o), ctypes.byref(st))
+        ok = getattr(self.L, "ref_build_" + self.s)(self.h, ctypes.byref(o), ctypes.byref(st), int(threads))
         return bool(ok), {
             "max_tree_depth": st.max_tree_depth,
             "num_leaf_nodes": st.num_leaf_nodes,

@@ -81,8 +81,13 @@ void *Create(const T *v, size_t stride, const uint32_t *f, uint32_t nf) {
 }
 
 template <typename T>
-int Build(void *h, const ShimBuildOptions *o, ShimStats *st) {
+int Build(void *h, const ShimBuildOptions *o, ShimStats *st, int num_threads) {
   RefAccel<T> *a = static_cast<RefAccel<T> *>(h);
+#ifdef _OPENMP
+  if (num_threads > 0) omp_set_num_threads(num_threads);
+#else
+  (void)num_threads;
+#endif
   nanort::BVHBuildOptions<T> opt;
   if (o) {
     opt.min_leaf_primitives = o->min_leaf_primitives;
@@ -196,7 +201,7 @@ int ref_sizeof(int what) {
 
 int ref_max_threads(void) {
 #ifdef _OPENMP
-  return omp_get_max_threads();
+  return omp_get_num_procs();
 #else
   return 1;
 #endif
@@ -207,8 +212,8 @@ int ref_max_threads(void) {
     return Create<T>(v, stride, f, nf);                                                 \
   }                                                                                     \
   void ref_destroy_##SUF(void *h) { delete static_cast<RefAccel<T> *>(h); }             \
-  int ref_build_##SUF(void *h, const ShimBuildOptions *o, ShimStats *st) {              \
-    return Build<T>(h, o, st);                                                          \
+  int ref_build_##SUF(void *h, const ShimBuildOptions *o, ShimStats *st, int threads) { \
+    return Build<T>(h, o, st, threads);                                                 \
   }                                                                                     \
   uint64_t ref_num_nodes_##SUF(void *h) {                                               \
     return static_cast<RefAccel<T> *>(h)->accel.GetNodes().size();                      \
