@@ -287,7 +287,7 @@ __device__ __forceinline__ uint32_t classify(uint32_t n, uint32_t depth, uint32_
 }
 
 template <typename T>
-__global__ void k_make_root(const BoundsAcc<T> *scene, uint32_t n, uint32_t max_depth, TopNode<T> *top,
+__global__ void k_make_root(const BoundsAcc<T> *scene, uint32_t n, uint32_t max_depth, uint32_t buf, TopNode<T> *top,
                             uint32_t *small_list, LevelInfo *info) {
   if (threadIdx.x != 0) return;
   TopNode<T> t;
@@ -308,11 +308,147 @@ __global__ void k_make_root(const BoundsAcc<T> *scene, uint32_t n, uint32_t max_
   t.child0 = 0;
   t.size = 1;
   t.dfs = 0;
-  t.buf = 0;
+  t.buf = buf;
   t.chunk_base = 0;
   t.nchunks = 0;
   top[0] = t;
   if (t.kind == KIND_SMALL) small_list[atomicAdd(&info->num_small, 1u)] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// Morton pre-pass: 30-bit code of the centroid inside the scene's centroid bounds, then a
+// stable LSD radix sort of (code, record index) pairs, 8 bits per pass.  Scatter is done
+// wave by wave: each wave owns a contiguous 1024-key slice of the block's tile and ranks
+// one row of 64 keys at a time with __ballot ("which lanes hold my digit"), so equal
+// digits keep their order without any atomics.
+// ---------------------------------------------------------------------------
+constexpr int kSortTile = 4096; // keys per block (256 threads x 16 rows of 64 per wave)
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_morton_keys(const PrimRec<T> *__restrict__ recs, uint32_t n,
+                                                     const BoundsAcc<T> *__restrict__ scene,
+                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint32_t q[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const T lo = Ord<T>::dec(scene->v[6 + k]), hi = Ord<T>::dec(scene->v[9 + k]);
+    q[k] = (uint32_t)bin_of<T>(recs[i].c[k], lo, bin_scale<T>(lo, hi, 1024), 1024);
+  }
+  keys[i] = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
+  vals[i] = i;
+}
+
+// block_hist is digit-major: [256 digits][num_blocks]
+__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t *__restrict__ keys, uint32_t n, int shift,
+                                                    uint32_t *__restrict__ block_hist, uint32_t num_blocks) {
+  __shared__ uint32_t s_h[256];
+  s_h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * kSortTile;
+  for (uint32_t k = threadIdx.x; k < (uint32_t)kSortTile; k += 256u) {
+    const uint32_t i = base + k;
+    if (i < n) atomicAdd(&s_h[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  block_hist[(size_t)threadIdx.x * num_blocks + blockIdx.x] = s_h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t *hist, uint32_t count) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < count; base += 1024u) {
+    const uint32_t i = base + tid;
+    const uint32_t v = i < count ? hist[i] : 0u;
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off);
+      if (lane >= (unsigned)off) inc += t;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    uint32_t pre = s_carry;
+    for (unsigned j = 0; j < w; j++) pre += s_wave[j];
+    if (i < count) hist[i] = pre + inc - v;
+    __syncthreads();
+    if (tid == 1023) s_carry = pre + inc;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t *__restrict__ keys_in,
+                                                       const uint32_t *__restrict__ vals_in,
+                                                       uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                       uint32_t n, int shift, const uint32_t *__restrict__ block_hist,
+                                                       uint32_t num_blocks) {
+  __shared__ uint32_t s_off[4][256]; // running output offset per wave per digit
+  const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t base = blockIdx.x * kSortTile + w * (kSortTile / 4);
+  for (int d = lane; d < 256; d += 64) s_off[w][d] = 0;
+  __syncthreads();
+  // per-wave digit counts of its slice
+  for (uint32_t r = 0; r < (uint32_t)kSortTile / 4; r += 64u) {
+    const uint32_t i = base + r + lane;
+    if (i < n) atomicAdd(&s_off[w][(keys_in[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  { // exclusive prefix over the 4 waves + the block's global offset, one digit per thread
+    const uint32_t g = block_hist[(size_t)tid * num_blocks + blockIdx.x];
+    uint32_t run = g;
+    for (int ww = 0; ww < 4; ww++) {
+      const uint32_t c = s_off[ww][tid];
+      s_off[ww][tid] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (uint32_t r = 0; r < (uint32_t)kSortTile / 4; r += 64u) {
+    const uint32_t i = base + r + lane;
+    const bool valid = i < n;
+    uint32_t key = 0, val = 0, d = 0;
+    if (valid) {
+      key = keys_in[i];
+      val = vals_in[i];
+      d = (key >> shift) & 255u;
+    }
+    // lanes holding the same digit as me (invalid lanes form their own group via bit 8)
+    unsigned long long same = valid ? __ballot(valid) : ~__ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      same &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    if (valid) {
+      const uint32_t rank = (uint32_t)__builtin_popcountll(same & lt);
+      const uint32_t off = s_off[w][d];
+      keys_out[off + rank] = key;
+      vals_out[off + rank] = val;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (valid && (same & lt) == 0ull) s_off[w][d] += (uint32_t)__builtin_popcountll(same); // group leader
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_records(const PrimRec<T> *__restrict__ in,
+                                                        const uint32_t *__restrict__ order, uint32_t n,
+                                                        PrimRec<T> *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) out[i] = in[order[i]];
 }
 
 // ---------------------------------------------------------------------------
@@ -1251,7 +1387,7 @@ template <typename T>
 struct BuildPlan { // carve-up of the build workspace for n primitives
   size_t max_top, max_active, max_chunks;
   size_t off_recs0, off_recs1, off_scratch, off_top, off_child_acc, off_active, off_chunk_base, off_gbins,
-      off_chunk_hist, off_chunk_left, off_small, off_scene, off_info, total;
+      off_chunk_hist, off_chunk_left, off_small, off_scene, off_info, off_sort, sort_blocks, total;
   BuildPlan(uint32_t n, size_t top_scale) {
     typedef typename Wire<T>::Node Node;
     max_active = (size_t)n / kSmall + 2;
@@ -1276,6 +1412,9 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
     off_small = take((max_top + 1) * sizeof(uint32_t));
     off_scene = take(sizeof(BoundsAcc<T>));
     off_info = take(sizeof(LevelInfo));
+    // Morton sort: keys/values ping-pong (4 x n u32) + digit-major block histograms
+    sort_blocks = ((size_t)n + kSortTile - 1) / kSortTile;
+    off_sort = take((4 * (size_t)n + 256 * sort_blocks) * sizeof(uint32_t));
     total = o;
   }
 };
@@ -1294,8 +1433,8 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
 // run out of large nodes, one to size the node array.
 template <typename T>
 hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, uint32_t n, uint32_t min_leaf,
-                     uint32_t max_depth, uint32_t bin_size, DevBuf *workspace, DevBuf *nodes_buf, DevBuf *indices_buf,
-                     BuildResult *res, std::string *err) {
+                     uint32_t max_depth, uint32_t bin_size, bool morton_order, DevBuf *workspace, DevBuf *nodes_buf,
+                     DevBuf *indices_buf, BuildResult *res, std::string *err) {
   typedef typename Wire<T>::Node Node;
   const int K = (int)(bin_size < 2 ? 2 : (bin_size > (uint32_t)kMaxBins ? (uint32_t)kMaxBins : bin_size));
   const int Ks = K < kSmallBins ? K : kSmallBins;
@@ -1324,12 +1463,30 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, u
       unsigned grid = (unsigned)std::min<size_t>(((size_t)n + 255) / 256, 2048);
       hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, n, recs[0], scene);
     }
-    hipLaunchKernelGGL((k_make_root<T>), dim3(1), dim3(64), 0, s, scene, n, max_depth, top, small_list, info);
+    int cur = 0; // buffer holding the ranges of the nodes being split
+    if (morton_order && n > 1) {
+      uint32_t *keys[2] = {(uint32_t *)(base + plan.off_sort), (uint32_t *)(base + plan.off_sort) + (size_t)n};
+      uint32_t *vals[2] = {keys[1] + (size_t)n, keys[1] + 2 * (size_t)n};
+      uint32_t *block_hist = keys[1] + 3 * (size_t)n;
+      const unsigned nb = (unsigned)plan.sort_blocks;
+      hipLaunchKernelGGL((k_morton_keys<T>), dim3((n + 255) / 256), dim3(256), 0, s, recs[0], n, scene, keys[0], vals[0]);
+      int pp = 0;
+      for (int shift = 0; shift < 32; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(nb), dim3(256), 0, s, keys[pp], n, shift, block_hist, nb);
+        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, block_hist, 256u * nb);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nb), dim3(256), 0, s, keys[pp], vals[pp], keys[1 - pp], vals[1 - pp], n,
+                           shift, block_hist, nb);
+        pp = 1 - pp;
+      }
+      hipLaunchKernelGGL((k_gather_records<T>), dim3((n + 255) / 256), dim3(256), 0, s, recs[0], vals[pp], n, recs[1]);
+      cur = 1;
+    }
+    hipLaunchKernelGGL((k_make_root<T>), dim3(1), dim3(64), 0, s, scene, n, max_depth, (uint32_t)cur, top, small_list,
+                       info);
     BCHK(hipGetLastError());
 
     // ---- top phase: level after level, grids sized by upper bounds ----------------------------
     LevelInfo h;
-    int cur = 0; // buffer holding the ranges of the nodes being split
     int expect = 0;
     for (size_t m = (size_t)n / kSmall; m > 0; m >>= 1) expect++;
     int next_check = (n <= (uint32_t)kSmall) ? 0 : expect + 2;
@@ -1392,8 +1549,8 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, u
 }
 
 template hipError_t gpu_build<float>(hipStream_t, const float *, const uint32_t *, uint32_t, uint32_t, uint32_t,
-                                     uint32_t, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
+                                     uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
 template hipError_t gpu_build<double>(hipStream_t, const double *, const uint32_t *, uint32_t, uint32_t, uint32_t,
-                                      uint32_t, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
+                                      uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
 
 } // namespace nrt

@@ -192,3 +192,62 @@ def test_smoke_entry_point():
     import __graft_entry__
 
     __graft_entry__.smoke()
+
+
+def test_morton_prepass_gives_a_valid_equal_quality_tree(oracle, monkeypatch):
+    """NRT_MORTON=1: 30-bit Morton codes + stable wavefront radix sort of the primitive records before the
+    top-down build (the north-star's pre-pass).  The tree must stay valid and of the same SAH quality; hit
+    records do not depend on it."""
+    v, f = scenes.sphere(160, 80)
+    a0, n0, i0 = build(np.float32, v, f)
+    monkeypatch.setenv("NRT_MORTON", "1")
+    a1, n1, i1 = build(np.float32, v, f)
+    m0 = validate_bvh(n0, i0, v, f, stats=a0.GetStatistics())
+    m1 = validate_bvh(n1, i1, v, f, stats=a1.GetStatistics())
+    assert abs(m1["sah_cost"] - m0["sah_cost"]) <= 1e-3 * m0["sah_cost"]
+    rays = scenes.camera_rays(320, 180)
+    h0, k0 = a0.TraverseBatch(rays)
+    h1, k1 = a1.TraverseBatch(rays)
+    onodes, oidx, _ = oracle.build(v, f)
+    oh, om = oracle.traverse(onodes, oidx, v, f, rays)
+    assert_hits_match(oh, om, h1, k1, oracle, onodes, oidx, v, f, rays, max_ties=100)
+    assert np.array_equal(h0["t"], h1["t"]) and np.array_equal(k0, k1)
+    # sorted-order build is deterministic too
+    a2, n2, i2 = build(np.float32, v, f)
+    assert n1.tobytes() == n2.tobytes() and np.array_equal(i1, i2)
+
+
+def test_c5_fp64_plane_1m_full_frame(oracle, golden_dir):
+    """Config C5: fp64 build + traverse, 1M triangles, 1920x1080 (checksums of the reference's fp64 frame)."""
+    v, f = scenes.plane(1000, 500)
+    v64 = v.astype(np.float64)
+    a, nodes, idx = build(np.float64, v64, f)
+    validate_bvh(nodes, idx, v64, f, stats=a.GetStatistics())
+    rays = widen_rays(scenes.camera_rays(1920, 1080))
+    h, mk = a.TraverseBatch(rays)
+    ka = json.load(open(os.path.join(golden_dir, "known_answers.json")))["KA4"]["wave_1920x1080_f64"]
+    assert int(mk.sum()) == ka["num_hits"]
+    assert float(h["t"][mk == 1].sum()) == ka["sum_t"]
+    sub = rays[::211]
+    oh, om = oracle.traverse(nodes, idx, v64, f, sub)
+    assert_hits_identical(oh, om, h[::211], mk[::211])
+
+
+def test_c4_10m_triangles_4k_tile(oracle):
+    """Config C4 sizing on one GPU: Plane(2500,2000) = 10 000 000 triangles; one 4096x512 tile of the 4096x4096
+    frame (what each of 8 GPUs traces).  Valid tree, CPU restatement agrees on a subsample, permutation property."""
+    v, f = scenes.plane(2500, 2000)
+    assert f.shape[0] == 10_000_000
+    a, nodes, idx = build(np.float32, v, f)
+    m = validate_bvh(nodes, idx, v, f, stats=a.GetStatistics())
+    assert m["max_depth"] < 64
+    rays = scenes.camera_rays(4096, 4096, 1792, 2304)  # the central tile
+    h, mk = a.TraverseBatch(rays)
+    assert int(mk.sum()) > rays.shape[0] // 2
+    sub = slice(None, None, 1009)
+    oh, om = oracle.traverse(nodes, idx, v, f, rays[sub])
+    assert_hits_identical(oh, om, h[sub], mk[sub])
+    perm = np.random.default_rng(1).permutation(rays.shape[0])[:500000]
+    hp, mp = a.TraverseBatch(rays[perm])
+    assert hp.tobytes() == h[perm].tobytes() and np.array_equal(mp, mk[perm])
+    print("C4: build %.2f ms, %d nodes, depth %d" % (a.LastBuildMs(), m["num_nodes"], m["max_depth"]))
