@@ -155,7 +155,7 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
       (e = hipEventCreate(&c->ev_t0)) != hipSuccess || (e = hipEventCreate(&c->ev_t1)) != hipSuccess ||
       (e = hipEventCreate(&c->ev_b0)) != hipSuccess || (e = hipEventCreate(&c->ev_b1)) != hipSuccess ||
       (e = hipMalloc((void **)&c->d_cursor, kCursorStrideWords * 4 * kMaxParts)) != hipSuccess ||
-      (e = hipMalloc((void **)&c->d_counters, 4 * sizeof(unsigned long long))) != hipSuccess) {
+      (e = hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) {
     fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
     delete c;
     return NRT_ERR_DEVICE;
@@ -469,7 +469,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.trav_min = c->trav_min;
 
   HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, kCursorStrideWords * 4 * c->num_parts, s));
-  if (count) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), s));
+  if (count || (c->debug_flags & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s));
   if (timed) HIPCHK(c, hipEventRecord(c->ev_t0, s));
   if (use_wide)
     HIPCHK(c, launch_traverse_wide<T>(a, grid, c->wide_stack, s));
@@ -596,6 +596,15 @@ float nrtLastTraverseMs(nrt_ctx *c) {
   float ms = -1.f;
   if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) != hipSuccess) return -1.f;
   return ms;
+}
+
+// Profiling aid (not part of the public header): loop-occupancy counters of the last launch made with
+// NRT_DEBUG bit 32 set.  out[0..6] = it1, act1, trav1, it2, act2, refills, refilled.
+NRT_API int nrtDebugCounters(nrt_ctx *c, unsigned long long *out) {
+  if (!c || !out) return 1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return hipMemcpy(out, c->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 
 float nrtLastBuildMs(nrt_ctx *c) {

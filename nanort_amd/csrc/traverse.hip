@@ -443,7 +443,7 @@ __device__ __forceinline__ bool slab_test_tmin(const Lane<T> &L, const T box[6],
 
 enum : int { W_IDLE = 0, W_TRAV = 1, W_LEAF = 2, W_POP = 3 };
 
-template <typename T, int STACK>
+template <typename T, int STACK, bool STATS>
 __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const TraverseArgs<T> a) {
   __shared__ uint32_t s_ref[STACK][kTraverseBlock];
   __shared__ T s_tmin[STACK][kTraverseBlock];
@@ -464,6 +464,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
   int sp = 0;
   Claim ck;
   claim_init<T>(a, ck);
+  // STATS (profiling instantiation only): wave-level loop occupancy
+  unsigned long long st_it1 = 0, st_act1 = 0, st_trav1 = 0, st_it2 = 0, st_act2 = 0, st_refills = 0, st_refilled = 0;
 
   for (;;) {
     // ---- refill idle lanes ---------------------------------------------------------
@@ -489,6 +491,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           state = root_hit ? (root.flag == 0 ? W_TRAV : W_LEAF) : W_POP; // W_POP with sp == 0 finishes the ray
           if (a.debug_flags & 2u) state = W_POP;
         }
+        if (STATS) {
+          st_refills++;
+          st_refilled += take;
+        }
         ck.next += take;
         idle = __ballot(state == W_IDLE);
       }
@@ -500,6 +506,11 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
 
     // ---- phase 1: inner nodes / stack pops ---------------------------------------------
     while (state == W_TRAV || state == W_POP) {
+      if (STATS) {
+        st_it1++;
+        st_act1 += (unsigned)__builtin_popcountll(__ballot(true));
+        st_trav1 += (unsigned)__builtin_popcountll(__ballot(state == W_TRAV));
+      }
       if (state == W_TRAV) {
         const WideNode<T> w = a.wide[cur];
         T tm0, tm1;
@@ -576,6 +587,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
       }
       if (a.debug_flags & 1u) cnt = 0;
       for (uint32_t i = 0; __ballot(i < cnt) != 0ull; i++) {
+        if (STATS) {
+          st_it2++;
+          st_act2 += (unsigned)__builtin_popcountll(__ballot(i < cnt));
+        }
         if (i < cnt) {
           const LeafTri<T> tri = a.tris[first + i];
           tri_test<T>(L, tri, a.range0, a.range1, a.skip_prim, cull);
@@ -583,6 +598,15 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
       }
       state = (state == W_LEAF) ? W_POP : state;
     }
+  }
+  if (STATS && lane == 0) { // counters[0..6]: it1, act1, trav1, it2, act2, refills, refilled
+    atomicAdd(&a.counters[0], st_it1);
+    atomicAdd(&a.counters[1], st_act1);
+    atomicAdd(&a.counters[2], st_trav1);
+    atomicAdd(&a.counters[3], st_it2);
+    atomicAdd(&a.counters[4], st_act2);
+    atomicAdd(&a.counters[5], st_refills);
+    atomicAdd(&a.counters[6], st_refilled);
   }
 }
 
@@ -738,10 +762,15 @@ int traverse_blocks_per_cu(int lds_stack) {
 template <typename T>
 hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int lds_stack, hipStream_t s) {
   switch (lds_stack) {
-    case 8: hipLaunchKernelGGL((k_traverse_wide<T, 8>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
-    case 10: hipLaunchKernelGGL((k_traverse_wide<T, 10>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
-    case 12: hipLaunchKernelGGL((k_traverse_wide<T, 12>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
-    default: hipLaunchKernelGGL((k_traverse_wide<T, 16>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
+    case 8: hipLaunchKernelGGL((k_traverse_wide<T, 8, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
+    case 10:
+      if (args.debug_flags & 32u)
+        hipLaunchKernelGGL((k_traverse_wide<T, 10, true>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+      else
+        hipLaunchKernelGGL((k_traverse_wide<T, 10, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+      break;
+    case 12: hipLaunchKernelGGL((k_traverse_wide<T, 12, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
+    default: hipLaunchKernelGGL((k_traverse_wide<T, 16, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
   }
   return hipGetLastError();
 }
@@ -751,10 +780,10 @@ int traverse_wide_blocks_per_cu(int lds_stack) {
   int n = 0;
   hipError_t e;
   switch (lds_stack) {
-    case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 8>, kTraverseBlock, 0); break;
-    case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10>, kTraverseBlock, 0); break;
-    case 12: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 12>, kTraverseBlock, 0); break;
-    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 16>, kTraverseBlock, 0); break;
+    case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 8, false>, kTraverseBlock, 0); break;
+    case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false>, kTraverseBlock, 0); break;
+    case 12: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 12, false>, kTraverseBlock, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 16, false>, kTraverseBlock, 0); break;
   }
   if (e != hipSuccess || n < 1) n = 4;
   return n > 8 ? 8 : n;
