@@ -155,3 +155,32 @@ def test_hip_backend_build_and_traverse_batch(tmp_path, oracle, f64):
     onodes, oidx, _ = oracle.build(v, f)
     oh, om = oracle.traverse(onodes, oidx, v, f, rays)
     assert_hits_match(oh, om, hits, mask, oracle, onodes, oidx, v, f, rays, max_ties=200)
+
+
+def test_wavefront_path_tracer_example_host_path(tmp_path):
+    """the wavefront restructuring of the reference's path tracer; host path (per-ray Traverse)."""
+    exe = tmp_path / "wf"
+    cxx(["-std=c++11", "-O2", "-fopenmp", "-Wall", "-Wextra", "-I", INC,
+         os.path.join(ROOT, "examples", "wavefront_path_tracer", "main.cc"), "-o", str(exe)])
+    out = tmp_path / "img.ppm"
+    r = subprocess.run([str(exe), "--size", "96", "54", "--spp", "1", "--depth", "2", "--grid", "40", "20", "--out", str(out)],
+                       stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and "per-ray Traverse" in r.stdout, r.stdout
+    data = open(out, "rb").read()
+    assert data.startswith(b"P6\n96 54\n255\n") and len(data) == len(b"P6\n96 54\n255\n") + 96 * 54 * 3
+    assert len(set(data[-96 * 54 * 3:])) > 20  # not a flat image
+
+
+@pytest.mark.gpu
+def test_wavefront_path_tracer_example_gpu_equals_host(tmp_path):
+    """With the HIP backend every wave goes through TraverseBatch(); --verify re-renders with the per-ray host
+    Traverse() over the same (GPU-built) tree and the two images must agree in every float."""
+    exe = tmp_path / "wf_hip"
+    cxx(["-std=c++11", "-O2", "-fopenmp", "-Wall", "-Wextra", "-DNANORT_USE_HIP_BACKEND", "-I", INC,
+         os.path.join(ROOT, "examples", "wavefront_path_tracer", "main.cc"), "-o", str(exe),
+         "-L", LIBDIR, "-lnanort_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    r = subprocess.run([str(exe), "--size", "480", "270", "--spp", "2", "--depth", "3", "--grid", "400", "200", "--verify",
+                        "--out", str(tmp_path / "img.ppm")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "verify: 0 differing float components" in r.stdout
+    print(r.stdout)
