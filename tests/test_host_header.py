@@ -184,3 +184,83 @@ def test_wavefront_path_tracer_example_gpu_equals_host(tmp_path):
     assert r.returncode == 0, r.stdout
     assert "verify: 0 differing float components" in r.stdout
     print(r.stdout)
+
+
+SERIALIZE_SRC = r"""
+#define NANORT_ENABLE_SERIALIZATION
+#include "nanort.h"
+#include <stdio.h>
+#include <vector>
+// Build (GPU when the backend is compiled in), Dump, Load into a second accel, compare node arrays and hits.
+int main(int argc, char **argv) {
+  const int nx = 64, ny = 48;
+  std::vector<float> v; std::vector<unsigned int> f;
+  for (int j = 0; j <= ny; j++) for (int i = 0; i <= nx; i++) { v.push_back(-10.f + 20.f * i / nx); v.push_back(-5.f + 20.f * j / ny); v.push_back(0.5f * sinf(0.9f * i) * cosf(0.7f * j)); }
+  for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) { unsigned a = j * (nx + 1) + i, b = a + 1, c = a + nx + 1, d = c + 1; unsigned t[6] = {a, b, d, a, d, c}; f.insert(f.end(), t, t + 6); }
+  const unsigned n = (unsigned)(f.size() / 3);
+  nanort::TriangleMesh<float> mesh(v.data(), f.data(), 12);
+  nanort::TriangleSAHPred<float> pred(v.data(), f.data(), 12);
+  nanort::BVHAccel<float> a, b;
+  if (!a.Build(n, mesh, pred)) return 1;
+  if (!a.Dump(argv[1])) return 2;
+  if (!b.Load(argv[1])) return 3;
+  if (a.GetNodes().size() != b.GetNodes().size() || memcmp(a.GetNodes().data(), b.GetNodes().data(), a.GetNodes().size() * sizeof(nanort::BVHNode<float>))) return 4;
+  if (a.GetIndices() != b.GetIndices()) return 5;
+  size_t bad = 0, hits = 0;
+  std::vector<nanort::Ray<float> > rays;
+  for (int y = 0; y < 90; y++) for (int x = 0; x < 160; x++) {
+    nanort::Ray<float> r; r.org[0] = 0; r.org[1] = 5; r.org[2] = 20;
+    nanort::real3<float> d = nanort::vnormalize(nanort::real3<float>(x / 160.f - .5f, y / 90.f - .5f, -1.f));
+    r.dir[0] = d[0]; r.dir[1] = d[1]; r.dir[2] = d[2]; r.min_t = 0; r.max_t = 1e30f; rays.push_back(r);
+  }
+  std::vector<nanort::TriangleIntersection<float> > ha(rays.size()), hb(rays.size());
+  for (size_t i = 0; i < rays.size(); i++) {
+    nanort::TriangleIntersector<float> ia(v.data(), f.data(), 12), ib(v.data(), f.data(), 12);
+    const bool x = a.Traverse(rays[i], ia, &ha[i]), y = b.Traverse(rays[i], ib, &hb[i]);
+    if (x != y || (x && (ha[i].t != hb[i].t || ha[i].prim_id != hb[i].prim_id))) bad++;
+    hits += x;
+  }
+#ifdef NANORT_USE_HIP_BACKEND
+  // `a` was built on the GPU; Load() into it marks the device copy stale: TraverseBatch re-uploads lazily
+  if (!a.Load(argv[1])) return 6;
+  std::vector<nanort::TriangleIntersection<float> > hc(rays.size());
+  std::vector<unsigned char> mk(rays.size());
+  if (!a.TraverseBatch(rays.data(), rays.size(), hc.data(), mk.data())) { fprintf(stderr, "%s\n", a.LastBackendError().c_str()); return 7; }
+  for (size_t i = 0; i < rays.size(); i++) {
+    nanort::TriangleIntersector<float> ib(v.data(), f.data(), 12);
+    nanort::TriangleIntersection<float> h; const bool y = b.Traverse(rays[i], ib, &h);
+    if ((mk[i] != 0) != y || (y && (hc[i].t != h.t || hc[i].u != h.u || hc[i].v != h.v || hc[i].prim_id != h.prim_id))) bad++;
+  }
+#endif
+  printf("nodes %zu hits %zu bad %zu\n", a.GetNodes().size(), hits, bad);
+  return bad ? 8 : 0;
+}
+"""
+
+
+def test_dump_load_round_trip_host(tmp_path):
+    """Dump()/Load() keep the reference's raw format (ref nanort.h:2164-2276): size_t count, nodes, size_t count, indices."""
+    src = tmp_path / "ser.cc"
+    src.write_text(SERIALIZE_SRC)
+    exe = tmp_path / "ser"
+    cxx(["-std=c++11", "-O1", "-I", INC, str(src), "-o", str(exe)])
+    dump = tmp_path / "tree.bin"
+    r = subprocess.run([str(exe), str(dump)], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and " bad 0" in r.stdout, r.stdout
+    raw = open(dump, "rb").read()
+    nn = int(np.frombuffer(raw[:8], dtype=np.uint64)[0])
+    ni = int(np.frombuffer(raw[8 + nn * 40: 16 + nn * 40], dtype=np.uint64)[0])
+    assert ni == 64 * 48 * 2 and len(raw) == 16 + nn * 40 + ni * 4
+
+
+@pytest.mark.gpu
+def test_dump_load_round_trip_gpu_tree(tmp_path):
+    """A GPU-built tree survives Dump/Load bit for bit, and TraverseBatch after Load() (stale device copy,
+    re-uploaded through nrtSetTree) equals the per-ray host traversal of the loaded tree."""
+    src = tmp_path / "ser.cc"
+    src.write_text(SERIALIZE_SRC)
+    exe = tmp_path / "ser_hip"
+    cxx(["-std=c++11", "-O1", "-DNANORT_USE_HIP_BACKEND", "-I", INC, str(src), "-o", str(exe),
+         "-L", LIBDIR, "-lnanort_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    r = subprocess.run([str(exe), str(tmp_path / "tree.bin")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and " bad 0" in r.stdout, r.stdout
