@@ -511,34 +511,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
         st_act1 += (unsigned)__builtin_popcountll(__ballot(true));
         st_trav1 += (unsigned)__builtin_popcountll(__ballot(state == W_TRAV));
       }
-      if (state == W_TRAV) {
-        const WideNode<T> w = a.wide[cur];
-        T tm0, tm1;
-        const bool h0 = slab_test_tmin<T>(L, w.box0, tm0);
-        const bool h1 = slab_test_tmin<T>(L, w.box1, tm1);
-        const int near = sel3(L.sign0, L.sign1, L.sign2, w.axis); // near child = data[dir_sign[axis]] (nanort.h:2538)
-        const uint32_t rn = near ? w.c1 : w.c0, rf = near ? w.c0 : w.c1;
-        const bool hn = near ? h1 : h0, hf = near ? h0 : h1;
-        const T tf = near ? tm0 : tm1;
-        if (hn && hf) { // far child waits with its t_min
-          if (sp < STACK) {
-            s_ref[sp][tid] = rf;
-            s_tmin[sp][tid] = tf;
-          } else {
-            const size_t o = (size_t)(sp - STACK) * a.spill_stride + gslot;
-            a.spill[o] = rf;
-            a.spill_tmin[o] = tf;
-          }
-          sp++;
-        }
-        const uint32_t next = hn ? rn : rf;
-        if (hn || hf) {
-          cur = next & ~kLeafBit;
-          state = (next & kLeafBit) ? W_LEAF : W_TRAV;
-        } else {
-          state = W_POP;
-        }
-      } else { // W_POP
+      // a lane that must pop does so first and, if the popped entry survives, steps into it in the same iteration
+      if (state == W_POP) {
         const bool fin = (sp == 0);
         if (fin) { // PostTraversal (nanort.h:1205-1211), strict final predicate (:2552)
           const bool hit = L.hit_t < L.max_t;
@@ -568,6 +542,34 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
         cur = enter ? (ref & ~kLeafBit) : cur;
         state = fin ? W_IDLE : (enter ? ((ref & kLeafBit) ? W_LEAF : W_TRAV) : W_POP);
         rid = fin ? kInvalid : rid;
+      }
+      if (state == W_TRAV) {
+        const WideNode<T> w = a.wide[cur];
+        T tm0, tm1;
+        const bool h0 = slab_test_tmin<T>(L, w.box0, tm0);
+        const bool h1 = slab_test_tmin<T>(L, w.box1, tm1);
+        const int near = sel3(L.sign0, L.sign1, L.sign2, w.axis); // near child = data[dir_sign[axis]] (nanort.h:2538)
+        const uint32_t rn = near ? w.c1 : w.c0, rf = near ? w.c0 : w.c1;
+        const bool hn = near ? h1 : h0, hf = near ? h0 : h1;
+        const T tf = near ? tm0 : tm1;
+        if (hn && hf) { // far child waits with its t_min
+          if (sp < STACK) {
+            s_ref[sp][tid] = rf;
+            s_tmin[sp][tid] = tf;
+          } else {
+            const size_t o = (size_t)(sp - STACK) * a.spill_stride + gslot;
+            a.spill[o] = rf;
+            a.spill_tmin[o] = tf;
+          }
+          sp++;
+        }
+        const uint32_t next = hn ? rn : rf;
+        if (hn || hf) {
+          cur = next & ~kLeafBit;
+          state = (next & kLeafBit) ? W_LEAF : W_TRAV;
+        } else {
+          state = W_POP;
+        }
       }
       if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < a.trav_min) break;
     }
