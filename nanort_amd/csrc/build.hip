@@ -193,6 +193,76 @@ __device__ __forceinline__ unsigned lane_id_b() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// ---- DPP (data-parallel primitive) moves inside 16-lane rows: VALU operand modifiers, no LDS
+// crossbar (ds_bpermute) round trip.  row_shr:n = 0x110+n, row_shl:n = 0x100+n; a lane without a
+// source keeps `old`, so `old` = the identity of the operation gives a clean scan step.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+  return __builtin_bit_cast(float, dpp_u32<CTRL>(__builtin_bit_cast(uint32_t, old), __builtin_bit_cast(uint32_t, src)));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double old, double src) {
+  const unsigned long long o = __builtin_bit_cast(unsigned long long, old), v = __builtin_bit_cast(unsigned long long, src);
+  const uint32_t lo = dpp_u32<CTRL>((uint32_t)o, (uint32_t)v), hi = dpp_u32<CTRL>((uint32_t)(o >> 32), (uint32_t)(v >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src) {
+  return dpp_u32<CTRL>(old, src);
+}
+
+// One scan step over a {count, AABB} record inside each 16-lane row.
+template <typename T, int CTRL>
+__device__ __forceinline__ void row_scan_step(uint32_t &cnt, T mn[3], T mx[3]) {
+  cnt += dpp_mov<CTRL>(0u, cnt);
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    mn[d] = tmin(mn[d], dpp_mov<CTRL>(Lim<T>::max(), mn[d]));
+    mx[d] = tmax(mx[d], dpp_mov<CTRL>(-Lim<T>::max(), mx[d]));
+  }
+}
+// inclusive prefix (lanes 0..i of the row) / suffix (lanes i..15 of the row)
+template <typename T>
+__device__ __forceinline__ void row_prefix(uint32_t &cnt, T mn[3], T mx[3]) {
+  row_scan_step<T, 0x111>(cnt, mn, mx);
+  row_scan_step<T, 0x112>(cnt, mn, mx);
+  row_scan_step<T, 0x114>(cnt, mn, mx);
+  row_scan_step<T, 0x118>(cnt, mn, mx);
+}
+template <typename T>
+__device__ __forceinline__ void row_suffix(uint32_t &cnt, T mn[3], T mx[3]) {
+  row_scan_step<T, 0x101>(cnt, mn, mx);
+  row_scan_step<T, 0x102>(cnt, mn, mx);
+  row_scan_step<T, 0x104>(cnt, mn, mx);
+  row_scan_step<T, 0x108>(cnt, mn, mx);
+}
+// all-reduce min / max over the 64 lanes: 4 DPP steps inside rows (quad_perm [1,0,3,2], [2,3,0,1],
+// row_half_mirror, row_mirror), then two cross-row exchanges.
+template <typename T>
+__device__ __forceinline__ T wave_min(T x) {
+  x = tmin(x, dpp_mov<0xB1>(x, x));
+  x = tmin(x, dpp_mov<0x4E>(x, x));
+  x = tmin(x, dpp_mov<0x141>(x, x));
+  x = tmin(x, dpp_mov<0x140>(x, x));
+  x = tmin(x, __shfl_xor(x, 16));
+  x = tmin(x, __shfl_xor(x, 32));
+  return x;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T x) {
+  x = tmax(x, dpp_mov<0xB1>(x, x));
+  x = tmax(x, dpp_mov<0x4E>(x, x));
+  x = tmax(x, dpp_mov<0x141>(x, x));
+  x = tmax(x, dpp_mov<0x140>(x, x));
+  x = tmax(x, __shfl_xor(x, 16));
+  x = tmax(x, __shfl_xor(x, 32));
+  return x;
+}
+
 // ---------------------------------------------------------------------------
 // primitive records + scene bounds
 // ---------------------------------------------------------------------------
@@ -1026,15 +1096,14 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
         }
       }
 #pragma unroll
-      for (int d = 0; d < 3; d++)
-        for (int off = 32; off > 0; off >>= 1) {
-          cmn[d] = tmin(cmn[d], __shfl_xor(cmn[d], off));
-          cmx[d] = tmax(cmx[d], __shfl_xor(cmx[d], off));
-          if (need_box) {
-            amn[d] = tmin(amn[d], __shfl_xor(amn[d], off));
-            amx[d] = tmax(amx[d], __shfl_xor(amx[d], off));
-          }
+      for (int d = 0; d < 3; d++) {
+        cmn[d] = wave_min<T>(cmn[d]);
+        cmx[d] = wave_max<T>(cmx[d]);
+        if (need_box) {
+          amn[d] = wave_min<T>(amn[d]);
+          amx[d] = wave_max<T>(amx[d]);
         }
+      }
       if (need_box) {
 #pragma unroll
         for (int d = 0; d < 3; d++) {
@@ -1116,43 +1185,18 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
           }
         }
       }
-      uint32_t pc = cnt, sc_n = cnt; // inclusive prefix / suffix inside the 16-lane group
+      uint32_t pc = cnt, sc_n = cnt; // inclusive prefix / suffix inside the 16-lane row (DPP row shifts)
       T pmn[3] = {bmn[0], bmn[1], bmn[2]}, pmx[3] = {bmx[0], bmx[1], bmx[2]};
       T smn[3] = {bmn[0], bmn[1], bmn[2]}, smx[3] = {bmx[0], bmx[1], bmx[2]};
-      for (int off = 1; off < 16; off <<= 1) {
-        const uint32_t tc = __shfl_up(pc, off, 16), uc = __shfl_down(sc_n, off, 16);
-        T t0[3], t1[3], u0[3], u1[3];
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          t0[d] = __shfl_up(pmn[d], off, 16);
-          t1[d] = __shfl_up(pmx[d], off, 16);
-          u0[d] = __shfl_down(smn[d], off, 16);
-          u1[d] = __shfl_down(smx[d], off, 16);
-        }
-        if (bn >= off) {
-          pc += tc;
-#pragma unroll
-          for (int d = 0; d < 3; d++) {
-            pmn[d] = tmin(pmn[d], t0[d]);
-            pmx[d] = tmax(pmx[d], t1[d]);
-          }
-        }
-        if (bn + off < 16) {
-          sc_n += uc;
-#pragma unroll
-          for (int d = 0; d < 3; d++) {
-            smn[d] = tmin(smn[d], u0[d]);
-            smx[d] = tmax(smx[d], u1[d]);
-          }
-        }
-      }
+      row_prefix<T>(pc, pmn, pmx);
+      row_suffix<T>(sc_n, smn, smx);
       // candidate (ax, s = bn), s in 1..K-1: low side = bins [0, s), high side = bins [s, K)
-      const uint32_t nl = __shfl_up(pc, 1, 16);
+      const uint32_t nl = dpp_mov<0x111>(0u, pc);
       T lmn[3], lmx[3];
 #pragma unroll
       for (int d = 0; d < 3; d++) {
-        lmn[d] = __shfl_up(pmn[d], 1, 16);
-        lmx[d] = __shfl_up(pmx[d], 1, 16);
+        lmn[d] = dpp_mov<0x111>(Lim<T>::max(), pmn[d]);
+        lmx[d] = dpp_mov<0x111>(-Lim<T>::max(), pmx[d]);
       }
       T cost = Lim<T>::inf();
       if (ax < 3 && bn >= 1 && bn < K && nl > 0 && sc_n > 0)
