@@ -173,34 +173,47 @@ def main():
     d_rays2 = torch.from_numpy(rays2.view(np.uint8)).cuda()
     d_hits2 = torch.empty(max(1, n2) * HIT_F32.itemsize, dtype=torch.uint8, device="cuda")
     d_mask2 = torch.empty(max(1, n2), dtype=torch.uint8, device="cuda")
-    gathered = None
-    if world > 1:
-        gathered = torch.empty(world * n1 * HIT_F32.itemsize, dtype=torch.uint8, device="cuda")
+    # N > 1: wave-1 hit records are double-buffered so that the all-gather of step k (RCCL, its own stream)
+    # overlaps wave 2 of step k and all of step k+1; it is waited for before its buffers are reused.
+    hit_bufs = [d_hits1, torch.empty_like(d_hits1)] if world > 1 else [d_hits1]
+    gathered = [torch.empty(world * n1 * HIT_F32.itemsize, dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else []
+    pending = [None, None]
 
     # ---- work counters -> algorithmic bytes per launch ---------------------------
     c1 = accel.TraverseCountDevice(d_rays1)
     c2 = accel.TraverseCountDevice(d_rays2)
     bytes1, bytes2 = algorithmic_bytes(c1), algorithmic_bytes(c2)
 
+    step_no = [0]
+
     def step(ev=None):
-        work = None
+        b = step_no[0] % len(hit_bufs)
+        step_no[0] += 1
+        if world > 1 and pending[b] is not None:
+            pending[b].wait()  # the gather that last used this buffer pair (two steps ago)
+            pending[b] = None
         if ev is not None:
             ev[0].record()
-        accel.TraverseBatchDevice(d_rays1, d_hits1, d_mask1)
+        accel.TraverseBatchDevice(d_rays1, hit_bufs[b], d_mask1)
         if ev is not None:
             ev[1].record()
         if world > 1:
-            work = dist.all_gather_into_tensor(gathered, d_hits1, async_op=True)  # overlaps wave 2
+            pending[b] = dist.all_gather_into_tensor(gathered[b], hit_bufs[b], async_op=True)
         if ev is not None:
             ev[2].record()
         accel.TraverseBatchDevice(d_rays2, d_hits2, d_mask2)
         if ev is not None:
             ev[3].record()
-        if work is not None:
-            work.wait()
+
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
@@ -208,6 +221,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
+    drain()  # every gather issued inside the timed region completes inside it
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -255,7 +269,7 @@ def main():
                 "workload": "C3: Plane(1000,500) = 1,000,000 triangles fp32; %dx%d objrender-camera primaries "
                             "+ 1 cosine bounce per hit (%d + %d rays per GPU per step)" % (WIDTH, HEIGHT, n1, n2),
                 "parallelism": "replicated BVH, interleaved image rows per GPU%s" % (
-                    ", RCCL all-gather of wave-1 hit records overlapped with wave 2" if world > 1 else ""),
+                    ", RCCL all-gather of wave-1 hit records, double-buffered and overlapped with the following waves" if world > 1 else ""),
                 "rays_per_step": int(total_rays),
             },
             "build_ms": round(float(np.median(build_ms)), 4),
