@@ -247,6 +247,39 @@ NRT_API nrt_status nrtTraverseCountDevice_f64(nrt_ctx *ctx, const nrt_ray_f64 *d
  * Synchronises with that work. */
 NRT_API float nrtLastTraverseMs(nrt_ctx *ctx);
 NRT_API float nrtLastBuildMs(nrt_ctx *ctx);
+/* Profiling aid: loop-occupancy counters of the last traversal launched with the environment variable
+ * NRT_DEBUG bit 32 set (a separately instantiated, slower kernel).  out8[0..6] = phase-1 wave iterations,
+ * sum of active lanes, sum of lanes walking inner nodes, phase-2 iterations, sum of lanes testing a
+ * triangle, refill events, lanes refilled.  Returns 0 on success. */
+NRT_API int nrtDebugCounters(nrt_ctx *ctx, unsigned long long *out8);
+
+/* ---- two-level scenes (instancing): replaces nanosg::Scene<float, M> -----------------------
+ * examples/nanosg/nanosg.h — AddNode :682, Commit :700-760 (per-node world AABB / inverse
+ * transforms, nanosg.h:397-437), Traverse :773-870 on top of BVHAccel::ListNodeIntersections
+ * (nanort.h:781-784, 2608-2692).  Semantics kept, including the reference's quirks: the 64 nearest
+ * node boxes by entry distance are considered (kMaxIntersections), front to back with the early
+ * cull `t_nearest < t_min`; the local ray carries the default [0, FLT_MAX] interval and default
+ * trace options (the world ray's interval and the cull flag never reach the per-node Traverse);
+ * the reported t is the WORLD distance |xform(P_local) - org| and a node replaces the current hit
+ * only when strictly nearer.  A node is a built nrt_ctx (f32) plus nanosg's T[4][4] local transform
+ * (row 3 = translation, nanosg.h:232-240); the mesh contexts must outlive the scene. */
+typedef struct nrt_scene nrt_scene;
+typedef struct {
+  float t;
+  float u;
+  float v;
+  uint32_t prim_id;
+  uint32_t node_id;
+} nrt_scene_hit_f32; /* the fields of nanosg::Intersection<float> the traversal fills; miss: t = ray.max_t, ids = 0xFFFFFFFF */
+
+NRT_API nrt_status nrtSceneCreate(int device, nrt_scene **out);
+NRT_API void nrtSceneDestroy(nrt_scene *scene);
+NRT_API const char *nrtSceneLastError(const nrt_scene *scene);
+NRT_API nrt_status nrtSceneAddNode_f32(nrt_scene *scene, nrt_ctx *built_mesh, const float local_xform[16],
+                                       uint32_t *node_id_out);
+NRT_API nrt_status nrtSceneCommit(nrt_scene *scene);
+NRT_API nrt_status nrtSceneTraverseBatch_f32(nrt_scene *scene, const nrt_ray_f32 *rays, uint64_t num_rays,
+                                             nrt_scene_hit_f32 *hits_out, uint8_t *hit_mask_out);
 
 #ifdef __cplusplus
 }

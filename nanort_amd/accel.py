@@ -215,3 +215,56 @@ class BVHAccel:
             "max_stack": int(c.max_stack),
             "num_rays": int(n),
         }
+
+
+class Scene:
+    """nanosg::Scene<float, M> on one MI355X (reference examples/nanosg/nanosg.h:668-905): instanced two-level
+    traversal.  Nodes are built `BVHAccel(np.float32)` objects plus nanosg's 4x4 local transform (row 3 =
+    translation); `Traverse` of the reference becomes `TraverseBatch`."""
+
+    def __init__(self, device=0):
+        self._L = capi.lib()
+        h = ctypes.c_void_p()
+        st = self._L.nrtSceneCreate(int(device), ctypes.byref(h))
+        if st != capi.NRT_OK:
+            raise capi.NrtError(st, self._L.nrtSceneLastError(None).decode())
+        self._h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nrtSceneDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != capi.NRT_OK:
+            raise capi.NrtError(st, self._L.nrtSceneLastError(self._h).decode())
+
+    def AddNode(self, accel, local_xform):
+        x = np.ascontiguousarray(local_xform, dtype=np.float32).reshape(16)
+        nid = ctypes.c_uint32(0)
+        self._check(self._L.nrtSceneAddNode_f32(self._h, accel._h, _p(x), ctypes.byref(nid)))
+        self._keep.append(accel)
+        return int(nid.value)
+
+    def Commit(self):
+        st = self._L.nrtSceneCommit(self._h)
+        if st == capi.NRT_ERR_EMPTY:
+            return False
+        self._check(st)
+        return True
+
+    def TraverseBatch(self, rays):
+        from .wire import RAY_F32, SCENE_HIT_F32
+
+        rays = np.ascontiguousarray(rays, dtype=RAY_F32)
+        hits = np.zeros((rays.shape[0],), dtype=SCENE_HIT_F32)
+        mask = np.zeros((rays.shape[0],), dtype=np.uint8)
+        self._check(self._L.nrtSceneTraverseBatch_f32(self._h, _p(rays), rays.shape[0], _p(hits), _p(mask)))
+        return hits, mask

@@ -22,7 +22,9 @@ SYMBOLS = [
     "nrtTraverseBatch_f32", "nrtTraverseBatch_f64",
     "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64",
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
-    "nrtLastTraverseMs", "nrtLastBuildMs",
+    "nrtLastTraverseMs", "nrtLastBuildMs", "nrtDebugCounters",
+    "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit",
+    "nrtSceneTraverseBatch_f32",
 ]
 
 
@@ -95,6 +97,18 @@ def lib():
         f = getattr(L, "nrtTraverseCountDevice_" + s)
         f.argtypes = [vp, vp, u64, vp, ctypes.POINTER(TraceCounters)]
         f.restype = i32
+    L.nrtSceneCreate.argtypes = [i32, ctypes.POINTER(vp)]
+    L.nrtSceneCreate.restype = i32
+    L.nrtSceneDestroy.argtypes = [vp]
+    L.nrtSceneDestroy.restype = None
+    L.nrtSceneLastError.argtypes = [vp]
+    L.nrtSceneLastError.restype = ctypes.c_char_p
+    L.nrtSceneAddNode_f32.argtypes = [vp, vp, vp, ctypes.POINTER(u32)]
+    L.nrtSceneAddNode_f32.restype = i32
+    L.nrtSceneCommit.argtypes = [vp]
+    L.nrtSceneCommit.restype = i32
+    L.nrtSceneTraverseBatch_f32.argtypes = [vp, vp, u64, vp, vp]
+    L.nrtSceneTraverseBatch_f32.restype = i32
     L.nrtLastTraverseMs.argtypes = [vp]
     L.nrtLastTraverseMs.restype = ctypes.c_float
     L.nrtLastBuildMs.argtypes = [vp]

@@ -600,7 +600,7 @@ float nrtLastTraverseMs(nrt_ctx *c) {
 
 // Profiling aid (not part of the public header): loop-occupancy counters of the last launch made with
 // NRT_DEBUG bit 32 set.  out[0..6] = it1, act1, trav1, it2, act2, refills, refilled.
-NRT_API int nrtDebugCounters(nrt_ctx *c, unsigned long long *out) {
+int nrtDebugCounters(nrt_ctx *c, unsigned long long *out) {
   if (!c || !out) return 1;
   if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
   if (hipDeviceSynchronize() != hipSuccess) return 1;

@@ -78,6 +78,10 @@ assert HIT_F32.itemsize == 16 and HIT_F64.itemsize == 32
 assert TRACE_OPTIONS.itemsize == 16 and BUILD_STATS.itemsize == 16
 assert BUILD_OPTIONS_F32.itemsize == 28 and BUILD_OPTIONS_F64.itemsize == 32
 
+# nanosg::Intersection<float> fields the two-level traversal fills (reference examples/nanosg/nanosg.h:307-318)
+SCENE_HIT_F32 = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim_id", "<u4"), ("node_id", "<u4")])
+assert SCENE_HIT_F32.itemsize == 20
+
 MISS_PRIM_ID = 0xFFFFFFFF
 
 

@@ -239,3 +239,126 @@ def fnv1a64(data):
     for b in memoryview(data).tobytes():
         h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
     return h
+
+
+# ---------------------------------------------------------------------------
+# Two-level scenes: reference nanosg behind a shim, and its C restatement
+# ---------------------------------------------------------------------------
+SCENE_HIT = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim_id", "<u4"), ("node_id", "<u4")])
+REF_SCENE_PATH = os.path.join(_HERE, "_ref", "libnanosg_ref.so")
+
+
+def scene_reference_available():
+    return os.path.exists(REF_SCENE_PATH)
+
+
+class SceneReference:
+    """The unmodified examples/nanosg Scene<float, Mesh> (oracle/ref_scene_shim.cc)."""
+
+    def __init__(self):
+        L = ctypes.CDLL(REF_SCENE_PATH)
+        vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+        L.refsg_create.restype = vp
+        L.refsg_destroy.argtypes = [vp]
+        L.refsg_add_node.argtypes = [vp, vp, u32, vp, u32, vp]
+        L.refsg_add_node.restype = ctypes.c_int
+        L.refsg_commit.argtypes = [vp]
+        L.refsg_commit.restype = ctypes.c_int
+        L.refsg_node_state.argtypes = [vp, u32, vp]
+        L.refsg_traverse.argtypes = [vp, vp, u64, ctypes.c_int, vp, vp]
+        self.L = L
+        self.h = L.refsg_create()
+        self.n = 0
+
+    def __del__(self):
+        try:
+            self.L.refsg_destroy(self.h)
+        except Exception:
+            pass
+
+    def add_node(self, verts, faces, xform):
+        verts = np.ascontiguousarray(verts, dtype=np.float32)
+        faces = np.ascontiguousarray(faces, dtype=np.uint32)
+        xform = np.ascontiguousarray(xform, dtype=np.float32).reshape(4, 4)
+        self.n += 1
+        return self.L.refsg_add_node(self.h, _p(verts), verts.shape[0], _p(faces), faces.shape[0], _p(xform))
+
+    def commit(self):
+        return bool(self.L.refsg_commit(self.h))
+
+    def node_state(self, i):
+        out = np.zeros(54, dtype=np.float32)
+        self.L.refsg_node_state(self.h, i, _p(out))
+        return {"xbmin": out[0:3], "xbmax": out[3:6], "inv_xform": out[6:22].reshape(4, 4),
+                "inv_xform33": out[22:38].reshape(4, 4), "xform": out[38:54].reshape(4, 4)}
+
+    def traverse(self, rays, cull_back_face=False):
+        rays = np.ascontiguousarray(rays, dtype=ray_dtype(np.float32))
+        hits = np.zeros((rays.shape[0],), dtype=SCENE_HIT)
+        mask = np.zeros((rays.shape[0],), dtype=np.uint8)
+        self.L.refsg_traverse(self.h, _p(rays), rays.shape[0], 1 if cull_back_face else 0, _p(hits), _p(mask))
+        return hits, mask
+
+
+class _SgNode(ctypes.Structure):
+    _fields_ = [
+        ("nodes", ctypes.c_void_p), ("indices", ctypes.c_void_p), ("verts", ctypes.c_void_p), ("faces", ctypes.c_void_p),
+        ("local_xform", ctypes.c_float * 16), ("lbmin", ctypes.c_float * 3), ("lbmax", ctypes.c_float * 3),
+        ("xform", ctypes.c_float * 16), ("inv_xform", ctypes.c_float * 16), ("inv_xform33", ctypes.c_float * 16),
+        ("xbmin", ctypes.c_float * 3), ("xbmax", ctypes.c_float * 3),
+    ]
+
+
+class SceneOracle:
+    """C restatement of the two-level traversal (oracle/nanosg_oracle.c); per-node trees from `Oracle.build`."""
+
+    def __init__(self, oracle=None):
+        self.o = oracle or Oracle()
+        L = self.o.L
+        L.sgo_node_update.argtypes = [ctypes.c_void_p]
+        L.sgo_traverse.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        L.sgo_sizeof_node.restype = ctypes.c_int
+        assert L.sgo_sizeof_node() == ctypes.sizeof(_SgNode)
+        self.L = L
+        self.keep = []
+        self.nodes = []
+
+    def add_node(self, verts, faces, xform, tree=None):
+        verts = np.ascontiguousarray(verts, dtype=np.float32)
+        faces = np.ascontiguousarray(faces, dtype=np.uint32)
+        if tree is None:
+            nodes, idx, _ = self.o.build(verts, faces)
+        else:
+            nodes, idx = tree
+        nodes = np.ascontiguousarray(nodes)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        self.keep.append((verts, faces, nodes, idx))
+        n = _SgNode()
+        n.nodes, n.indices, n.verts, n.faces = nodes.ctypes.data, idx.ctypes.data, verts.ctypes.data, faces.ctypes.data
+        x = np.ascontiguousarray(xform, dtype=np.float32).reshape(16)
+        for i in range(16):
+            n.local_xform[i] = float(x[i])
+        for k in range(3):
+            n.lbmin[k] = float(nodes[0]["bmin"][k])
+            n.lbmax[k] = float(nodes[0]["bmax"][k])
+        self.nodes.append(n)
+        return len(self.nodes) - 1
+
+    def commit(self):
+        self.arr = (_SgNode * len(self.nodes))(*self.nodes)
+        for i in range(len(self.nodes)):
+            self.L.sgo_node_update(ctypes.byref(self.arr[i]))
+        return True
+
+    def node_state(self, i):
+        n = self.arr[i]
+        f = lambda a, shape: np.array(list(a), dtype=np.float32).reshape(shape)
+        return {"xbmin": f(n.xbmin, 3), "xbmax": f(n.xbmax, 3), "inv_xform": f(n.inv_xform, (4, 4)),
+                "inv_xform33": f(n.inv_xform33, (4, 4)), "xform": f(n.xform, (4, 4))}
+
+    def traverse(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=ray_dtype(np.float32))
+        hits = np.zeros((rays.shape[0],), dtype=SCENE_HIT)
+        mask = np.zeros((rays.shape[0],), dtype=np.uint8)
+        self.L.sgo_traverse(ctypes.cast(self.arr, ctypes.c_void_p), len(self.nodes), _p(rays), rays.shape[0], _p(hits), _p(mask))
+        return hits, mask

@@ -227,6 +227,24 @@ def main():
         os.path.join(GOLDEN, "sphere_sample.npz"), stride=np.array(STRIDE), hits=hs_[::STRIDE], mask=ms_[::STRIDE]
     )
 
+    # ---- two-level scene (nanosg), SURVEY §8f row 3 ---------------------------------
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scene_fixture import instances
+    from oracle.bindings import SceneReference
+
+    RS2 = SceneReference()
+    for v_, f_, x_ in instances():
+        RS2.add_node(v_, f_, x_)
+    assert RS2.commit()
+    srays = scenes.camera_rays(320, 180)
+    sh, sm = RS2.traverse(srays)
+    sc = {"hits": sh, "mask": sm}
+    for i in range(5):
+        for k_, val in RS2.node_state(i).items():
+            sc["node%d_%s" % (i, k_)] = val
+    np.savez_compressed(os.path.join(GOLDEN, "scene_ref.npz"), **sc)
+    ka["scene"] = {"num_hits": int(sm.sum()), "sha256_hits": sha(sh)}
+
     with open(os.path.join(GOLDEN, "known_answers.json"), "w") as f:
         json.dump(ka, f, indent=1, sort_keys=True)
     print(json.dumps(ka, indent=1, sort_keys=True)[:3000])
