@@ -251,3 +251,55 @@ def test_c4_10m_triangles_4k_tile(oracle):
     hp, mp = a.TraverseBatch(rays[perm])
     assert hp.tobytes() == h[perm].tobytes() and np.array_equal(mp, mk[perm])
     print("C4: build %.2f ms, %d nodes, depth %d" % (a.LastBuildMs(), m["num_nodes"], m["max_depth"]))
+
+
+def test_context_reuse_across_mesh_sizes(oracle):
+    """One context, rebuilt over meshes of different sizes (grow-only workspace, no stale state): each tree is valid
+    and traces like a fresh context's."""
+    a = BVHAccel(np.float32)
+    rays = scenes.camera_rays(160, 90)
+    for nx, ny in ((20, 10), (300, 200), (8, 8), (120, 60), (300, 200)):
+        v, f = scenes.plane(nx, ny)
+        assert a.Build(f.shape[0], TriangleMesh(v, f))
+        nodes, idx = a.GetTree()
+        validate_bvh(nodes, idx, v, f, stats=a.GetStatistics())
+        h, m = a.TraverseBatch(rays)
+        oh, om = oracle.traverse(nodes, idx, v, f, rays)
+        assert_hits_identical(oh, om, h, m)
+
+
+def test_two_contexts_from_two_threads(oracle):
+    """Distinct contexts may be driven from distinct host threads concurrently (ctypes drops the GIL)."""
+    import threading
+
+    meshes = [scenes.plane(150, 100), scenes.sphere(96, 48)]
+    rays = scenes.camera_rays(320, 180)
+    results = [None, None]
+    errors = []
+
+    def worker(k):
+        try:
+            v, f = meshes[k]
+            a = BVHAccel(np.float32)
+            out = []
+            for _ in range(6):
+                assert a.Build(f.shape[0], TriangleMesh(v, f))
+                h, m = a.TraverseBatch(rays)
+                out.append((h.tobytes(), m.tobytes()))
+            nodes, idx = a.GetTree()
+            results[k] = (out, nodes, idx)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        out, nodes, idx = results[k]
+        assert all(o == out[0] for o in out), "results changed between iterations"
+        v, f = meshes[k]
+        oh, om = oracle.traverse(nodes, idx, v, f, rays)
+        assert out[0][0] == oh.tobytes() and out[0][1] == om.tobytes()
