@@ -137,12 +137,14 @@ __device__ __forceinline__ bool slab_test(const Lane<T> &L, const T bmin[3], con
 }
 
 // TriangleIntersector::Intersect (nanort.h:1054-1150) against one leaf record.
+// Written as one running predicate with select-style updates (the reference's early returns
+// in the same order): all loads of the record are issued together, and the lane state stays
+// in the same registers on every path.
 template <typename T>
-__device__ __forceinline__ void tri_test(Lane<T> &L, const LeafTri<T> &tri, uint32_t range0,
+__device__ __forceinline__ void tri_test(Lane<T> &L, const LeafTri<T> &tri, bool active, uint32_t range0,
                                          uint32_t range1, uint32_t skip, bool cull) {
   const uint32_t prim = tri.prim_id;
-  if (prim < range0 || prim >= range1) return;
-  if (prim == skip) return;
+  bool ok = active & (prim >= range0) & (prim < range1) & (prim != skip); // nanort.h:2387-2395
   const T A0 = tri.p0[0] - L.org[0], A1 = tri.p0[1] - L.org[1], A2 = tri.p0[2] - L.org[2];
   const T B0 = tri.p1[0] - L.org[0], B1 = tri.p1[1] - L.org[1], B2 = tri.p1[2] - L.org[2];
   const T C0 = tri.p2[0] - L.org[0], C1 = tri.p2[1] - L.org[1], C2 = tri.p2[2] - L.org[2];
@@ -156,7 +158,7 @@ __device__ __forceinline__ void tri_test(Lane<T> &L, const LeafTri<T> &tri, uint
   T U = Cx * By - Cy * Bx;
   T V = Ax * Cy - Ay * Cx;
   T W = Bx * Ay - By * Ax;
-  if (U == T(0) || V == T(0) || W == T(0)) { // nanort.h:1094-1107
+  if (ok && (U == T(0) || V == T(0) || W == T(0))) { // nanort.h:1094-1107 (rare: a wave-level branch)
     const double CxBy = double(Cx) * double(By), CyBx = double(Cy) * double(Bx);
     const double AxCy = double(Ax) * double(Cy), AyCx = double(Ay) * double(Cx);
     const double BxAy = double(Bx) * double(Ay), ByAx = double(By) * double(Ax);
@@ -164,21 +166,24 @@ __device__ __forceinline__ void tri_test(Lane<T> &L, const LeafTri<T> &tri, uint
     V = T(AxCy - AyCx);
     W = T(BxAy - ByAx);
   }
-  if (U < T(0) || V < T(0) || W < T(0)) { // nanort.h:1109-1116
-    if (cull || (U > T(0) || V > T(0) || W > T(0))) return;
-  }
+  const bool neg = (U < T(0)) | (V < T(0)) | (W < T(0)); // nanort.h:1109-1116
+  const bool pos = (U > T(0)) | (V > T(0)) | (W > T(0));
+  ok = ok & !(neg & (cull | pos));
   const T det = U + V + W;
-  if (det == T(0)) return;
-  const T Az = L.Sz * Akz, Bz = L.Sz * Bkz, Cz = L.Sz * Ckz;
-  const T D = U * Az + V * Bz + W * Cz;
-  const T rcp = T(1.0) / det;
-  const T tt = D * rcp;
-  if (tt > L.hit_t) return; // equality accepted (nanort.h:1133)
-  if (tt < L.min_t) return; // nanort.h:1137
-  L.hit_t = tt;
-  L.u = V * rcp;
-  L.v = W * rcp;
-  L.prim = prim;
+  ok = ok & !(det == T(0));
+  if (ok) { // skipped by the whole wave when no lane got this far
+    const T Az = L.Sz * Akz, Bz = L.Sz * Bkz, Cz = L.Sz * Ckz;
+    const T D = U * Az + V * Bz + W * Cz;
+    const T rcp = T(1.0) / det;
+    const T tt = D * rcp;
+    // `if (tt > t) return; if (tt < min_t) return;` — equality (and NaN) accepted (nanort.h:1133-1139)
+    const bool acc = !(tt > L.hit_t) & !(tt < L.min_t);
+    const T uu = V * rcp, vv = W * rcp;
+    L.hit_t = acc ? tt : L.hit_t;
+    L.u = acc ? uu : L.u;
+    L.v = acc ? vv : L.v;
+    L.prim = acc ? prim : L.prim;
+  }
 }
 
 __device__ __forceinline__ unsigned lane_id() {
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<
         if (i < cnt) {
           const LeafTri<T> tri = a.tris[leaf_first + i];
           if (COUNT) c_tris++;
-          tri_test<T>(L, tri, a.range0, a.range1, a.skip_prim, cull);
+          tri_test<T>(L, tri, true, a.range0, a.range1, a.skip_prim, cull);
         }
       }
       if (state == LANE_LEAF) NRT_POP_OR_FINISH();
@@ -443,10 +448,76 @@ __device__ __forceinline__ bool slab_test_tmin(const Lane<T> &L, const T box[6],
 
 enum : int { W_IDLE = 0, W_TRAV = 1, W_LEAF = 2, W_POP = 3 };
 
+// Both child boxes of one WideNode at once.  For fp32 the two boxes ride in the two halves of
+// 64-bit register pairs, so the subtract / multiply chain issues as v_pk_add_f32 / v_pk_mul_f32
+// (one VALU slot for two IEEE operations: same operations, same rounding, half the issue slots).
+template <typename T>
+struct SlabPair {
+  bool h0, h1;
+  T tm0, tm1;
+};
+
+__device__ __forceinline__ SlabPair<float> slab_pair(const Lane<float> &L, const WideNode<float> &w) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 mm = {Const<float>::maxmult(), Const<float>::maxmult()};
+  float tmin0 = L.min_t, tmin1 = L.min_t, tmax0 = L.hit_t, tmax1 = L.hit_t;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int sg = k == 0 ? L.sign0 : (k == 1 ? L.sign1 : L.sign2);
+    const f2 lo = {sg ? w.box0[3 + k] : w.box0[k], sg ? w.box1[3 + k] : w.box1[k]};
+    const f2 hi = {sg ? w.box0[k] : w.box0[3 + k], sg ? w.box1[k] : w.box1[3 + k]};
+    const f2 o = {L.org[k], L.org[k]};
+    const f2 iv = {L.inv[k], L.inv[k]};
+    const f2 t0 = (lo - o) * iv;
+    const f2 t1 = ((hi - o) * iv) * mm;
+    tmin0 = Const<float>::fmax(t0.x, tmin0); // see slab_test
+    tmin1 = Const<float>::fmax(t0.y, tmin1);
+    tmax0 = Const<float>::fmin(t1.x, tmax0);
+    tmax1 = Const<float>::fmin(t1.y, tmax1);
+  }
+  SlabPair<float> r;
+  r.h0 = tmin0 <= tmax0;
+  r.h1 = tmin1 <= tmax1;
+  r.tm0 = tmin0;
+  r.tm1 = tmin1;
+  return r;
+}
+
+__device__ __forceinline__ SlabPair<double> slab_pair(const Lane<double> &L, const WideNode<double> &w) {
+  SlabPair<double> r;
+  r.h0 = slab_test_tmin<double>(L, w.box0, r.tm0);
+  r.h1 = slab_test_tmin<double>(L, w.box1, r.tm1);
+  return r;
+}
+
+// One stack entry: child reference + its t_min (the t_min is kept as raw bits next to the reference so
+// that one LDS access moves both).
+template <typename T>
+struct StackEntry;
+template <>
+struct StackEntry<float> {
+  typedef uint2 type;
+  static __device__ __forceinline__ type make(uint32_t ref, float tm) { return make_uint2(ref, __float_as_uint(tm)); }
+  static __device__ __forceinline__ uint32_t ref(const type &e) { return e.x; }
+  static __device__ __forceinline__ float tmin(const type &e) { return __uint_as_float(e.y); }
+};
+template <>
+struct StackEntry<double> {
+  typedef uint4 type; // {ref, pad, t_min lo, t_min hi}
+  static __device__ __forceinline__ type make(uint32_t ref, double tm) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(tm);
+    return make_uint4(ref, 0u, (uint32_t)b, (uint32_t)(b >> 32));
+  }
+  static __device__ __forceinline__ uint32_t ref(const type &e) { return e.x; }
+  static __device__ __forceinline__ double tmin(const type &e) {
+    return __longlong_as_double((long long)(((unsigned long long)e.w << 32) | e.z));
+  }
+};
+
 template <typename T, int STACK, bool STATS>
 __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const TraverseArgs<T> a) {
-  __shared__ uint32_t s_ref[STACK][kTraverseBlock];
-  __shared__ T s_tmin[STACK][kTraverseBlock];
+  typedef StackEntry<T> SE;
+  __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
 
   typedef typename Wire<T>::Node Node;
   typedef typename Wire<T>::Ray Ray;
@@ -458,8 +529,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
   const bool cull = a.cull_back_face != 0;
 
   Lane<T> L;
-  uint32_t rid = kInvalid;
-  uint32_t cur = 0; // W_TRAV: WideNode index; W_LEAF: BVHNode index of the leaf
+  uint32_t rid = kInvalid; // ray whose result this lane holds (W_IDLE with rid valid: finished, not yet written)
+  uint32_t cur = 0;        // W_TRAV: WideNode index; W_LEAF: leaf reference without the leaf bit
   int state = W_IDLE;
   int sp = 0;
   Claim ck;
@@ -467,17 +538,35 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
   // STATS (profiling instantiation only): wave-level loop occupancy
   unsigned long long st_it1 = 0, st_act1 = 0, st_trav1 = 0, st_it2 = 0, st_act2 = 0, st_refills = 0, st_refilled = 0;
 
+  // PostTraversal (nanort.h:1205-1211) with the strict final predicate (:2552).  Finished lanes keep
+  // their result in registers until the lane is refilled (or the wave runs out of rays), so the
+  // stores are issued by many lanes at once instead of by the odd lane of every loop iteration.
+#define NRT_WRITE_RESULT()                              \
+  do {                                                  \
+    const bool hit_ = L.hit_t < L.max_t;                \
+    Hit h_;                                             \
+    h_.u = hit_ ? L.u : T(0);                           \
+    h_.v = hit_ ? L.v : T(0);                           \
+    h_.t = hit_ ? L.hit_t : L.max_t;                    \
+    h_.prim_id = hit_ ? L.prim : kInvalid;              \
+    store_hit_nt<T>(a.hits + rid, h_);                  \
+    if (a.mask) a.mask[rid] = hit_ ? 1 : 0;             \
+  } while (0)
+
   for (;;) {
     // ---- refill idle lanes ---------------------------------------------------------
     unsigned long long idle = __ballot(state == W_IDLE);
     if (!ck.exhausted && (unsigned)__builtin_popcountll(idle) >= a.refill_min) {
-      while (idle != 0ull && !ck.exhausted) {
-        if (ck.next == ck.end && !claim_chunk<T>(a, ck, lane, __builtin_ctzll(idle))) break;
-        const unsigned want = (unsigned)__builtin_popcountll(idle);
+      // lanes that still hold a result and lanes that never had a ray are both W_IDLE
+      unsigned long long fresh = idle;
+      while (fresh != 0ull && !ck.exhausted) {
+        if (ck.next == ck.end && !claim_chunk<T>(a, ck, lane, __builtin_ctzll(fresh))) break;
+        const unsigned want = (unsigned)__builtin_popcountll(fresh);
         const unsigned avail = ck.end - ck.next;
         const unsigned take = want < avail ? want : avail;
-        const unsigned rank = (unsigned)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+        const unsigned rank = (unsigned)__builtin_popcountll(fresh & ((1ull << lane) - 1ull));
         if (state == W_IDLE && rank < take) {
+          if (rid != kInvalid) NRT_WRITE_RESULT();
           rid = ck.next + rank;
           const Ray r = (a.debug_flags & 4u) ? a.rays[rid] : load_ray_nt<T>(a.rays + rid);
           lane_init<T>(L, r);
@@ -496,8 +585,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           st_refilled += take;
         }
         ck.next += take;
-        idle = __ballot(state == W_IDLE);
+        fresh = __ballot(state == W_IDLE);
       }
+      idle = __ballot(state == W_IDLE);
     }
     if (idle == ~0ull) {
       if (ck.exhausted) break;
@@ -513,49 +603,29 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
       }
       // a lane that must pop does so first and, if the popped entry survives, steps into it in the same iteration
       if (state == W_POP) {
-        const bool fin = (sp == 0);
-        if (fin) { // PostTraversal (nanort.h:1205-1211), strict final predicate (:2552)
-          const bool hit = L.hit_t < L.max_t;
-          Hit h;
-          h.u = hit ? L.u : T(0);
-          h.v = hit ? L.v : T(0);
-          h.t = hit ? L.hit_t : L.max_t;
-          h.prim_id = hit ? L.prim : kInvalid;
-          store_hit_nt<T>(a.hits + rid, h);
-          if (a.mask) a.mask[rid] = hit ? 1 : 0;
+        const int s1 = sp > 0 ? sp - 1 : 0;
+        typename SE::type e = s_stack[s1 < STACK ? s1 : STACK - 1][tid];
+        if (s1 >= STACK) { // rare: the entry lives in the global overflow stack
+          const size_t o = (size_t)(s1 - STACK) * a.spill_stride + gslot;
+          e = SE::make(a.spill[o], a.spill_tmin[o]);
         }
-        uint32_t ref = 0;
-        T tm = T(0);
-        if (!fin) {
-          const int s1 = sp - 1;
-          if (s1 < STACK) {
-            ref = s_ref[s1][tid];
-            tm = s_tmin[s1][tid];
-          } else {
-            const size_t o = (size_t)(s1 - STACK) * a.spill_stride + gslot;
-            ref = a.spill[o];
-            tm = a.spill_tmin[o];
-          }
-        }
-        const bool enter = !fin && (tm <= L.hit_t); // the reference's slab test at pop time
-        sp = fin ? sp : sp - 1;
+        const bool fin = (sp == 0);                                // empty stack: the ray is done
+        const bool enter = !fin & (SE::tmin(e) <= L.hit_t);        // the reference's slab test at pop time
+        const uint32_t ref = SE::ref(e);
+        sp = s1;
         cur = enter ? (ref & ~kLeafBit) : cur;
         state = fin ? W_IDLE : (enter ? ((ref & kLeafBit) ? W_LEAF : W_TRAV) : W_POP);
-        rid = fin ? kInvalid : rid;
       }
       if (state == W_TRAV) {
         const WideNode<T> w = a.wide[cur];
-        T tm0, tm1;
-        const bool h0 = slab_test_tmin<T>(L, w.box0, tm0);
-        const bool h1 = slab_test_tmin<T>(L, w.box1, tm1);
-        const int near = sel3(L.sign0, L.sign1, L.sign2, w.axis); // near child = data[dir_sign[axis]] (nanort.h:2538)
-        const uint32_t rn = near ? w.c1 : w.c0, rf = near ? w.c0 : w.c1;
-        const bool hn = near ? h1 : h0, hf = near ? h0 : h1;
-        const T tf = near ? tm0 : tm1;
-        if (hn && hf) { // far child waits with its t_min
+        const SlabPair<T> sl = slab_pair(L, w);
+        const bool near1 = sel3(L.sign0, L.sign1, L.sign2, w.axis) != 0; // near child = data[dir_sign[axis]] (nanort.h:2538)
+        const bool both = sl.h0 & sl.h1, any = sl.h0 | sl.h1;
+        if (both) { // the far child waits with its t_min
+          const uint32_t rf = near1 ? w.c0 : w.c1;
+          const T tf = near1 ? sl.tm0 : sl.tm1;
           if (sp < STACK) {
-            s_ref[sp][tid] = rf;
-            s_tmin[sp][tid] = tf;
+            s_stack[sp][tid] = SE::make(rf, tf);
           } else {
             const size_t o = (size_t)(sp - STACK) * a.spill_stride + gslot;
             a.spill[o] = rf;
@@ -563,13 +633,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           }
           sp++;
         }
-        const uint32_t next = hn ? rn : rf;
-        if (hn || hf) {
-          cur = next & ~kLeafBit;
-          state = (next & kLeafBit) ? W_LEAF : W_TRAV;
-        } else {
-          state = W_POP;
-        }
+        // both hit: the near one; one hit: that one
+        const uint32_t next = (both ? near1 : sl.h1) ? w.c1 : w.c0;
+        cur = any ? (next & ~kLeafBit) : cur;
+        state = any ? ((next & kLeafBit) ? W_LEAF : W_TRAV) : W_POP;
       }
       if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < a.trav_min) break;
     }
@@ -593,14 +660,15 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           st_it2++;
           st_act2 += (unsigned)__builtin_popcountll(__ballot(i < cnt));
         }
-        if (i < cnt) {
-          const LeafTri<T> tri = a.tris[first + i];
-          tri_test<T>(L, tri, a.range0, a.range1, a.skip_prim, cull);
-        }
+        // no divergent region here: lanes past their count re-test their first record with ok = false
+        const LeafTri<T> tri = a.tris[first + (i < cnt ? i : 0u)];
+        tri_test<T>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull);
       }
       state = (state == W_LEAF) ? W_POP : state;
     }
   }
+  if (rid != kInvalid) NRT_WRITE_RESULT(); // results still held in registers
+#undef NRT_WRITE_RESULT
   if (STATS && lane == 0) { // counters[0..6]: it1, act1, trav1, it2, act2, refills, refilled
     atomicAdd(&a.counters[0], st_it1);
     atomicAdd(&a.counters[1], st_act1);
