@@ -117,6 +117,28 @@ def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, budget_s=12
             "build_ms": round(build_ms, 1)}
 
 
+def pipelined(accel, torch, wave1, wave2, steps, rays_per_step, frames_in_flight=2):
+    """K steps with `frames_in_flight` independent frames in flight, one stream per frame (one context: every
+    launch owns a launch slot).  Same work as the timed region; reported beside it, never as `value`."""
+    streams = [torch.cuda.Stream() for _ in range(frames_in_flight)]
+    bufs = [(wave1, wave2)] + [tuple((w[0], torch.empty_like(w[1]), torch.empty_like(w[2])) for w in (wave1, wave2))
+                               for _ in range(frames_in_flight - 1)]
+    def run(k):
+        for i in range(k):
+            w1, w2 = bufs[i % frames_in_flight]
+            with torch.cuda.stream(streams[i % frames_in_flight]):
+                accel.TraverseBatchDevice(*w1)
+                accel.TraverseBatchDevice(*w2)
+    run(2 * frames_in_flight)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"frames_in_flight": frames_in_flight, "value": round(rays_per_step * steps / dt / 1e6, 1), "unit": "Mrays/s",
+            "ms_per_step": round(dt / steps * 1e3, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -294,6 +316,21 @@ def main():
                 },
             },
         }
+        if world == 1:
+            # extras, outside the timed region: (a) the same K steps with two frames in flight (steps alternate
+            # between two streams; a launch's drain tail is filled by the next frame's rays), (b) SURVEY 8(d)'s
+            # primary + shadow pair
+            out["pipelined"] = pipelined(accel, torch, (d_rays1, d_hits1, d_mask1), (d_rays2, d_hits2, d_mask2), args.steps, n1 + n2)
+            rays_s = scenes.secondary_rays("shadow", verts, faces, rays1, hits1, mask1)
+            d_rs = torch.from_numpy(rays_s.view(np.uint8)).cuda()
+            d_hs = torch.empty(max(1, rays_s.shape[0]) * HIT_F32.itemsize, dtype=torch.uint8, device="cuda")
+            ts = []
+            for _ in range(5):
+                accel.TraverseBatchDevice(d_rs, d_hs)
+                ts.append(accel.LastTraverseMs())
+            ms_s = float(np.median(ts))
+            out["primary_plus_shadow"] = {"value": round((n1 + rays_s.shape[0]) / (k_ms1 + ms_s) / 1e3, 1), "unit": "Mrays/s",
+                                          "shadow_ms": round(ms_s, 4), "shadow_rays": int(rays_s.shape[0])}
         if world == 1 and not args.no_cpu_baseline:
             nodes, indices = accel.GetTree()
             out["cpu_baseline"] = cpu_baseline(verts, faces, rays1, rays2, nodes, indices)

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -69,14 +70,26 @@ struct nrt_ctx {
   uint32_t packed_leaves = 0;
   nrt_build_stats stats = {0, 0, 0, 0.f};
 
-  // traversal scratch
-  uint32_t *d_cursor = nullptr;              // ray cursor
-  unsigned long long *d_counters = nullptr;  // 4 x u64
-  DevBuf spill, st_rays, st_hits, st_mask;
+  // traversal scratch.  Every launch owns one LaunchSlot (work cursors + overflow stacks) until it
+  // completes, so launches issued on different streams may overlap on the GPU: the drain tail of one
+  // batch is filled by the start of the next.  Launches on one stream keep reusing one slot.
+  struct LaunchSlot {
+    uint32_t *d_cursor = nullptr; // ray cursors (one per partition, 4 KiB apart)
+    DevBuf spill, spill_tmin;
+    hipEvent_t done = nullptr;    // recorded after the slot's last launch
+    hipStream_t stream = nullptr; // stream of that launch
+    bool used = false;
+  };
+  static constexpr int kSlots = 4;
+  LaunchSlot slots[kSlots];
+  unsigned next_victim = 0;
+  std::mutex launch_mutex; // slot selection + launch (nrtTraverseBatchDevice may be called from several host threads)
+  unsigned long long *d_counters = nullptr;  // 8 x u64 (counting pass / profiling instantiation only)
+  DevBuf st_rays, st_hits, st_mask;
 
   // traversal tuning (env NRT_LDS_STACK / NRT_REFILL_MIN / NRT_TRAV_MIN / NRT_CHUNK override)
   int lds_stack = kLdsStackDefault;
-  unsigned blocks_per_cu = 0, chunk = 64, refill_min = 48, trav_min = 8;
+  unsigned blocks_per_cu = 0, chunk = 64, refill_min = 48, trav_min = 8, leaf_min = 32, old_age = 0;
   unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
   unsigned debug_flags = 0;
   int morton = 0; // Morton-order the primitive records before the build (env NRT_MORTON=1): measured +0.4 ms at 1M tris for an identical tree, so off by default
@@ -84,7 +97,6 @@ struct nrt_ctx {
   unsigned max_blocks_per_cu = 0; // env NRT_BLOCKS_PER_CU caps the persistent grid
   int wide = 1, wide_stack = 10; // production path: WideNode kernel (env NRT_WIDE=0 selects the binary kernel)
   unsigned wide_blocks_per_cu = 0;
-  DevBuf spill_tmin;
 
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
   bool have_traverse_time = false, have_build_time = false;
@@ -154,11 +166,18 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
       (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&c->ev_t0)) != hipSuccess || (e = hipEventCreate(&c->ev_t1)) != hipSuccess ||
       (e = hipEventCreate(&c->ev_b0)) != hipSuccess || (e = hipEventCreate(&c->ev_b1)) != hipSuccess ||
-      (e = hipMalloc((void **)&c->d_cursor, kCursorStrideWords * 4 * kMaxParts)) != hipSuccess ||
       (e = hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) {
     fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
-    delete c;
+    nrtDestroy(c);
     return NRT_ERR_DEVICE;
+  }
+  for (nrt_ctx::LaunchSlot &sl : c->slots) {
+    if ((e = hipMalloc((void **)&sl.d_cursor, kCursorStrideWords * 4 * kMaxParts)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess) {
+      fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
+      nrtDestroy(c);
+      return NRT_ERR_DEVICE;
+    }
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -169,6 +188,8 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   }
   if (const char *e = getenv("NRT_REFILL_MIN")) c->refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
   if (const char *e = getenv("NRT_TRAV_MIN")) c->trav_min = (unsigned)std::min(64, std::max(1, atoi(e)));
+  if (const char *e = getenv("NRT_OLD_AGE")) c->old_age = (unsigned)std::max(0, atoi(e));
+  if (const char *e = getenv("NRT_LEAF_MIN")) c->leaf_min = (unsigned)std::min(64, std::max(1, atoi(e)));
   if (const char *e = getenv("NRT_CHUNK")) c->chunk = (unsigned)std::max(16, atoi(e));
   if (const char *e = getenv("NRT_PARTS")) c->num_parts = (unsigned)std::min((int)kMaxParts, std::max(1, atoi(e)));
   if (const char *e = getenv("NRT_DEBUG")) c->debug_flags = (unsigned)atoi(e);
@@ -187,14 +208,19 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
 void nrtDestroy(nrt_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (nrt_ctx::LaunchSlot &sl : c->slots) { // launches still in flight on the caller's streams
+    if (sl.used && sl.done) (void)hipEventSynchronize(sl.done);
+    if (sl.d_cursor) (void)hipFree(sl.d_cursor);
+    if (sl.spill.p) (void)hipFree(sl.spill.p);
+    if (sl.spill_tmin.p) (void)hipFree(sl.spill_tmin.p);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
   free_tree(c);
   free_mesh(c);
-  DevBuf *bufs[] = {&c->spill,   &c->spill_tmin, &c->st_rays, &c->st_hits,         &c->st_mask,    &c->b_nodes,
-                    &c->b_indices, &c->b_tris,     &c->b_wide,  &c->b_wide_scratch, &c->b_build_ws};
+  DevBuf *bufs[] = {&c->st_rays, &c->st_hits, &c->st_mask, &c->b_nodes, &c->b_indices, &c->b_tris, &c->b_wide, &c->b_wide_scratch, &c->b_build_ws};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
-  if (c->d_cursor) (void)hipFree(c->d_cursor);
   if (c->d_counters) (void)hipFree(c->d_counters);
   hipEvent_t evs[] = {c->ev_t0, c->ev_t1, c->ev_b0, c->ev_b1};
   for (hipEvent_t ev : evs)
@@ -413,7 +439,28 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   if (!d_rays) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatch: NULL rays");
   if (n > 0x7FFFFFFFull) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatch: more than 2^31-1 rays in one call");
   if (!opt) opt = &kDefaultTrace;
+  std::lock_guard<std::mutex> lock(c->launch_mutex);
   HIPCHK(c, hipSetDevice(c->device));
+
+  // launch slot: the one this stream used last (stream order already serialises the two launches), else
+  // a fresh one, else the oldest — whose previous launch this stream then waits for on the device
+  nrt_ctx::LaunchSlot *slot = nullptr;
+  for (nrt_ctx::LaunchSlot &sl : c->slots)
+    if (sl.used && sl.stream == s) {
+      slot = &sl;
+      break;
+    }
+  if (!slot)
+    for (nrt_ctx::LaunchSlot &sl : c->slots)
+      if (!sl.used) {
+        slot = &sl;
+        break;
+      }
+  if (!slot) {
+    slot = &c->slots[c->next_victim];
+    c->next_victim = (c->next_victim + 1) % nrt_ctx::kSlots;
+    HIPCHK(c, hipStreamWaitEvent(s, slot->done, 0));
+  }
 
   // persistent grid: every block resident (occupancy of the chosen variant)
   const bool use_wide = c->wide && !count && c->d_wide;
@@ -431,11 +478,11 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   // static share: a multiple of 64 rays per wave, c->static_pct percent of the batch in total
   const uint32_t static_per_wave = (uint32_t)(((uint64_t)n * c->static_pct / 100) / total_waves / 64) * 64;
   const uint32_t levels = c->tree_depth + 2 > (uint32_t)stack_entries ? c->tree_depth + 2 - stack_entries : 0;
-  if (levels) {
-    nrt_status st = ensure(c, c->spill, (size_t)levels * total_threads * sizeof(uint32_t));
+  if (levels) { // (growing a buffer frees the old one, which waits for every launch in flight)
+    nrt_status st = ensure(c, slot->spill, (size_t)levels * total_threads * sizeof(uint32_t));
     if (st) return st;
     if (use_wide) {
-      st = ensure(c, c->spill_tmin, (size_t)levels * total_threads * sizeof(T));
+      st = ensure(c, slot->spill_tmin, (size_t)levels * total_threads * sizeof(T));
       if (st) return st;
     }
   }
@@ -446,7 +493,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.wide = (const WideNode<T> *)c->d_wide;
   a.packed_leaves = c->packed_leaves;
   a.debug_flags = c->debug_flags;
-  a.spill_tmin = (T *)c->spill_tmin.p;
+  a.spill_tmin = (T *)slot->spill_tmin.p;
   a.rays = d_rays;
   a.hits = d_hits;
   a.mask = d_mask;
@@ -455,10 +502,10 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.range1 = opt->prim_ids_range[1];
   a.skip_prim = opt->skip_prim_id;
   a.cull_back_face = opt->cull_back_face ? 1u : 0u;
-  a.spill = (uint32_t *)c->spill.p;
+  a.spill = (uint32_t *)slot->spill.p;
   a.spill_stride = total_threads;
   a.spill_levels = levels;
-  a.ray_cursor = c->d_cursor;
+  a.ray_cursor = slot->d_cursor;
   a.num_parts = parts;
   a.static_per_wave = static_per_wave;
   a.dyn_begin = static_per_wave * total_waves;
@@ -467,8 +514,10 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.chunk = c->chunk;
   a.refill_min = c->refill_min;
   a.trav_min = c->trav_min;
+  a.leaf_min = c->leaf_min;
+  a.old_age = c->old_age;
 
-  HIPCHK(c, hipMemsetAsync(c->d_cursor, 0, kCursorStrideWords * 4 * c->num_parts, s));
+  HIPCHK(c, hipMemsetAsync(slot->d_cursor, 0, kCursorStrideWords * 4 * c->num_parts, s));
   if (count || (c->debug_flags & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s));
   if (timed) HIPCHK(c, hipEventRecord(c->ev_t0, s));
   if (use_wide)
@@ -479,6 +528,9 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
     HIPCHK(c, hipEventRecord(c->ev_t1, s));
     c->have_traverse_time = true;
   }
+  HIPCHK(c, hipEventRecord(slot->done, s));
+  slot->stream = s;
+  slot->used = true;
   return NRT_OK;
 }
 

@@ -533,10 +533,14 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
   uint32_t cur = 0;        // W_TRAV: WideNode index; W_LEAF: leaf reference without the leaf bit
   int state = W_IDLE;
   int sp = 0;
+  uint32_t birth = 0;     // value of `iter` when this lane's ray started
+  uint32_t iter = 0;      // inner-loop iterations of this wave (wave-uniform)
+  bool boosted = false;   // wave priority currently raised
   Claim ck;
   claim_init<T>(a, ck);
   // STATS (profiling instantiation only): wave-level loop occupancy
-  unsigned long long st_it1 = 0, st_act1 = 0, st_trav1 = 0, st_it2 = 0, st_act2 = 0, st_refills = 0, st_refilled = 0;
+  unsigned long long st_it1 = 0, st_act1 = 0, st_idle2 = 0, st_it2 = 0, st_act2 = 0, st_refills = 0, st_refilled = 0, st_entries2 = 0;
+  uint32_t st_steps = 0, st_tris = 0; // per ray; with debug flag 64 they replace u, v of the hit record
 
   // PostTraversal (nanort.h:1205-1211) with the strict final predicate (:2552).  Finished lanes keep
   // their result in registers until the lane is refilled (or the wave runs out of rays), so the
@@ -547,6 +551,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
     Hit h_;                                             \
     h_.u = hit_ ? L.u : T(0);                           \
     h_.v = hit_ ? L.v : T(0);                           \
+    if (STATS && (a.debug_flags & 64u)) {               \
+      h_.u = T(st_steps);                               \
+      h_.v = T(st_tris);                                \
+    }                                                   \
     h_.t = hit_ ? L.hit_t : L.max_t;                    \
     h_.prim_id = hit_ ? L.prim : kInvalid;              \
     store_hit_nt<T>(a.hits + rid, h_);                  \
@@ -571,6 +579,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           const Ray r = (a.debug_flags & 4u) ? a.rays[rid] : load_ray_nt<T>(a.rays + rid);
           lane_init<T>(L, r);
           sp = 0;
+          birth = iter;
+          if (STATS) st_steps = st_tris = 0;
           // the reference pops and tests the root first (nanort.h:2526-2533)
           const Node root = a.nodes[0];
           const bool root_hit = slab_test<T>(L, root.bmin, root.bmax);
@@ -596,10 +606,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
 
     // ---- phase 1: inner nodes / stack pops ---------------------------------------------
     while (state == W_TRAV || state == W_POP) {
+      iter++;
       if (STATS) {
         st_it1++;
         st_act1 += (unsigned)__builtin_popcountll(__ballot(true));
-        st_trav1 += (unsigned)__builtin_popcountll(__ballot(state == W_TRAV));
       }
       // a lane that must pop does so first and, if the popped entry survives, steps into it in the same iteration
       if (state == W_POP) {
@@ -617,6 +627,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
         state = fin ? W_IDLE : (enter ? ((ref & kLeafBit) ? W_LEAF : W_TRAV) : W_POP);
       }
       if (state == W_TRAV) {
+        if (STATS) st_steps++;
         const WideNode<T> w = a.wide[cur];
         const SlabPair<T> sl = slab_pair(L, w);
         const bool near1 = sel3(L.sign0, L.sign1, L.sign2, w.axis) != 0; // near child = data[dir_sign[axis]] (nanort.h:2538)
@@ -641,8 +652,27 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
       if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < a.trav_min) break;
     }
 
+    // A ray that has been walking for a long time is on the launch's critical path (the step counts are
+    // heavy-tailed: the longest ray of a wave of incoherent rays takes ~8x the mean): the wave that holds
+    // one asks the instruction arbiter for priority, so that the ray advances at single-wave latency
+    // instead of at 1/occupancy of it.
+    if (a.old_age != 0u) {
+      const bool old = __ballot(state != W_IDLE && iter - birth > a.old_age) != 0ull;
+      if (old != boosted) {
+        if (old) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+        boosted = old;
+      }
+    }
+
     // ---- phase 2: leaves ------------------------------------------------------------------
-    if (__ballot(state == W_LEAF) != 0ull) {
+    // With only a few lanes at a leaf and a refill due, take the refill first: the new rays walk to
+    // their first leaves while these lanes wait, and the triangle loop then runs with many more
+    // lanes.  (Every skip is followed by a refill that hands out at least one ray or marks the
+    // claim exhausted, so this always makes progress.)
+    const unsigned n_leaf = (unsigned)__builtin_popcountll(__ballot(state == W_LEAF));
+    const bool refill_due = !ck.exhausted && (unsigned)__builtin_popcountll(__ballot(state == W_IDLE)) >= a.refill_min;
+    if (n_leaf != 0u && !(n_leaf < a.leaf_min && refill_due)) {
       uint32_t cnt = 0, first = 0;
       if (state == W_LEAF) {
         if (a.packed_leaves) {
@@ -655,10 +685,15 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
         }
       }
       if (a.debug_flags & 1u) cnt = 0;
+      if (STATS) {
+        st_entries2++;
+        st_idle2 += (unsigned)__builtin_popcountll(__ballot(state == W_IDLE));
+      }
       for (uint32_t i = 0; __ballot(i < cnt) != 0ull; i++) {
         if (STATS) {
           st_it2++;
           st_act2 += (unsigned)__builtin_popcountll(__ballot(i < cnt));
+          if (i < cnt) st_tris++;
         }
         // no divergent region here: lanes past their count re-test their first record with ok = false
         const LeafTri<T> tri = a.tris[first + (i < cnt ? i : 0u)];
@@ -669,14 +704,15 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
   }
   if (rid != kInvalid) NRT_WRITE_RESULT(); // results still held in registers
 #undef NRT_WRITE_RESULT
-  if (STATS && lane == 0) { // counters[0..6]: it1, act1, trav1, it2, act2, refills, refilled
+  if (STATS && lane == 0) { // counters[0..7]: it1, act1, idle lanes at phase-2 entry, it2, act2, refills, refilled, phase-2 entries
     atomicAdd(&a.counters[0], st_it1);
     atomicAdd(&a.counters[1], st_act1);
-    atomicAdd(&a.counters[2], st_trav1);
+    atomicAdd(&a.counters[2], st_idle2);
     atomicAdd(&a.counters[3], st_it2);
     atomicAdd(&a.counters[4], st_act2);
     atomicAdd(&a.counters[5], st_refills);
     atomicAdd(&a.counters[6], st_refilled);
+    atomicAdd(&a.counters[7], st_entries2);
   }
 }
 

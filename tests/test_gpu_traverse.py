@@ -152,6 +152,36 @@ def test_device_resident_entry_point_matches_host_entry_point(c1):
     assert a.LastTraverseMs() > 0
 
 
+def test_launches_on_several_streams_overlap_safely():
+    """One context, launches issued back to back on more streams than there are launch slots, no host sync in
+    between (each launch owns its cursors and overflow stacks): every result equals the serial one."""
+    import torch
+
+    v, f = scenes.plane(200, 100)
+    a = BVHAccel(np.float32)
+    assert a.Build(f.shape[0], TriangleMesh(v, f))
+    rays1 = scenes.camera_rays(480, 270)
+    h1, m1 = a.TraverseBatch(rays1)
+    rays2 = scenes.secondary_rays("bounce", v, f, rays1, h1, m1)
+    h2, m2 = a.TraverseBatch(rays2)
+    batches = [(rays1, h1, m1), (rays2, h2, m2)]
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    dev = []
+    for k in range(18):
+        r, h, m = batches[k % 2]
+        dev.append((torch.from_numpy(r.view(np.uint8)).cuda(), torch.zeros(r.shape[0] * 16, dtype=torch.uint8, device="cuda"),
+                    torch.zeros(r.shape[0], dtype=torch.uint8, device="cuda")))
+    torch.cuda.synchronize()
+    for k, (d_r, d_h, d_m) in enumerate(dev):
+        with torch.cuda.stream(streams[k % len(streams)]):
+            a.TraverseBatchDevice(d_r, d_h, d_m)
+    torch.cuda.synchronize()
+    for k, (d_r, d_h, d_m) in enumerate(dev):
+        r, h, m = batches[k % 2]
+        assert d_h.cpu().numpy().tobytes() == h.tobytes(), "launch %d" % k
+        assert np.array_equal(d_m.cpu().numpy(), m)
+
+
 def test_error_paths(c1_mesh):
     from nanort_amd import NrtError
 

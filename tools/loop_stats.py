@@ -16,7 +16,7 @@ for name, rays in (('primary', rays1), ('bounce', rays2)):
     d = torch.from_numpy(rays.view(np.uint8)).cuda(); o = torch.empty(len(rays) * 16, dtype=torch.uint8, device='cuda')
     a.TraverseBatchDevice(d, o); ms = a.LastTraverseMs()
     c = np.zeros(8, dtype=np.uint64); L.nrtDebugCounters(a._h, c.ctypes.data_as(ctypes.c_void_p))
-    it1, act1, trav1, it2, act2, refills, refilled = [int(x) for x in c[:7]]
+    it1, act1, idle2, it2, act2, refills, refilled, ent2 = [int(x) for x in c[:8]]
     n = len(rays)
-    print(name, 'ms %.3f' % ms, 'phase1: wave-iters/ray-group %.1f' % (it1 / (n / 64)), 'avg active lanes %.1f (TRAV %.1f)' % (act1 / it1, trav1 / it1),
-          '| phase2: wave-iters/ray-group %.1f avg active %.1f' % (it2 / (n / 64), act2 / max(1, it2)), '| refills/group %.2f lanes/refill %.1f' % (refills / (n / 64), refilled / max(1, refills)))
+    print(name, 'ms %.3f' % ms, 'phase1: wave-iters/ray-group %.1f' % (it1 / (n / 64)), 'avg active lanes %.1f' % (act1 / it1),
+          '| phase2: wave-iters/ray-group %.1f avg active %.1f' % (it2 / (n / 64), act2 / max(1, it2)), 'entries/group %.2f idle lanes at entry %.1f' % (ent2 / (n / 64), idle2 / max(1, ent2)), '| refills/group %.2f lanes/refill %.1f' % (refills / (n / 64), refilled / max(1, refills)))
