@@ -64,6 +64,7 @@ struct nrt_ctx {
   uint32_t *d_indices = nullptr; // == b_indices.p
   void *d_tris = nullptr;        // LeafTri<T>[num_indices] == b_tris.p
   void *d_wide = nullptr;        // WideNode<T>[branches]   == b_wide.p
+  uint32_t num_branch_records = 0; // nodes with flag == 0 in the node array (reachable or not)
   uint64_t num_nodes = 0, num_indices = 0;
   uint32_t tree_depth = 0;
   uint32_t max_leaf_count = 0, min_leaf_count = 0; // over the leaves of the current tree
@@ -89,7 +90,7 @@ struct nrt_ctx {
 
   // traversal tuning (env NRT_LDS_STACK / NRT_REFILL_MIN / NRT_TRAV_MIN / NRT_CHUNK override)
   int lds_stack = kLdsStackDefault;
-  unsigned blocks_per_cu = 0, chunk = 64, refill_min = 48, trav_min = 8, leaf_min = 32, old_age = 0;
+  unsigned blocks_per_cu = 0, chunk = 64, refill_min = 48, trav_min = 8, leaf_min = 32;
   unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
   unsigned debug_flags = 0;
   int morton = 0; // Morton-order the primitive records before the build (env NRT_MORTON=1): measured +0.4 ms at 1M tris for an identical tree, so off by default
@@ -188,7 +189,6 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   }
   if (const char *e = getenv("NRT_REFILL_MIN")) c->refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
   if (const char *e = getenv("NRT_TRAV_MIN")) c->trav_min = (unsigned)std::min(64, std::max(1, atoi(e)));
-  if (const char *e = getenv("NRT_OLD_AGE")) c->old_age = (unsigned)std::max(0, atoi(e));
   if (const char *e = getenv("NRT_LEAF_MIN")) c->leaf_min = (unsigned)std::min(64, std::max(1, atoi(e)));
   if (const char *e = getenv("NRT_CHUNK")) c->chunk = (unsigned)std::max(16, atoi(e));
   if (const char *e = getenv("NRT_PARTS")) c->num_parts = (unsigned)std::min((int)kMaxParts, std::max(1, atoi(e)));
@@ -292,7 +292,8 @@ static nrt_status finish_tree(nrt_ctx *c) {
   HIPCHK(c, launch_gather_leaf_tris<T>(c->d_indices, c->d_faces, (const T *)c->d_verts,
                                        (LeafTri<T> *)c->d_tris, (uint32_t)c->num_indices, c->stream));
   // one WideNode per branch; a binary tree has (num_nodes - 1) / 2 of them
-  if ((st = ensure(c, c->b_wide, std::max<size_t>(1, c->num_nodes / 2 + 1) * sizeof(WideNode<T>)))) return st;
+  // one WideNode per record with flag == 0 (a loaded tree may carry unreachable ones)
+  if ((st = ensure(c, c->b_wide, std::max<size_t>(1, c->num_branch_records) * sizeof(WideNode<T>)))) return st;
   c->d_wide = c->b_wide.p;
   c->packed_leaves = (c->min_leaf_count >= 1 && c->max_leaf_count <= kPackedMaxCount &&
                       c->num_indices <= (uint64_t)kPackedFirstMask) ? 1u : 0u;
@@ -350,6 +351,9 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
   c->tree_depth = depth;
   c->max_leaf_count = max_leaf;
   c->min_leaf_count = min_leaf;
+  c->num_branch_records = 0;
+  for (uint64_t i = 0; i < num_nodes; i++)
+    if (nodes[i].flag == 0) c->num_branch_records++;
   nrt_status st;
   if ((st = ensure(c, c->b_nodes, num_nodes * sizeof(typename Wire<T>::Node)))) return st;
   if ((st = ensure(c, c->b_indices, std::max<uint64_t>(1, num_indices) * sizeof(uint32_t)))) return st;
@@ -407,6 +411,7 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   c->num_indices = c->num_faces;
   c->tree_depth = res.max_depth;
   c->max_leaf_count = res.max_leaf_count;
+  c->num_branch_records = res.num_branches;
   c->min_leaf_count = 1; // the GPU builder never emits an empty leaf
   nrt_status fst = finish_tree<T>(c); // leaf-ordered triangles + WideNode array: part of the build
   if (fst) return fst;
@@ -515,7 +520,6 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.refill_min = c->refill_min;
   a.trav_min = c->trav_min;
   a.leaf_min = c->leaf_min;
-  a.old_age = c->old_age;
 
   HIPCHK(c, hipMemsetAsync(slot->d_cursor, 0, kCursorStrideWords * 4 * c->num_parts, s));
   if (count || (c->debug_flags & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s));

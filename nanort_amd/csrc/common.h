@@ -124,7 +124,6 @@ struct TraverseArgs {
   uint32_t chunk;                    // rays claimed per atomic
   uint32_t refill_min;               // refill idle lanes once this many are idle (1..64)
   uint32_t trav_min;                 // leave the inner-node loop when fewer lanes than this are walking
-  uint32_t old_age;                  // a wave holding a ray older than this many inner-loop iterations raises its issue priority (0 = never)
   uint32_t leaf_min;                 // with fewer lanes than this waiting at a leaf, refill first (if a refill is due) and test triangles later
 };
 

@@ -533,9 +533,6 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
   uint32_t cur = 0;        // W_TRAV: WideNode index; W_LEAF: leaf reference without the leaf bit
   int state = W_IDLE;
   int sp = 0;
-  uint32_t birth = 0;     // value of `iter` when this lane's ray started
-  uint32_t iter = 0;      // inner-loop iterations of this wave (wave-uniform)
-  bool boosted = false;   // wave priority currently raised
   Claim ck;
   claim_init<T>(a, ck);
   // STATS (profiling instantiation only): wave-level loop occupancy
@@ -579,7 +576,6 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           const Ray r = (a.debug_flags & 4u) ? a.rays[rid] : load_ray_nt<T>(a.rays + rid);
           lane_init<T>(L, r);
           sp = 0;
-          birth = iter;
           if (STATS) st_steps = st_tris = 0;
           // the reference pops and tests the root first (nanort.h:2526-2533)
           const Node root = a.nodes[0];
@@ -606,7 +602,6 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
 
     // ---- phase 1: inner nodes / stack pops ---------------------------------------------
     while (state == W_TRAV || state == W_POP) {
-      iter++;
       if (STATS) {
         st_it1++;
         st_act1 += (unsigned)__builtin_popcountll(__ballot(true));
@@ -650,19 +645,6 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
         state = any ? ((next & kLeafBit) ? W_LEAF : W_TRAV) : W_POP;
       }
       if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < a.trav_min) break;
-    }
-
-    // A ray that has been walking for a long time is on the launch's critical path (the step counts are
-    // heavy-tailed: the longest ray of a wave of incoherent rays takes ~8x the mean): the wave that holds
-    // one asks the instruction arbiter for priority, so that the ray advances at single-wave latency
-    // instead of at 1/occupancy of it.
-    if (a.old_age != 0u) {
-      const bool old = __ballot(state != W_IDLE && iter - birth > a.old_age) != 0ull;
-      if (old != boosted) {
-        if (old) __builtin_amdgcn_s_setprio(3);
-        else __builtin_amdgcn_s_setprio(0);
-        boosted = old;
-      }
     }
 
     // ---- phase 2: leaves ------------------------------------------------------------------
@@ -790,6 +772,7 @@ __global__ __launch_bounds__(256) void k_make_wide(const typename Wire<T>::Node 
   if (i >= n) return;
   const typename Wire<T>::Node nd = nodes[i];
   if (nd.flag != 0) return;
+  if (nd.data[0] >= n || nd.data[1] >= n) return; // an unreachable record of a loaded tree: never visited
   const typename Wire<T>::Node a = nodes[nd.data[0]], b = nodes[nd.data[1]];
   WideNode<T> w;
 #pragma unroll

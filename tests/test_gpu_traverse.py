@@ -182,6 +182,25 @@ def test_launches_on_several_streams_overlap_safely():
         assert np.array_equal(d_m.cpu().numpy(), m)
 
 
+def test_loaded_tree_with_unreachable_records(oracle, c1):
+    """A loaded node array may carry records no path reaches (the reference's Load() takes any array,
+    nanort.h:2219-2275); they must be ignored, whatever they contain."""
+    v, f, nodes, idx, _ = c1
+    junk = np.zeros(5, dtype=nodes.dtype)
+    junk["flag"] = 0                      # look like branches
+    junk["data"][:, 0] = 0xFFFFFFF0       # children far out of range
+    junk["data"][:, 1] = 5
+    junk["axis"] = 7
+    padded = np.concatenate([nodes, junk])
+    a = BVHAccel(np.float32)
+    a.SetMesh(TriangleMesh(v, f))
+    a.SetTree(padded, idx)
+    rays = scenes.camera_rays(128, 128)
+    h, m = a.TraverseBatch(rays)
+    oh, om = oracle.traverse(nodes, idx, v, f, rays)
+    assert_hits_identical(oh, om, h, m)
+
+
 def test_error_paths(c1_mesh):
     from nanort_amd import NrtError
 
