@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--builds", type=int, default=5)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras (2 frames in flight, primary+shadow): use for rocprofv3 runs, so that the "
+                         "kernel statistics hold the timed region's launches only")
     args = ap.parse_args()
 
     import torch
@@ -316,7 +319,7 @@ def main():
                 },
             },
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # extras, outside the timed region: (a) the same K steps with two frames in flight (steps alternate
             # between two streams; a launch's drain tail is filled by the next frame's rays), (b) SURVEY 8(d)'s
             # primary + shadow pair

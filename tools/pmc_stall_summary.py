@@ -16,14 +16,16 @@ dur = defaultdict(list)
 for path in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
     rows = [r for r in csv.DictReader(open(path)) if "k_traverse_wide<float, 10" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # dispatch order of tools/pmc_traffic.py: one host-path primary launch, then (primary, bounce) pairs
     for k, r in enumerate(rows):
-        dur[k % 2].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        if k >= 1:
+            dur[(k - 1) % 2].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k in (0, 1):
     if dur[k]:
         print("%s launch: %.1f us mean under the profiler (%d launches)" % (("primary", "bounce")[k], sum(dur[k]) / len(dur[k]), len(dur[k])))
 print("%-40s %16s %16s" % ("counter", "primary", "bounce"))
 for c in sorted(vals):
-    p = [sum(v) for d, v in vals[c].items() if d % 2 == 0 and d >= 2]
-    b = [sum(v) for d, v in vals[c].items() if d % 2 == 1 and d >= 2]
+    p = [sum(v) for d, v in vals[c].items() if d % 2 == 1]
+    b = [sum(v) for d, v in vals[c].items() if d % 2 == 0 and d >= 2]
     if p and b:
         print("%-40s %16.0f %16.0f" % (c, sum(p) / len(p), sum(b) / len(b)))
