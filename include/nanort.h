@@ -557,6 +557,116 @@ inline bool IntersectRayAABB(T *tminOut, T *tmaxOut, T min_t, T max_t, const T b
 }
 
 // ---------------------------------------------------------------------------
+// Built-in sphere ("particle") primitive.  Not in the reference header: the reference ships it as user code in
+// examples/particle_primitive/main.cc (SpherePred :82-108, SphereGeometry :113-147, SphereIntersection :149-159,
+// SphereIntersector :161-291).  Same concepts, same arithmetic, same names — an application drops its local
+// copies and uses these; with NANORT_USE_HIP_BACKEND, Build() over (SphereGeometry, SpherePred) and
+// TraverseBatch() with SphereIntersection run on the GPU (nrtSetSpheres_f32).  fp32, like the example.
+// ---------------------------------------------------------------------------
+class SpherePred {
+ public:
+  explicit SpherePred(const float *centers) : axis_(0), pos_(0.0f), centers_(centers) {}
+  void Set(int axis, float pos) const {
+    axis_ = axis;
+    pos_ = pos;
+  }
+  bool operator()(unsigned int i) const { return centers_[3 * i + axis_] < pos_; }
+
+ private:
+  mutable int axis_;
+  mutable float pos_;
+  const float *centers_;
+};
+
+class SphereGeometry {
+ public:
+  SphereGeometry(const float *centers, const float *radii) : centers_(centers), radii_(radii) {}
+  void BoundingBox(real3<float> *bmin, real3<float> *bmax, unsigned int i) const {
+    for (int k = 0; k < 3; k++) {
+      (*bmin)[k] = centers_[3 * i + k] - radii_[i];
+      (*bmax)[k] = centers_[3 * i + k] + radii_[i];
+    }
+  }
+  void BoundingBoxAndCenter(real3<float> *bmin, real3<float> *bmax, real3<float> *center, unsigned int i) const {
+    BoundingBox(bmin, bmax, i);
+    for (int k = 0; k < 3; k++) (*center)[k] = centers_[3 * i + k];
+  }
+  const float *GetCenters() const { return centers_; }
+  const float *GetRadii() const { return radii_; }
+
+ private:
+  const float *centers_;
+  const float *radii_;
+};
+
+class SphereIntersection {
+ public:
+  SphereIntersection() : u(0.0f), v(0.0f), t(std::numeric_limits<float>::max()), prim_id(static_cast<unsigned int>(-1)) {}
+  float u, v;  // spherical coordinates of the hit normal, both in [0, 1]
+  float t;
+  unsigned int prim_id;
+};
+
+template <class H = SphereIntersection>
+class SphereIntersector {
+ public:
+  SphereIntersector(const float *centers, const float *radii) : centers_(centers), radii_(radii), t_(0.0f), prim_id_(0) {}
+
+  // Nearest root of |org + t dir - c|^2 = r^2 that lies in front of the origin, accepted iff <= *t_inout.
+  bool Intersect(float *t_inout, unsigned int i) const {
+    if (i < opts_.prim_ids_range[0] || i >= opts_.prim_ids_range[1]) return false;
+    const real3<float> oc = org_ - real3<float>(&centers_[3 * i]);
+    const float a = vdot(dir_, dir_);
+    const float b = 2.0f * vdot(dir_, oc);
+    const float c = vdot(oc, oc) - radii_[i] * radii_[i];
+    const float disc = b * b - 4.0f * a * c;
+    if (disc < 0.0f) return false;
+    float t0, t1;
+    if (std::fabs(disc) < std::numeric_limits<float>::epsilon()) {
+      t0 = t1 = -0.5f * (b / a);
+    } else {
+      const float root = std::sqrt(disc);
+      const float q = (b < 0) ? (-b - root) / 2.0f : (-b + root) / 2.0f;
+      t0 = q / a;
+      t1 = c / q;
+    }
+    if (t0 > t1) std::swap(t0, t1);
+    if (t1 < 0) return false;
+    const float t = (t0 < 0) ? t1 : t0;
+    if (t > *t_inout) return false;
+    *t_inout = t;
+    return true;
+  }
+  float GetT() const { return t_; }
+  void Update(float t, unsigned int i) const {
+    t_ = t;
+    prim_id_ = i;
+  }
+  void PrepareTraversal(const Ray<float> &ray, const BVHTraceOptions &options) const {
+    org_ = real3<float>(ray.org);
+    dir_ = real3<float>(ray.dir);
+    opts_ = options;
+  }
+  void PostTraversal(const Ray<float> &, bool hit, H *isect) const {
+    if (!hit) return;
+    const real3<float> n = vnormalize((org_ + t_ * dir_) - real3<float>(&centers_[3 * prim_id_]));
+    const double pi = 3.14159265358979323846;
+    isect->t = t_;
+    isect->prim_id = prim_id_;
+    isect->u = float(std::atan2(double(n[0]), double(n[2])) + pi) * 0.5f * float(1.0 / pi);
+    isect->v = float(std::acos(double(n[1])) / pi);
+  }
+
+ private:
+  const float *centers_;
+  const float *radii_;
+  mutable real3<float> org_, dir_;
+  mutable BVHTraceOptions opts_;
+  mutable float t_;
+  mutable unsigned int prim_id_;
+};
+
+// ---------------------------------------------------------------------------
 // BVHAccel
 // ---------------------------------------------------------------------------
 namespace detail {
@@ -570,11 +680,14 @@ struct same_type<A, A> {
 };
 struct generic_tag {};
 struct triangle_tag {};
+struct sphere_tag {};
 template <typename T, class Prim, class Pred>
 struct build_tag {
 #ifdef NANORT_USE_HIP_BACKEND
-  typedef typename std::conditional<same_type<Prim, TriangleMesh<T> >::value && same_type<Pred, TriangleSAHPred<T> >::value,
-                                    triangle_tag, generic_tag>::type type;
+  typedef typename std::conditional<
+      same_type<Prim, TriangleMesh<T> >::value && same_type<Pred, TriangleSAHPred<T> >::value, triangle_tag,
+      typename std::conditional<same_type<T, float>::value && same_type<Prim, SphereGeometry>::value && same_type<Pred, SpherePred>::value,
+                                sphere_tag, generic_tag>::type>::type type;
 #else
   typedef generic_tag type;
 #endif
@@ -791,9 +904,22 @@ class BVHAccel {
   // (LastBackendError() tells why).
   bool TraverseBatch(const Ray<T> *rays, size_t num_rays, TriangleIntersection<T> *isects, unsigned char *hit_out = NULL,
                      const BVHTraceOptions &options = BVHTraceOptions()) const {
+    return TraverseBatchImpl(rays, num_rays, isects, hit_out, options);
+  }
+  // Same for a tree built over the built-in sphere primitive (SphereGeometry + SpherePred).
+  bool TraverseBatch(const Ray<T> *rays, size_t num_rays, SphereIntersection *isects, unsigned char *hit_out = NULL,
+                     const BVHTraceOptions &options = BVHTraceOptions()) const {
+    static_assert(detail::same_type<T, float>::value, "the sphere primitive is fp32");
+    return TraverseBatchImpl(rays, num_rays, isects, hit_out, options);
+  }
+  const std::string &LastBackendError() const { return backend_error_; }
+
+ private:
+  template <class Hit>
+  bool TraverseBatchImpl(const Ray<T> *rays, size_t num_rays, Hit *isects, unsigned char *hit_out, const BVHTraceOptions &options) const {
     typedef detail::HipApi<T> Api;
     static_assert(sizeof(Ray<T>) == sizeof(typename Api::RayPod), "Ray layout");
-    static_assert(sizeof(TriangleIntersection<T>) == sizeof(typename Api::HitPod), "TriangleIntersection layout");
+    static_assert(sizeof(Hit) == sizeof(typename Api::HitPod), "intersection record layout");
     static_assert(sizeof(BVHTraceOptions) == sizeof(nrt_trace_options), "BVHTraceOptions layout");
     if (!ctx_) {
       backend_error_ = "TraverseBatch: no GPU context (Build() with TriangleMesh/TriangleSAHPred first)";
@@ -808,7 +934,7 @@ class BVHAccel {
       device_tree_stale_ = false;
     }
     if (num_rays == 0) return true;
-    std::vector<TriangleIntersection<T> > tmp(num_rays);
+    std::vector<Hit> tmp(num_rays);
     std::vector<unsigned char> mask(num_rays);
     nrt_trace_options o;
     std::memcpy(&o, &options, sizeof(o));
@@ -823,7 +949,8 @@ class BVHAccel {
     }
     return true;
   }
-  const std::string &LastBackendError() const { return backend_error_; }
+
+ public:
 #endif
 
   const std::vector<BVHNode<T> > &GetNodes() const { return nodes_; }
@@ -992,14 +1119,25 @@ class BVHAccel {
   }
 
 #ifdef NANORT_USE_HIP_BACKEND
-  // Built-in triangle types: construction on the GPU through the C ABI.
+  // Built-in primitive types: construction on the GPU through the C ABI.
   bool BuildImpl(unsigned int n, const TriangleMesh<T> &mesh, const TriangleSAHPred<T> &pred, const BVHBuildOptions<T> &options,
                  detail::triangle_tag) {
+    (void)pred;
+    typedef detail::HipApi<T> Api;
+    return HipBuild(n, options, [&](nrt_ctx *c) { return Api::SetMesh(c, mesh.GetVertices(), mesh.GetVertexStrideBytes(), mesh.GetFaces(), n); });
+  }
+  bool BuildImpl(unsigned int n, const SphereGeometry &geom, const SpherePred &pred, const BVHBuildOptions<T> &options,
+                 detail::sphere_tag) {
+    (void)pred;
+    return HipBuild(n, options, [&](nrt_ctx *c) { return nrtSetSpheres_f32(c, geom.GetCenters(), geom.GetRadii(), n); });
+  }
+
+  template <class SetPrims>
+  bool HipBuild(unsigned int n, const BVHBuildOptions<T> &options, SetPrims set_prims) {
     typedef detail::HipApi<T> Api;
     static_assert(sizeof(BVHNode<T>) == sizeof(typename Api::NodePod), "BVHNode layout");
     static_assert(sizeof(BVHBuildOptions<T>) == sizeof(typename Api::BuildPod), "BVHBuildOptions layout");
     static_assert(sizeof(BVHBuildStatistics) == sizeof(nrt_build_stats), "BVHBuildStatistics layout");
-    (void)pred;
     options_ = options;
     stats_ = BVHBuildStatistics();
     nodes_.clear();
@@ -1022,8 +1160,7 @@ class BVHAccel {
     std::memcpy(&o, &options, sizeof(o));
     nrt_build_stats st;
     uint64_t num_nodes = 0;
-    if (Api::SetMesh(c, mesh.GetVertices(), mesh.GetVertexStrideBytes(), mesh.GetFaces(), n) != NRT_OK ||
-        Api::Build(c, &o, &st, &num_nodes) != NRT_OK) {
+    if (set_prims(c) != NRT_OK || Api::Build(c, &o, &st, &num_nodes) != NRT_OK) {
       backend_error_ = nrtLastError(c);
       fprintf(stderr, "[nanort] HIP build failed: %s\n", backend_error_.c_str());
       return false;

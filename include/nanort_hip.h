@@ -181,6 +181,16 @@ NRT_API nrt_status nrtSetMesh_f32(nrt_ctx *ctx, const float *vertices, size_t ve
 NRT_API nrt_status nrtSetMesh_f64(nrt_ctx *ctx, const double *vertices, size_t vertex_stride_bytes,
                                   const uint32_t *faces, uint32_t num_faces);
 
+/* ---- sphere primitives: replaces the SpherePred / SphereGeometry / SphereIntersector constructors of the
+ * reference's custom-primitive example (examples/particle_primitive/main.cc:82-147, 161-166) -------------
+ * `centers` holds xyz per sphere (tight), `radii` one radius per sphere.  After this call nrtBuild_f32 builds
+ * over the spheres' boxes (centre +- radius, SAH position = the centre) and nrtTraverseBatch*_f32 runs that
+ * example's intersector: nearest root of the quadratic with the reference's acceptance rules (main.cc:174-236),
+ * hit record {u, v, t, prim_id} with u, v the spherical coordinates of the hit normal (main.cc:262-277).
+ * BVHTraceOptions: prim_ids_range is honoured; skip_prim_id and cull_back_face do not exist in that intersector
+ * and are ignored.  Replaces the mesh of the context (one primitive kind per context). */
+NRT_API nrt_status nrtSetSpheres_f32(nrt_ctx *ctx, const float *centers, const float *radii, uint32_t num_spheres);
+
 /* ---- build: replaces BVHAccel<T>::Build (nanort.h:716-718, 1892-2149) ----
  * Binned-SAH construction on the GPU over the mesh set above.  Honours
  * min_leaf_primitives, max_tree_depth and bin_size; shallow_depth,

@@ -58,8 +58,21 @@ class TriangleMesh:
         return self.vertex_stride_bytes
 
 
+class SphereGeometry:
+    """The sphere ("particle") custom primitive of the reference (examples/particle_primitive/main.cc:82-291:
+    SpherePred + SphereGeometry + SphereIntersector rolled into one description): xyz centres and one radius each."""
+
+    def __init__(self, centers, radii):
+        self.centers = np.ascontiguousarray(centers, dtype=np.float32).reshape(-1, 3)
+        self.radii = np.ascontiguousarray(radii, dtype=np.float32).reshape(-1)
+        if self.centers.shape[0] != self.radii.shape[0]:
+            raise ValueError("one radius per centre")
+        self.num_spheres = int(self.radii.shape[0])
+        self.num_faces = self.num_spheres  # "number of primitives", under the name Build() checks
+
+
 class BVHAccel:
-    """nanort::BVHAccel<T> on one MI355X (built-in triangle geometry only)."""
+    """nanort::BVHAccel<T> on one MI355X (built-in triangle geometry, or the sphere primitive in fp32)."""
 
     def __init__(self, real=np.float32, device=0):
         self.real = np.dtype(real)
@@ -93,6 +106,12 @@ class BVHAccel:
 
     # -- mesh / build -------------------------------------------------------
     def SetMesh(self, mesh):
+        if isinstance(mesh, SphereGeometry):
+            if self.real != np.float32:
+                raise TypeError("sphere primitives are fp32 (as the reference example)")
+            self._check(self._L.nrtSetSpheres_f32(self._h, _p(mesh.centers), _p(mesh.radii), mesh.num_spheres))
+            self._mesh = mesh
+            return
         if mesh.vertices.dtype != self.real:
             raise TypeError("mesh precision %s != accel precision %s" % (mesh.vertices.dtype, self.real))
         self._check(
@@ -105,7 +124,10 @@ class BVHAccel:
     def Build(self, num_primitives, mesh, options=None):
         """BVHAccel::Build (reference nanort.h:1892-2149). Returns False iff n == 0."""
         if num_primitives != mesh.num_faces:
-            mesh = TriangleMesh(mesh.vertices, mesh.faces[:num_primitives], mesh.vertex_stride_bytes)
+            if isinstance(mesh, SphereGeometry):
+                mesh = SphereGeometry(mesh.centers[:num_primitives], mesh.radii[:num_primitives])
+            else:
+                mesh = TriangleMesh(mesh.vertices, mesh.faces[:num_primitives], mesh.vertex_stride_bytes)
         self.SetMesh(mesh)
         if options is not None:
             want = BUILD_OPTIONS_F32 if self.real == np.float32 else BUILD_OPTIONS_F64

@@ -15,7 +15,7 @@ NRT_OK, NRT_ERR_INVALID, NRT_ERR_EMPTY, NRT_ERR_DEVICE, NRT_ERR_PRECISION = 0, 1
 # header and this table against the built library).
 SYMBOLS = [
     "nrtCreate", "nrtDestroy", "nrtLastError", "nrtVersion",
-    "nrtSetMesh_f32", "nrtSetMesh_f64",
+    "nrtSetMesh_f32", "nrtSetMesh_f64", "nrtSetSpheres_f32",
     "nrtBuild_f32", "nrtBuild_f64",
     "nrtGetTree_f32", "nrtGetTree_f64", "nrtTreeSize",
     "nrtSetTree_f32", "nrtSetTree_f64",
@@ -97,6 +97,8 @@ def lib():
         f = getattr(L, "nrtTraverseCountDevice_" + s)
         f.argtypes = [vp, vp, u64, vp, ctypes.POINTER(TraceCounters)]
         f.restype = i32
+    L.nrtSetSpheres_f32.argtypes = [vp, vp, vp, u32]
+    L.nrtSetSpheres_f32.restype = i32
     L.nrtSceneCreate.argtypes = [i32, ctypes.POINTER(vp)]
     L.nrtSceneCreate.restype = i32
     L.nrtSceneDestroy.argtypes = [vp]

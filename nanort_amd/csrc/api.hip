@@ -23,9 +23,11 @@ hipError_t launch_traverse(const TraverseArgs<T> &, unsigned grid, bool count, i
 template <typename T>
 int traverse_blocks_per_cu(int lds_stack);
 template <typename T>
-hipError_t launch_traverse_wide(const TraverseArgs<T> &, unsigned grid, int lds_stack, hipStream_t);
+hipError_t launch_traverse_wide(const TraverseArgs<T> &, unsigned grid, int lds_stack, int prim_kind, hipStream_t);
 template <typename T>
-int traverse_wide_blocks_per_cu(int lds_stack);
+int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind);
+template <typename T>
+hipError_t launch_gather_leaf_spheres(const uint32_t *, const T *, const T *, LeafSphere<T> *, uint32_t, hipStream_t);
 template <typename T>
 hipError_t launch_make_wide(const typename Wire<T>::Node *, uint32_t, uint32_t packed, uint32_t *scratch, WideNode<T> *,
                             hipStream_t);
@@ -37,7 +39,7 @@ struct BuildResult {
   uint32_t max_depth, num_leaves, num_branches, max_leaf_count;
 };
 template <typename T>
-hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, uint32_t num_faces,
+hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, uint32_t num_faces,
                      uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, bool morton_order,
                      DevBuf *workspace, DevBuf *nodes_buf, DevBuf *indices_buf, BuildResult *res, std::string *err);
 } // namespace nrt
@@ -54,7 +56,9 @@ struct nrt_ctx {
   int num_cus = 256;
 
   // mesh (tight xyz in HBM)
+  int prim_kind = kPrimTriangles; // kPrimSpheres: d_verts = centers, d_radii = radii, no faces
   void *d_verts = nullptr;
+  void *d_radii = nullptr;
   uint32_t *d_faces = nullptr;
   uint32_t num_faces = 0, num_verts = 0;
 
@@ -97,7 +101,7 @@ struct nrt_ctx {
   unsigned static_pct = 75; // share of a batch handed out statically, percent (env NRT_STATIC_PCT)
   unsigned max_blocks_per_cu = 0; // env NRT_BLOCKS_PER_CU caps the persistent grid
   int wide = 1, wide_stack = 10; // production path: WideNode kernel (env NRT_WIDE=0 selects the binary kernel)
-  unsigned wide_blocks_per_cu = 0;
+  unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
 
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
   bool have_traverse_time = false, have_build_time = false;
@@ -142,8 +146,10 @@ static void free_tree(nrt_ctx *c) {
 static void free_mesh(nrt_ctx *c) {
   if (c->d_verts) (void)hipFree(c->d_verts);
   if (c->d_faces) (void)hipFree(c->d_faces);
+  if (c->d_radii) (void)hipFree(c->d_radii);
   c->d_verts = nullptr;
   c->d_faces = nullptr;
+  c->d_radii = nullptr;
   c->num_faces = c->num_verts = 0;
 }
 
@@ -251,6 +257,7 @@ static nrt_status set_mesh(nrt_ctx *c, const T *vertices, size_t stride, const u
   free_tree(c);
   free_mesh(c);
   c->prec = (int)sizeof(T);
+  c->prim_kind = kPrimTriangles;
   c->num_faces = num_faces;
   if (num_faces == 0) return NRT_OK;
   // The reference's mesh carries no vertex count (nanort.h:925-930): derive it.
@@ -280,17 +287,47 @@ static nrt_status set_mesh(nrt_ctx *c, const T *vertices, size_t stride, const u
   return NRT_OK;
 }
 
+// Sphere primitives (SphereGeometry of examples/particle_primitive/main.cc:113-147): xyz centres, one radius each.
+template <typename T>
+static nrt_status set_spheres(nrt_ctx *c, const T *centers, const T *radii, uint32_t n) {
+  if (!c) return NRT_ERR_INVALID;
+  if (c->prec != 0 && c->prec != (int)sizeof(T))
+    return fail(c, NRT_ERR_PRECISION, "nrtSetSpheres: context already holds %s primitives", c->prec == 4 ? "f32" : "f64");
+  if (n && (!centers || !radii)) return fail(c, NRT_ERR_INVALID, "nrtSetSpheres: NULL pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_tree(c);
+  free_mesh(c);
+  c->prec = (int)sizeof(T);
+  c->prim_kind = kPrimSpheres;
+  c->num_faces = n;
+  c->num_verts = n;
+  if (n == 0) return NRT_OK;
+  HIPCHK(c, hipMalloc(&c->d_verts, 3 * (size_t)n * sizeof(T)));
+  HIPCHK(c, hipMalloc(&c->d_radii, (size_t)n * sizeof(T)));
+  HIPCHK(c, hipMemcpy(c->d_verts, centers, 3 * (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_radii, radii, (size_t)n * sizeof(T), hipMemcpyHostToDevice));
+  return NRT_OK;
+}
+
 // ---------------------------------------------------------------------------
 // tree adoption / retrieval
 // ---------------------------------------------------------------------------
 template <typename T>
 static nrt_status finish_tree(nrt_ctx *c) {
   nrt_status st;
-  // leaf-ordered triangle records for the traversal kernel
-  if ((st = ensure(c, c->b_tris, std::max<size_t>(1, c->num_indices) * sizeof(LeafTri<T>)))) return st;
-  c->d_tris = c->b_tris.p;
-  HIPCHK(c, launch_gather_leaf_tris<T>(c->d_indices, c->d_faces, (const T *)c->d_verts,
-                                       (LeafTri<T> *)c->d_tris, (uint32_t)c->num_indices, c->stream));
+  // leaf-ordered primitive records for the traversal kernel
+  if (c->prim_kind == kPrimSpheres) {
+    if ((st = ensure(c, c->b_tris, std::max<size_t>(1, c->num_indices) * sizeof(LeafSphere<T>)))) return st;
+    c->d_tris = c->b_tris.p;
+    HIPCHK(c, launch_gather_leaf_spheres<T>(c->d_indices, (const T *)c->d_verts, (const T *)c->d_radii,
+                                            (LeafSphere<T> *)c->d_tris, (uint32_t)c->num_indices, c->stream));
+  } else {
+    if ((st = ensure(c, c->b_tris, std::max<size_t>(1, c->num_indices) * sizeof(LeafTri<T>)))) return st;
+    c->d_tris = c->b_tris.p;
+    HIPCHK(c, launch_gather_leaf_tris<T>(c->d_indices, c->d_faces, (const T *)c->d_verts,
+                                         (LeafTri<T> *)c->d_tris, (uint32_t)c->num_indices, c->stream));
+  }
   // one WideNode per branch; a binary tree has (num_nodes - 1) / 2 of them
   // one WideNode per record with flag == 0 (a loaded tree may carry unreachable ones)
   if ((st = ensure(c, c->b_wide, std::max<size_t>(1, c->num_branch_records) * sizeof(WideNode<T>)))) return st;
@@ -402,7 +439,7 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   BuildResult res;
   std::string err;
   HIPCHK(c, hipEventRecord(c->ev_b0, c->stream));
-  hipError_t e = gpu_build<T>(c->stream, (const T *)c->d_verts, c->d_faces, c->num_faces, min_leaf, max_depth,
+  hipError_t e = gpu_build<T>(c->stream, (const T *)c->d_verts, c->d_faces, (const T *)c->d_radii, c->num_faces, min_leaf, max_depth,
                               bin_size, c->morton != 0, &c->b_build_ws, &c->b_nodes, &c->b_indices, &res, &err);
   if (e != hipSuccess) return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s (%s)", err.c_str(), hipGetErrorString(e));
   c->d_nodes = c->b_nodes.p;
@@ -468,12 +505,16 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   }
 
   // persistent grid: every block resident (occupancy of the chosen variant)
-  const bool use_wide = c->wide && !count && c->d_wide;
+  const bool spheres = c->prim_kind == kPrimSpheres;
+  if (spheres && (count || !c->d_wide))
+    return fail(c, NRT_ERR_INVALID, "nrtTraverse: sphere primitives run on the WideNode kernel only (no counting pass)");
+  const bool use_wide = (c->wide || spheres) && !count && c->d_wide;
   if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
-  if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack);
-  unsigned blocks_per_cu = use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu;
+  if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles);
+  if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, kPrimSpheres);
+  unsigned blocks_per_cu = spheres ? c->sphere_blocks_per_cu : (use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu);
   if (c->max_blocks_per_cu && blocks_per_cu > c->max_blocks_per_cu) blocks_per_cu = c->max_blocks_per_cu;
-  const int stack_entries = use_wide ? c->wide_stack : c->lds_stack;
+  const int stack_entries = spheres ? 10 : (use_wide ? c->wide_stack : c->lds_stack);
   uint64_t need_blocks = (n + kTraverseBlock - 1) / kTraverseBlock;
   unsigned grid = (unsigned)std::min<uint64_t>(need_blocks, (uint64_t)c->num_cus * blocks_per_cu);
   const unsigned parts = std::max(1u, std::min(c->num_parts, grid));
@@ -495,6 +536,8 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   TraverseArgs<T> a;
   a.nodes = (const typename Wire<T>::Node *)c->d_nodes;
   a.tris = (const LeafTri<T> *)c->d_tris;
+  a.spheres = (const LeafSphere<T> *)c->d_tris;
+  a.centers = (const T *)c->d_verts;
   a.wide = (const WideNode<T> *)c->d_wide;
   a.packed_leaves = c->packed_leaves;
   a.debug_flags = c->debug_flags;
@@ -525,7 +568,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   if (count || (c->debug_flags & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s));
   if (timed) HIPCHK(c, hipEventRecord(c->ev_t0, s));
   if (use_wide)
-    HIPCHK(c, launch_traverse_wide<T>(a, grid, c->wide_stack, s));
+    HIPCHK(c, launch_traverse_wide<T>(a, grid, c->wide_stack, c->prim_kind, s));
   else
     HIPCHK(c, launch_traverse<T>(a, grid, count, c->lds_stack, s));
   if (timed) {
@@ -589,6 +632,10 @@ nrt_status nrtSetMesh_f32(nrt_ctx *c, const float *v, size_t stride, const uint3
 }
 nrt_status nrtSetMesh_f64(nrt_ctx *c, const double *v, size_t stride, const uint32_t *f, uint32_t nf) {
   return set_mesh<double>(c, v, stride, f, nf);
+}
+
+nrt_status nrtSetSpheres_f32(nrt_ctx *c, const float *centers, const float *radii, uint32_t n) {
+  return set_spheres<float>(c, centers, radii, n);
 }
 
 nrt_status nrtBuild_f32(nrt_ctx *c, const nrt_build_options_f32 *o, nrt_build_stats *st, uint64_t *nn) {

@@ -268,7 +268,8 @@ __device__ __forceinline__ T wave_max(T x) {
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_prim_records(const T *__restrict__ verts,
-                                                      const uint32_t *__restrict__ faces, uint32_t n,
+                                                      const uint32_t *__restrict__ faces,
+                                                      const T *__restrict__ radii, uint32_t n,
                                                       PrimRec<T> *__restrict__ recs,
                                                       BoundsAcc<T> *__restrict__ scene) {
   typedef typename Ord<T>::U U;
@@ -282,15 +283,27 @@ __global__ __launch_bounds__(256) void k_prim_records(const T *__restrict__ vert
     hi[k] = chi[k] = -Lim<T>::max();
   }
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    const uint32_t f0 = faces[3 * (size_t)i], f1 = faces[3 * (size_t)i + 1], f2 = faces[3 * (size_t)i + 2];
     PrimRec<T> r;
     const T third = T(1) / T(3);
+    uint32_t f0 = 0, f1 = 0, f2 = 0;
+    if (faces) {
+      f0 = faces[3 * (size_t)i];
+      f1 = faces[3 * (size_t)i + 1];
+      f2 = faces[3 * (size_t)i + 2];
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      const T p0 = verts[3 * (size_t)f0 + k], p1 = verts[3 * (size_t)f1 + k], p2 = verts[3 * (size_t)f2 + k];
-      r.bmin[k] = tmin(p0, tmin(p1, p2)); // nanort.h:967-968
-      r.bmax[k] = tmax(p0, tmax(p1, p2));
-      r.c[k] = ((p0 + p1) + p2) * third; // nanort.h:970
+      if (faces) { // triangles
+        const T p0 = verts[3 * (size_t)f0 + k], p1 = verts[3 * (size_t)f1 + k], p2 = verts[3 * (size_t)f2 + k];
+        r.bmin[k] = tmin(p0, tmin(p1, p2)); // nanort.h:967-968
+        r.bmax[k] = tmax(p0, tmax(p1, p2));
+        r.c[k] = ((p0 + p1) + p2) * third; // nanort.h:970
+      } else { // spheres: SphereGeometry::BoundingBoxAndCenter (examples/particle_primitive/main.cc:124-136)
+        const T c = verts[3 * (size_t)i + k], rad = radii[i];
+        r.bmin[k] = c - rad;
+        r.bmax[k] = c + rad;
+        r.c[k] = c;
+      }
       lo[k] = tmin(lo[k], r.bmin[k]);
       hi[k] = tmax(hi[k], r.bmax[k]);
       clo[k] = tmin(clo[k], r.c[k]);
@@ -1476,8 +1489,8 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
 // per-frame rebuild).  Host synchronisations: one or two to learn that the top phase has
 // run out of large nodes, one to size the node array.
 template <typename T>
-hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, uint32_t n, uint32_t min_leaf,
-                     uint32_t max_depth, uint32_t bin_size, bool morton_order, DevBuf *workspace, DevBuf *nodes_buf,
+hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, uint32_t n,
+                     uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, bool morton_order, DevBuf *workspace, DevBuf *nodes_buf,
                      DevBuf *indices_buf, BuildResult *res, std::string *err) {
   typedef typename Wire<T>::Node Node;
   const int K = (int)(bin_size < 2 ? 2 : (bin_size > (uint32_t)kMaxBins ? (uint32_t)kMaxBins : bin_size));
@@ -1505,7 +1518,7 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, u
     hipLaunchKernelGGL((k_init_scene<T>), dim3(1), dim3(64), 0, s, scene, info, (uint32_t)plan.max_top);
     {
       unsigned grid = (unsigned)std::min<size_t>(((size_t)n + 255) / 256, 2048);
-      hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, n, recs[0], scene);
+      hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, d_radii, n, recs[0], scene);
     }
     int cur = 0; // buffer holding the ranges of the nodes being split
     if (morton_order && n > 1) {
@@ -1592,9 +1605,9 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, u
   }
 }
 
-template hipError_t gpu_build<float>(hipStream_t, const float *, const uint32_t *, uint32_t, uint32_t, uint32_t,
-                                     uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
-template hipError_t gpu_build<double>(hipStream_t, const double *, const uint32_t *, uint32_t, uint32_t, uint32_t,
-                                      uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
+template hipError_t gpu_build<float>(hipStream_t, const float *, const uint32_t *, const float *, uint32_t, uint32_t,
+                                     uint32_t, uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
+template hipError_t gpu_build<double>(hipStream_t, const double *, const uint32_t *, const double *, uint32_t, uint32_t,
+                                      uint32_t, uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
 
 } // namespace nrt

@@ -73,6 +73,17 @@ struct alignas(8) LeafTri {
   uint32_t prim_id;
 };
 static_assert(sizeof(LeafTri<float>) == 40, "LeafTri<float>");
+
+// Leaf-ordered sphere record (primitive kind 1: the particle primitive of
+// examples/particle_primitive/main.cc:82-291).
+template <typename T>
+struct LeafSphere {
+  T c[3];
+  T r;
+  uint32_t prim_id;
+};
+static_assert(sizeof(LeafSphere<float>) == 20, "LeafSphere<float>");
+enum : int { kPrimTriangles = 0, kPrimSpheres = 1 };
 static_assert(sizeof(LeafTri<double>) == 80, "LeafTri<double>");
 
 // Private traversal layout: one record per BRANCH node holding BOTH children's boxes, so a
@@ -101,7 +112,9 @@ constexpr uint32_t kPackedMaxCount = 16;
 template <typename T>
 struct TraverseArgs {
   const typename Wire<T>::Node *nodes;
-  const LeafTri<T> *tris;
+  const LeafTri<T> *tris;        // primitive kind 0
+  const LeafSphere<T> *spheres;  // primitive kind 1 (leaf order)
+  const T *centers;              // primitive kind 1: xyz per primitive id (PostTraversal)
   const WideNode<T> *wide; // may be null (binary kernel only)
   uint32_t packed_leaves;  // leaf references of `wide` are PACKED (see WideNode)
   uint32_t debug_flags;    // profiling only (env NRT_DEBUG): 1 = skip triangle tests, 2 = skip traversal

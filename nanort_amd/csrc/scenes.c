@@ -280,3 +280,72 @@ uint64_t nrt_rays_secondary(int kind, const float *verts, const uint32_t *faces,
   }
   return m;
 }
+
+/* ---- the particle example's workload (examples/particle_primitive/main.cc) ------------------------------ */
+
+/* PCG32 as that example uses it (main.cc:23-52): one float in [0, 1) per call. */
+typedef struct {
+  unsigned long long state, inc;
+} particle_rng;
+static float particle_random(particle_rng *rng) {
+  const unsigned long long old = rng->state;
+  unsigned int xorshifted, rot, ret;
+  rng->state = old * 6364136223846793005ULL + rng->inc;
+  xorshifted = (unsigned int)(((old >> 18u) ^ old) >> 27u);
+  rot = (unsigned int)(old >> 59u);
+  ret = (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31u));
+  return (float)((double)ret / 4294967296.0);
+}
+
+/* GenerateRandomSpheres (main.cc:295-325): n spheres with centres uniform in [bmin, bmax), seed (0, 1), all
+ * radii = largest box extent / sqrt(n). */
+void nrt_scene_random_spheres(uint64_t n, const float bmin[3], const float bmax[3], float *centers, float *radii) {
+  particle_rng rng;
+  float bsize = bmax[0] - bmin[0];
+  uint64_t i;
+  rng.state = 0u;
+  rng.inc = (1ULL << 1u) | 1u;
+  (void)particle_random(&rng);
+  rng.state += 0ULL;
+  (void)particle_random(&rng);
+  if (bsize < bmax[1] - bmin[1]) bsize = bmax[1] - bmin[1];
+  if (bsize < bmax[2] - bmin[2]) bsize = bmax[2] - bmin[2];
+  for (i = 0; i < n; i++) {
+    const float x = particle_random(&rng), y = particle_random(&rng), z = particle_random(&rng);
+    centers[3 * i + 0] = x * (bmax[0] - bmin[0]) + bmin[0];
+    centers[3 * i + 1] = y * (bmax[1] - bmin[1]) + bmin[1];
+    centers[3 * i + 2] = z * (bmax[2] - bmin[2]) + bmin[2];
+    radii[i] = bsize / (float)sqrt((double)n);
+  }
+}
+
+/* That example's camera (main.cc:367-389): org = (0, 0, 4), dir = vnormalize(x/W - 0.5, y/H - 0.5, -1)
+ * (nanort.h:383-398: scaled by 1/len when len > FLT_EPSILON), min_t = 0, max_t = 1e30; row-major. */
+void nrt_rays_particle_camera(uint32_t W, uint32_t H, ray_f32 *out) {
+  uint32_t x, y;
+  for (y = 0; y < H; y++) {
+    for (x = 0; x < W; x++) {
+      ray_f32 *r = &out[(size_t)y * W + x];
+      float d[3], len;
+      d[0] = (x / (float)W) - 0.5f;
+      d[1] = (y / (float)H) - 0.5f;
+      d[2] = -1.0f;
+      len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      if (fabsf(len) > 1.1920928955078125e-07f) {
+        const float inv_len = 1.0f / len;
+        d[0] *= inv_len;
+        d[1] *= inv_len;
+        d[2] *= inv_len;
+      }
+      r->org[0] = 0.0f;
+      r->org[1] = 0.0f;
+      r->org[2] = 4.0f;
+      r->dir[0] = d[0];
+      r->dir[1] = d[1];
+      r->dir[2] = d[2];
+      r->min_t = 0.0f;
+      r->max_t = 1.0e30f;
+      r->type = 0x1u;
+    }
+  }
+}

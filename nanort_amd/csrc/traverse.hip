@@ -28,6 +28,7 @@ struct Const<float> {
   static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
   static __device__ __forceinline__ float fmax(float a, float b) { return __builtin_fmaxf(a, b); }
   static __device__ __forceinline__ float fmin(float a, float b) { return __builtin_fminf(a, b); }
+  static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
 };
 template <>
 struct Const<double> {
@@ -37,6 +38,7 @@ struct Const<double> {
   static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
   static __device__ __forceinline__ double fmax(double a, double b) { return __builtin_fmax(a, b); }
   static __device__ __forceinline__ double fmin(double a, double b) { return __builtin_fmin(a, b); }
+  static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }
 };
 
 template <typename T>
@@ -60,6 +62,7 @@ struct Lane {
   T org[3];
   T inv[3];
   T min_t, max_t, hit_t; // hit_t == intersector t_ == best so far
+  T d0, d1, d2;          // ray direction (sphere kind only; dead otherwise)
   T Sx, Sy, Sz;
   T u, v;
   uint32_t prim;
@@ -70,6 +73,9 @@ struct Lane {
 template <typename T>
 __device__ __forceinline__ void lane_init(Lane<T> &L, const typename Wire<T>::Ray &r) {
   T d0 = r.dir[0], d1 = r.dir[1], d2 = r.dir[2];
+  L.d0 = d0;
+  L.d1 = d1;
+  L.d2 = d2;
   L.org[0] = r.org[0];
   L.org[1] = r.org[1];
   L.org[2] = r.org[2];
@@ -182,6 +188,43 @@ __device__ __forceinline__ void tri_test(Lane<T> &L, const LeafTri<T> &tri, bool
     L.hit_t = acc ? tt : L.hit_t;
     L.u = acc ? uu : L.u;
     L.v = acc ? vv : L.v;
+    L.prim = acc ? prim : L.prim;
+  }
+}
+
+// SphereIntersector::Intersect (examples/particle_primitive/main.cc:161-236) against one leaf record: the
+// quadratic in the reference's own operation order (vdot = (x*x + y*y) + z*z, nanort.h:410-412), IEEE sqrt and
+// divisions, no contraction.  No min_t test and no skip_prim_id in that intersector; equality with the best t
+// is accepted (`if (t > *t_inout) return false`).
+template <typename T>
+__device__ __forceinline__ void sphere_test(Lane<T> &L, const LeafSphere<T> &sp, bool active, uint32_t range0,
+                                            uint32_t range1) {
+  const uint32_t prim = sp.prim_id;
+  bool ok = active & (prim >= range0) & (prim < range1);
+  const T oc0 = L.org[0] - sp.c[0], oc1 = L.org[1] - sp.c[1], oc2 = L.org[2] - sp.c[2];
+  const T a = (L.d0 * L.d0 + L.d1 * L.d1) + L.d2 * L.d2;
+  const T b = T(2.0) * ((L.d0 * oc0 + L.d1 * oc1) + L.d2 * oc2);
+  const T c = ((oc0 * oc0 + oc1 * oc1) + oc2 * oc2) - sp.r * sp.r;
+  const T disc = b * b - T(4.0) * a * c;
+  ok = ok & !(disc < T(0));
+  if (ok) {
+    T t0, t1;
+    if (Const<T>::abs(disc) < Const<T>::eps()) {
+      t0 = t1 = T(-0.5) * (b / a);
+    } else {
+      const T ds = Const<T>::sqrt(disc);
+      const T q = (b < T(0)) ? (-b - ds) / T(2.0) : (-b + ds) / T(2.0);
+      t0 = q / a;
+      t1 = c / q;
+    }
+    if (t0 > t1) {
+      const T tmp = t0;
+      t0 = t1;
+      t1 = tmp;
+    }
+    const T t = (t0 < T(0)) ? t1 : t0;
+    const bool acc = ok & !(t1 < T(0)) & !(t > L.hit_t);
+    L.hit_t = acc ? t : L.hit_t;
     L.prim = acc ? prim : L.prim;
   }
 }
@@ -448,6 +491,35 @@ __device__ __forceinline__ bool slab_test_tmin(const Lane<T> &L, const T box[6],
 
 enum : int { W_IDLE = 0, W_TRAV = 1, W_LEAF = 2, W_POP = 3 };
 
+// SphereIntersector::PostTraversal (examples/particle_primitive/main.cc:262-277) as a pass over the finished
+// hit records (the double-precision atan2/acos would otherwise cost the traversal kernel half its occupancy):
+// u, v = spherical coordinates of the unit normal at the hit point; atan2/acos in double as there (device
+// libm agrees with glibc to the last place or so of the double, i.e. to ~1 ulp of the float result).
+template <typename T>
+__global__ __launch_bounds__(256) void k_sphere_uv(const typename Wire<T>::Ray *__restrict__ rays,
+                                                   typename Wire<T>::Hit *__restrict__ hits,
+                                                   const T *__restrict__ centers, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  typename Wire<T>::Hit h = hits[i];
+  if (h.prim_id == kInvalid) return;
+  const typename Wire<T>::Ray r = rays[i];
+  const double kPi = 3.14159265358979323846;
+  const T h0 = r.org[0] + h.t * r.dir[0], h1 = r.org[1] + h.t * r.dir[1], h2 = r.org[2] + h.t * r.dir[2];
+  T n0 = h0 - centers[3 * (size_t)h.prim_id + 0], n1 = h1 - centers[3 * (size_t)h.prim_id + 1],
+    n2 = h2 - centers[3 * (size_t)h.prim_id + 2];
+  const T len = Const<T>::sqrt((n0 * n0 + n1 * n1) + n2 * n2); // vnormalize (nanort.h:383-398)
+  if (Const<T>::abs(len) > Const<T>::eps()) {
+    const T inv_len = T(1.0) / len;
+    n0 *= inv_len;
+    n1 *= inv_len;
+    n2 *= inv_len;
+  }
+  h.u = T(float(atan2(double(n0), double(n2)) + kPi) * 0.5f * float(1.0 / kPi));
+  h.v = T(float(acos(double(n1)) / kPi));
+  hits[i] = h;
+}
+
 // Both child boxes of one WideNode at once.  For fp32 the two boxes ride in the two halves of
 // 64-bit register pairs, so the subtract / multiply chain issues as v_pk_add_f32 / v_pk_mul_f32
 // (one VALU slot for two IEEE operations: same operations, same rounding, half the issue slots).
@@ -514,7 +586,7 @@ struct StackEntry<double> {
   }
 };
 
-template <typename T, int STACK, bool STATS>
+template <typename T, int STACK, bool STATS, int KIND>
 __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const TraverseArgs<T> a) {
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
@@ -678,8 +750,13 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           if (i < cnt) st_tris++;
         }
         // no divergent region here: lanes past their count re-test their first record with ok = false
-        const LeafTri<T> tri = a.tris[first + (i < cnt ? i : 0u)];
-        tri_test<T>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull);
+        if (KIND == kPrimSpheres) {
+          const LeafSphere<T> sp = a.spheres[first + (i < cnt ? i : 0u)];
+          sphere_test<T>(L, sp, i < cnt, a.range0, a.range1);
+        } else {
+          const LeafTri<T> tri = a.tris[first + (i < cnt ? i : 0u)];
+          tri_test<T>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull);
+        }
       }
       state = (state == W_LEAF) ? W_POP : state;
     }
@@ -813,6 +890,22 @@ __global__ __launch_bounds__(256) void k_gather_leaf_tris(const uint32_t *__rest
   out[s] = t;
 }
 
+// Leaf-ordered sphere records from (indices, centers, radii).
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_leaf_spheres(const uint32_t *__restrict__ indices,
+                                                             const T *__restrict__ centers, const T *__restrict__ radii,
+                                                             LeafSphere<T> *__restrict__ out, uint32_t n) {
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t prim = indices[s];
+  LeafSphere<T> r;
+#pragma unroll
+  for (int k = 0; k < 3; k++) r.c[k] = centers[3 * (size_t)prim + k];
+  r.r = radii[prim];
+  r.prim_id = prim;
+  out[s] = r;
+}
+
 // ---- host-side launchers (called from api.hip) ------------------------------
 
 template <typename T, int STACK>
@@ -849,30 +942,41 @@ int traverse_blocks_per_cu(int lds_stack) {
 }
 
 template <typename T>
-hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int lds_stack, hipStream_t s) {
+hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int lds_stack, int prim_kind, hipStream_t s) {
+  if (prim_kind == kPrimSpheres) { // one instantiation: 10 LDS entries (the caller sizes the overflow stack for it)
+    hipLaunchKernelGGL((k_traverse_wide<T, 10, false, kPrimSpheres>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+    if (args.hits)
+      hipLaunchKernelGGL((k_sphere_uv<T>), dim3((args.num_rays + 255u) / 256u), dim3(256), 0, s, args.rays, args.hits,
+                         args.centers, args.num_rays);
+    return hipGetLastError();
+  }
   switch (lds_stack) {
-    case 8: hipLaunchKernelGGL((k_traverse_wide<T, 8, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
+    case 8: hipLaunchKernelGGL((k_traverse_wide<T, 8, false, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
     case 10:
       if (args.debug_flags & 32u)
-        hipLaunchKernelGGL((k_traverse_wide<T, 10, true>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+        hipLaunchKernelGGL((k_traverse_wide<T, 10, true, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
       else
-        hipLaunchKernelGGL((k_traverse_wide<T, 10, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+        hipLaunchKernelGGL((k_traverse_wide<T, 10, false, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
       break;
-    case 12: hipLaunchKernelGGL((k_traverse_wide<T, 12, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
-    default: hipLaunchKernelGGL((k_traverse_wide<T, 16, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
+    case 12: hipLaunchKernelGGL((k_traverse_wide<T, 12, false, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
+    default: hipLaunchKernelGGL((k_traverse_wide<T, 16, false, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
   }
   return hipGetLastError();
 }
 
 template <typename T>
-int traverse_wide_blocks_per_cu(int lds_stack) {
+int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind) {
   int n = 0;
   hipError_t e;
-  switch (lds_stack) {
-    case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 8, false>, kTraverseBlock, 0); break;
-    case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false>, kTraverseBlock, 0); break;
-    case 12: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 12, false>, kTraverseBlock, 0); break;
-    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 16, false>, kTraverseBlock, 0); break;
+  if (prim_kind == kPrimSpheres) {
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimSpheres>, kTraverseBlock, 0);
+  } else {
+    switch (lds_stack) {
+      case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 8, false, kPrimTriangles>, kTraverseBlock, 0); break;
+      case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimTriangles>, kTraverseBlock, 0); break;
+      case 12: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 12, false, kPrimTriangles>, kTraverseBlock, 0); break;
+      default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 16, false, kPrimTriangles>, kTraverseBlock, 0); break;
+    }
   }
   if (e != hipSuccess || n < 1) n = 4;
   return n > 8 ? 8 : n;
@@ -901,12 +1005,24 @@ hipError_t launch_gather_leaf_tris(const uint32_t *indices, const uint32_t *face
   return hipGetLastError();
 }
 
+template <typename T>
+hipError_t launch_gather_leaf_spheres(const uint32_t *indices, const T *centers, const T *radii, LeafSphere<T> *out,
+                                      uint32_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((k_gather_leaf_spheres<T>), dim3((n + 255u) / 256u), dim3(256), 0, s, indices, centers, radii, out, n);
+  return hipGetLastError();
+}
+
 template hipError_t launch_traverse<float>(const TraverseArgs<float> &, unsigned, bool, int, hipStream_t);
 template hipError_t launch_traverse<double>(const TraverseArgs<double> &, unsigned, bool, int, hipStream_t);
-template hipError_t launch_traverse_wide<float>(const TraverseArgs<float> &, unsigned, int, hipStream_t);
-template hipError_t launch_traverse_wide<double>(const TraverseArgs<double> &, unsigned, int, hipStream_t);
-template int traverse_wide_blocks_per_cu<float>(int);
-template int traverse_wide_blocks_per_cu<double>(int);
+template hipError_t launch_traverse_wide<float>(const TraverseArgs<float> &, unsigned, int, int, hipStream_t);
+template hipError_t launch_traverse_wide<double>(const TraverseArgs<double> &, unsigned, int, int, hipStream_t);
+template int traverse_wide_blocks_per_cu<float>(int, int);
+template int traverse_wide_blocks_per_cu<double>(int, int);
+template hipError_t launch_gather_leaf_spheres<float>(const uint32_t *, const float *, const float *, LeafSphere<float> *,
+                                                      uint32_t, hipStream_t);
+template hipError_t launch_gather_leaf_spheres<double>(const uint32_t *, const double *, const double *,
+                                                       LeafSphere<double> *, uint32_t, hipStream_t);
 template hipError_t launch_make_wide<float>(const nrt_node_f32 *, uint32_t, uint32_t, uint32_t *, WideNode<float> *,
                                             hipStream_t);
 template hipError_t launch_make_wide<double>(const nrt_node_f64 *, uint32_t, uint32_t, uint32_t *, WideNode<double> *,

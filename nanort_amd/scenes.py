@@ -34,6 +34,10 @@ def _lib():
         L.nrt_rays_camera_rows.restype = None
         L.nrt_rays_secondary.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, u64, u64, vp]
         L.nrt_rays_secondary.restype = u64
+        L.nrt_scene_random_spheres.argtypes = [u64, vp, vp, vp, vp]
+        L.nrt_scene_random_spheres.restype = None
+        L.nrt_rays_particle_camera.argtypes = [u32, u32, vp]
+        L.nrt_rays_particle_camera.restype = None
         _LIB = L
     return _LIB
 
@@ -56,6 +60,23 @@ def sphere(nu=264, nv=132):
     faces = np.empty((2 * nu * (nv - 1), 3), dtype=np.uint32)
     _lib().nrt_scene_sphere(nu, nv, _p(verts), _p(faces))
     return verts, faces
+
+
+def random_spheres(n, bmin=(-1.0, -1.0, -1.0), bmax=(1.0, 1.0, 1.0)):
+    """The particle example's scene (reference examples/particle_primitive/main.cc:295-325): centres (n, 3), radii (n,)."""
+    centers = np.empty((n, 3), dtype=np.float32)
+    radii = np.empty((n,), dtype=np.float32)
+    lo = np.asarray(bmin, dtype=np.float32)
+    hi = np.asarray(bmax, dtype=np.float32)
+    _lib().nrt_scene_random_spheres(n, _p(lo), _p(hi), _p(centers), _p(radii))
+    return centers, radii
+
+
+def particle_camera_rays(width, height):
+    """That example's camera (main.cc:367-389), row-major."""
+    rays = np.empty((width * height,), dtype=RAY_F32)
+    _lib().nrt_rays_particle_camera(width, height, _p(rays))
+    return rays
 
 
 def camera_rays(width, height, y0=0, y1=None):

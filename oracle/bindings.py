@@ -362,3 +362,89 @@ class SceneOracle:
         mask = np.zeros((rays.shape[0],), dtype=np.uint8)
         self.L.sgo_traverse(ctypes.cast(self.arr, ctypes.c_void_p), len(self.nodes), _p(rays), rays.shape[0], _p(hits), _p(mask))
         return hits, mask
+
+
+# ---- sphere ("particle") custom primitive ----------------------------------------------------------------
+REF_SPHERE_PATH = os.path.join(_HERE, "_ref", "libsphere_ref.so")
+_HIT_F32 = hit_dtype(np.float32)
+_NODE_F32 = node_dtype(np.float32)
+
+
+def have_sphere_reference():
+    return os.path.exists(REF_SPHERE_PATH)
+
+
+class SphereOracle:
+    """oracle/sphere_oracle.c: C restatement of the sphere intersector traced through Traverse."""
+
+    def __init__(self):
+        L = ctypes.CDLL(ORACLE_PATH)
+        vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+        L.spo_traverse.argtypes = [vp, vp, vp, vp, vp, u64, u32, u32, vp, vp]
+        L.spo_traverse.restype = None
+        self.L = L
+
+    def traverse(self, nodes, indices, centers, radii, rays, prim_ids_range=(0, 0x7FFFFFFF)):
+        nodes = np.ascontiguousarray(nodes)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        centers = np.ascontiguousarray(centers, dtype=np.float32)
+        radii = np.ascontiguousarray(radii, dtype=np.float32)
+        rays = np.ascontiguousarray(rays)
+        n = rays.shape[0]
+        hits = np.zeros(n, dtype=_HIT_F32)
+        mask = np.zeros(n, dtype=np.uint8)
+        self.L.spo_traverse(_p(nodes), _p(indices), _p(centers), _p(radii), _p(rays), n, prim_ids_range[0],
+                            prim_ids_range[1], _p(hits), _p(mask))
+        return hits, mask
+
+
+class SphereReference:
+    """The unmodified examples/particle_primitive classes over the unmodified nanort.h (oracle/ref_sphere_shim.cc)."""
+
+    def __init__(self):
+        L = ctypes.CDLL(REF_SPHERE_PATH)
+        vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+        L.refsp_generate.argtypes = [vp, vp, u64, vp, vp]
+        L.refsp_build.argtypes = [vp, vp, u32, vp, vp]
+        L.refsp_build.restype = vp
+        L.refsp_get_tree.argtypes = [vp, vp, vp]
+        L.refsp_destroy.argtypes = [vp]
+        L.refsp_traverse.argtypes = [vp, vp, u64, u32, u32, vp, vp]
+        self.L = L
+        self.h = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.refsp_destroy(self.h)
+        except Exception:
+            pass
+
+    def generate(self, n, bmin=(-1, -1, -1), bmax=(1, 1, 1)):
+        centers = np.empty((n, 3), dtype=np.float32)
+        radii = np.empty((n,), dtype=np.float32)
+        lo, hi = np.asarray(bmin, dtype=np.float32), np.asarray(bmax, dtype=np.float32)
+        self.L.refsp_generate(_p(centers), _p(radii), n, _p(lo), _p(hi))
+        return centers, radii
+
+    def build(self, centers, radii):
+        centers = np.ascontiguousarray(centers, dtype=np.float32)
+        radii = np.ascontiguousarray(radii, dtype=np.float32)
+        nn = ctypes.c_uint32(0)
+        stats = np.zeros(3, dtype=np.uint32)
+        if self.h:
+            self.L.refsp_destroy(self.h)
+        self.h = self.L.refsp_build(_p(centers), _p(radii), radii.shape[0], ctypes.byref(nn), _p(stats))
+        assert self.h
+        nodes = np.zeros(nn.value, dtype=_NODE_F32)
+        indices = np.zeros(radii.shape[0], dtype=np.uint32)
+        self.L.refsp_get_tree(self.h, _p(nodes), _p(indices))
+        return nodes, indices, {"max_tree_depth": int(stats[0]), "num_leaf_nodes": int(stats[1]), "num_branch_nodes": int(stats[2])}
+
+    def traverse(self, rays, prim_ids_range=(0, 0x7FFFFFFF)):
+        rays = np.ascontiguousarray(rays)
+        n = rays.shape[0]
+        hits = np.zeros(n, dtype=_HIT_F32)
+        mask = np.zeros(n, dtype=np.uint8)
+        self.L.refsp_traverse(self.h, _p(rays), n, prim_ids_range[0], prim_ids_range[1], _p(hits), _p(mask))
+        return hits, mask

@@ -2,6 +2,8 @@
 //
 //   host_check regress30 [x]          the scenario of the reference's
 //                                     test/regression/possible-accuracy-problem-30 (fp64, one triangle)
+//   host_check spheres N W H OUT      the reference's particle example (examples/particle_primitive/main.cc) with the
+//                                     header's built-in sphere primitive: Build + per-ray Traverse (+ TraverseBatch)
 //   host_check trace MESH RAYS OUT    Build + per-ray Traverse (and, with the HIP backend compiled in,
 //                                     TraverseBatch) over a raw mesh / ray file; hit records to OUT
 //
@@ -9,7 +11,11 @@
 // -DNANORT_USE_HIP_BACKEND -lnanort_hip (GPU Build + TraverseBatch).
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
+#include <cmath>
 
 #include <vector>
 
@@ -121,11 +127,88 @@ static int trace(const char *mesh_path, const char *rays_path, const char *out_p
   return 0;
 }
 
+// The particle example's main() (scene, build, camera loop: examples/particle_primitive/main.cc:329-400) over the
+// header's built-in sphere classes; the spheres come from a raw file {u32 n; float xyz[n]; float r[n]}.
+static int spheres(const char *scene_path, int W, int H, const char *out_path) {
+  FILE *fp = fopen(scene_path, "rb");
+  if (!fp) return 2;
+  uint32_t n = 0;
+  if (fread(&n, 4, 1, fp) != 1) return 2;
+  std::vector<float> centers(3 * (size_t)n), radii(n);
+  if (fread(centers.data(), 4, centers.size(), fp) != centers.size() || fread(radii.data(), 4, n, fp) != n) return 2;
+  fclose(fp);
+  nanort::BVHBuildOptions<float> options;
+  options.cache_bbox = false;
+  nanort::SphereGeometry geom(centers.data(), radii.data());
+  nanort::SpherePred pred(centers.data());
+  nanort::BVHAccel<float> accel;
+  if (!accel.Build(n, geom, pred, options)) return 3;
+  const uint64_t nr = (uint64_t)W * H;
+  std::vector<nanort::Ray<float> > rays(nr);
+  std::vector<nanort::SphereIntersection> hits(nr);
+  std::vector<unsigned char> mask(nr, 0);
+  for (int y = 0; y < H; y++) {
+    for (int x = 0; x < W; x++) {
+      nanort::Ray<float> &ray = rays[(size_t)y * W + x];
+      ray.org[0] = 0.0f;
+      ray.org[1] = 0.0f;
+      ray.org[2] = 4.0f;
+      nanort::real3<float> dir((x / (float)W) - 0.5f, (y / (float)H) - 0.5f, -1.0f);
+      dir = vnormalize(dir);
+      ray.dir[0] = dir[0];
+      ray.dir[1] = dir[1];
+      ray.dir[2] = dir[2];
+      ray.min_t = 0.0f;
+      ray.max_t = 1.0e+30f;
+      nanort::SphereIntersector<nanort::SphereIntersection> isecter(centers.data(), radii.data());
+      nanort::SphereIntersection isect;
+      isect.u = isect.v = 0.0f;
+      isect.t = ray.max_t;
+      isect.prim_id = 0xFFFFFFFFu;
+      mask[(size_t)y * W + x] = accel.Traverse(ray, isecter, &isect) ? 1 : 0;
+      hits[(size_t)y * W + x] = isect;
+    }
+  }
+#ifdef NANORT_USE_HIP_BACKEND
+  std::vector<nanort::SphereIntersection> bhits(nr);
+  std::vector<unsigned char> bmask(nr, 0);
+  for (uint64_t i = 0; i < nr; i++) {
+    bhits[i].u = bhits[i].v = 0.0f;
+    bhits[i].t = rays[i].max_t;
+    bhits[i].prim_id = 0xFFFFFFFFu;
+  }
+  if (!accel.TraverseBatch(rays.data(), nr, bhits.data(), bmask.data())) {
+    fprintf(stderr, "TraverseBatch failed: %s\n", accel.LastBackendError().c_str());
+    return 4;
+  }
+  uint64_t bad = 0;
+  double worst_uv = 0.0;
+  for (uint64_t i = 0; i < nr; i++) {
+    if (bmask[i] != mask[i] || bhits[i].t != hits[i].t || bhits[i].prim_id != hits[i].prim_id) bad++;
+    worst_uv = std::max(worst_uv, (double)std::fabs(bhits[i].u - hits[i].u));
+    worst_uv = std::max(worst_uv, (double)std::fabs(bhits[i].v - hits[i].v));
+  }
+  printf("batch_vs_per_ray_mismatches %llu worst_uv %.3g\n", (unsigned long long)bad, worst_uv);
+  if (bad || worst_uv > 1e-6) return 5;
+#endif
+  fp = fopen(out_path, "wb");
+  if (!fp) return 2;
+  fwrite(hits.data(), sizeof(hits[0]), nr, fp);
+  fwrite(mask.data(), 1, nr, fp);
+  uint64_t nn = accel.GetNodes().size();
+  fwrite(&nn, 8, 1, fp);
+  fwrite(accel.GetNodes().data(), sizeof(nanort::BVHNode<float>), nn, fp);
+  fwrite(accel.GetIndices().data(), 4, n, fp);
+  fclose(fp);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc >= 2 && !strcmp(argv[1], "regress30")) return regress30(argc > 2);
+  if (argc == 6 && !strcmp(argv[1], "spheres")) return spheres(argv[2], atoi(argv[3]), atoi(argv[4]), argv[5]);
   if (argc == 6 && !strcmp(argv[1], "trace")) {
     return !strcmp(argv[2], "f64") ? trace<double>(argv[3], argv[4], argv[5]) : trace<float>(argv[3], argv[4], argv[5]);
   }
-  fprintf(stderr, "usage: host_check regress30 [x] | trace f32|f64 MESH RAYS OUT\n");
+  fprintf(stderr, "usage: host_check regress30 [x] | trace f32|f64 MESH RAYS OUT | spheres SCENE W H OUT\n");
   return 64;
 }

@@ -79,6 +79,57 @@ def read_output(path, n, nf, f64):
     return hits, mask, nodes, idx
 
 
+def write_spheres(d, c, r):
+    path = os.path.join(d, "spheres.bin")
+    with open(path, "wb") as fp:
+        fp.write(np.array([r.shape[0]], dtype=np.uint32).tobytes())
+        fp.write(np.ascontiguousarray(c, dtype=np.float32).tobytes())
+        fp.write(np.ascontiguousarray(r, dtype=np.float32).tobytes())
+    return path
+
+
+def test_builtin_sphere_primitive_host_path(host_check):
+    """The header's built-in sphere classes (the reference ships them as user code in
+    examples/particle_primitive/main.cc) through the generic host Build/Traverse: hit records equal the sphere
+    oracle's on the same node array, bit for bit (the oracle is pinned on the unmodified example)."""
+    from oracle.bindings import SphereOracle
+
+    exe, d = host_check
+    c, r = scenes.random_spheres(3000)
+    out = os.path.join(str(d), "spheres_out.bin")
+    W, H = 96, 97
+    rr = subprocess.run([exe, "spheres", write_spheres(str(d), c, r), str(W), str(H), out], stdout=subprocess.PIPE,
+                        stderr=subprocess.STDOUT, text=True)
+    assert rr.returncode == 0, rr.stdout
+    hits, mask, nodes, idx = read_output(out, W * H, 3000, False)
+    rays = scenes.particle_camera_rays(W, H)
+    oh, om = SphereOracle().traverse(nodes, idx, c, r, rays)
+    assert np.array_equal(mask, om) and hits.tobytes() == oh.tobytes()
+    assert 0 < int(mask.sum()) < W * H
+
+
+@pytest.mark.gpu
+def test_builtin_sphere_primitive_hip_backend(tmp_path):
+    """-DNANORT_USE_HIP_BACKEND: Build(SphereGeometry, SpherePred) runs on the GPU, TraverseBatch(SphereIntersection)
+    equals the per-ray host Traverse over the same tree (t, prim_id bit-exact; u, v to 1e-6) and the sphere oracle."""
+    from oracle.bindings import SphereOracle
+
+    exe = tmp_path / "host_check_hip"
+    cxx(["-std=c++11", "-O2", "-Wall", "-Wextra", "-DNANORT_USE_HIP_BACKEND", "-I", INC,
+         os.path.join(ROOT, "tests", "cpp", "host_check.cc"), "-o", str(exe),
+         "-L", LIBDIR, "-lnanort_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    c, r = scenes.random_spheres(20000)
+    out = os.path.join(str(tmp_path), "out.bin")
+    W, H = 256, 257
+    rr = subprocess.run([str(exe), "spheres", write_spheres(str(tmp_path), c, r), str(W), str(H), out],
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert rr.returncode == 0, rr.stdout
+    assert "batch_vs_per_ray_mismatches 0" in rr.stdout
+    hits, mask, nodes, idx = read_output(out, W * H, 20000, False)
+    oh, om = SphereOracle().traverse(nodes, idx, c, r, scenes.particle_camera_rays(W, H))
+    assert np.array_equal(mask, om) and hits.tobytes() == oh.tobytes()
+
+
 @pytest.mark.parametrize("f64", [False, True])
 def test_generic_host_path_matches_the_oracle(host_check, oracle, c1_mesh, f64):
     """Host builder (all three axes binned) + per-ray Traverse of include/nanort.h on C1: a valid tree and the
