@@ -667,6 +667,189 @@ class SphereIntersector {
 };
 
 // ---------------------------------------------------------------------------
+// Built-in cylinder primitive: the reference's second custom-primitive example, examples/cylinder_primitive/main.cc
+// (solve2e :61-90, CylinderPred :94-120, CylinderGeometry :124-210, CylinderIntersection :213-224,
+// CylinderIntersector :226-424) — same concepts, same arithmetic.  Two end points and two radii per cylinder (the
+// intersector uses the larger radius for the whole cylinder).  With NANORT_USE_HIP_BACKEND, Build() over
+// (CylinderGeometry, CylinderPred) and TraverseBatch() with CylinderIntersection run on the GPU.
+// One difference: PostTraversal also stores isect->t (the example leaves it untouched).
+// ---------------------------------------------------------------------------
+class CylinderPred {
+ public:
+  explicit CylinderPred(const float *endpoints) : axis_(0), pos_(0.0f), endpoints_(endpoints) {}
+  void Set(int axis, float pos) const {
+    axis_ = axis;
+    pos_ = pos;
+  }
+  bool operator()(unsigned int i) const { return (endpoints_[6 * i + axis_] + endpoints_[6 * i + 3 + axis_]) / 2.0f < pos_; }
+
+ private:
+  mutable int axis_;
+  mutable float pos_;
+  const float *endpoints_;
+};
+
+class CylinderGeometry {
+ public:
+  CylinderGeometry(const float *endpoints, const float *radii) : endpoints_(endpoints), radii_(radii) {}
+  void BoundingBox(real3<float> *bmin, real3<float> *bmax, unsigned int i) const {
+    for (int k = 0; k < 3; k++) {
+      const float a = endpoints_[6 * i + k], b = endpoints_[6 * i + 3 + k];
+      (*bmin)[k] = std::min(b - radii_[2 * i + 1], a - radii_[2 * i]);
+      (*bmax)[k] = std::max(b + radii_[2 * i + 1], a + radii_[2 * i]);
+    }
+  }
+  void BoundingBoxAndCenter(real3<float> *bmin, real3<float> *bmax, real3<float> *center, unsigned int i) const {
+    BoundingBox(bmin, bmax, i);
+    for (int k = 0; k < 3; k++) (*center)[k] = (endpoints_[6 * i + k] + endpoints_[6 * i + 3 + k]) / 2.0f;
+  }
+  const float *GetEndpoints() const { return endpoints_; }
+  const float *GetRadii() const { return radii_; }
+
+ private:
+  const float *endpoints_;
+  const float *radii_;
+};
+
+class CylinderIntersection {
+ public:
+  CylinderIntersection() : u(0.0f), v(0.0f), normal(0.0f), t(std::numeric_limits<float>::max()), prim_id(static_cast<unsigned int>(-1)) {}
+  float u;  // distance from the axis on a cap hit, 0 on the side
+  float v;  // 0 / 1 on the first / second cap, the axis parameter in [0, 1] on the side
+  real3<float> normal;
+  float t;
+  unsigned int prim_id;
+};
+
+template <class H = CylinderIntersection>
+class CylinderIntersector {
+ public:
+  CylinderIntersector(const float *endpoints, const float *radii, bool test_cap = true)
+      : endpoints_(endpoints), radii_(radii), test_cap_(test_cap), t_(0.0f), prim_id_(0), hit_cap_(false), u_param_(0.0f), v_param_(0.0f) {}
+
+  bool Intersect(float *t_inout, unsigned int i) const {
+    if (i < opts_.prim_ids_range[0] || i >= opts_.prim_ids_range[1]) return false;
+    const float eps = 1.0e-6f;
+    const real3<float> p0(&endpoints_[6 * i]), p1(&endpoints_[6 * i + 3]);
+    const float tmax = *t_inout;
+    const float rr = std::max<float>(radii_[2 * i], radii_[2 * i + 1]);
+    const real3<float> d = p1 - p0, m = org_ - p0;
+    const float md = vdot(m, d), nd = vdot(dir_, d), dd = vdot(d, d);
+    bool hit_cap = false;
+    float cap_t = std::numeric_limits<float>::max();
+    if (test_cap_) {  // the two end planes first
+      const real3<float> n0 = vnormalize(p0 - p1), n1 = vneg(n0), rd = vnormalize(dir_);
+      if (std::fabs(vdot(dir_, n0)) > eps) {
+        const float d0 = -vdot(p0, n0), d1 = -vdot(p1, n1);
+        const float t0 = -(vdot(org_, n0) + d0) / vdot(rd, n0);
+        const float t1 = -(vdot(org_, n1) + d1) / vdot(rd, n1);
+        const real3<float> q0 = org_ + t0 * rd, q1 = org_ + t1 * rd;
+        const float r0sq = vdot(q0 - p0, q0 - p0), r1sq = vdot(q1 - p1, q1 - p1);
+        if (t0 > 0.0 && t0 < tmax && (r0sq < rr * rr)) {
+          hit_cap_ = hit_cap = true;
+          cap_t = t0;
+          *t_inout = cap_t;
+          u_param_ = std::sqrt(r0sq);
+          v_param_ = 0;
+        }
+        if (t1 > 0.0 && t1 < tmax && t1 < cap_t && (r1sq < rr * rr)) {
+          hit_cap_ = hit_cap = true;
+          cap_t = t1;
+          *t_inout = cap_t;
+          u_param_ = std::sqrt(r1sq);
+          v_param_ = 1.0;
+        }
+      }
+    }
+    if (md <= 0.0 && nd <= 0.0) return hit_cap;  // origin behind the first cap, pointing away
+    if (md >= dd && nd >= 0.0) return hit_cap;   // origin beyond the second cap, pointing away
+    const float nn = vdot(dir_, dir_), mn = vdot(m, dir_);
+    const float A = dd * nn - nd * nd;
+    const float k = vdot(m, m) - rr * rr;
+    const float C = dd * k - md * md;
+    const float B = dd * mn - nd * md;
+    float root = 0.0f;
+    if (SmallerRoot(&root, A, B, C)) {
+      const float t = root;
+      if (0 <= t && t <= tmax && t <= cap_t) {
+        float s = md + t * nd;
+        s /= dd;
+        if (0 <= s && s <= 1) {
+          hit_cap_ = false;
+          *t_inout = t;
+          u_param_ = 0;
+          v_param_ = s;
+          return true;
+        }
+      }
+    }
+    return hit_cap;
+  }
+  float GetT() const { return t_; }
+  void Update(float t, unsigned int i) const {
+    t_ = t;
+    prim_id_ = i;
+  }
+  void PrepareTraversal(const Ray<float> &ray, const BVHTraceOptions &options) const {
+    org_ = real3<float>(ray.org);
+    dir_ = real3<float>(ray.dir);
+    opts_ = options;
+  }
+  void PostTraversal(const Ray<float> &, bool hit, H *isect) const {
+    if (!hit) return;
+    const real3<float> p0(&endpoints_[6 * prim_id_]), p1(&endpoints_[6 * prim_id_ + 3]);
+    const real3<float> axis_point = p0 + real3<float>(v_param_, v_param_, v_param_) * (p1 - p0);
+    const real3<float> position = org_ + t_ * dir_;
+    real3<float> n;
+    if (hit_cap_) {
+      const real3<float> mid = 0.5f * (p1 - p0) + p0;
+      n = vnormalize(p1 - p0);
+      if (!(vdot(position - mid, n) > 0.0)) n = vneg(n);
+    } else {
+      n = vnormalize(position - axis_point);
+    }
+    isect->u = u_param_;
+    isect->v = v_param_;
+    isect->normal = n;
+    isect->t = t_;
+    isect->prim_id = prim_id_;
+  }
+
+ private:
+  // The smaller root of A x^2 + 2 B x + C = 0 in the example's formulation (its solve2e); false when there is none.
+  static bool SmallerRoot(float *root, float A, float B, float C) {
+    if (std::fabs(A) <= 1.0e-6f) {
+      *root = -C / B;
+      return true;
+    }
+    const float D = B * B - A * C;
+    if (D < 0) return false;
+    if (D == 0) {
+      *root = -B / A;
+      return true;
+    }
+    float x1 = (std::fabs(B) + std::sqrt(D)) / A;
+    if (B >= 0.0) x1 = -x1;
+    const float x2 = C / (A * x1);
+    *root = (x1 > x2) ? x2 : x1;
+    return true;
+  }
+
+  const float *endpoints_;
+  const float *radii_;
+  const bool test_cap_;
+  mutable real3<float> org_, dir_;
+  mutable BVHTraceOptions opts_;
+  mutable float t_;
+  mutable unsigned int prim_id_;
+  mutable bool hit_cap_;
+  mutable float u_param_, v_param_;
+
+ public:
+  bool TestsCaps() const { return test_cap_; }
+};
+
+// ---------------------------------------------------------------------------
 // BVHAccel
 // ---------------------------------------------------------------------------
 namespace detail {
@@ -681,13 +864,16 @@ struct same_type<A, A> {
 struct generic_tag {};
 struct triangle_tag {};
 struct sphere_tag {};
+struct cylinder_tag {};
 template <typename T, class Prim, class Pred>
 struct build_tag {
 #ifdef NANORT_USE_HIP_BACKEND
   typedef typename std::conditional<
       same_type<Prim, TriangleMesh<T> >::value && same_type<Pred, TriangleSAHPred<T> >::value, triangle_tag,
-      typename std::conditional<same_type<T, float>::value && same_type<Prim, SphereGeometry>::value && same_type<Pred, SpherePred>::value,
-                                sphere_tag, generic_tag>::type>::type type;
+      typename std::conditional<
+          same_type<T, float>::value && same_type<Prim, SphereGeometry>::value && same_type<Pred, SpherePred>::value, sphere_tag,
+          typename std::conditional<same_type<T, float>::value && same_type<Prim, CylinderGeometry>::value && same_type<Pred, CylinderPred>::value,
+                                    cylinder_tag, generic_tag>::type>::type>::type type;
 #else
   typedef generic_tag type;
 #endif
@@ -912,6 +1098,41 @@ class BVHAccel {
     static_assert(detail::same_type<T, float>::value, "the sphere primitive is fp32");
     return TraverseBatchImpl(rays, num_rays, isects, hit_out, options);
   }
+  // Same for a tree built over the built-in cylinder primitive (CylinderGeometry + CylinderPred); `test_cap` is the
+  // CylinderIntersector constructor flag.
+  bool TraverseBatch(const Ray<T> *rays, size_t num_rays, CylinderIntersection *isects, unsigned char *hit_out = NULL,
+                     const BVHTraceOptions &options = BVHTraceOptions(), bool test_cap = true) const {
+    static_assert(detail::same_type<T, float>::value, "the cylinder primitive is fp32");
+    static_assert(sizeof(CylinderIntersection) == sizeof(nrt_cyl_hit_f32), "CylinderIntersection layout");
+    if (!ctx_ || !cyl_endpoints_) {
+      backend_error_ = "TraverseBatch: Build() with CylinderGeometry/CylinderPred first";
+      return false;
+    }
+    if (test_cap != cyl_test_cap_ || device_tree_stale_) {  // the flag lives with the primitives on the device
+      if (nodes_.empty() || nrtSetCylinders_f32(ctx_.get(), cyl_endpoints_, cyl_radii_, static_cast<unsigned int>(indices_.size()), test_cap ? 1 : 0) != NRT_OK ||
+          nrtSetTree_f32(ctx_.get(), reinterpret_cast<const nrt_node_f32 *>(&nodes_[0]), nodes_.size(), &indices_[0], indices_.size()) != NRT_OK) {
+        backend_error_ = nodes_.empty() ? "TraverseBatch: empty tree" : nrtLastError(ctx_.get());
+        return false;
+      }
+      cyl_test_cap_ = test_cap;
+      device_tree_stale_ = false;
+    }
+    if (num_rays == 0) return true;
+    std::vector<CylinderIntersection> tmp(num_rays);
+    std::vector<unsigned char> mask(num_rays);
+    nrt_trace_options o;
+    std::memcpy(&o, &options, sizeof(o));
+    if (nrtTraverseBatchCylinders_f32(ctx_.get(), reinterpret_cast<const nrt_ray_f32 *>(rays), num_rays, &o,
+                                      reinterpret_cast<nrt_cyl_hit_f32 *>(&tmp[0]), &mask[0]) != NRT_OK) {
+      backend_error_ = nrtLastError(ctx_.get());
+      return false;
+    }
+    for (size_t i = 0; i < num_rays; i++) {
+      if (mask[i]) isects[i] = tmp[i];
+      if (hit_out) hit_out[i] = mask[i];
+    }
+    return true;
+  }
   const std::string &LastBackendError() const { return backend_error_; }
 
  private:
@@ -1132,6 +1353,16 @@ class BVHAccel {
     return HipBuild(n, options, [&](nrt_ctx *c) { return nrtSetSpheres_f32(c, geom.GetCenters(), geom.GetRadii(), n); });
   }
 
+  // (the intersector's test_cap flag is a traversal-time property: TraverseBatch() re-sends the primitives if it differs)
+  bool BuildImpl(unsigned int n, const CylinderGeometry &geom, const CylinderPred &pred, const BVHBuildOptions<T> &options,
+                 detail::cylinder_tag) {
+    (void)pred;
+    cyl_endpoints_ = geom.GetEndpoints();
+    cyl_radii_ = geom.GetRadii();
+    cyl_test_cap_ = true;
+    return HipBuild(n, options, [&](nrt_ctx *c) { return nrtSetCylinders_f32(c, geom.GetEndpoints(), geom.GetRadii(), n, 1); });
+  }
+
   template <class SetPrims>
   bool HipBuild(unsigned int n, const BVHBuildOptions<T> &options, SetPrims set_prims) {
     typedef detail::HipApi<T> Api;
@@ -1190,6 +1421,9 @@ class BVHAccel {
 #ifdef NANORT_USE_HIP_BACKEND
   std::shared_ptr<nrt_ctx> ctx_;
   mutable bool device_tree_stale_ = false;
+  const float *cyl_endpoints_ = NULL;  // cylinder primitive: what Build() was given
+  const float *cyl_radii_ = NULL;
+  mutable bool cyl_test_cap_ = true;
   mutable std::string backend_error_;
 #endif
 };

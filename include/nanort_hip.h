@@ -191,6 +191,31 @@ NRT_API nrt_status nrtSetMesh_f64(nrt_ctx *ctx, const double *vertices, size_t v
  * and are ignored.  Replaces the mesh of the context (one primitive kind per context). */
 NRT_API nrt_status nrtSetSpheres_f32(nrt_ctx *ctx, const float *centers, const float *radii, uint32_t num_spheres);
 
+/* ---- cylinder primitives: replaces the CylinderPred / CylinderGeometry / CylinderIntersector constructors of the
+ * reference's second custom-primitive example (examples/cylinder_primitive/main.cc:94-232) ------------------
+ * `endpoints` holds two xyz points per cylinder (tight), `radii` two radii per cylinder (the example's intersector
+ * uses the larger of the two for the whole cylinder), `test_cap` is that intersector's constructor flag.
+ * nrtBuild_f32 then builds over the example's boxes (union of end point +- radius, SAH position = the midpoint)
+ * and nrtTraverseBatchCylinders*_f32 runs its intersector (main.cc:237-343: two cap planes, then the side via
+ * solve2e :61-90) and PostTraversal (:367-418).  Hit record: the example's CylinderIntersection (:213-224) —
+ * {u, v, normal[3], t, prim_id}; `t` is the intersector's hit distance (the example itself never stores it).
+ * A miss leaves {0, 0, (0,0,0), ray.max_t, 0xFFFFFFFF}.  Of BVHTraceOptions only prim_ids_range exists there. */
+typedef struct nrt_cyl_hit_f32 {
+  float u, v;
+  float normal[3];
+  float t;
+  uint32_t prim_id;
+} nrt_cyl_hit_f32;
+NRT_API nrt_status nrtSetCylinders_f32(nrt_ctx *ctx, const float *endpoints, const float *radii, uint32_t num_cylinders,
+                                       int test_cap);
+NRT_API nrt_status nrtTraverseBatchCylinders_f32(nrt_ctx *ctx, const nrt_ray_f32 *rays, uint64_t num_rays,
+                                                 const nrt_trace_options *options, nrt_cyl_hit_f32 *hits_out,
+                                                 uint8_t *hit_mask_out);
+/* Same with HBM-resident buffers, asynchronous on `hip_stream` (a hipStream_t). */
+NRT_API nrt_status nrtTraverseBatchCylindersDevice_f32(nrt_ctx *ctx, const nrt_ray_f32 *d_rays, uint64_t num_rays,
+                                                       const nrt_trace_options *options, nrt_cyl_hit_f32 *d_hits_out,
+                                                       uint8_t *d_hit_mask_out, void *hip_stream);
+
 /* ---- build: replaces BVHAccel<T>::Build (nanort.h:716-718, 1892-2149) ----
  * Binned-SAH construction on the GPU over the mesh set above.  Honours
  * min_leaf_primitives, max_tree_depth and bin_size; shallow_depth,

@@ -8,5 +8,5 @@ BVHAccel::Build + BVHAccel::Traverse for triangle meshes.
   nanort_amd/scenes.py   the synthetic workloads of SURVEY.md §8(d)
 """
 from . import wire  # noqa: F401
-from .accel import BVHAccel, Scene, SphereGeometry, TriangleMesh  # noqa: F401
+from .accel import BVHAccel, CylinderGeometry, Scene, SphereGeometry, TriangleMesh  # noqa: F401
 from .capi import NrtError  # noqa: F401

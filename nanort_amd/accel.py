@@ -71,8 +71,22 @@ class SphereGeometry:
         self.num_faces = self.num_spheres  # "number of primitives", under the name Build() checks
 
 
+class CylinderGeometry:
+    """The cylinder custom primitive of the reference (examples/cylinder_primitive/main.cc:94-424: CylinderPred +
+    CylinderGeometry + CylinderIntersector): two end points (n, 2, 3) and two radii (n, 2) per cylinder, and the
+    intersector's test_cap flag."""
+
+    def __init__(self, endpoints, radii, test_cap=True):
+        self.endpoints = np.ascontiguousarray(endpoints, dtype=np.float32).reshape(-1, 2, 3)
+        self.radii = np.ascontiguousarray(radii, dtype=np.float32).reshape(-1, 2)
+        if self.endpoints.shape[0] != self.radii.shape[0]:
+            raise ValueError("two radii per cylinder")
+        self.test_cap = bool(test_cap)
+        self.num_faces = int(self.radii.shape[0])
+
+
 class BVHAccel:
-    """nanort::BVHAccel<T> on one MI355X (built-in triangle geometry, or the sphere primitive in fp32)."""
+    """nanort::BVHAccel<T> on one MI355X (built-in triangle geometry, or the sphere / cylinder primitives in fp32)."""
 
     def __init__(self, real=np.float32, device=0):
         self.real = np.dtype(real)
@@ -106,6 +120,12 @@ class BVHAccel:
 
     # -- mesh / build -------------------------------------------------------
     def SetMesh(self, mesh):
+        if isinstance(mesh, CylinderGeometry):
+            if self.real != np.float32:
+                raise TypeError("cylinder primitives are fp32 (as the reference example)")
+            self._check(self._L.nrtSetCylinders_f32(self._h, _p(mesh.endpoints), _p(mesh.radii), mesh.num_faces, int(mesh.test_cap)))
+            self._mesh = mesh
+            return
         if isinstance(mesh, SphereGeometry):
             if self.real != np.float32:
                 raise TypeError("sphere primitives are fp32 (as the reference example)")
@@ -124,7 +144,9 @@ class BVHAccel:
     def Build(self, num_primitives, mesh, options=None):
         """BVHAccel::Build (reference nanort.h:1892-2149). Returns False iff n == 0."""
         if num_primitives != mesh.num_faces:
-            if isinstance(mesh, SphereGeometry):
+            if isinstance(mesh, CylinderGeometry):
+                mesh = CylinderGeometry(mesh.endpoints[:num_primitives], mesh.radii[:num_primitives], mesh.test_cap)
+            elif isinstance(mesh, SphereGeometry):
                 mesh = SphereGeometry(mesh.centers[:num_primitives], mesh.radii[:num_primitives])
             else:
                 mesh = TriangleMesh(mesh.vertices, mesh.faces[:num_primitives], mesh.vertex_stride_bytes)
@@ -191,10 +213,16 @@ class BVHAccel:
         """N x BVHAccel::Traverse (reference nanort.h:2487-2556). Returns (hits, mask)."""
         rays = np.ascontiguousarray(rays, dtype=ray_dtype(self.real))
         n = rays.shape[0]
-        hits = np.zeros((n,), dtype=hit_dtype(self.real))
         mask = np.zeros((n,), dtype=np.uint8)
         if options is not None:
             options = np.asarray(options, dtype=TRACE_OPTIONS).reshape(1)
+        if isinstance(self._mesh, CylinderGeometry):  # the example's 28-byte CylinderIntersection records
+            from .wire import CYL_HIT_F32
+
+            hits = np.zeros((n,), dtype=CYL_HIT_F32)
+            self._check(self._L.nrtTraverseBatchCylinders_f32(self._h, _p(rays), n, _p(options), _p(hits), _p(mask)))
+            return hits, mask
+        hits = np.zeros((n,), dtype=hit_dtype(self.real))
         self._check(
             getattr(self._L, "nrtTraverseBatch_" + self._s)(self._h, _p(rays), n, _p(options), _p(hits), _p(mask))
         )
@@ -205,13 +233,18 @@ class BVHAccel:
         (default: torch's current stream)."""
         import torch
 
-        rsz, hsz = ray_dtype(self.real).itemsize, hit_dtype(self.real).itemsize
+        cyl = isinstance(self._mesh, CylinderGeometry)
+        rsz, hsz = ray_dtype(self.real).itemsize, (28 if cyl else hit_dtype(self.real).itemsize)
         n = d_rays.numel() * d_rays.element_size() // rsz
         assert d_hits.numel() * d_hits.element_size() >= n * hsz
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         if options is not None:
             options = np.asarray(options, dtype=TRACE_OPTIONS).reshape(1)
+        if cyl:
+            self._check(self._L.nrtTraverseBatchCylindersDevice_f32(
+                self._h, d_rays.data_ptr(), n, _p(options), d_hits.data_ptr(), None if d_mask is None else d_mask.data_ptr(), stream))
+            return n
         self._check(
             getattr(self._L, "nrtTraverseBatchDevice_" + self._s)(
                 self._h, d_rays.data_ptr(), n, _p(options), d_hits.data_ptr(),

@@ -16,6 +16,7 @@ NRT_OK, NRT_ERR_INVALID, NRT_ERR_EMPTY, NRT_ERR_DEVICE, NRT_ERR_PRECISION = 0, 1
 SYMBOLS = [
     "nrtCreate", "nrtDestroy", "nrtLastError", "nrtVersion",
     "nrtSetMesh_f32", "nrtSetMesh_f64", "nrtSetSpheres_f32",
+    "nrtSetCylinders_f32", "nrtTraverseBatchCylinders_f32", "nrtTraverseBatchCylindersDevice_f32",
     "nrtBuild_f32", "nrtBuild_f64",
     "nrtGetTree_f32", "nrtGetTree_f64", "nrtTreeSize",
     "nrtSetTree_f32", "nrtSetTree_f64",
@@ -99,6 +100,12 @@ def lib():
         f.restype = i32
     L.nrtSetSpheres_f32.argtypes = [vp, vp, vp, u32]
     L.nrtSetSpheres_f32.restype = i32
+    L.nrtSetCylinders_f32.argtypes = [vp, vp, vp, u32, i32]
+    L.nrtSetCylinders_f32.restype = i32
+    L.nrtTraverseBatchCylinders_f32.argtypes = [vp, vp, u64, vp, vp, vp]
+    L.nrtTraverseBatchCylinders_f32.restype = i32
+    L.nrtTraverseBatchCylindersDevice_f32.argtypes = [vp, vp, u64, vp, vp, vp, vp]
+    L.nrtTraverseBatchCylindersDevice_f32.restype = i32
     L.nrtSceneCreate.argtypes = [i32, ctypes.POINTER(vp)]
     L.nrtSceneCreate.restype = i32
     L.nrtSceneDestroy.argtypes = [vp]

@@ -29,6 +29,10 @@ int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind);
 template <typename T>
 hipError_t launch_gather_leaf_spheres(const uint32_t *, const T *, const T *, LeafSphere<T> *, uint32_t, hipStream_t);
 template <typename T>
+hipError_t launch_gather_leaf_cylinders(const uint32_t *, const T *, const T *, LeafCylinder<T> *, uint32_t, hipStream_t);
+hipError_t launch_cylinder_post(const nrt_ray_f32 *, const nrt_hit_f32 *, const uint8_t *, const float *, uint32_t, void *,
+                                uint8_t *, hipStream_t);
+template <typename T>
 hipError_t launch_make_wide(const typename Wire<T>::Node *, uint32_t, uint32_t packed, uint32_t *scratch, WideNode<T> *,
                             hipStream_t);
 template <typename T>
@@ -39,7 +43,7 @@ struct BuildResult {
   uint32_t max_depth, num_leaves, num_branches, max_leaf_count;
 };
 template <typename T>
-hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, uint32_t num_faces,
+hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, bool cylinders, uint32_t num_faces,
                      uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, bool morton_order,
                      DevBuf *workspace, DevBuf *nodes_buf, DevBuf *indices_buf, BuildResult *res, std::string *err);
 } // namespace nrt
@@ -56,7 +60,8 @@ struct nrt_ctx {
   int num_cus = 256;
 
   // mesh (tight xyz in HBM)
-  int prim_kind = kPrimTriangles; // kPrimSpheres: d_verts = centers, d_radii = radii, no faces
+  int prim_kind = kPrimTriangles; // kPrimSpheres: d_verts = centres, d_radii = radii, no faces; kPrimCylinders: d_verts = 2 end points, d_radii = 2 radii per primitive
+  uint32_t cyl_test_cap = 1;
   void *d_verts = nullptr;
   void *d_radii = nullptr;
   uint32_t *d_faces = nullptr;
@@ -81,6 +86,7 @@ struct nrt_ctx {
   struct LaunchSlot {
     uint32_t *d_cursor = nullptr; // ray cursors (one per partition, 4 KiB apart)
     DevBuf spill, spill_tmin;
+    DevBuf cyl_hits, cyl_bits;    // cylinder kind: compact records + {hit, cap} bits between the traversal and its post pass
     hipEvent_t done = nullptr;    // recorded after the slot's last launch
     hipStream_t stream = nullptr; // stream of that launch
     bool used = false;
@@ -220,6 +226,8 @@ void nrtDestroy(nrt_ctx *c) {
     if (sl.d_cursor) (void)hipFree(sl.d_cursor);
     if (sl.spill.p) (void)hipFree(sl.spill.p);
     if (sl.spill_tmin.p) (void)hipFree(sl.spill_tmin.p);
+    if (sl.cyl_hits.p) (void)hipFree(sl.cyl_hits.p);
+    if (sl.cyl_bits.p) (void)hipFree(sl.cyl_bits.p);
     if (sl.done) (void)hipEventDestroy(sl.done);
   }
   free_tree(c);
@@ -310,6 +318,29 @@ static nrt_status set_spheres(nrt_ctx *c, const T *centers, const T *radii, uint
   return NRT_OK;
 }
 
+// Cylinder primitives (CylinderGeometry of examples/cylinder_primitive/main.cc:124-210): two end points and two radii each.
+static nrt_status set_cylinders(nrt_ctx *c, const float *endpoints, const float *radii, uint32_t n, int test_cap) {
+  if (!c) return NRT_ERR_INVALID;
+  if (c->prec != 0 && c->prec != 4) return fail(c, NRT_ERR_PRECISION, "nrtSetCylinders: context already holds f64 primitives");
+  if (n && (!endpoints || !radii)) return fail(c, NRT_ERR_INVALID, "nrtSetCylinders: NULL pointer");
+  if (n >= 0x40000000u) return fail(c, NRT_ERR_INVALID, "nrtSetCylinders: too many cylinders");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_tree(c);
+  free_mesh(c);
+  c->prec = 4;
+  c->prim_kind = kPrimCylinders;
+  c->cyl_test_cap = test_cap ? 1u : 0u;
+  c->num_faces = n;
+  c->num_verts = 2 * n;
+  if (n == 0) return NRT_OK;
+  HIPCHK(c, hipMalloc(&c->d_verts, 6 * (size_t)n * sizeof(float)));
+  HIPCHK(c, hipMalloc(&c->d_radii, 2 * (size_t)n * sizeof(float)));
+  HIPCHK(c, hipMemcpy(c->d_verts, endpoints, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_radii, radii, 2 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  return NRT_OK;
+}
+
 // ---------------------------------------------------------------------------
 // tree adoption / retrieval
 // ---------------------------------------------------------------------------
@@ -322,6 +353,11 @@ static nrt_status finish_tree(nrt_ctx *c) {
     c->d_tris = c->b_tris.p;
     HIPCHK(c, launch_gather_leaf_spheres<T>(c->d_indices, (const T *)c->d_verts, (const T *)c->d_radii,
                                             (LeafSphere<T> *)c->d_tris, (uint32_t)c->num_indices, c->stream));
+  } else if (c->prim_kind == kPrimCylinders) {
+    if ((st = ensure(c, c->b_tris, std::max<size_t>(1, c->num_indices) * sizeof(LeafCylinder<T>)))) return st;
+    c->d_tris = c->b_tris.p;
+    HIPCHK(c, launch_gather_leaf_cylinders<T>(c->d_indices, (const T *)c->d_verts, (const T *)c->d_radii,
+                                              (LeafCylinder<T> *)c->d_tris, (uint32_t)c->num_indices, c->stream));
   } else {
     if ((st = ensure(c, c->b_tris, std::max<size_t>(1, c->num_indices) * sizeof(LeafTri<T>)))) return st;
     c->d_tris = c->b_tris.p;
@@ -439,7 +475,7 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   BuildResult res;
   std::string err;
   HIPCHK(c, hipEventRecord(c->ev_b0, c->stream));
-  hipError_t e = gpu_build<T>(c->stream, (const T *)c->d_verts, c->d_faces, (const T *)c->d_radii, c->num_faces, min_leaf, max_depth,
+  hipError_t e = gpu_build<T>(c->stream, (const T *)c->d_verts, c->d_faces, (const T *)c->d_radii, c->prim_kind == kPrimCylinders, c->num_faces, min_leaf, max_depth,
                               bin_size, c->morton != 0, &c->b_build_ws, &c->b_nodes, &c->b_indices, &res, &err);
   if (e != hipSuccess) return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s (%s)", err.c_str(), hipGetErrorString(e));
   c->d_nodes = c->b_nodes.p;
@@ -474,8 +510,11 @@ static const nrt_trace_options kDefaultTrace = {{0u, 0x7FFFFFFFu}, 0xFFFFFFFFu, 
 template <typename T>
 static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_rays, uint64_t n,
                                   const nrt_trace_options *opt, typename Wire<T>::Hit *d_hits, uint8_t *d_mask,
-                                  hipStream_t s, bool count, bool timed) {
+                                  hipStream_t s, bool count, bool timed, void *d_cyl_hits = nullptr) {
   if (c->prec != (int)sizeof(T)) return fail(c, NRT_ERR_PRECISION, "nrtTraverseBatch: precision mismatch");
+  if ((c->prim_kind == kPrimCylinders) != (d_cyl_hits != nullptr))
+    return fail(c, NRT_ERR_INVALID, "cylinder primitives are traced with nrtTraverseBatchCylinders*_f32 (28-byte records), "
+                                    "every other primitive kind with nrtTraverseBatch*");
   if (!c->d_nodes) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatch: no tree (call nrtBuild or nrtSetTree)");
   if (n == 0) return NRT_OK;
   if (!d_rays) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatch: NULL rays");
@@ -505,13 +544,13 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   }
 
   // persistent grid: every block resident (occupancy of the chosen variant)
-  const bool spheres = c->prim_kind == kPrimSpheres;
+  const bool spheres = c->prim_kind != kPrimTriangles; // the custom primitives share one launch geometry
   if (spheres && (count || !c->d_wide))
-    return fail(c, NRT_ERR_INVALID, "nrtTraverse: sphere primitives run on the WideNode kernel only (no counting pass)");
+    return fail(c, NRT_ERR_INVALID, "nrtTraverse: custom primitives run on the WideNode kernel only (no counting pass)");
   const bool use_wide = (c->wide || spheres) && !count && c->d_wide;
   if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
   if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles);
-  if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, kPrimSpheres);
+  if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind);
   unsigned blocks_per_cu = spheres ? c->sphere_blocks_per_cu : (use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu);
   if (c->max_blocks_per_cu && blocks_per_cu > c->max_blocks_per_cu) blocks_per_cu = c->max_blocks_per_cu;
   const int stack_entries = spheres ? 10 : (use_wide ? c->wide_stack : c->lds_stack);
@@ -538,6 +577,8 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.tris = (const LeafTri<T> *)c->d_tris;
   a.spheres = (const LeafSphere<T> *)c->d_tris;
   a.centers = (const T *)c->d_verts;
+  a.cylinders = (const LeafCylinder<T> *)c->d_tris;
+  a.cyl_test_cap = c->cyl_test_cap;
   a.wide = (const WideNode<T> *)c->d_wide;
   a.packed_leaves = c->packed_leaves;
   a.debug_flags = c->debug_flags;
@@ -545,6 +586,13 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.rays = d_rays;
   a.hits = d_hits;
   a.mask = d_mask;
+  if (d_cyl_hits) { // compact records + {hit, cap} bits, expanded by the post pass below
+    nrt_status st = ensure(c, slot->cyl_hits, (size_t)n * sizeof(typename Wire<T>::Hit));
+    if (st) return st;
+    if ((st = ensure(c, slot->cyl_bits, (size_t)n))) return st;
+    a.hits = (typename Wire<T>::Hit *)slot->cyl_hits.p;
+    a.mask = (uint8_t *)slot->cyl_bits.p;
+  }
   a.num_rays = (uint32_t)n;
   a.range0 = opt->prim_ids_range[0];
   a.range1 = opt->prim_ids_range[1];
@@ -571,6 +619,9 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
     HIPCHK(c, launch_traverse_wide<T>(a, grid, c->wide_stack, c->prim_kind, s));
   else
     HIPCHK(c, launch_traverse<T>(a, grid, count, c->lds_stack, s));
+  if (d_cyl_hits)
+    HIPCHK(c, launch_cylinder_post((const nrt_ray_f32 *)d_rays, (const nrt_hit_f32 *)slot->cyl_hits.p, (const uint8_t *)slot->cyl_bits.p,
+                                   (const float *)c->d_verts, (uint32_t)n, d_cyl_hits, d_mask, s));
   if (timed) {
     HIPCHK(c, hipEventRecord(c->ev_t1, s));
     c->have_traverse_time = true;
@@ -632,6 +683,41 @@ nrt_status nrtSetMesh_f32(nrt_ctx *c, const float *v, size_t stride, const uint3
 }
 nrt_status nrtSetMesh_f64(nrt_ctx *c, const double *v, size_t stride, const uint32_t *f, uint32_t nf) {
   return set_mesh<double>(c, v, stride, f, nf);
+}
+
+nrt_status nrtSetCylinders_f32(nrt_ctx *c, const float *endpoints, const float *radii, uint32_t n, int test_cap) {
+  return set_cylinders(c, endpoints, radii, n, test_cap);
+}
+
+nrt_status nrtTraverseBatchCylindersDevice_f32(nrt_ctx *c, const nrt_ray_f32 *r, uint64_t n, const nrt_trace_options *o,
+                                               nrt_cyl_hit_f32 *h, uint8_t *m, void *s) {
+  if (!c) return NRT_ERR_INVALID;
+  if (n && !h) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchCylindersDevice: NULL hits");
+  return traverse_device<float>(c, r, n, o, nullptr, m, (hipStream_t)s, false, true, h);
+}
+
+nrt_status nrtTraverseBatchCylinders_f32(nrt_ctx *c, const nrt_ray_f32 *rays, uint64_t n, const nrt_trace_options *opt,
+                                         nrt_cyl_hit_f32 *hits, uint8_t *mask) {
+  if (!c) return NRT_ERR_INVALID;
+  if (n == 0) return NRT_OK;
+  if (!rays || !hits) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchCylinders: NULL rays/hits");
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t kMaxChunk = 1ull << 26;
+  for (uint64_t off = 0; off < n; off += kMaxChunk) {
+    const uint64_t m = std::min(kMaxChunk, n - off);
+    nrt_status st;
+    if ((st = ensure(c, c->st_rays, m * sizeof(nrt_ray_f32)))) return st;
+    if ((st = ensure(c, c->st_hits, m * sizeof(nrt_cyl_hit_f32)))) return st;
+    if ((st = ensure(c, c->st_mask, m))) return st;
+    HIPCHK(c, hipMemcpyAsync(c->st_rays.p, rays + off, m * sizeof(nrt_ray_f32), hipMemcpyHostToDevice, c->stream));
+    st = traverse_device<float>(c, (const nrt_ray_f32 *)c->st_rays.p, m, opt, nullptr, (uint8_t *)c->st_mask.p, c->stream, false,
+                                true, c->st_hits.p);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(hits + off, c->st_hits.p, m * sizeof(nrt_cyl_hit_f32), hipMemcpyDeviceToHost, c->stream));
+    if (mask) HIPCHK(c, hipMemcpyAsync(mask + off, c->st_mask.p, m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return NRT_OK;
 }
 
 nrt_status nrtSetSpheres_f32(nrt_ctx *c, const float *centers, const float *radii, uint32_t n) {

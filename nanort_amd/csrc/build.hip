@@ -269,7 +269,7 @@ __device__ __forceinline__ T wave_max(T x) {
 template <typename T>
 __global__ __launch_bounds__(256) void k_prim_records(const T *__restrict__ verts,
                                                       const uint32_t *__restrict__ faces,
-                                                      const T *__restrict__ radii, uint32_t n,
+                                                      const T *__restrict__ radii, bool cylinders, uint32_t n,
                                                       PrimRec<T> *__restrict__ recs,
                                                       BoundsAcc<T> *__restrict__ scene) {
   typedef typename Ord<T>::U U;
@@ -298,11 +298,17 @@ __global__ __launch_bounds__(256) void k_prim_records(const T *__restrict__ vert
         r.bmin[k] = tmin(p0, tmin(p1, p2)); // nanort.h:967-968
         r.bmax[k] = tmax(p0, tmax(p1, p2));
         r.c[k] = ((p0 + p1) + p2) * third; // nanort.h:970
-      } else { // spheres: SphereGeometry::BoundingBoxAndCenter (examples/particle_primitive/main.cc:124-136)
+      } else if (!cylinders) { // spheres: SphereGeometry::BoundingBoxAndCenter (examples/particle_primitive/main.cc:124-136)
         const T c = verts[3 * (size_t)i + k], rad = radii[i];
         r.bmin[k] = c - rad;
         r.bmax[k] = c + rad;
         r.c[k] = c;
+      } else { // cylinders: CylinderGeometry::BoundingBoxAndCenter (examples/cylinder_primitive/main.cc:166-205)
+        const T a0 = verts[3 * (size_t)(2 * i) + k], a1 = verts[3 * (size_t)(2 * i + 1) + k];
+        const T r0 = radii[2 * (size_t)i], r1 = radii[2 * (size_t)i + 1];
+        r.bmin[k] = tmin(a1 - r1, a0 - r0); // std::min(second, first): identical unless NaN
+        r.bmax[k] = tmax(a1 + r1, a0 + r0);
+        r.c[k] = (a0 + a1) / T(2.0);
       }
       lo[k] = tmin(lo[k], r.bmin[k]);
       hi[k] = tmax(hi[k], r.bmax[k]);
@@ -1489,7 +1495,7 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
 // per-frame rebuild).  Host synchronisations: one or two to learn that the top phase has
 // run out of large nodes, one to size the node array.
 template <typename T>
-hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, uint32_t n,
+hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, bool cylinders, uint32_t n,
                      uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, bool morton_order, DevBuf *workspace, DevBuf *nodes_buf,
                      DevBuf *indices_buf, BuildResult *res, std::string *err) {
   typedef typename Wire<T>::Node Node;
@@ -1518,7 +1524,7 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     hipLaunchKernelGGL((k_init_scene<T>), dim3(1), dim3(64), 0, s, scene, info, (uint32_t)plan.max_top);
     {
       unsigned grid = (unsigned)std::min<size_t>(((size_t)n + 255) / 256, 2048);
-      hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, d_radii, n, recs[0], scene);
+      hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, d_radii, cylinders, n, recs[0], scene);
     }
     int cur = 0; // buffer holding the ranges of the nodes being split
     if (morton_order && n > 1) {
@@ -1605,9 +1611,9 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
   }
 }
 
-template hipError_t gpu_build<float>(hipStream_t, const float *, const uint32_t *, const float *, uint32_t, uint32_t,
+template hipError_t gpu_build<float>(hipStream_t, const float *, const uint32_t *, const float *, bool, uint32_t, uint32_t,
                                      uint32_t, uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
-template hipError_t gpu_build<double>(hipStream_t, const double *, const uint32_t *, const double *, uint32_t, uint32_t,
+template hipError_t gpu_build<double>(hipStream_t, const double *, const uint32_t *, const double *, bool, uint32_t, uint32_t,
                                       uint32_t, uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
 
 } // namespace nrt

@@ -83,7 +83,17 @@ struct LeafSphere {
   uint32_t prim_id;
 };
 static_assert(sizeof(LeafSphere<float>) == 20, "LeafSphere<float>");
-enum : int { kPrimTriangles = 0, kPrimSpheres = 1 };
+
+// Leaf-ordered cylinder record (primitive kind 2: examples/cylinder_primitive/main.cc:94-424).
+template <typename T>
+struct LeafCylinder {
+  T p0[3];
+  T p1[3];
+  T r0, r1;
+  uint32_t prim_id;
+};
+static_assert(sizeof(LeafCylinder<float>) == 36, "LeafCylinder<float>");
+enum : int { kPrimTriangles = 0, kPrimSpheres = 1, kPrimCylinders = 2 };
 static_assert(sizeof(LeafTri<double>) == 80, "LeafTri<double>");
 
 // Private traversal layout: one record per BRANCH node holding BOTH children's boxes, so a
@@ -115,6 +125,8 @@ struct TraverseArgs {
   const LeafTri<T> *tris;        // primitive kind 0
   const LeafSphere<T> *spheres;  // primitive kind 1 (leaf order)
   const T *centers;              // primitive kind 1: xyz per primitive id (PostTraversal)
+  const LeafCylinder<T> *cylinders; // primitive kind 2 (leaf order)
+  uint32_t cyl_test_cap;         // primitive kind 2: the intersector's test_cap flag
   const WideNode<T> *wide; // may be null (binary kernel only)
   uint32_t packed_leaves;  // leaf references of `wide` are PACKED (see WideNode)
   uint32_t debug_flags;    // profiling only (env NRT_DEBUG): 1 = skip triangle tests, 2 = skip traversal

@@ -349,3 +349,30 @@ void nrt_rays_particle_camera(uint32_t W, uint32_t H, ray_f32 *out) {
     }
   }
 }
+
+/* GenerateRandomCylinders (examples/cylinder_primitive/main.cc:428-462): n cylinders with both end points uniform in
+ * [bmin, bmax), seed (0, 1), radii = 0.25 * largest box extent / sqrt(n) (double arithmetic, then float).
+ * verts: 2 x xyz per cylinder; radii: 2 per cylinder. */
+void nrt_scene_random_cylinders(uint64_t n, const float bmin[3], const float bmax[3], float *verts, float *radii) {
+  particle_rng rng;
+  float bsize = bmax[0] - bmin[0];
+  uint64_t i;
+  int k;
+  rng.state = 0u;
+  rng.inc = (1ULL << 1u) | 1u;
+  (void)particle_random(&rng);
+  rng.state += 0ULL;
+  (void)particle_random(&rng);
+  if (bsize < bmax[1] - bmin[1]) bsize = bmax[1] - bmin[1];
+  if (bsize < bmax[2] - bmin[2]) bsize = bmax[2] - bmin[2];
+  for (i = 0; i < n; i++) {
+    float u[6];
+    for (k = 0; k < 6; k++) u[k] = particle_random(&rng);
+    for (k = 0; k < 3; k++) {
+      verts[3 * (2 * i + 0) + k] = u[k] * (bmax[k] - bmin[k]) + bmin[k];
+      verts[3 * (2 * i + 1) + k] = u[3 + k] * (bmax[k] - bmin[k]) + bmin[k];
+    }
+    radii[2 * i + 0] = (float)((0.25 * bsize) / sqrt((double)n));
+    radii[2 * i + 1] = (float)((0.25 * bsize) / sqrt((double)n));
+  }
+}

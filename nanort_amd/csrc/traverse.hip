@@ -29,6 +29,7 @@ struct Const<float> {
   static __device__ __forceinline__ float fmax(float a, float b) { return __builtin_fmaxf(a, b); }
   static __device__ __forceinline__ float fmin(float a, float b) { return __builtin_fminf(a, b); }
   static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+  static __device__ __forceinline__ float fltmax() { return 3.402823466e+38f; }
 };
 template <>
 struct Const<double> {
@@ -39,6 +40,7 @@ struct Const<double> {
   static __device__ __forceinline__ double fmax(double a, double b) { return __builtin_fmax(a, b); }
   static __device__ __forceinline__ double fmin(double a, double b) { return __builtin_fmin(a, b); }
   static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }
+  static __device__ __forceinline__ double fltmax() { return 3.402823466e+38; } // the example is fp32 only
 };
 
 template <typename T>
@@ -62,7 +64,8 @@ struct Lane {
   T org[3];
   T inv[3];
   T min_t, max_t, hit_t; // hit_t == intersector t_ == best so far
-  T d0, d1, d2;          // ray direction (sphere kind only; dead otherwise)
+  T d0, d1, d2;          // ray direction (sphere / cylinder kinds; dead otherwise)
+  uint32_t cap;          // cylinder kind: hit_cap_ of the accepted hit (u, v hold u_param_, v_param_)
   T Sx, Sy, Sz;
   T u, v;
   uint32_t prim;
@@ -83,6 +86,7 @@ __device__ __forceinline__ void lane_init(Lane<T> &L, const typename Wire<T>::Ra
   L.max_t = r.max_t;
   L.hit_t = r.max_t; // nanort.h:2494, 2501
   L.prim = kInvalid;
+  L.cap = 0u;
   L.u = T(0);
   L.v = T(0);
   // PrepareTraversal (nanort.h:1170-1193)
@@ -227,6 +231,129 @@ __device__ __forceinline__ void sphere_test(Lane<T> &L, const LeafSphere<T> &sp,
     L.hit_t = acc ? t : L.hit_t;
     L.prim = acc ? prim : L.prim;
   }
+}
+
+// CylinderIntersector::Intersect (examples/cylinder_primitive/main.cc:237-343) with solve2e (:61-90) against one leaf
+// record, as one running predicate (the reference's early returns in the same order, every comparison in the
+// reference's own form so that NaNs take the same side).  The intersector's mutable members hit_cap_, u_param_,
+// v_param_ are the lane's cap, u, v: as there, they change exactly when the primitive is accepted.
+template <typename T>
+__device__ __forceinline__ void cyl_normalize(const T a[3], T o[3]) { // vnormalize, nanort.h:383-398
+  const T len = Const<T>::sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+  o[0] = a[0];
+  o[1] = a[1];
+  o[2] = a[2];
+  if (Const<T>::abs(len) > Const<T>::eps()) {
+    const T inv_len = T(1.0) / len;
+    o[0] *= inv_len;
+    o[1] *= inv_len;
+    o[2] *= inv_len;
+  }
+}
+template <typename T>
+__device__ __forceinline__ T cyl_dot(const T a[3], const T b[3]) {
+  return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+
+template <typename T>
+__device__ __forceinline__ void cylinder_test(Lane<T> &L, const LeafCylinder<T> &cy, bool active, uint32_t range0,
+                                              uint32_t range1, bool test_cap) {
+  const uint32_t prim = cy.prim_id;
+  const bool ok = active & (prim >= range0) & (prim < range1);
+  const T kEPS = T(1.0e-6f);
+  const T org[3] = {L.org[0], L.org[1], L.org[2]}, dir[3] = {L.d0, L.d1, L.d2};
+  const T tmax = L.hit_t;
+  const T rr = (cy.r0 < cy.r1) ? cy.r1 : cy.r0; // std::max(r0, r1)
+  T d[3], m[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    d[k] = cy.p1[k] - cy.p0[k];
+    m[k] = org[k] - cy.p0[k];
+  }
+  const T md = cyl_dot(m, d), nd = cyl_dot(dir, d), dd = cyl_dot(d, d);
+  bool hitCap = false;
+  T capT = Const<T>::fltmax();
+  T t_new = tmax, u_new = L.u, v_new = L.v;
+  uint32_t cap_new = L.cap;
+  if (test_cap) {
+    T t01[3], dN0[3], dN1[3], rd[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t01[k] = cy.p0[k] - cy.p1[k];
+    cyl_normalize<T>(t01, dN0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) dN1[k] = -dN0[k];
+    cyl_normalize<T>(dir, rd);
+    const bool facing = Const<T>::abs(cyl_dot(dir, dN0)) > kEPS;
+    const T p0D = -cyl_dot(cy.p0, dN0), p1D = -cyl_dot(cy.p1, dN1);
+    const T p0T = -(cyl_dot(org, dN0) + p0D) / cyl_dot(rd, dN0);
+    const T p1T = -(cyl_dot(org, dN1) + p1D) / cyl_dot(rd, dN1);
+    T e0[3], e1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      e0[k] = (org[k] + rd[k] * p0T) - cy.p0[k];
+      e1[k] = (org[k] + rd[k] * p1T) - cy.p1[k];
+    }
+    const T qp0Sqr = cyl_dot(e0, e0), qp1Sqr = cyl_dot(e1, e1);
+    const bool c0 = facing & (p0T > T(0)) & (p0T < tmax) & (qp0Sqr < rr * rr);
+    hitCap = c0;
+    capT = c0 ? p0T : capT;
+    t_new = c0 ? p0T : t_new;
+    u_new = c0 ? Const<T>::sqrt(qp0Sqr) : u_new;
+    v_new = c0 ? T(0) : v_new;
+    const bool c1 = facing & (p1T > T(0)) & (p1T < tmax) & (p1T < capT) & (qp1Sqr < rr * rr);
+    hitCap = hitCap | c1;
+    capT = c1 ? p1T : capT;
+    t_new = c1 ? p1T : t_new;
+    u_new = c1 ? Const<T>::sqrt(qp1Sqr) : u_new;
+    v_new = c1 ? T(1.0) : v_new;
+    cap_new = hitCap ? 1u : cap_new;
+  }
+  bool accept = hitCap;
+  const bool outside = ((md <= T(0)) & (nd <= T(0))) | ((md >= dd) & (nd >= T(0)));
+  {
+    const T nn = cyl_dot(dir, dir), mn = cyl_dot(m, dir);
+    const T A = dd * nn - nd * nd;
+    const T kk = cyl_dot(m, m) - rr * rr;
+    const T C = dd * kk - md * md;
+    const T B = dd * mn - nd * md;
+    // solve2e: the smaller root (root[0]) and whether there is one
+    T root;
+    bool have;
+    if (Const<T>::abs(A) <= kEPS) {
+      root = -C / B;
+      have = true;
+    } else {
+      const T D = B * B - A * C;
+      if (D < T(0)) {
+        root = T(0);
+        have = false;
+      } else if (D == T(0)) {
+        root = -B / A;
+        have = true;
+      } else {
+        T x1 = (Const<T>::abs(B) + Const<T>::sqrt(D)) / A;
+        if (B >= T(0)) x1 = -x1;
+        const T x2 = C / (A * x1);
+        root = (x1 > x2) ? x2 : x1;
+        have = true;
+      }
+    }
+    const T t = root;
+    T sv = md + t * nd;
+    sv = sv / dd;
+    const bool side = !outside & have & (T(0) <= t) & (t <= tmax) & (t <= capT) & (T(0) <= sv) & (sv <= T(1));
+    accept = accept | side;
+    t_new = side ? t : t_new;
+    u_new = side ? T(0) : u_new;
+    v_new = side ? sv : v_new;
+    cap_new = side ? 0u : cap_new;
+  }
+  accept = accept & ok;
+  L.hit_t = accept ? t_new : L.hit_t;
+  L.u = accept ? u_new : L.u;
+  L.v = accept ? v_new : L.v;
+  L.cap = accept ? cap_new : L.cap;
+  L.prim = accept ? prim : L.prim;
 }
 
 __device__ __forceinline__ unsigned lane_id() {
@@ -520,6 +647,67 @@ __global__ __launch_bounds__(256) void k_sphere_uv(const typename Wire<T>::Ray *
   hits[i] = h;
 }
 
+// CylinderIntersector::PostTraversal (examples/cylinder_primitive/main.cc:367-418) as a pass over the finished compact
+// records {u_param, v_param, t, prim} + mask {bit 0 hit, bit 1 hit_cap_}: the surface normal, into the caller's
+// 28-byte records {u, v, normal[3], t, prim_id} (t is the intersector's t; the example never writes isect->t) and
+// 0/1 mask.  `verts` holds the two end points of every cylinder (2 x xyz).  A miss writes {0, 0, 0, max_t, ~0}.
+struct CylHit32 {
+  float u, v, normal[3], t;
+  uint32_t prim_id;
+};
+static_assert(sizeof(CylHit32) == 28, "nrt_cyl_hit_f32");
+
+__global__ __launch_bounds__(256) void k_cylinder_post(const Wire<float>::Ray *__restrict__ rays,
+                                                       const Wire<float>::Hit *__restrict__ compact,
+                                                       const uint8_t *__restrict__ bits, const float *__restrict__ verts,
+                                                       uint32_t n, CylHit32 *__restrict__ out, uint8_t *__restrict__ mask) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const Wire<float>::Hit h = compact[i];
+  const uint8_t b = bits[i];
+  CylHit32 o;
+  if (b & 1u) {
+    const Wire<float>::Ray r = rays[i];
+    const float *p0 = verts + 3 * (size_t)(2 * h.prim_id), *p1 = p0 + 3;
+    float d01[3], pos[3], nrm[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      d01[k] = p1[k] - p0[k];
+      pos[k] = r.org[k] + r.dir[k] * h.t;
+    }
+    if (b & 2u) { // a cap: +-axis, whichever faces the hit point from the cylinder's middle
+      float pc[3];
+      cyl_normalize<float>(d01, nrm);
+#pragma unroll
+      for (int k = 0; k < 3; k++) pc[k] = pos[k] - (d01[k] * 0.5f + p0[k]);
+      if (!(cyl_dot<float>(pc, nrm) > 0.0f)) {
+        nrm[0] = -nrm[0];
+        nrm[1] = -nrm[1];
+        nrm[2] = -nrm[2];
+      }
+    } else { // the side: away from the axis point at parameter v
+      float pc[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) pc[k] = pos[k] - (p0[k] + h.v * d01[k]);
+      cyl_normalize<float>(pc, nrm);
+    }
+    o.u = h.u;
+    o.v = h.v;
+    o.normal[0] = nrm[0];
+    o.normal[1] = nrm[1];
+    o.normal[2] = nrm[2];
+    o.t = h.t;
+    o.prim_id = h.prim_id;
+  } else {
+    o.u = o.v = 0.0f;
+    o.normal[0] = o.normal[1] = o.normal[2] = 0.0f;
+    o.t = h.t; // the kernel's miss record carries max_t
+    o.prim_id = kInvalid;
+  }
+  out[i] = o;
+  if (mask) mask[i] = b & 1u;
+}
+
 // Both child boxes of one WideNode at once.  For fp32 the two boxes ride in the two halves of
 // 64-bit register pairs, so the subtract / multiply chain issues as v_pk_add_f32 / v_pk_mul_f32
 // (one VALU slot for two IEEE operations: same operations, same rounding, half the issue slots).
@@ -627,7 +815,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
     h_.t = hit_ ? L.hit_t : L.max_t;                    \
     h_.prim_id = hit_ ? L.prim : kInvalid;              \
     store_hit_nt<T>(a.hits + rid, h_);                  \
-    if (a.mask) a.mask[rid] = hit_ ? 1 : 0;             \
+    if (a.mask) a.mask[rid] = hit_ ? (KIND == kPrimCylinders ? (uint8_t)(1u | (L.cap << 1)) : (uint8_t)1) : (uint8_t)0; \
   } while (0)
 
   for (;;) {
@@ -753,6 +941,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
         if (KIND == kPrimSpheres) {
           const LeafSphere<T> sp = a.spheres[first + (i < cnt ? i : 0u)];
           sphere_test<T>(L, sp, i < cnt, a.range0, a.range1);
+        } else if (KIND == kPrimCylinders) {
+          const LeafCylinder<T> cy = a.cylinders[first + (i < cnt ? i : 0u)];
+          cylinder_test<T>(L, cy, i < cnt, a.range0, a.range1, a.cyl_test_cap != 0u);
         } else {
           const LeafTri<T> tri = a.tris[first + (i < cnt ? i : 0u)];
           tri_test<T>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull);
@@ -906,6 +1097,26 @@ __global__ __launch_bounds__(256) void k_gather_leaf_spheres(const uint32_t *__r
   out[s] = r;
 }
 
+// Leaf-ordered cylinder records from (indices, end points, radii).
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_leaf_cylinders(const uint32_t *__restrict__ indices,
+                                                               const T *__restrict__ verts, const T *__restrict__ radii,
+                                                               LeafCylinder<T> *__restrict__ out, uint32_t n) {
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t prim = indices[s];
+  LeafCylinder<T> r;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    r.p0[k] = verts[3 * (size_t)(2 * prim) + k];
+    r.p1[k] = verts[3 * (size_t)(2 * prim + 1) + k];
+  }
+  r.r0 = radii[2 * (size_t)prim];
+  r.r1 = radii[2 * (size_t)prim + 1];
+  r.prim_id = prim;
+  out[s] = r;
+}
+
 // ---- host-side launchers (called from api.hip) ------------------------------
 
 template <typename T, int STACK>
@@ -950,6 +1161,10 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
                          args.centers, args.num_rays);
     return hipGetLastError();
   }
+  if (prim_kind == kPrimCylinders) {
+    hipLaunchKernelGGL((k_traverse_wide<T, 10, false, kPrimCylinders>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+    return hipGetLastError();
+  }
   switch (lds_stack) {
     case 8: hipLaunchKernelGGL((k_traverse_wide<T, 8, false, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
     case 10:
@@ -970,6 +1185,8 @@ int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind) {
   hipError_t e;
   if (prim_kind == kPrimSpheres) {
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimSpheres>, kTraverseBlock, 0);
+  } else if (prim_kind == kPrimCylinders) {
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimCylinders>, kTraverseBlock, 0);
   } else {
     switch (lds_stack) {
       case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 8, false, kPrimTriangles>, kTraverseBlock, 0); break;
@@ -1010,6 +1227,26 @@ hipError_t launch_gather_leaf_spheres(const uint32_t *indices, const T *centers,
                                       uint32_t n, hipStream_t s) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL((k_gather_leaf_spheres<T>), dim3((n + 255u) / 256u), dim3(256), 0, s, indices, centers, radii, out, n);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_gather_leaf_cylinders(const uint32_t *indices, const T *verts, const T *radii, LeafCylinder<T> *out,
+                                        uint32_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((k_gather_leaf_cylinders<T>), dim3((n + 255u) / 256u), dim3(256), 0, s, indices, verts, radii, out, n);
+  return hipGetLastError();
+}
+template hipError_t launch_gather_leaf_cylinders<float>(const uint32_t *, const float *, const float *, LeafCylinder<float> *,
+                                                        uint32_t, hipStream_t);
+template hipError_t launch_gather_leaf_cylinders<double>(const uint32_t *, const double *, const double *,
+                                                         LeafCylinder<double> *, uint32_t, hipStream_t);
+
+hipError_t launch_cylinder_post(const nrt_ray_f32 *rays, const nrt_hit_f32 *compact, const uint8_t *bits, const float *verts,
+                                uint32_t n, void *out, uint8_t *mask, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cylinder_post, dim3((n + 255u) / 256u), dim3(256), 0, s, rays, compact, bits, verts, n,
+                     (CylHit32 *)out, mask);
   return hipGetLastError();
 }
 

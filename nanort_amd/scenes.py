@@ -37,6 +37,8 @@ def _lib():
         L.nrt_scene_random_spheres.argtypes = [u64, vp, vp, vp, vp]
         L.nrt_scene_random_spheres.restype = None
         L.nrt_rays_particle_camera.argtypes = [u32, u32, vp]
+        L.nrt_scene_random_cylinders.argtypes = [u64, vp, vp, vp, vp]
+        L.nrt_scene_random_cylinders.restype = None
         L.nrt_rays_particle_camera.restype = None
         _LIB = L
     return _LIB
@@ -70,6 +72,17 @@ def random_spheres(n, bmin=(-1.0, -1.0, -1.0), bmax=(1.0, 1.0, 1.0)):
     hi = np.asarray(bmax, dtype=np.float32)
     _lib().nrt_scene_random_spheres(n, _p(lo), _p(hi), _p(centers), _p(radii))
     return centers, radii
+
+
+def random_cylinders(n, bmin=(-1.0, -1.0, -1.0), bmax=(1.0, 1.0, 1.0)):
+    """The cylinder example's scene (reference examples/cylinder_primitive/main.cc:428-462): end points (n, 2, 3),
+    radii (n, 2)."""
+    verts = np.empty((n, 2, 3), dtype=np.float32)
+    radii = np.empty((n, 2), dtype=np.float32)
+    lo = np.asarray(bmin, dtype=np.float32)
+    hi = np.asarray(bmax, dtype=np.float32)
+    _lib().nrt_scene_random_cylinders(n, _p(lo), _p(hi), _p(verts), _p(radii))
+    return verts, radii
 
 
 def particle_camera_rays(width, height):

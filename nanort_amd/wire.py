@@ -82,6 +82,10 @@ assert BUILD_OPTIONS_F32.itemsize == 28 and BUILD_OPTIONS_F64.itemsize == 32
 SCENE_HIT_F32 = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim_id", "<u4"), ("node_id", "<u4")])
 assert SCENE_HIT_F32.itemsize == 20
 
+# CylinderIntersection of the reference's cylinder example (examples/cylinder_primitive/main.cc:213-224)
+CYL_HIT_F32 = np.dtype([("u", "<f4"), ("v", "<f4"), ("normal", "<f4", 3), ("t", "<f4"), ("prim_id", "<u4")])
+assert CYL_HIT_F32.itemsize == 28
+
 MISS_PRIM_ID = 0xFFFFFFFF
 
 

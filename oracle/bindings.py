@@ -448,3 +448,90 @@ class SphereReference:
         mask = np.zeros(n, dtype=np.uint8)
         self.L.refsp_traverse(self.h, _p(rays), n, prim_ids_range[0], prim_ids_range[1], _p(hits), _p(mask))
         return hits, mask
+
+
+# ---- cylinder custom primitive ------------------------------------------------------------------------------
+REF_CYLINDER_PATH = os.path.join(_HERE, "_ref", "libcylinder_ref.so")
+CYL_HIT_F32 = np.dtype([("u", "<f4"), ("v", "<f4"), ("normal", "<f4", 3), ("t", "<f4"), ("prim_id", "<u4")])
+assert CYL_HIT_F32.itemsize == 28
+
+
+def have_cylinder_reference():
+    return os.path.exists(REF_CYLINDER_PATH)
+
+
+class CylinderOracle:
+    """oracle/cylinder_oracle.c: C restatement of the cylinder intersector traced through Traverse."""
+
+    def __init__(self):
+        L = ctypes.CDLL(ORACLE_PATH)
+        vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+        L.cyo_traverse.argtypes = [vp, vp, vp, vp, ctypes.c_int, vp, u64, u32, u32, vp, vp]
+        L.cyo_traverse.restype = None
+        self.L = L
+
+    def traverse(self, nodes, indices, verts, radii, rays, prim_ids_range=(0, 0x7FFFFFFF), test_cap=True):
+        nodes = np.ascontiguousarray(nodes)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        verts = np.ascontiguousarray(verts, dtype=np.float32)
+        radii = np.ascontiguousarray(radii, dtype=np.float32)
+        rays = np.ascontiguousarray(rays)
+        n = rays.shape[0]
+        hits = np.zeros(n, dtype=CYL_HIT_F32)
+        mask = np.zeros(n, dtype=np.uint8)
+        self.L.cyo_traverse(_p(nodes), _p(indices), _p(verts), _p(radii), int(bool(test_cap)), _p(rays), n,
+                            prim_ids_range[0], prim_ids_range[1], _p(hits), _p(mask))
+        return hits, mask
+
+
+class CylinderReference:
+    """The unmodified examples/cylinder_primitive classes over the unmodified nanort.h (oracle/ref_cylinder_shim.cc)."""
+
+    def __init__(self):
+        L = ctypes.CDLL(REF_CYLINDER_PATH)
+        vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+        L.refcy_generate.argtypes = [vp, vp, u64, vp, vp]
+        L.refcy_build.argtypes = [vp, vp, u32, vp, vp]
+        L.refcy_build.restype = vp
+        L.refcy_get_tree.argtypes = [vp, vp, vp]
+        L.refcy_destroy.argtypes = [vp]
+        L.refcy_traverse.argtypes = [vp, vp, u64, u32, u32, ctypes.c_int, vp, vp]
+        self.L = L
+        self.h = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.refcy_destroy(self.h)
+        except Exception:
+            pass
+
+    def generate(self, n, bmin=(-1, -1, -1), bmax=(1, 1, 1)):
+        verts = np.empty((n, 2, 3), dtype=np.float32)
+        radii = np.empty((n, 2), dtype=np.float32)
+        lo, hi = np.asarray(bmin, dtype=np.float32), np.asarray(bmax, dtype=np.float32)
+        self.L.refcy_generate(_p(verts), _p(radii), n, _p(lo), _p(hi))
+        return verts, radii
+
+    def build(self, verts, radii):
+        verts = np.ascontiguousarray(verts, dtype=np.float32)
+        radii = np.ascontiguousarray(radii, dtype=np.float32)
+        n = radii.size // 2
+        nn = ctypes.c_uint32(0)
+        stats = np.zeros(3, dtype=np.uint32)
+        if self.h:
+            self.L.refcy_destroy(self.h)
+        self.h = self.L.refcy_build(_p(verts), _p(radii), n, ctypes.byref(nn), _p(stats))
+        assert self.h
+        nodes = np.zeros(nn.value, dtype=_NODE_F32)
+        indices = np.zeros(n, dtype=np.uint32)
+        self.L.refcy_get_tree(self.h, _p(nodes), _p(indices))
+        return nodes, indices, {"max_tree_depth": int(stats[0]), "num_leaf_nodes": int(stats[1]), "num_branch_nodes": int(stats[2])}
+
+    def traverse(self, rays, prim_ids_range=(0, 0x7FFFFFFF), test_cap=True):
+        rays = np.ascontiguousarray(rays)
+        n = rays.shape[0]
+        hits = np.zeros(n, dtype=CYL_HIT_F32)
+        mask = np.zeros(n, dtype=np.uint8)
+        self.L.refcy_traverse(self.h, _p(rays), n, prim_ids_range[0], prim_ids_range[1], int(bool(test_cap)), _p(hits), _p(mask))
+        return hits, mask

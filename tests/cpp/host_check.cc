@@ -4,6 +4,7 @@
 //                                     test/regression/possible-accuracy-problem-30 (fp64, one triangle)
 //   host_check spheres N W H OUT      the reference's particle example (examples/particle_primitive/main.cc) with the
 //                                     header's built-in sphere primitive: Build + per-ray Traverse (+ TraverseBatch)
+//   host_check cylinders SCENE W H OUT  the same for the cylinder example (examples/cylinder_primitive/main.cc)
 //   host_check trace MESH RAYS OUT    Build + per-ray Traverse (and, with the HIP backend compiled in,
 //                                     TraverseBatch) over a raw mesh / ray file; hit records to OUT
 //
@@ -203,12 +204,85 @@ static int spheres(const char *scene_path, int W, int H, const char *out_path) {
   return 0;
 }
 
+// The cylinder example's main() over the header's built-in cylinder classes; scene file {u32 n; float ends[n][2][3];
+// float radii[n][2]}.  Records are compared field by field (all of them are exact: no libm beyond sqrt).
+static int cylinders(const char *scene_path, int W, int H, const char *out_path) {
+  FILE *fp = fopen(scene_path, "rb");
+  if (!fp) return 2;
+  uint32_t n = 0;
+  if (fread(&n, 4, 1, fp) != 1) return 2;
+  std::vector<float> ends(6 * (size_t)n), radii(2 * (size_t)n);
+  if (fread(ends.data(), 4, ends.size(), fp) != ends.size() || fread(radii.data(), 4, radii.size(), fp) != radii.size()) return 2;
+  fclose(fp);
+  nanort::BVHBuildOptions<float> options;
+  options.cache_bbox = false;
+  nanort::CylinderGeometry geom(ends.data(), radii.data());
+  nanort::CylinderPred pred(ends.data());
+  nanort::BVHAccel<float> accel;
+  if (!accel.Build(n, geom, pred, options)) return 3;
+  const uint64_t nr = (uint64_t)W * H;
+  std::vector<nanort::Ray<float> > rays(nr);
+  std::vector<nanort::CylinderIntersection> hits(nr);
+  std::vector<unsigned char> mask(nr, 0);
+  for (int y = 0; y < H; y++) {
+    for (int x = 0; x < W; x++) {
+      nanort::Ray<float> &ray = rays[(size_t)y * W + x];
+      ray.org[0] = 0.0f;
+      ray.org[1] = 0.0f;
+      ray.org[2] = 4.0f;
+      nanort::real3<float> dir((x / (float)W) - 0.5f, (y / (float)H) - 0.5f, -1.0f);
+      dir = vnormalize(dir);
+      ray.dir[0] = dir[0];
+      ray.dir[1] = dir[1];
+      ray.dir[2] = dir[2];
+      ray.min_t = 0.0f;
+      ray.max_t = 1.0e+30f;
+      nanort::CylinderIntersector<nanort::CylinderIntersection> isecter(ends.data(), radii.data());
+      nanort::CylinderIntersection isect;
+      memset(&isect, 0, sizeof(isect));
+      isect.t = ray.max_t;
+      isect.prim_id = 0xFFFFFFFFu;
+      mask[(size_t)y * W + x] = accel.Traverse(ray, isecter, &isect) ? 1 : 0;
+      hits[(size_t)y * W + x] = isect;
+    }
+  }
+#ifdef NANORT_USE_HIP_BACKEND
+  std::vector<nanort::CylinderIntersection> bhits(nr);
+  std::vector<unsigned char> bmask(nr, 0);
+  for (uint64_t i = 0; i < nr; i++) {
+    memset(&bhits[i], 0, sizeof(bhits[i]));
+    bhits[i].t = rays[i].max_t;
+    bhits[i].prim_id = 0xFFFFFFFFu;
+  }
+  if (!accel.TraverseBatch(rays.data(), nr, bhits.data(), bmask.data())) {
+    fprintf(stderr, "TraverseBatch failed: %s\n", accel.LastBackendError().c_str());
+    return 4;
+  }
+  uint64_t bad = 0;
+  for (uint64_t i = 0; i < nr; i++)
+    if (bmask[i] != mask[i] || memcmp(&bhits[i], &hits[i], sizeof(hits[i])) != 0) bad++;
+  printf("batch_vs_per_ray_mismatches %llu\n", (unsigned long long)bad);
+  if (bad) return 5;
+#endif
+  fp = fopen(out_path, "wb");
+  if (!fp) return 2;
+  fwrite(hits.data(), sizeof(hits[0]), nr, fp);
+  fwrite(mask.data(), 1, nr, fp);
+  uint64_t nn = accel.GetNodes().size();
+  fwrite(&nn, 8, 1, fp);
+  fwrite(accel.GetNodes().data(), sizeof(nanort::BVHNode<float>), nn, fp);
+  fwrite(accel.GetIndices().data(), 4, n, fp);
+  fclose(fp);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc >= 2 && !strcmp(argv[1], "regress30")) return regress30(argc > 2);
+  if (argc == 6 && !strcmp(argv[1], "cylinders")) return cylinders(argv[2], atoi(argv[3]), atoi(argv[4]), argv[5]);
   if (argc == 6 && !strcmp(argv[1], "spheres")) return spheres(argv[2], atoi(argv[3]), atoi(argv[4]), argv[5]);
   if (argc == 6 && !strcmp(argv[1], "trace")) {
     return !strcmp(argv[2], "f64") ? trace<double>(argv[3], argv[4], argv[5]) : trace<float>(argv[3], argv[4], argv[5]);
   }
-  fprintf(stderr, "usage: host_check regress30 [x] | trace f32|f64 MESH RAYS OUT | spheres SCENE W H OUT\n");
+  fprintf(stderr, "usage: host_check regress30 [x] | trace f32|f64 MESH RAYS OUT | spheres|cylinders SCENE W H OUT\n");
   return 64;
 }

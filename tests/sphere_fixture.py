@@ -7,6 +7,7 @@ from nanort_amd import scenes
 from nanort_amd.wire import RAY_F32
 
 N_SPHERES = 5000
+N_CYLINDERS = 4000
 CAM_W, CAM_H = 160, 161
 
 

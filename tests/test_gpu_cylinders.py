@@ -1,0 +1,85 @@
+"""SURVEY §8f row 4 (cylinders) on the GPU: nrtSetCylinders_f32 + nrtBuild / nrtSetTree + nrtTraverseBatchCylinders.
+Every field of the 28-byte record {u, v, normal, t, prim_id} and the hit mask are bit-exact against the oracle on the
+same node array (the example's arithmetic has no libm call beyond sqrt)."""
+import os
+
+import numpy as np
+import pytest
+
+from nanort_amd import BVHAccel, CylinderGeometry, scenes
+from nanort_amd.wire import default_trace_options
+from oracle import bindings as ob
+import sphere_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def check(h, m, oh, om):
+    assert np.array_equal(m, om)
+    for f in ("t", "u", "v", "prim_id", "normal"):
+        assert np.ascontiguousarray(h[f]).tobytes() == np.ascontiguousarray(oh[f]).tobytes(), f
+
+
+def test_reference_tree_matches_golden_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "cylinders_ref.npz"))
+    v, r = scenes.random_cylinders(sphere_fixture.N_CYLINDERS)
+    rays = sphere_fixture.rays()
+    for key, cap, rng in (("", True, None), ("_nocap", False, None), ("_range", True, (500, 2500))):
+        a = BVHAccel(np.float32)
+        a.SetMesh(CylinderGeometry(v, r, test_cap=cap))
+        a.SetTree(g["nodes"], g["indices"])
+        o = None
+        if rng:
+            o = default_trace_options()
+            o["prim_ids_range"] = rng
+        h, m = a.TraverseBatch(rays, o)
+        check(h, m, g["hits" + key], g["mask" + key])
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 257, 4000, 100000])
+def test_gpu_built_tree(n):
+    v, r = scenes.random_cylinders(n)
+    a = BVHAccel(np.float32)
+    assert a.Build(n, CylinderGeometry(v, r))
+    nodes, idx = a.GetTree()
+    st = a.GetStatistics()
+    assert int(st["num_leaf_nodes"]) + int(st["num_branch_nodes"]) == nodes.shape[0]
+    assert sorted(idx.tolist()) == list(range(n))
+    lo = np.minimum(v[:, 0] - r[:, 0, None], v[:, 1] - r[:, 1, None])
+    hi = np.maximum(v[:, 0] + r[:, 0, None], v[:, 1] + r[:, 1, None])
+    for i in range(min(nodes.shape[0], 2000)):
+        nd = nodes[i]
+        if nd["flag"] == 1:
+            cnt, first = int(nd["data"][0]), int(nd["data"][1])
+            assert 1 <= cnt <= 4
+            p = idx[first:first + cnt]
+            assert np.all(lo[p] >= nd["bmin"]) and np.all(hi[p] <= nd["bmax"])
+        else:
+            for ch in nd["data"]:
+                assert np.all(nodes[ch]["bmin"] >= nd["bmin"]) and np.all(nodes[ch]["bmax"] <= nd["bmax"])
+    rays = sphere_fixture.rays() if n >= 4000 else sphere_fixture.rays()[::7]
+    h, m = a.TraverseBatch(rays)
+    oh, om = ob.CylinderOracle().traverse(nodes, idx, v, r, rays)
+    check(h, m, oh, om)
+    assert int(m.sum()) > 0
+
+
+def test_device_entry_point_and_errors():
+    import torch
+
+    from nanort_amd import NrtError
+    from nanort_amd.wire import CYL_HIT_F32
+
+    v, r = scenes.random_cylinders(3000)
+    a = BVHAccel(np.float32)
+    assert a.Build(3000, CylinderGeometry(v, r))
+    rays = scenes.particle_camera_rays(200, 201)
+    h, m = a.TraverseBatch(rays)
+    d_r = torch.from_numpy(rays.view(np.uint8)).cuda()
+    d_h = torch.zeros(rays.shape[0] * 28, dtype=torch.uint8, device="cuda")
+    d_m = torch.zeros(rays.shape[0], dtype=torch.uint8, device="cuda")
+    a.TraverseBatchDevice(d_r, d_h, d_m)
+    torch.cuda.synchronize()
+    assert d_h.cpu().numpy().view(CYL_HIT_F32).tobytes() == h.tobytes() and np.array_equal(d_m.cpu().numpy(), m)
+    with pytest.raises(NrtError):  # 16-byte entry point on a cylinder context
+        a._check(a._L.nrtTraverseBatchDevice_f32(a._h, d_r.data_ptr(), 10, None, d_h.data_ptr(), None, None))

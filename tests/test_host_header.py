@@ -88,6 +88,69 @@ def write_spheres(d, c, r):
     return path
 
 
+def read_cyl_output(path, n, nprims):
+    from oracle.bindings import CYL_HIT_F32
+
+    raw = open(path, "rb").read()
+    hits = np.frombuffer(raw, dtype=CYL_HIT_F32, count=n, offset=0)
+    o = n * 28
+    mask = np.frombuffer(raw, dtype=np.uint8, count=n, offset=o)
+    o += n
+    nn = int(np.frombuffer(raw, dtype=np.uint64, count=1, offset=o)[0])
+    o += 8
+    nodes = np.frombuffer(raw, dtype=NODE_F32, count=nn, offset=o)
+    o += nn * NODE_F32.itemsize
+    idx = np.frombuffer(raw, dtype=np.uint32, count=nprims, offset=o)
+    return hits, mask, nodes, idx
+
+
+def write_cylinders(d, v, r):
+    path = os.path.join(d, "cylinders.bin")
+    with open(path, "wb") as fp:
+        fp.write(np.array([r.shape[0]], dtype=np.uint32).tobytes())
+        fp.write(np.ascontiguousarray(v, dtype=np.float32).tobytes())
+        fp.write(np.ascontiguousarray(r, dtype=np.float32).tobytes())
+    return path
+
+
+def test_builtin_cylinder_primitive_host_path(host_check):
+    """The header's built-in cylinder classes through the generic host Build/Traverse == the cylinder oracle (pinned on
+    the unmodified example) on the same node array, every field of the record."""
+    from oracle.bindings import CylinderOracle
+
+    exe, d = host_check
+    v, r = scenes.random_cylinders(2000)
+    out = os.path.join(str(d), "cyl_out.bin")
+    W, H = 96, 97
+    rr = subprocess.run([exe, "cylinders", write_cylinders(str(d), v, r), str(W), str(H), out], stdout=subprocess.PIPE,
+                        stderr=subprocess.STDOUT, text=True)
+    assert rr.returncode == 0, rr.stdout
+    hits, mask, nodes, idx = read_cyl_output(out, W * H, 2000)
+    oh, om = CylinderOracle().traverse(nodes, idx, v, r, scenes.particle_camera_rays(W, H))
+    assert np.array_equal(mask, om) and hits.tobytes() == oh.tobytes()
+    assert 0 < int(mask.sum()) < W * H
+
+
+@pytest.mark.gpu
+def test_builtin_cylinder_primitive_hip_backend(tmp_path):
+    from oracle.bindings import CylinderOracle
+
+    exe = tmp_path / "host_check_hip"
+    cxx(["-std=c++11", "-O2", "-Wall", "-Wextra", "-DNANORT_USE_HIP_BACKEND", "-I", INC,
+         os.path.join(ROOT, "tests", "cpp", "host_check.cc"), "-o", str(exe),
+         "-L", LIBDIR, "-lnanort_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    v, r = scenes.random_cylinders(20000)
+    out = os.path.join(str(tmp_path), "out.bin")
+    W, H = 256, 257
+    rr = subprocess.run([str(exe), "cylinders", write_cylinders(str(tmp_path), v, r), str(W), str(H), out],
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert rr.returncode == 0, rr.stdout
+    assert "batch_vs_per_ray_mismatches 0" in rr.stdout
+    hits, mask, nodes, idx = read_cyl_output(out, W * H, 20000)
+    oh, om = CylinderOracle().traverse(nodes, idx, v, r, scenes.particle_camera_rays(W, H))
+    assert np.array_equal(mask, om) and hits.tobytes() == oh.tobytes()
+
+
 def test_builtin_sphere_primitive_host_path(host_check):
     """The header's built-in sphere classes (the reference ships them as user code in
     examples/particle_primitive/main.cc) through the generic host Build/Traverse: hit records equal the sphere
