@@ -9,8 +9,8 @@ for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recur
     for row in csv.DictReader(open(path)):
         k = row["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-prod = [k for k in acc if "k_traverse_wide<float, 10>" in k]
-cal = [k for k in acc if "k_traverse_wide<float, 16>" in k]
+prod = [k for k in acc if "k_traverse_wide<float, 10" in k]
+cal = [k for k in acc if "k_traverse_wide<float, 16" in k]
 out = {}
 if prod and cal:
     P, C = acc[prod[0]], acc[cal[0]]
