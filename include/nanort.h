@@ -1134,6 +1134,8 @@ class BVHAccel {
     return true;
   }
   const std::string &LastBackendError() const { return backend_error_; }
+  // The C-ABI context behind this accel (NULL before a GPU Build()): what nrtSceneAddNode_f32 takes (include/nanosg_hip.h).
+  nrt_ctx *HipContext() const { return device_tree_stale_ ? NULL : ctx_.get(); }
 
  private:
   template <class Hit>

@@ -315,6 +315,13 @@ class Scene:
         self._check(st)
         return True
 
+    def NodeState(self, node_id):
+        """xform, inv_xform, inv_xform33, inv_transpose_xform33 of a committed node (reference nanosg.h:397-437)."""
+        out = np.zeros(64, dtype=np.float32)
+        self._check(self._L.nrtSceneNodeState_f32(self._h, int(node_id), _p(out)))
+        m = out.reshape(4, 4, 4)
+        return {"xform": m[0], "inv_xform": m[1], "inv_xform33": m[2], "inv_transpose_xform33": m[3]}
+
     def TraverseBatch(self, rays):
         from .wire import RAY_F32, SCENE_HIT_F32
 

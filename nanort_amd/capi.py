@@ -24,7 +24,7 @@ SYMBOLS = [
     "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64",
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
     "nrtLastTraverseMs", "nrtLastBuildMs", "nrtDebugCounters",
-    "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit",
+    "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
     "nrtSceneTraverseBatch_f32",
 ]
 
@@ -115,6 +115,8 @@ def lib():
     L.nrtSceneAddNode_f32.argtypes = [vp, vp, vp, ctypes.POINTER(u32)]
     L.nrtSceneAddNode_f32.restype = i32
     L.nrtSceneCommit.argtypes = [vp]
+    L.nrtSceneNodeState_f32.argtypes = [vp, u32, vp]
+    L.nrtSceneNodeState_f32.restype = i32
     L.nrtSceneCommit.restype = i32
     L.nrtSceneTraverseBatch_f32.argtypes = [vp, vp, u64, vp, vp]
     L.nrtSceneTraverseBatch_f32.restype = i32

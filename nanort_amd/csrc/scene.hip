@@ -384,6 +384,22 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
   return NRT_OK;
 }
 
+// What Node::Update derives from the local transform (nanosg.h:397-437), for callers that finish the
+// reference's Intersection record (P, Ns, Ng) on the host: xform, inv_xform, inv_xform33 and
+// inv_transpose_xform33 = transpose(inv_xform33) (nanosg.h:430-432), 16 floats each, row-major T[4][4].
+nrt_status nrtSceneNodeState_f32(nrt_scene *s, uint32_t node_id, float out[64]) {
+  if (!s || !out) return NRT_ERR_INVALID;
+  if (!s->committed) return sfail(s, NRT_ERR_INVALID, "nrtSceneNodeState: commit the scene first");
+  if (node_id >= s->host_nodes.size()) return sfail(s, NRT_ERR_INVALID, "nrtSceneNodeState: node %u out of range", node_id);
+  const NodeDev &nd = s->host_nodes[node_id];
+  memcpy(out, nd.xform, 64);
+  memcpy(out + 16, nd.inv_xform, 64);
+  memcpy(out + 32, nd.inv_xform33, 64);
+  for (int j = 0; j < 4; j++)
+    for (int i = 0; i < 4; i++) out[48 + 4 * j + i] = nd.inv_xform33[i][j];
+  return NRT_OK;
+}
+
 nrt_status nrtSceneTraverseBatch_f32(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t n64, nrt_scene_hit_f32 *hits_out,
                                      uint8_t *mask_out) {
   if (!s) return NRT_ERR_INVALID;

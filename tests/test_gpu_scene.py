@@ -80,3 +80,79 @@ def test_scene_error_paths_and_empty_scene(c1_mesh):
     # identity instance: the hit mask equals the single-level traversal's, and node_id is 0 on every hit
     h1, m1 = a.TraverseBatch(scenes.camera_rays(64, 64))
     assert np.array_equal(m, m1) and (h["node_id"][m == 1] == 0).all()
+
+
+def test_node_state_matches_the_reference(golden_dir, oracle):
+    """nrtSceneNodeState_f32: the matrices Node::Update derives, bit for bit as the unmodified nanosg computed them."""
+    g = np.load(os.path.join(golden_dir, "scene_ref.npz"))
+    sc = Scene()
+    keep = []
+    for v, f, x in instances():
+        a = BVHAccel(np.float32)
+        a.SetMesh(TriangleMesh(v, f))
+        nodes, idx, _ = oracle.build(v, f)
+        a.SetTree(nodes, idx)
+        keep.append(a)
+        sc.AddNode(a, x)
+    assert sc.Commit()
+    for i in range(5):
+        st = sc.NodeState(i)
+        for k in ("xform", "inv_xform", "inv_xform33"):
+            assert np.array_equal(st[k], g["node%d_%s" % (i, k)]), (i, k)
+        assert np.array_equal(st["inv_transpose_xform33"], g["node%d_inv_xform33" % i].T)
+
+
+def test_nanosg_batch_tracer_addon(tmp_path):
+    """include/nanosg_hip.h: BatchTracer over a NanoSG-shaped scene == the C ABI's compact records, plus the rest of the
+    reference's Intersection record (P on the ray at distance t, normals through inv_transpose_xform33)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc, libdir = os.path.join(root, "include"), os.path.join(root, "nanort_amd", "lib")
+    exe = tmp_path / "nanosg_batch_check"
+    r = subprocess.run(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-DNANORT_USE_HIP_BACKEND", "-I", inc,
+                        os.path.join(root, "tests", "cpp", "nanosg_batch_check.cc"), "-o", str(exe), "-L", libdir, "-lnanort_hip",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    inst = instances()
+    scene_path, rays_path, out_path = (str(tmp_path / n) for n in ("scene.bin", "rays.bin", "out.bin"))
+    with open(scene_path, "wb") as fp:
+        fp.write(np.array([len(inst)], dtype=np.uint32).tobytes())
+        for v, f, x in inst:
+            fp.write(np.array([v.shape[0], f.shape[0]], dtype=np.uint32).tobytes())
+            fp.write(np.ascontiguousarray(v, dtype=np.float32).tobytes())
+            fp.write(np.ascontiguousarray(f, dtype=np.uint32).tobytes())
+            fp.write(np.ascontiguousarray(x, dtype=np.float32).tobytes())
+    rays = scenes.camera_rays(320, 180)
+    with open(rays_path, "wb") as fp:
+        fp.write(np.array([rays.shape[0]], dtype=np.uint64).tobytes())
+        fp.write(rays.tobytes())
+    r = subprocess.run([str(exe), scene_path, rays_path, out_path], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    n = rays.shape[0]
+    rec = np.dtype([("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim_id", "<u4"), ("node_id", "<u4"), ("P", "<f4", 3),
+                    ("Ns", "<f4", 3), ("Ng", "<f4", 3)])
+    raw = open(out_path, "rb").read()
+    out = np.frombuffer(raw, dtype=rec, count=n)
+    mask = np.frombuffer(raw, dtype=np.uint8, count=n, offset=n * rec.itemsize)
+    # the same scene through the Python mirror of the C ABI (GPU-built local trees: the builder is deterministic)
+    sc = Scene()
+    keep = []
+    for v, f, x in inst:
+        a = BVHAccel(np.float32)
+        assert a.Build(f.shape[0], TriangleMesh(v, f))
+        keep.append(a)
+        sc.AddNode(a, x)
+    assert sc.Commit()
+    h, m = sc.TraverseBatch(rays)
+    assert np.array_equal(mask, m) and int(m.sum()) > 1000
+    hit = m == 1
+    assert fields_equal(out[hit], h[hit], ("t", "u", "v", "prim_id", "node_id"))
+    d = rays["dir"][hit] / np.linalg.norm(rays["dir"][hit], axis=1, keepdims=True)
+    assert np.allclose(out["P"][hit], rays["org"][hit] + d * out["t"][hit, None], rtol=0, atol=2e-4)
+    assert np.array_equal(out["Ns"][hit], out["Ng"][hit])
+    # normals: the flat triangle normal through inv_transpose_xform33 of its node; check direction for node 0 (identity)
+    n0 = hit & (out["node_id"] == 0)
+    assert np.allclose(np.linalg.norm(out["Ng"][n0], axis=1), 1.0, atol=1e-5)
+    assert set(np.unique(out["node_id"][hit]).tolist()) == {0, 1, 2, 3}

@@ -236,6 +236,23 @@ def test_reference_programs_compile_unchanged(src, flags, backend):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")), reason="reference tree not present")
+def test_nanosg_hip_addon_fits_the_unmodified_nanosg(tmp_path):
+    """include/nanosg_hip.h (BatchTracer) type-checks against the reference's own examples/nanosg/nanosg.h compiled over
+    this repository's nanort.h: the add-on needs no change to NanoSG."""
+    tu = tmp_path / "sg.cc"
+    tu.write_text(
+        '#include "nanort.h"\n#include "nanosg.h"\n#include "nanosg_hip.h"\n'
+        "struct Mesh { std::vector<float> vertices; std::vector<unsigned int> faces; size_t stride;\n"
+        "  void GetNormal(float Ng[3], float Ns[3], unsigned int, float, float) const { Ng[0]=Ns[0]=0; Ng[1]=Ns[1]=0; Ng[2]=Ns[2]=1; } };\n"
+        "int main() { Mesh m; nanosg::Node<float, Mesh> node(&m); nanosg::Scene<float, Mesh> scene; scene.AddNode(node); scene.Commit();\n"
+        "  nanosg::BatchTracer<nanosg::Scene<float, Mesh> > tr(scene); std::vector<nanort::Ray<float> > rays(4);\n"
+        "  std::vector<nanosg::Intersection<float> > is(4); std::vector<unsigned char> hit(4);\n"
+        "  return tr.Traverse(rays.data(), 4, is.data(), hit.data()) ? 0 : 1; }\n")
+    cxx(["-std=c++11", "-fsyntax-only", "-Wall", "-Wextra", "-DNANORT_USE_HIP_BACKEND", "-I", INC,
+         "-I", os.path.join(REFERENCE, "examples", "nanosg"), str(tu)])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")), reason="reference tree not present")
 def test_reference_regression_program_runs_against_this_header(tmp_path):
     exe = tmp_path / "regress"
     cxx(["-std=c++11", "-O0", "-I", INC, os.path.join(REFERENCE, "test/regression/possible-accuracy-problem-30/main.cc"), "-o", str(exe)])
