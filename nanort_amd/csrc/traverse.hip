@@ -861,6 +861,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
     }
 
     // ---- phase 1: inner nodes / stack pops ---------------------------------------------
+    // (lanes that leave the loop are invisible to its ballots: the wave counts those waiting at a leaf itself)
+    unsigned n_wait_leaf = (unsigned)__builtin_popcountll(__ballot(state == W_LEAF));
     while (state == W_TRAV || state == W_POP) {
       if (STATS) {
         st_it1++;
@@ -904,7 +906,13 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
         cur = any ? (next & ~kLeafBit) : cur;
         state = any ? ((next & kLeafBit) ? W_LEAF : W_TRAV) : W_POP;
       }
-      if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < a.trav_min) break;
+      // Leave when only a few lanes still walk — unless nothing else could be done anyway: no lane waits at a leaf
+      // and there are no rays left to hand out (the drain of a launch: the last long rays then stay in this
+      // tight loop instead of paying the outer loop's bookkeeping on every step).
+      n_wait_leaf += (unsigned)__builtin_popcountll(__ballot(state == W_LEAF));
+      if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < a.trav_min &&
+          (n_wait_leaf != 0u || !ck.exhausted))
+        break;
     }
 
     // ---- phase 2: leaves ------------------------------------------------------------------
