@@ -84,7 +84,8 @@ struct nrt_ctx {
   // completes, so launches issued on different streams may overlap on the GPU: the drain tail of one
   // batch is filled by the start of the next.  Launches on one stream keep reusing one slot.
   struct LaunchSlot {
-    uint32_t *d_cursor = nullptr; // ray cursors (one per partition, 4 KiB apart)
+    uint32_t *d_cursor = nullptr; // two sets of ray cursors (one per partition, 4 KiB apart): a launch uses one and zeroes the other
+    unsigned parity = 0;
     DevBuf spill, spill_tmin;
     DevBuf cyl_hits, cyl_bits;    // cylinder kind: compact records + {hit, cap} bits between the traversal and its post pass
     hipEvent_t done = nullptr;    // recorded after the slot's last launch
@@ -185,7 +186,8 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
     return NRT_ERR_DEVICE;
   }
   for (nrt_ctx::LaunchSlot &sl : c->slots) {
-    if ((e = hipMalloc((void **)&sl.d_cursor, kCursorStrideWords * 4 * kMaxParts)) != hipSuccess ||
+    if ((e = hipMalloc((void **)&sl.d_cursor, 2 * kCursorStrideWords * 4 * kMaxParts)) != hipSuccess ||
+        (e = hipMemset(sl.d_cursor, 0, 2 * kCursorStrideWords * 4 * kMaxParts)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess) {
       fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
       nrtDestroy(c);
@@ -601,7 +603,8 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.spill = (uint32_t *)slot->spill.p;
   a.spill_stride = total_threads;
   a.spill_levels = levels;
-  a.ray_cursor = slot->d_cursor;
+  a.ray_cursor = slot->d_cursor + (size_t)slot->parity * kCursorStrideWords * kMaxParts;
+  a.next_cursor = slot->d_cursor + (size_t)(slot->parity ^ 1u) * kCursorStrideWords * kMaxParts;
   a.num_parts = parts;
   a.static_per_wave = static_per_wave;
   a.dyn_begin = static_per_wave * total_waves;
@@ -612,7 +615,6 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.trav_min = c->trav_min;
   a.leaf_min = c->leaf_min;
 
-  HIPCHK(c, hipMemsetAsync(slot->d_cursor, 0, kCursorStrideWords * 4 * c->num_parts, s));
   if (count || (c->debug_flags & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s));
   if (timed) HIPCHK(c, hipEventRecord(c->ev_t0, s));
   if (use_wide)
@@ -627,6 +629,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
     c->have_traverse_time = true;
   }
   HIPCHK(c, hipEventRecord(slot->done, s));
+  slot->parity ^= 1u;
   slot->stream = s;
   slot->used = true;
   return NRT_OK;

@@ -140,7 +140,8 @@ struct TraverseArgs {
   T *spill_tmin;          // same shape, entry t_min (wide kernel)
   uint32_t spill_stride;  // == total threads of the launch
   uint32_t spill_levels;
-  uint32_t *ray_cursor;              // persistent-thread work counters, one per ray partition, 64 B apart (zeroed per launch)
+  uint32_t *ray_cursor;              // persistent-thread work counters, one per ray partition, 4 KiB apart, zero at launch
+  uint32_t *next_cursor;             // the set the NEXT launch of this slot will use: block 0 zeroes it (no memset launch)
   uint32_t num_parts;                // ray partitions (== XCDs): contiguous ranges of the ray array, one home range per XCD
   uint32_t static_per_wave;          // rays [rank*static_per_wave, +static_per_wave) belong to wave `rank` without any atomic
   uint32_t dyn_begin;                // rays [dyn_begin, num_rays) are claimed dynamically (per-partition cursors)

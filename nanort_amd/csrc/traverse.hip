@@ -455,6 +455,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<
 
   Claim ck; // wave-uniform claimed range
   claim_init<T>(a, ck);
+  if (blockIdx.x == 0 && threadIdx.x < kMaxParts) a.next_cursor[kCursorStrideWords * threadIdx.x] = 0u;
 
   unsigned long long c_nodes = 0, c_leaves = 0, c_tris = 0, c_stack = 0;
 
@@ -795,6 +796,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
   int sp = 0;
   Claim ck;
   claim_init<T>(a, ck);
+  if (blockIdx.x == 0 && threadIdx.x < kMaxParts) a.next_cursor[kCursorStrideWords * threadIdx.x] = 0u;
   // STATS (profiling instantiation only): wave-level loop occupancy
   unsigned long long st_it1 = 0, st_act1 = 0, st_idle2 = 0, st_it2 = 0, st_act2 = 0, st_refills = 0, st_refilled = 0, st_entries2 = 0;
   uint32_t st_steps = 0, st_tris = 0; // per ray; with debug flag 64 they replace u, v of the hit record
