@@ -218,3 +218,48 @@ def test_error_paths(c1_mesh):
     bad["data"] = (5, 6)
     with pytest.raises(NrtError):  # child index out of range
         a.SetTree(bad, np.arange(f.shape[0], dtype=np.uint32))
+
+
+def test_contexts_release_their_device_memory():
+    """Create / use / destroy many contexts (triangles, spheres, cylinders, a two-level scene): free HBM returns to where
+    it started (the contexts own grow-only buffers and launch slots; nrtDestroy must release all of them)."""
+    import gc
+
+    import torch
+
+    from nanort_amd import CylinderGeometry, Scene, SphereGeometry
+
+    v, f = scenes.plane(64, 32)
+    c, r = scenes.random_spheres(2000)
+    cv, cr = scenes.random_cylinders(500)
+    rays = scenes.camera_rays(160, 90)
+    prays = scenes.particle_camera_rays(64, 65)
+
+    def cycle():
+        a = BVHAccel(np.float32)
+        assert a.Build(f.shape[0], TriangleMesh(v, f))
+        a.TraverseBatch(rays)
+        s = BVHAccel(np.float32)
+        assert s.Build(2000, SphereGeometry(c, r))
+        s.TraverseBatch(prays)
+        y = BVHAccel(np.float32)
+        assert y.Build(500, CylinderGeometry(cv, cr))
+        y.TraverseBatch(prays)
+        sc = Scene()
+        sc.AddNode(a, np.eye(4, dtype=np.float32))
+        assert sc.Commit()
+        sc.TraverseBatch(rays)
+        del sc
+        for x in (a, s, y):
+            x.close()
+
+    cycle()
+    gc.collect()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(25):
+        cycle()
+    gc.collect()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, "leaked %.1f MiB over 25 cycles" % ((free0 - free1) / 2**20)
