@@ -896,6 +896,9 @@ struct HipApi<float> {
   static nrt_status Traverse(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, HitPod *h, uint8_t *m) {
     return nrtTraverseBatch_f32(c, r, n, o, h, m);
   }
+  static nrt_status TraverseDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, HitPod *h, uint8_t *m, void *s) {
+    return nrtTraverseBatchDevice_f32(c, r, n, o, h, m, s);
+  }
 };
 template <>
 struct HipApi<double> {
@@ -909,6 +912,9 @@ struct HipApi<double> {
   static nrt_status SetTree(nrt_ctx *c, const NodePod *n, uint64_t nn, const uint32_t *i, uint64_t ni) { return nrtSetTree_f64(c, n, nn, i, ni); }
   static nrt_status Traverse(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, HitPod *h, uint8_t *m) {
     return nrtTraverseBatch_f64(c, r, n, o, h, m);
+  }
+  static nrt_status TraverseDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, HitPod *h, uint8_t *m, void *s) {
+    return nrtTraverseBatchDevice_f64(c, r, n, o, h, m, s);
   }
 };
 struct CtxDeleter {
@@ -1092,6 +1098,24 @@ class BVHAccel {
                      const BVHTraceOptions &options = BVHTraceOptions()) const {
     return TraverseBatchImpl(rays, num_rays, isects, hit_out, options);
   }
+  // The same launch for callers that keep their ray waves in HBM (a wavefront renderer whose shading runs on the GPU):
+  // `d_rays`, `d_isects`, `d_hit` are device pointers, the call is asynchronous on `hip_stream` (a hipStream_t).
+  // Unlike the host variant every record is written: a miss stores {u = 0, v = 0, t = ray.max_t, prim_id = 0xFFFFFFFF}.
+  // Launches on different streams may overlap on the GPU.
+  bool TraverseBatchDevice(const Ray<T> *d_rays, size_t num_rays, TriangleIntersection<T> *d_isects, unsigned char *d_hit,
+                           void *hip_stream, const BVHTraceOptions &options = BVHTraceOptions()) const {
+    if (!ctx_ || device_tree_stale_) {
+      backend_error_ = "TraverseBatchDevice: no tree on the GPU (Build() with the built-in triangle types, or TraverseBatch() once after Load())";
+      return false;
+    }
+    nrt_trace_options o;
+    std::memcpy(&o, &options, sizeof(o));
+    if (DeviceLaunch(ctx_.get(), d_rays, num_rays, &o, d_isects, d_hit, hip_stream) != NRT_OK) {
+      backend_error_ = nrtLastError(ctx_.get());
+      return false;
+    }
+    return true;
+  }
   // Same for a tree built over the built-in sphere primitive (SphereGeometry + SpherePred).
   bool TraverseBatch(const Ray<T> *rays, size_t num_rays, SphereIntersection *isects, unsigned char *hit_out = NULL,
                      const BVHTraceOptions &options = BVHTraceOptions()) const {
@@ -1138,6 +1162,11 @@ class BVHAccel {
   nrt_ctx *HipContext() const { return device_tree_stale_ ? NULL : ctx_.get(); }
 
  private:
+  static nrt_status DeviceLaunch(nrt_ctx *c, const Ray<T> *r, size_t n, const nrt_trace_options *o, TriangleIntersection<T> *h,
+                                 unsigned char *m, void *stream) {
+    typedef detail::HipApi<T> Api;
+    return Api::TraverseDevice(c, reinterpret_cast<const typename Api::RayPod *>(r), n, o, reinterpret_cast<typename Api::HitPod *>(h), m, stream);
+  }
   template <class Hit>
   bool TraverseBatchImpl(const Ray<T> *rays, size_t num_rays, Hit *isects, unsigned char *hit_out, const BVHTraceOptions &options) const {
     typedef detail::HipApi<T> Api;

@@ -21,6 +21,9 @@
 #include <vector>
 
 #include "nanort.h"
+#ifdef NANORT_USE_HIP_BACKEND
+#include <hip/hip_runtime_api.h>  // the device-resident variant is checked with plain runtime calls
+#endif
 
 static int regress30(bool tiny) {
   typedef double real;
@@ -114,6 +117,37 @@ static int trace(const char *mesh_path, const char *rays_path, const char *out_p
   }
   printf("batch_vs_per_ray_mismatches %llu\n", (unsigned long long)bad);
   if (bad) return 5;
+  {  // device-resident variant: rays and records stay in HBM, asynchronous on a stream of the caller's
+    void *d_rays = NULL, *d_hits = NULL, *d_mask = NULL;
+    hipStream_t stream;
+    if (hipStreamCreate(&stream) != hipSuccess || hipMalloc(&d_rays, n * sizeof(rays[0])) != hipSuccess ||
+        hipMalloc(&d_hits, n * sizeof(hits[0])) != hipSuccess || hipMalloc(&d_mask, n) != hipSuccess)
+      return 6;
+    hipMemcpyAsync(d_rays, rays.data(), n * sizeof(rays[0]), hipMemcpyHostToDevice, stream);
+    if (!accel.TraverseBatchDevice(static_cast<const nanort::Ray<T> *>(d_rays), n, static_cast<nanort::TriangleIntersection<T> *>(d_hits),
+                                   static_cast<unsigned char *>(d_mask), stream)) {
+      fprintf(stderr, "TraverseBatchDevice failed: %s\n", accel.LastBackendError().c_str());
+      return 6;
+    }
+    std::vector<nanort::TriangleIntersection<T> > dh(n);
+    std::vector<unsigned char> dm(n);
+    hipMemcpyAsync(dh.data(), d_hits, n * sizeof(hits[0]), hipMemcpyDeviceToHost, stream);
+    hipMemcpyAsync(dm.data(), d_mask, n, hipMemcpyDeviceToHost, stream);
+    hipStreamSynchronize(stream);
+    uint64_t dbad = 0;
+    for (uint64_t i = 0; i < n; i++) {
+      if (dm[i] != mask[i]) dbad++;
+      if (mask[i] ? (dh[i].t != hits[i].t || dh[i].u != hits[i].u || dh[i].v != hits[i].v || dh[i].prim_id != hits[i].prim_id)
+                  : (dh[i].t != rays[i].max_t || dh[i].prim_id != 0xFFFFFFFFu))
+        dbad++;
+    }
+    printf("device_variant_mismatches %llu\n", (unsigned long long)dbad);
+    hipFree(d_rays);
+    hipFree(d_hits);
+    hipFree(d_mask);
+    hipStreamDestroy(stream);
+    if (dbad) return 6;
+  }
 #endif
   fp = fopen(out_path, "wb");
   if (!fp) return 2;
@@ -239,7 +273,7 @@ static int cylinders(const char *scene_path, int W, int H, const char *out_path)
       ray.max_t = 1.0e+30f;
       nanort::CylinderIntersector<nanort::CylinderIntersection> isecter(ends.data(), radii.data());
       nanort::CylinderIntersection isect;
-      memset(&isect, 0, sizeof(isect));
+      memset(static_cast<void *>(&isect), 0, sizeof(isect));
       isect.t = ray.max_t;
       isect.prim_id = 0xFFFFFFFFu;
       mask[(size_t)y * W + x] = accel.Traverse(ray, isecter, &isect) ? 1 : 0;
@@ -250,7 +284,7 @@ static int cylinders(const char *scene_path, int W, int H, const char *out_path)
   std::vector<nanort::CylinderIntersection> bhits(nr);
   std::vector<unsigned char> bmask(nr, 0);
   for (uint64_t i = 0; i < nr; i++) {
-    memset(&bhits[i], 0, sizeof(bhits[i]));
+    memset(static_cast<void *>(&bhits[i]), 0, sizeof(bhits[i]));
     bhits[i].t = rays[i].max_t;
     bhits[i].prim_id = 0xFFFFFFFFu;
   }
