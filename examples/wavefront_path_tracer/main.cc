@@ -12,7 +12,7 @@
 //
 //   g++ -O2 -std=c++11 -fopenmp -DNANORT_USE_HIP_BACKEND -I../../include main.cc
 //       -L../../nanort_amd/lib -lnanort_hip -Wl,-rpath,$PWD/../../nanort_amd/lib -L/opt/rocm/lib -lamdhip64
-//   ./a.out [--size W H] [--spp N] [--depth D] [--grid NX NY] [--out image.ppm] [--verify]
+//   ./a.out [--size W H] [--spp N] [--depth D] [--grid NX NY] [--out image.ppm] [--raw image.f32] [--verify]
 //
 // Scene: a displaced grid (procedural, 2*NX*NY triangles) under a point light; per-pixel RNG is a
 // counter-based hash, so the image is a pure function of the arguments (unlike the reference's
@@ -242,7 +242,7 @@ static void SavePPM(const char *path, const std::vector<float> &img, int W, int 
 int main(int argc, char **argv) {
   int W = 512, H = 288, spp = 4, depth = 3, nx = 300, ny = 150;
   bool verify = false;
-  std::string out = "wavefront.ppm";
+  std::string out = "wavefront.ppm", raw;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--size") && i + 2 < argc) {
       W = atoi(argv[++i]);
@@ -256,6 +256,8 @@ int main(int argc, char **argv) {
       ny = atoi(argv[++i]);
     } else if (!strcmp(argv[i], "--out") && i + 1 < argc) {
       out = argv[++i];
+    } else if (!strcmp(argv[i], "--raw") && i + 1 < argc) {
+      raw = argv[++i];  // the accumulated float RGB image, row-major, for comparisons
     } else if (!strcmp(argv[i], "--verify")) {
       verify = true;
     }
@@ -289,6 +291,12 @@ int main(int argc, char **argv) {
   printf("%s: %llu rays in %.3f s of tracing = %.2f Mrays/s (host-visible, PCIe included)\n", batch ? "TraverseBatch" : "per-ray Traverse",
          (unsigned long long)rays, secs, (double)rays / secs / 1e6);
   SavePPM(out.c_str(), image, W, H);
+  if (!raw.empty()) {
+    if (FILE *fp = fopen(raw.c_str(), "wb")) {
+      fwrite(image.data(), sizeof(float), image.size(), fp);
+      fclose(fp);
+    }
+  }
 
   if (verify && batch) {
     std::vector<float> ref;
