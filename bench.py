@@ -161,13 +161,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    # Test hook (tests/test_bench_multi.py): NRT_BENCH_TEST_SHARED_GPU=1 lets N ranks share GPU 0 so that the N > 1
+    # control flow can be run on a one-GPU box; RCCL cannot put two ranks on one device, so the collectives then go
+    # through gloo with CPU staging.  Never set by the driver: its numbers come from one rank per GPU over RCCL.
+    shared = world > 1 and os.environ.get("NRT_BENCH_TEST_SHARED_GPU") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if shared:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    comm_dev = "cpu" if shared else "cuda"
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -201,7 +211,7 @@ def main():
     # N > 1: wave-1 hit records are double-buffered so that the all-gather of step k (RCCL, its own stream)
     # overlaps wave 2 of step k and all of step k+1; it is waited for before its buffers are reused.
     hit_bufs = [d_hits1, torch.empty_like(d_hits1)] if world > 1 else [d_hits1]
-    gathered = [torch.empty(world * n1 * HIT_F32.itemsize, dtype=torch.uint8, device="cuda") for _ in range(2)] if world > 1 else []
+    gathered = [torch.empty(world * n1 * HIT_F32.itemsize, dtype=torch.uint8, device=comm_dev) for _ in range(2)] if world > 1 else []
     pending = [None, None]
 
     # ---- work counters -> algorithmic bytes per launch ---------------------------
@@ -223,7 +233,8 @@ def main():
         if ev is not None:
             ev[1].record()
         if world > 1:
-            pending[b] = dist.all_gather_into_tensor(gathered[b], hit_bufs[b], async_op=True)
+            src = hit_bufs[b].cpu() if shared else hit_bufs[b]  # (test hook: staged through the host for gloo)
+            pending[b] = dist.all_gather_into_tensor(gathered[b], src, async_op=True)
         if ev is not None:
             ev[2].record()
         accel.TraverseBatchDevice(d_rays2, d_hits2, d_mask2)
@@ -257,7 +268,7 @@ def main():
     rays_per_step = n1 + n2
     if world > 1:
         t = torch.tensor([dt, float(rays_per_step), float(bytes1 + bytes2), k_ms1 + k_ms2], dtype=torch.float64,
-                         device="cuda")
+                         device=comm_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
