@@ -1186,20 +1186,28 @@ class BVHAccel {
       device_tree_stale_ = false;
     }
     if (num_rays == 0) return true;
-    std::vector<Hit> tmp(num_rays);
-    std::vector<unsigned char> mask(num_rays);
+    // Raw staging for the records (PODs: no per-element construction) and, unless the caller wants the mask, for it.
+    typedef typename Api::HitPod HitPod;
+    HitPod *tmp = static_cast<HitPod *>(std::malloc(num_rays * sizeof(HitPod)));
+    unsigned char *mask = hit_out ? hit_out : static_cast<unsigned char *>(std::malloc(num_rays));
+    bool ok = tmp != NULL && mask != NULL;
+    if (!ok) backend_error_ = "TraverseBatch: out of host memory";
     nrt_trace_options o;
     std::memcpy(&o, &options, sizeof(o));
-    if (Api::Traverse(ctx_.get(), reinterpret_cast<const typename Api::RayPod *>(rays), num_rays, &o,
-                      reinterpret_cast<typename Api::HitPod *>(&tmp[0]), &mask[0]) != NRT_OK) {
+    if (ok && Api::Traverse(ctx_.get(), reinterpret_cast<const typename Api::RayPod *>(rays), num_rays, &o, tmp, mask) != NRT_OK) {
       backend_error_ = nrtLastError(ctx_.get());
-      return false;
+      ok = false;
     }
-    for (size_t i = 0; i < num_rays; i++) {
-      if (mask[i]) isects[i] = tmp[i];
-      if (hit_out) hit_out[i] = mask[i];
+    if (ok) {  // isects[i] is written only on a hit, like Traverse()
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+      for (long long i = 0; i < static_cast<long long>(num_rays); i++)
+        if (mask[i]) std::memcpy(static_cast<void *>(&isects[i]), &tmp[i], sizeof(HitPod));
     }
-    return true;
+    std::free(tmp);
+    if (!hit_out) std::free(mask);
+    return ok;
   }
 
  public:
