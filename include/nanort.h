@@ -1186,28 +1186,27 @@ class BVHAccel {
       device_tree_stale_ = false;
     }
     if (num_rays == 0) return true;
-    // Raw staging for the records (PODs: no per-element construction) and, unless the caller wants the mask, for it.
+    // Grow-only byte staging owned by the accel (PODs: no per-element construction, and no fresh pages to fault in on
+    // every wave); the caller's mask array is used directly when there is one.
     typedef typename Api::HitPod HitPod;
-    HitPod *tmp = static_cast<HitPod *>(std::malloc(num_rays * sizeof(HitPod)));
-    unsigned char *mask = hit_out ? hit_out : static_cast<unsigned char *>(std::malloc(num_rays));
-    bool ok = tmp != NULL && mask != NULL;
-    if (!ok) backend_error_ = "TraverseBatch: out of host memory";
+    if (stage_hits_.size() < num_rays * sizeof(HitPod)) stage_hits_.resize(num_rays * sizeof(HitPod));
+    if (!hit_out && stage_mask_.size() < num_rays) stage_mask_.resize(num_rays);
+    HitPod *tmp = reinterpret_cast<HitPod *>(&stage_hits_[0]);
+    unsigned char *mask = hit_out ? hit_out : &stage_mask_[0];
     nrt_trace_options o;
     std::memcpy(&o, &options, sizeof(o));
-    if (ok && Api::Traverse(ctx_.get(), reinterpret_cast<const typename Api::RayPod *>(rays), num_rays, &o, tmp, mask) != NRT_OK) {
+    if (Api::Traverse(ctx_.get(), reinterpret_cast<const typename Api::RayPod *>(rays), num_rays, &o, tmp, mask) != NRT_OK) {
       backend_error_ = nrtLastError(ctx_.get());
-      ok = false;
+      return false;
     }
-    if (ok) {  // isects[i] is written only on a hit, like Traverse()
+    // isects[i] is written only on a hit, like Traverse().  (A few threads at most: an OpenMP default of "all hardware
+    // threads" inside a CPU-quota'd container starves the HIP runtime's own threads — measured 10x slower.)
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(4) if (num_rays > (1u << 18))
 #endif
-      for (long long i = 0; i < static_cast<long long>(num_rays); i++)
-        if (mask[i]) std::memcpy(static_cast<void *>(&isects[i]), &tmp[i], sizeof(HitPod));
-    }
-    std::free(tmp);
-    if (!hit_out) std::free(mask);
-    return ok;
+    for (long long i = 0; i < static_cast<long long>(num_rays); i++)
+      if (mask[i]) std::memcpy(static_cast<void *>(&isects[i]), &tmp[i], sizeof(HitPod));
+    return true;
   }
 
  public:
@@ -1463,6 +1462,7 @@ class BVHAccel {
   const float *cyl_endpoints_ = NULL;  // cylinder primitive: what Build() was given
   const float *cyl_radii_ = NULL;
   mutable bool cyl_test_cap_ = true;
+  mutable std::vector<unsigned char> stage_hits_, stage_mask_;  // TraverseBatch staging (grow-only)
   mutable std::string backend_error_;
 #endif
 };
