@@ -62,7 +62,8 @@ struct nrt_ctx {
   // mesh (tight xyz in HBM)
   int prim_kind = kPrimTriangles; // kPrimSpheres: d_verts = centres, d_radii = radii, no faces; kPrimCylinders: d_verts = 2 end points, d_radii = 2 radii per primitive
   uint32_t cyl_test_cap = 1;
-  void *d_verts = nullptr;
+  DevBuf b_verts, b_radii, b_faces; // grow-only: a per-frame SetMesh allocates nothing in the steady state
+  void *d_verts = nullptr;          // == b_verts.p while primitives are set
   void *d_radii = nullptr;
   uint32_t *d_faces = nullptr;
   uint32_t num_faces = 0, num_verts = 0;
@@ -151,10 +152,7 @@ static void free_tree(nrt_ctx *c) {
 }
 
 static void free_mesh(nrt_ctx *c) {
-  if (c->d_verts) (void)hipFree(c->d_verts);
-  if (c->d_faces) (void)hipFree(c->d_faces);
-  if (c->d_radii) (void)hipFree(c->d_radii);
-  c->d_verts = nullptr;
+  c->d_verts = nullptr; // (the buffers stay allocated for the next primitives)
   c->d_faces = nullptr;
   c->d_radii = nullptr;
   c->num_faces = c->num_verts = 0;
@@ -234,7 +232,7 @@ void nrtDestroy(nrt_ctx *c) {
   }
   free_tree(c);
   free_mesh(c);
-  DevBuf *bufs[] = {&c->st_rays, &c->st_hits, &c->st_mask, &c->b_nodes, &c->b_indices, &c->b_tris, &c->b_wide, &c->b_wide_scratch, &c->b_build_ws};
+  DevBuf *bufs[] = {&c->b_verts, &c->b_radii, &c->b_faces, &c->st_rays, &c->st_hits, &c->st_mask, &c->b_nodes, &c->b_indices, &c->b_tris, &c->b_wide, &c->b_wide_scratch, &c->b_build_ws};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->d_counters) (void)hipFree(c->d_counters);
@@ -290,8 +288,10 @@ static nrt_status set_mesh(nrt_ctx *c, const T *vertices, size_t stride, const u
     }
     src = tight.data();
   }
-  HIPCHK(c, hipMalloc(&c->d_verts, 3 * (size_t)nv * sizeof(T)));
-  HIPCHK(c, hipMalloc((void **)&c->d_faces, ni * sizeof(uint32_t)));
+  nrt_status st;
+  if ((st = ensure(c, c->b_verts, 3 * (size_t)nv * sizeof(T))) || (st = ensure(c, c->b_faces, ni * sizeof(uint32_t)))) return st;
+  c->d_verts = c->b_verts.p;
+  c->d_faces = (uint32_t *)c->b_faces.p;
   HIPCHK(c, hipMemcpy(c->d_verts, src, 3 * (size_t)nv * sizeof(T), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_faces, faces, ni * sizeof(uint32_t), hipMemcpyHostToDevice));
   return NRT_OK;
@@ -313,8 +313,10 @@ static nrt_status set_spheres(nrt_ctx *c, const T *centers, const T *radii, uint
   c->num_faces = n;
   c->num_verts = n;
   if (n == 0) return NRT_OK;
-  HIPCHK(c, hipMalloc(&c->d_verts, 3 * (size_t)n * sizeof(T)));
-  HIPCHK(c, hipMalloc(&c->d_radii, (size_t)n * sizeof(T)));
+  nrt_status st;
+  if ((st = ensure(c, c->b_verts, 3 * (size_t)n * sizeof(T))) || (st = ensure(c, c->b_radii, (size_t)n * sizeof(T)))) return st;
+  c->d_verts = c->b_verts.p;
+  c->d_radii = c->b_radii.p;
   HIPCHK(c, hipMemcpy(c->d_verts, centers, 3 * (size_t)n * sizeof(T), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_radii, radii, (size_t)n * sizeof(T), hipMemcpyHostToDevice));
   return NRT_OK;
@@ -336,8 +338,10 @@ static nrt_status set_cylinders(nrt_ctx *c, const float *endpoints, const float 
   c->num_faces = n;
   c->num_verts = 2 * n;
   if (n == 0) return NRT_OK;
-  HIPCHK(c, hipMalloc(&c->d_verts, 6 * (size_t)n * sizeof(float)));
-  HIPCHK(c, hipMalloc(&c->d_radii, 2 * (size_t)n * sizeof(float)));
+  nrt_status st;
+  if ((st = ensure(c, c->b_verts, 6 * (size_t)n * sizeof(float))) || (st = ensure(c, c->b_radii, 2 * (size_t)n * sizeof(float)))) return st;
+  c->d_verts = c->b_verts.p;
+  c->d_radii = c->b_radii.p;
   HIPCHK(c, hipMemcpy(c->d_verts, endpoints, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_radii, radii, 2 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   return NRT_OK;
