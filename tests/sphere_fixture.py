@@ -35,3 +35,33 @@ def rays():
     k = rng.integers(0, N_SPHERES, size=500)
     extra["org"][3000:3500] = c[k] + (rng.uniform(-0.5, 0.5, size=(500, 3)) * r[k, None]).astype(np.float32)  # inside a sphere
     return np.concatenate([cam, extra])
+
+
+def hostile_rays():
+    """A thinned copy of rays() with zero, NaN and infinite components and negative max_t mixed in."""
+    r = rays()[::5].copy()
+    r["dir"][:50] = 0
+    r["dir"][50:80, 0] = np.nan
+    r["org"][80:100, 1] = np.inf
+    r["max_t"][100:120] = -1
+    return r
+
+
+def degenerate_spheres(n=400):
+    rng = np.random.default_rng(5)
+    c = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    r = rng.uniform(0.01, 0.2, n).astype(np.float32)
+    r[:20] = 0          # points
+    r[20:30] = -0.1     # negative radii: inverted boxes
+    c[30:40] = c[40:50]  # coincident centres
+    return c, r
+
+
+def degenerate_cylinders(n=400):
+    rng = np.random.default_rng(6)
+    v = rng.uniform(-1, 1, (n, 2, 3)).astype(np.float32)
+    r = rng.uniform(0.01, 0.1, (n, 2)).astype(np.float32)
+    v[:20, 1] = v[:20, 0]  # zero length
+    r[20:30] = 0           # zero radius
+    r[30:40, 0] = 0.2      # unequal radii (the intersector uses the larger)
+    return v, r

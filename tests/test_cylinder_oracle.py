@@ -39,3 +39,17 @@ def test_restatement_matches_live_reference(n):
         h, m = R.traverse(rays, test_cap=cap)
         oh, om = ob.CylinderOracle().traverse(nodes, idx, v, r, rays, test_cap=cap)
         assert np.array_equal(m, om) and h.tobytes() == oh.tobytes()
+
+
+@pytest.mark.skipif(not ob.have_cylinder_reference(), reason="oracle/_ref/libcylinder_ref.so not built")
+def test_degenerate_cylinders_and_hostile_rays_match_live_reference():
+    v, r = sphere_fixture.degenerate_cylinders()
+    rays = sphere_fixture.hostile_rays()
+    R = ob.CylinderReference()
+    nodes, idx, _ = R.build(v, r)
+    for cap in (True, False):
+        h, m = R.traverse(rays, test_cap=cap)
+        oh, om = ob.CylinderOracle().traverse(nodes, idx, v, r, rays, test_cap=cap)
+        assert np.array_equal(m, om)
+        for f in ("t", "u", "v", "prim_id", "normal"):
+            assert np.array_equal(h[f], oh[f], equal_nan=True), f

@@ -83,3 +83,18 @@ def test_device_entry_point_and_errors():
     assert d_h.cpu().numpy().view(CYL_HIT_F32).tobytes() == h.tobytes() and np.array_equal(d_m.cpu().numpy(), m)
     with pytest.raises(NrtError):  # 16-byte entry point on a cylinder context
         a._check(a._L.nrtTraverseBatchDevice_f32(a._h, d_r.data_ptr(), 10, None, d_h.data_ptr(), None, None))
+
+
+def test_degenerate_cylinders_and_hostile_rays():
+    v, r = sphere_fixture.degenerate_cylinders()
+    rays = sphere_fixture.hostile_rays()
+    for cap in (True, False):
+        a = BVHAccel(np.float32)
+        assert a.Build(v.shape[0], CylinderGeometry(v, r, test_cap=cap))
+        nodes, idx = a.GetTree()
+        assert sorted(idx.tolist()) == list(range(v.shape[0]))
+        h, m = a.TraverseBatch(rays)
+        oh, om = ob.CylinderOracle().traverse(nodes, idx, v, r, rays, test_cap=cap)
+        assert np.array_equal(m, om)
+        for f in ("t", "u", "v", "prim_id", "normal"):
+            assert np.array_equal(h[f], oh[f], equal_nan=True), (cap, f)

@@ -97,3 +97,20 @@ def test_device_entry_point_and_errors():
         a.TraverseCountDevice(d_r)
     with pytest.raises(TypeError):
         BVHAccel(np.float64).SetMesh(SphereGeometry(c, r))
+
+
+def test_degenerate_spheres_and_hostile_rays():
+    """Zero and negative radii (inverted boxes), coincident centres; zero / NaN / infinite ray components: the GPU
+    builder still emits a tree the traversal and the oracle agree on, bit for bit in t / prim_id / mask."""
+    c, r = sphere_fixture.degenerate_spheres()
+    rays = sphere_fixture.hostile_rays()
+    a = BVHAccel(np.float32)
+    assert a.Build(c.shape[0], SphereGeometry(c, r))
+    nodes, idx = a.GetTree()
+    assert sorted(idx.tolist()) == list(range(c.shape[0]))
+    h, m = a.TraverseBatch(rays)
+    oh, om = ob.SphereOracle().traverse(nodes, idx, c, r, rays)
+    assert np.array_equal(m, om)
+    assert np.array_equal(h["t"], oh["t"], equal_nan=True) and np.array_equal(h["prim_id"], oh["prim_id"])
+    fin = np.isfinite(oh["u"]) & np.isfinite(oh["v"])
+    assert np.max(np.abs(h["u"][fin] - oh["u"][fin]), initial=0.0) <= 1e-6 and np.max(np.abs(h["v"][fin] - oh["v"][fin]), initial=0.0) <= 1e-6

@@ -39,3 +39,14 @@ def test_restatement_matches_live_reference(n):
     h, m = R.traverse(rays)
     oh, om = ob.SphereOracle().traverse(nodes, idx, c, r, rays)
     assert np.array_equal(m, om) and h.tobytes() == oh.tobytes()
+
+
+@pytest.mark.skipif(not ob.have_sphere_reference(), reason="oracle/_ref/libsphere_ref.so not built")
+def test_degenerate_spheres_and_hostile_rays_match_live_reference():
+    c, r = sphere_fixture.degenerate_spheres()
+    rays = sphere_fixture.hostile_rays()
+    R = ob.SphereReference()
+    nodes, idx, _ = R.build(c, r)
+    h, m = R.traverse(rays)
+    oh, om = ob.SphereOracle().traverse(nodes, idx, c, r, rays)
+    assert np.array_equal(m, om) and h.tobytes() == oh.tobytes()
