@@ -18,12 +18,23 @@ def rows_per_rank(height, rank, world):
     return (height - rank + world - 1) // world
 
 
-def gather_hit_records(local_hits, world, dist, async_op=False):
-    """All-gather equal-sized per-rank hit buffers (torch uint8 tensors). Returns (gathered, work)."""
+def gather_buffer(local_hits, world, rank, dst=0):
+    """The root's receive buffer for gather_hit_records (None elsewhere): world equal slices, rank-major."""
     import torch
 
-    out = torch.empty(world * local_hits.numel(), dtype=local_hits.dtype, device=local_hits.device)
-    work = dist.all_gather_into_tensor(out, local_hits, async_op=async_op)
+    if rank != dst:
+        return None
+    return torch.empty(world * local_hits.numel(), dtype=local_hits.dtype, device=local_hits.device)
+
+
+def gather_hit_records(local_hits, world, rank, dist, out=None, dst=0, async_op=False):
+    """Gather equal-sized per-rank hit buffers (torch uint8 tensors) to rank `dst`: the root receives every rank's
+    records over its direct links at once, the others only send (an all-gather would move (world-1)x the data into
+    every GPU for nothing).  `out`: the root's buffer from gather_buffer() (allocated here when None).
+    Returns (out or None, work)."""
+    if out is None:
+        out = gather_buffer(local_hits, world, rank, dst)
+    work = dist.gather(local_hits, gather_list=list(out.chunk(world)) if rank == dst else None, dst=dst, async_op=async_op)
     return out, work
 
 

@@ -25,5 +25,5 @@ def test_two_ranks_share_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
     assert out["config"]["rays_per_step"] > 2 * 4_000_000 and out["value"] > 100.0
-    assert "all-gather" in out["config"]["parallelism"]
+    assert "RCCL gather" in out["config"]["parallelism"]
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out

@@ -37,8 +37,9 @@ def _worker(rank, world, port, out_path):
     rays = scenes.camera_rays_rows(W, H, rank, world, nd.rows_per_rank(H, rank, world))
     hits, _ = orc.traverse(nodes, idx, v, f, rays)
     local = torch.from_numpy(hits.view(np.uint8).copy())
-    gathered, work = nd.gather_hit_records(local, world, dist, async_op=True)
+    gathered, work = nd.gather_hit_records(local, world, rank, dist, async_op=True)
     work.wait()
+    assert (gathered is None) == (rank != 0)
     if rank == 0:
         img = nd.assemble_image(gathered.numpy(), W, H, world, HIT_F32)
         np.save(out_path, img)
