@@ -17,9 +17,17 @@
  *   - "host" entry points take host pointers in/out and own all device
  *     memory; "Device" entry points take device pointers (HBM-resident
  *     buffers, e.g. torch tensors) and a hipStream_t passed as void*;
- *   - one nrt_ctx per BVHAccel object; a context is bound to one GPU and is
- *     not re-entrant (like BVHAccel::Build, nanort.h:1892); distinct contexts
- *     may be used from distinct host threads.
+ *   - one nrt_ctx per BVHAccel object; a context is bound to one GPU.  The
+ *     primitive / build / tree calls and the host-buffer traversal calls are
+ *     not re-entrant on one context (like BVHAccel::Build, nanort.h:1892);
+ *     the Device traversal calls are: they may be issued from several host
+ *     threads and on several streams at once, and launches on different
+ *     streams overlap on the GPU (each launch owns its scratch until it
+ *     completes).  Distinct contexts may be used from distinct host threads.
+ *
+ * Beyond the triangle path: nrtSetSpheres_f32 /
+ * nrtSetCylinders_f32 (the reference's two custom-primitive examples as
+ * device primitives) and nrtScene* (NanoSG's instanced two-level traversal).
  */
 #ifndef NANORT_HIP_H_
 #define NANORT_HIP_H_
