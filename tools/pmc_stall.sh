@@ -14,6 +14,7 @@ for SET in \
   "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_GATE_EN1_sum" \
   "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum SQ_BUSY_CU_CYCLES" ; do
   i=$((i+1))
+  if [ -n "${NRT_PMC_PASSES:-}" ] && [[ " $NRT_PMC_PASSES " != *" $i "* ]]; then continue; fi
   timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -o p -- python tools/pmc_traffic.py > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python tools/pmc_stall_summary.py $OUT | tee $OUT/summary.txt
