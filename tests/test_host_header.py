@@ -222,6 +222,10 @@ REF_PROGRAMS = [
     ("examples/particle_primitive/main.cc", ["-Iexamples/particle_primitive", "-Iexamples/common"]),
     ("examples/cylinder_primitive/main.cc", ["-Iexamples/cylinder_primitive", "-Iexamples/common"]),
     ("examples/bidir_path_tracer/main.cc", ["-fopenmp", "-Iexamples/bidir_path_tracer", "-Iexamples/common"]),
+    ("examples/vrcamera/main.cc", ["-Iexamples/vrcamera", "-Iexamples/common"]),
+    ("examples/par_msquare/main.cc", ["-Iexamples/par_msquare", "-Iexamples/common"]),
+    ("examples/curves_primitive/main.cc", ["-Iexamples/curves_primitive", "-Iexamples/common"]),  # a third custom primitive
+    ("examples/uv_raster/main.cc", ["-Iexamples/uv_raster", "-Iexamples/common"]),
 ]
 
 
