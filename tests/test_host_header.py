@@ -256,6 +256,30 @@ def test_nanosg_hip_addon_fits_the_unmodified_nanosg(tmp_path):
          "-I", os.path.join(REFERENCE, "examples", "nanosg"), str(tu)])
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "examples", "objrender", "cornellbox_suzanne.obj")), reason="reference tree not present")
+def test_reference_objrender_renders_the_same_image(tmp_path):
+    """The reference's examples/objrender, compiled unchanged once against the reference's nanort.h and once against this
+    repository's, run on its own scene: render.exr and render.png are byte-identical (hit records do not depend on
+    which valid tree is traversed; the host builder of this header is a different one)."""
+    import shutil
+
+    src = os.path.join(REFERENCE, "examples", "objrender")
+    outs = {}
+    for tag, inc in (("ref", REFERENCE), ("mine", INC)):
+        d = tmp_path / tag
+        d.mkdir()
+        exe = d / "objrender"
+        cxx(["-O2", "-fopenmp", "-w", "-I", inc, "-I", src, "-I", os.path.join(REFERENCE, "examples", "common"),
+             os.path.join(src, "main.cc"), os.path.join(src, "tiny_obj_loader.cc"), "-o", str(exe)])
+        for f in ("cornellbox_suzanne.obj", "cornellbox_suzanne.mtl"):
+            shutil.copy(os.path.join(src, f), str(d / f))
+        r = subprocess.run([str(exe)], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0 and "Saved image" in r.stdout, r.stdout[-2000:]
+        outs[tag] = {f: open(str(d / f), "rb").read() for f in ("render.exr", "render.png")}
+    assert outs["ref"]["render.exr"] == outs["mine"]["render.exr"] and len(outs["ref"]["render.exr"]) > 100000
+    assert outs["ref"]["render.png"] == outs["mine"]["render.png"]
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")), reason="reference tree not present")
 def test_reference_regression_program_runs_against_this_header(tmp_path):
     exe = tmp_path / "regress"
