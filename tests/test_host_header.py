@@ -257,27 +257,31 @@ def test_nanosg_hip_addon_fits_the_unmodified_nanosg(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "examples", "objrender", "cornellbox_suzanne.obj")), reason="reference tree not present")
-def test_reference_objrender_renders_the_same_image(tmp_path):
-    """The reference's examples/objrender, compiled unchanged once against the reference's nanort.h and once against this
-    repository's, run on its own scene: render.exr and render.png are byte-identical (hit records do not depend on
-    which valid tree is traversed; the host builder of this header is a different one)."""
+@pytest.mark.parametrize("example,outputs", [("objrender", ("render.exr", "render.png")), ("double_precision", ("render.exr", "render.data"))])
+def test_reference_renderers_write_the_same_images(tmp_path, example, outputs):
+    """The reference's examples/objrender (fp32) and examples/double_precision (fp64), compiled unchanged once against the
+    reference's nanort.h and once against this repository's, run on their own scene: the image files are byte-identical
+    (hit records do not depend on which valid tree is traversed; the host builder of this header is a different one)."""
     import shutil
 
-    src = os.path.join(REFERENCE, "examples", "objrender")
-    outs = {}
+    src = os.path.join(REFERENCE, "examples", example)
+    results = {}
     for tag, inc in (("ref", REFERENCE), ("mine", INC)):
-        d = tmp_path / tag
-        d.mkdir()
-        exe = d / "objrender"
+        run = tmp_path / tag / "run"          # double_precision loads ../common/cornellbox_suzanne.obj
+        common = tmp_path / tag / "common"
+        run.mkdir(parents=True)
+        common.mkdir()
+        exe = tmp_path / tag / example
         cxx(["-O2", "-fopenmp", "-w", "-I", inc, "-I", src, "-I", os.path.join(REFERENCE, "examples", "common"),
              os.path.join(src, "main.cc"), os.path.join(src, "tiny_obj_loader.cc"), "-o", str(exe)])
         for f in ("cornellbox_suzanne.obj", "cornellbox_suzanne.mtl"):
-            shutil.copy(os.path.join(src, f), str(d / f))
-        r = subprocess.run([str(exe)], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            shutil.copy(os.path.join(REFERENCE, "examples", "common", f), str(common / f))
+            shutil.copy(os.path.join(REFERENCE, "examples", "common", f), str(run / f))
+        r = subprocess.run([str(exe)], cwd=str(run), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0 and "Saved image" in r.stdout, r.stdout[-2000:]
-        outs[tag] = {f: open(str(d / f), "rb").read() for f in ("render.exr", "render.png")}
-    assert outs["ref"]["render.exr"] == outs["mine"]["render.exr"] and len(outs["ref"]["render.exr"]) > 100000
-    assert outs["ref"]["render.png"] == outs["mine"]["render.png"]
+        results[tag] = {f: open(str(run / f), "rb").read() for f in outputs}
+    for f in outputs:
+        assert results["ref"][f] == results["mine"][f] and len(results["ref"][f]) > 100000, f
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")), reason="reference tree not present")
