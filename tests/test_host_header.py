@@ -285,6 +285,24 @@ def test_reference_renderers_write_the_same_images(tmp_path, example, outputs):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")), reason="reference tree not present")
+@pytest.mark.parametrize("example", ["particle_primitive", "cylinder_primitive"])
+def test_reference_custom_primitive_demos_write_the_same_image(tmp_path, example):
+    """The reference's two custom-primitive demos (their own Pred / Geometry / Intersector classes through the generic
+    Build / Traverse templates), unchanged, against both headers: byte-identical render.png for 2000 primitives."""
+    src = os.path.join(REFERENCE, "examples", example)
+    png = {}
+    for tag, inc in (("ref", REFERENCE), ("mine", INC)):
+        d = tmp_path / tag
+        d.mkdir()
+        exe = d / example
+        cxx(["-O2", "-w", "-I", inc, "-I", src, "-I", os.path.join(REFERENCE, "examples", "common"), os.path.join(src, "main.cc"), "-o", str(exe)])
+        r = subprocess.run([str(exe), "2000"], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+        png[tag] = open(str(d / "render.png"), "rb").read()
+    assert png["ref"] == png["mine"] and len(png["ref"]) > 1000
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")), reason="reference tree not present")
 def test_reference_regression_program_runs_against_this_header(tmp_path):
     exe = tmp_path / "regress"
     cxx(["-std=c++11", "-O0", "-I", INC, os.path.join(REFERENCE, "test/regression/possible-accuracy-problem-30/main.cc"), "-o", str(exe)])
