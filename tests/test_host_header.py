@@ -302,6 +302,34 @@ def test_reference_custom_primitive_demos_write_the_same_image(tmp_path, example
     assert png["ref"] == png["mine"] and len(png["ref"]) > 1000
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")) or os.environ.get("NRT_SLOW_TESTS") != "1",
+                    reason="slow (two single-threaded 512x512 x 100 spp renders, ~4 min): set NRT_SLOW_TESTS=1; needs the reference tree")
+def test_reference_path_tracer_writes_the_same_images(tmp_path):
+    """BASELINE.json's drop-in example: the reference's examples/path_tracer with the flags of its Makefile.omp, unchanged,
+    against both headers, on cornellbox_suzanne.obj with one OpenMP thread (its rand()-driven sampler is then
+    deterministic): render.data, render.exr and render.png are byte-identical after 100 spp x 10 bounces."""
+    import shutil
+
+    src = os.path.join(REFERENCE, "examples", "path_tracer")
+    out = {}
+    for tag, inc in (("ref", REFERENCE), ("mine", INC)):
+        run = tmp_path / tag / "run"
+        common = tmp_path / tag / "common"
+        run.mkdir(parents=True)
+        common.mkdir()
+        exe = tmp_path / tag / "path_tracer"
+        cxx(["-O3", "-fopenmp", "-w", "-I", inc, "-I", src, "-I", os.path.join(REFERENCE, "examples", "common"),
+             os.path.join(src, "main.cc"), os.path.join(src, "tiny_obj_loader.cc"), "-o", str(exe)])
+        for f in ("cornellbox_suzanne.obj", "cornellbox_suzanne.mtl"):
+            shutil.copy(os.path.join(REFERENCE, "examples", "common", f), str(common / f))
+        r = subprocess.run([str(exe), "../common/cornellbox_suzanne.obj"], cwd=str(run), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=1800)
+        assert r.returncode == 0
+        out[tag] = {f: open(str(run / f), "rb").read() for f in ("render.data", "render.exr", "render.png")}
+    for f in out["ref"]:
+        assert out["ref"][f] == out["mine"][f], f
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")), reason="reference tree not present")
 def test_reference_regression_program_runs_against_this_header(tmp_path):
     exe = tmp_path / "regress"
