@@ -302,8 +302,7 @@ def test_reference_custom_primitive_demos_write_the_same_image(tmp_path, example
     assert png["ref"] == png["mine"] and len(png["ref"]) > 1000
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")) or os.environ.get("NRT_SLOW_TESTS") != "1",
-                    reason="slow (two single-threaded 512x512 x 100 spp renders, ~4 min): set NRT_SLOW_TESTS=1; needs the reference tree")
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")), reason="reference tree not present")
 def test_reference_path_tracer_writes_the_same_images(tmp_path):
     """BASELINE.json's drop-in example: the reference's examples/path_tracer with the flags of its Makefile.omp, unchanged,
     against both headers, on cornellbox_suzanne.obj with one OpenMP thread (its rand()-driven sampler is then
