@@ -79,6 +79,7 @@ struct nrt_ctx {
   uint32_t tree_depth = 0;
   uint32_t max_leaf_count = 0, min_leaf_count = 0; // over the leaves of the current tree
   uint32_t packed_leaves = 0;
+  uint32_t root_is_branch = 0; // node 0 has flag == 0
   nrt_build_stats stats = {0, 0, 0, 0.f};
 
   // traversal scratch.  Every launch owns one LaunchSlot (work cursors + overflow stacks) until it
@@ -430,6 +431,7 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
   c->tree_depth = depth;
   c->max_leaf_count = max_leaf;
   c->min_leaf_count = min_leaf;
+  c->root_is_branch = nodes[0].flag == 0 ? 1u : 0u;
   c->num_branch_records = 0;
   for (uint64_t i = 0; i < num_nodes; i++)
     if (nodes[i].flag == 0) c->num_branch_records++;
@@ -491,6 +493,7 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   c->tree_depth = res.max_depth;
   c->max_leaf_count = res.max_leaf_count;
   c->num_branch_records = res.num_branches;
+  c->root_is_branch = res.num_nodes > 1 ? 1u : 0u;
   c->min_leaf_count = 1; // the GPU builder never emits an empty leaf
   nrt_status fst = finish_tree<T>(c); // leaf-ordered triangles + WideNode array: part of the build
   if (fst) return fst;
@@ -587,6 +590,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.cyl_test_cap = c->cyl_test_cap;
   a.wide = (const WideNode<T> *)c->d_wide;
   a.packed_leaves = c->packed_leaves;
+  a.root_is_branch = c->root_is_branch;
   a.debug_flags = c->debug_flags;
   a.spill_tmin = (T *)slot->spill_tmin.p;
   a.rays = d_rays;

@@ -129,6 +129,7 @@ struct TraverseArgs {
   uint32_t cyl_test_cap;         // primitive kind 2: the intersector's test_cap flag
   const WideNode<T> *wide; // may be null (binary kernel only)
   uint32_t packed_leaves;  // leaf references of `wide` are PACKED (see WideNode)
+  uint32_t root_is_branch; // node 0 is a branch (every tree of more than one node)
   uint32_t debug_flags;    // profiling only (env NRT_DEBUG): 1 = skip triangle tests, 2 = skip traversal
   const typename Wire<T>::Ray *rays;
   typename Wire<T>::Hit *hits; // may be null (counting pass)

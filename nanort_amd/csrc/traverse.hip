@@ -839,13 +839,18 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           lane_init<T>(L, r);
           sp = 0;
           if (STATS) st_steps = st_tris = 0;
-          // the reference pops and tests the root first (nanort.h:2526-2533)
-          const Node root = a.nodes[0];
-          const bool root_hit = slab_test<T>(L, root.bmin, root.bmax);
-          // root branch -> WideNode 0; root leaf -> its leaf reference
-          cur = (root.flag == 0) ? 0u
-                                 : (a.packed_leaves ? (((root.data[0] - 1u) << kPackedFirstBits) | root.data[1]) : 0u);
-          state = root_hit ? (root.flag == 0 ? W_TRAV : W_LEAF) : W_POP; // W_POP with sp == 0 finishes the ray
+          // The reference pops and tests the root first (nanort.h:2526-2533).  For a branch root that test is implied by
+          // the first step: a ray that misses the root's box misses both children's boxes (each lies inside it and the
+          // slab arithmetic is monotone), so the step on record 0 ends in W_POP with an empty stack — the same miss.
+          if (a.root_is_branch) {
+            cur = 0u;
+            state = W_TRAV;
+          } else { // single-leaf tree: test the root box, then its primitives
+            const Node root = a.nodes[0];
+            const bool root_hit = slab_test<T>(L, root.bmin, root.bmax);
+            cur = a.packed_leaves ? (((root.data[0] - 1u) << kPackedFirstBits) | root.data[1]) : 0u;
+            state = root_hit ? W_LEAF : W_POP; // W_POP with sp == 0 finishes the ray
+          }
           if (a.debug_flags & 2u) state = W_POP;
         }
         if (STATS) {
