@@ -608,6 +608,9 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.range1 = opt->prim_ids_range[1];
   a.skip_prim = opt->skip_prim_id;
   a.cull_back_face = opt->cull_back_face ? 1u : 0u;
+  // prim ids are < num_faces: nothing can be rejected by these options -> the kernel variant without the id tests
+  a.plain_options = (opt->prim_ids_range[0] == 0u && opt->prim_ids_range[1] >= c->num_faces && opt->skip_prim_id >= c->num_faces &&
+                     !opt->cull_back_face) ? 1u : 0u;
   a.spill = (uint32_t *)slot->spill.p;
   a.spill_stride = total_threads;
   a.spill_levels = levels;

@@ -775,7 +775,9 @@ struct StackEntry<double> {
   }
 };
 
-template <typename T, int STACK, bool STATS, int KIND>
+// PLAIN: the launch uses trace options that cannot reject a primitive (full prim_ids_range, no skip_prim_id, no
+// back-face culling — the reference's defaults): the three id comparisons per triangle test are compiled out.
+template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false>
 __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const TraverseArgs<T> a) {
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
@@ -961,7 +963,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           cylinder_test<T>(L, cy, i < cnt, a.range0, a.range1, a.cyl_test_cap != 0u);
         } else {
           const LeafTri<T> tri = a.tris[first + (i < cnt ? i : 0u)];
-          tri_test<T>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull);
+          if (PLAIN)
+            tri_test<T>(L, tri, i < cnt, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, false); // prim ids never reach 0xFFFFFFFF
+          else
+            tri_test<T>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull);
         }
       }
       state = (state == W_LEAF) ? W_POP : state;
@@ -1185,6 +1190,8 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
     case 10:
       if (args.debug_flags & 32u)
         hipLaunchKernelGGL((k_traverse_wide<T, 10, true, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+      else if (args.plain_options)
+        hipLaunchKernelGGL((k_traverse_wide<T, 10, false, kPrimTriangles, true>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
       else
         hipLaunchKernelGGL((k_traverse_wide<T, 10, false, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
       break;
