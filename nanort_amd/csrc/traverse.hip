@@ -150,11 +150,12 @@ __device__ __forceinline__ bool slab_test(const Lane<T> &L, const T bmin[3], con
 // Written as one running predicate with select-style updates (the reference's early returns
 // in the same order): all loads of the record are issued together, and the lane state stays
 // in the same registers on every path.
-template <typename T>
+template <typename T, bool PLAIN = false>
 __device__ __forceinline__ void tri_test(Lane<T> &L, const LeafTri<T> &tri, bool active, uint32_t range0,
                                          uint32_t range1, uint32_t skip, bool cull) {
   const uint32_t prim = tri.prim_id;
-  bool ok = active & (prim >= range0) & (prim < range1) & (prim != skip); // nanort.h:2387-2395
+  bool ok = PLAIN ? active : (active & (prim >= range0) & (prim < range1) & (prim != skip)); // nanort.h:2387-2395
+  if (PLAIN) cull = false;
   const T A0 = tri.p0[0] - L.org[0], A1 = tri.p0[1] - L.org[1], A2 = tri.p0[2] - L.org[2];
   const T B0 = tri.p1[0] - L.org[0], B1 = tri.p1[1] - L.org[1], B2 = tri.p1[2] - L.org[2];
   const T C0 = tri.p2[0] - L.org[0], C1 = tri.p2[1] - L.org[1], C2 = tri.p2[2] - L.org[2];
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
         } else {
           const LeafTri<T> tri = a.tris[first + (i < cnt ? i : 0u)];
           if (PLAIN)
-            tri_test<T>(L, tri, i < cnt, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, false); // prim ids never reach 0xFFFFFFFF
+            tri_test<T, true>(L, tri, i < cnt, 0u, 0u, 0u, false);
           else
             tri_test<T>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull);
         }
