@@ -30,6 +30,10 @@ Extra objects on the JSON line:
   cpu_baseline  the UNMODIFIED reference (oracle/_ref, OpenMP, all host cores)
                 on a bounded sample of the same ray buffers; falls back to the
                 single-thread C port (oracle/liboracle.so) when _ref is absent.
+                Carries the parity check of the same run: the GPU's
+                records of the timed waves against the reference on its own tree
+                (1e-5 tolerance, prim ids equal except at exact-t ties) and
+                against the reference over the GPU-built tree (bit-identical).
 """
 import argparse
 import json
@@ -53,8 +57,35 @@ def algorithmic_bytes(counters, real_bytes=4):
     return 104 * counters["num_rays"] + 64 * counters["nodes_visited"] + 88 * counters["tris_tested"]
 
 
-def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, budget_s=12.0):
-    """Reference (or port) timed on the host cores over a bounded sample of the same buffers."""
+def parity(ref_hits, ref_mask, gpu_hits, gpu_mask):
+    """SURVEY 8(d) parity check of one ray set: hit flags equal; |dt|, |du|, |dv| <= 1e-5 * max(1, |ref|); prim ids equal,
+    a different prim id being tolerated only at a true tie (both primitives at the same t: the reference keeps whichever
+    it tested last, so across different trees either may be named; u, v then belong to the named primitive)."""
+    both = (ref_mask == 1) & (gpu_mask == 1)
+
+    def rel(k, sel):
+        r = ref_hits[k][sel].astype(np.float64)
+        g = gpu_hits[k][sel].astype(np.float64)
+        return float(np.max(np.abs(g - r) / np.maximum(1.0, np.abs(r)))) if r.size else 0.0
+
+    same_prim = both & (ref_hits["prim_id"] == gpu_hits["prim_id"])
+    other_prim = both & ~same_prim
+    return {
+        "rays": int(ref_mask.shape[0]),
+        "hit_flag_mismatches": int((ref_mask != gpu_mask).sum()),
+        "max_rel_err_t": rel("t", both),
+        "max_rel_err_u_v_same_prim": max(rel("u", same_prim), rel("v", same_prim)),
+        "prim_id_mismatches": int(other_prim.sum()),
+        "prim_id_mismatches_at_exact_t_ties": int((other_prim & (ref_hits["t"] == gpu_hits["t"])).sum()),
+        "within_tolerance_1e-5": bool(rel("t", both) <= 1e-5 and max(rel("u", same_prim), rel("v", same_prim)) <= 1e-5
+                                      and int((ref_mask != gpu_mask).sum()) == 0
+                                      and int(other_prim.sum()) == int((other_prim & (ref_hits["t"] == gpu_hits["t"])).sum())),
+    }
+
+
+def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, gpu_results=None, budget_s=12.0):
+    """Reference (or port) timed on the host cores over a bounded sample of the same buffers; with `gpu_results` =
+    (hits1, mask1, hits2, mask2) of the GPU also the parity check of the same run."""
     from oracle import bindings as ob
 
     total = rays1.shape[0] + rays2.shape[0]
@@ -85,8 +116,8 @@ def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, budget_s=12
         s2 = rays2[:: max(1, step)]
         best = 1e30
         for _ in range(2):
-            _, _, t1 = R.traverse(s1, threads=best_t, chunk=WIDTH)
-            _, _, t2 = R.traverse(s2, threads=best_t, chunk=WIDTH)
+            rh1, rm1, t1 = R.traverse(s1, threads=best_t, chunk=WIDTH)
+            rh2, rm2, t2 = R.traverse(s2, threads=best_t, chunk=WIDTH)
             best = min(best, t1 + t2)
         value = (s1.shape[0] + s2.shape[0]) / best / 1e6
         out = {
@@ -99,10 +130,22 @@ def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, budget_s=12
             "build_ms": round(build_ms, 1),
         }
         # same traversal code over the GPU-built node array: separates "better tree" from "faster traversal"
+        if gpu_results is not None:  # reference on ITS tree vs GPU on the GPU-built tree: equal up to exact-t ties in prim_id / u / v
+            gh1, gm1, gh2, gm2 = gpu_results
+            W = WIDTH
+            out["parity_own_trees"] = {
+                "primary": parity(rh1, rm1, gh1.reshape(-1, W)[::step].reshape(-1), gm1.reshape(-1, W)[::step].reshape(-1)),
+                "bounce": parity(rh2, rm2, gh2[:: max(1, step)], gm2[:: max(1, step)])}
         if R.load_tree(gpu_nodes, gpu_indices):
-            _, _, t1 = R.traverse(rays1, threads=best_t, chunk=WIDTH)
-            _, _, t2 = R.traverse(rays2, threads=best_t, chunk=WIDTH)
+            th1, tm1, t1 = R.traverse(rays1, threads=best_t, chunk=WIDTH)
+            th2, tm2, t2 = R.traverse(rays2, threads=best_t, chunk=WIDTH)
             out["value_on_gpu_built_tree"] = round(total / (t1 + t2) / 1e6, 4)
+            if gpu_results is not None:  # same node array: every field must be bit-identical
+                gh1, gm1, gh2, gm2 = gpu_results
+                same = all(np.array_equal(a, b) for a, b in ((tm1, gm1), (tm2, gm2)))
+                for k in ("t", "u", "v", "prim_id"):
+                    same = same and th1[k].tobytes() == gh1[k].tobytes() and th2[k].tobytes() == gh2[k].tobytes()
+                out["parity_same_tree_bit_identical"] = bool(same)
         return out
     O = ob.Oracle()
     t0 = time.time()
@@ -354,7 +397,10 @@ def main():
                                           "shadow_ms": round(ms_s, 4), "shadow_rays": int(rays_s.shape[0])}
         if world == 1 and not args.no_cpu_baseline:
             nodes, indices = accel.GetTree()
-            out["cpu_baseline"] = cpu_baseline(verts, faces, rays1, rays2, nodes, indices)
+            torch.cuda.synchronize()
+            gpu_results = (d_hits1.cpu().numpy().view(HIT_F32), d_mask1.cpu().numpy(), d_hits2.cpu().numpy().view(HIT_F32)[:n2],
+                           d_mask2.cpu().numpy()[:n2])
+            out["cpu_baseline"] = cpu_baseline(verts, faces, rays1, rays2, nodes, indices, gpu_results)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
