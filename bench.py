@@ -129,6 +129,16 @@ def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, gpu_results
                           s1.shape[0], step, s2.shape[0], best_t, cands, hw, quota),
             "build_ms": round(build_ms, 1),
         }
+        if ob.reference_v3_available():  # the same code with -march=x86-64-v3: the stronger timing baseline of SURVEY 8(d)
+            try:
+                R3 = ob.ReferenceV3(verts, faces)
+                R3.build(parallel=True, threads=cands[0])
+                _, _, t1 = R3.traverse(s1, threads=best_t, chunk=WIDTH)
+                _, _, t2 = R3.traverse(s2, threads=best_t, chunk=WIDTH)
+                out["value_march_x86_64_v3"] = round((s1.shape[0] + s2.shape[0]) / (t1 + t2) / 1e6, 4)
+            except Exception as e:  # pragma: no cover
+                out["value_march_x86_64_v3"] = None
+                out["v3_error"] = repr(e)
         # same traversal code over the GPU-built node array: separates "better tree" from "faster traversal"
         if gpu_results is not None:  # reference on ITS tree vs GPU on the GPU-built tree: equal up to exact-t ties in prim_id / u / v
             gh1, gm1, gh2, gm2 = gpu_results

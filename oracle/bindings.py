@@ -134,13 +134,14 @@ class Reference:
     """One reference BVHAccel<T> over a caller-owned mesh (kept alive here)."""
 
     _lib = None
+    PATH = REF_PATH
 
     @classmethod
     def lib(cls):
         if cls._lib is None:
-            if not reference_available():
-                raise RuntimeError("%s missing: run `make -C oracle ref` where /root/reference exists" % REF_PATH)
-            L = ctypes.CDLL(REF_PATH)
+            if not os.path.exists(cls.PATH):
+                raise RuntimeError("%s missing: run `make -C oracle ref` where /root/reference exists" % cls.PATH)
+            L = ctypes.CDLL(cls.PATH)
             vp, u32, u64, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t
             L.ref_sizeof.argtypes = [ctypes.c_int]
             L.ref_sizeof.restype = ctypes.c_int
@@ -362,6 +363,21 @@ class SceneOracle:
         mask = np.zeros((rays.shape[0],), dtype=np.uint8)
         self.L.sgo_traverse(ctypes.cast(self.arr, ctypes.c_void_p), len(self.nodes), _p(rays), rays.shape[0], _p(hits), _p(mask))
         return hits, mask
+
+
+REF_V3_PATH = os.path.join(_HERE, "_ref", "libnanort_ref_v3.so")
+
+
+class ReferenceV3(Reference):
+    """The same shim compiled with -march=x86-64-v3 (AVX2 + FMA, contraction allowed): a stronger CPU TIMING baseline
+    (SURVEY 8d asks for one); its results are not used for parity."""
+
+    _lib = None
+    PATH = REF_V3_PATH
+
+
+def reference_v3_available():
+    return os.path.exists(REF_V3_PATH)
 
 
 # ---- sphere ("particle") custom primitive ----------------------------------------------------------------
