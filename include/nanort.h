@@ -899,6 +899,7 @@ struct HipApi<float> {
   static nrt_status TraverseDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, HitPod *h, uint8_t *m, void *s) {
     return nrtTraverseBatchDevice_f32(c, r, n, o, h, m, s);
   }
+  static nrt_status Occluded(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m) { return nrtOccludedBatch_f32(c, r, n, o, m); }
 };
 template <>
 struct HipApi<double> {
@@ -916,6 +917,7 @@ struct HipApi<double> {
   static nrt_status TraverseDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, HitPod *h, uint8_t *m, void *s) {
     return nrtTraverseBatchDevice_f64(c, r, n, o, h, m, s);
   }
+  static nrt_status Occluded(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m) { return nrtOccludedBatch_f64(c, r, n, o, m); }
 };
 struct CtxDeleter {
   void operator()(nrt_ctx *c) const { nrtDestroy(c); }
@@ -1111,6 +1113,22 @@ class BVHAccel {
     nrt_trace_options o;
     std::memcpy(&o, &options, sizeof(o));
     if (DeviceLaunch(ctx_.get(), d_rays, num_rays, &o, d_isects, d_hit, hip_stream) != NRT_OK) {
+      backend_error_ = nrtLastError(ctx_.get());
+      return false;
+    }
+    return true;
+  }
+  // Opt-in extension without a reference counterpart: occlusion queries.  occluded_out[i] is exactly what
+  // TraverseBatch() would report in hit_out[i], but a ray stops at the first primitive it accepts (shadow rays).
+  bool OccludedBatch(const Ray<T> *rays, size_t num_rays, unsigned char *occluded_out, const BVHTraceOptions &options = BVHTraceOptions()) const {
+    typedef detail::HipApi<T> Api;
+    if (!ctx_ || device_tree_stale_) {
+      backend_error_ = "OccludedBatch: no tree on the GPU (Build() with the built-in triangle types, or TraverseBatch() once after Load())";
+      return false;
+    }
+    nrt_trace_options o;
+    std::memcpy(&o, &options, sizeof(o));
+    if (Api::Occluded(ctx_.get(), reinterpret_cast<const typename Api::RayPod *>(rays), num_rays, &o, occluded_out) != NRT_OK) {
       backend_error_ = nrtLastError(ctx_.get());
       return false;
     }

@@ -189,6 +189,20 @@ NRT_API nrt_status nrtSetMesh_f32(nrt_ctx *ctx, const float *vertices, size_t ve
 NRT_API nrt_status nrtSetMesh_f64(nrt_ctx *ctx, const double *vertices, size_t vertex_stride_bytes,
                                   const uint32_t *faces, uint32_t num_faces);
 
+/* ---- occlusion queries: an OPT-IN EXTENSION with no reference counterpart ----------------------------------
+ * The reference answers "is anything in the way?" with a closest-hit Traverse (CheckForOccluder,
+ * examples/path_tracer/main.cc:675-701).  These entry points return only the hit flag — mask_out[i] is exactly what
+ * nrtTraverseBatch* would put in hit_mask_out[i], for every ray and option — but a ray stops at the first primitive it
+ * accepts instead of looking for the nearest one.  Triangle contexts only. */
+NRT_API nrt_status nrtOccludedBatch_f32(nrt_ctx *ctx, const nrt_ray_f32 *rays, uint64_t num_rays,
+                                        const nrt_trace_options *options, uint8_t *mask_out);
+NRT_API nrt_status nrtOccludedBatch_f64(nrt_ctx *ctx, const nrt_ray_f64 *rays, uint64_t num_rays,
+                                        const nrt_trace_options *options, uint8_t *mask_out);
+NRT_API nrt_status nrtOccludedBatchDevice_f32(nrt_ctx *ctx, const nrt_ray_f32 *d_rays, uint64_t num_rays,
+                                              const nrt_trace_options *options, uint8_t *d_mask_out, void *hip_stream);
+NRT_API nrt_status nrtOccludedBatchDevice_f64(nrt_ctx *ctx, const nrt_ray_f64 *d_rays, uint64_t num_rays,
+                                              const nrt_trace_options *options, uint8_t *d_mask_out, void *hip_stream);
+
 /* ---- sphere primitives: replaces the SpherePred / SphereGeometry / SphereIntersector constructors of the
  * reference's custom-primitive example (examples/particle_primitive/main.cc:82-147, 161-166) -------------
  * `centers` holds xyz per sphere (tight), `radii` one radius per sphere.  After this call nrtBuild_f32 builds

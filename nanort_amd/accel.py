@@ -253,6 +253,27 @@ class BVHAccel:
         )
         return n
 
+    def OccludedBatch(self, rays, options=None):
+        """Opt-in extension: only the hit flags of TraverseBatch(), each ray stopping at the first primitive it accepts."""
+        rays = np.ascontiguousarray(rays, dtype=ray_dtype(self.real))
+        mask = np.zeros((rays.shape[0],), dtype=np.uint8)
+        if options is not None:
+            options = np.asarray(options, dtype=TRACE_OPTIONS).reshape(1)
+        self._check(getattr(self._L, "nrtOccludedBatch_" + self._s)(self._h, _p(rays), rays.shape[0], _p(options), _p(mask)))
+        return mask
+
+    def OccludedBatchDevice(self, d_rays, d_mask, options=None, stream=None):
+        import torch
+
+        n = d_rays.numel() * d_rays.element_size() // ray_dtype(self.real).itemsize
+        assert d_mask.numel() >= n
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        if options is not None:
+            options = np.asarray(options, dtype=TRACE_OPTIONS).reshape(1)
+        self._check(getattr(self._L, "nrtOccludedBatchDevice_" + self._s)(self._h, d_rays.data_ptr(), n, _p(options), d_mask.data_ptr(), stream))
+        return n
+
     def TraverseCountDevice(self, d_rays, options=None):
         """Work counters (nodes visited, leaves, triangle tests, max stack) of one batch."""
         rsz = ray_dtype(self.real).itemsize

@@ -23,6 +23,7 @@ SYMBOLS = [
     "nrtTraverseBatch_f32", "nrtTraverseBatch_f64",
     "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64",
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
+    "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
     "nrtLastTraverseMs", "nrtLastBuildMs", "nrtDebugCounters",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
     "nrtSceneTraverseBatch_f32",
@@ -97,6 +98,13 @@ def lib():
         f.restype = i32
         f = getattr(L, "nrtTraverseCountDevice_" + s)
         f.argtypes = [vp, vp, u64, vp, ctypes.POINTER(TraceCounters)]
+        f.restype = i32
+    for sfx in ("f32", "f64"):
+        f = getattr(L, "nrtOccludedBatch_" + sfx)
+        f.argtypes = [vp, vp, u64, vp, vp]
+        f.restype = i32
+        f = getattr(L, "nrtOccludedBatchDevice_" + sfx)
+        f.argtypes = [vp, vp, u64, vp, vp, vp]
         f.restype = i32
     L.nrtSetSpheres_f32.argtypes = [vp, vp, vp, u32]
     L.nrtSetSpheres_f32.restype = i32

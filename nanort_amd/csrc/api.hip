@@ -519,7 +519,7 @@ static const nrt_trace_options kDefaultTrace = {{0u, 0x7FFFFFFFu}, 0xFFFFFFFFu, 
 template <typename T>
 static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_rays, uint64_t n,
                                   const nrt_trace_options *opt, typename Wire<T>::Hit *d_hits, uint8_t *d_mask,
-                                  hipStream_t s, bool count, bool timed, void *d_cyl_hits = nullptr) {
+                                  hipStream_t s, bool count, bool timed, void *d_cyl_hits = nullptr, bool any_hit = false) {
   if (c->prec != (int)sizeof(T)) return fail(c, NRT_ERR_PRECISION, "nrtTraverseBatch: precision mismatch");
   if ((c->prim_kind == kPrimCylinders) != (d_cyl_hits != nullptr))
     return fail(c, NRT_ERR_INVALID, "cylinder primitives are traced with nrtTraverseBatchCylinders*_f32 (28-byte records), "
@@ -556,7 +556,9 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   const bool spheres = c->prim_kind != kPrimTriangles; // the custom primitives share one launch geometry
   if (spheres && (count || !c->d_wide))
     return fail(c, NRT_ERR_INVALID, "nrtTraverse: custom primitives run on the WideNode kernel only (no counting pass)");
-  const bool use_wide = (c->wide || spheres) && !count && c->d_wide;
+  if (any_hit && (spheres || count || !c->d_wide))
+    return fail(c, NRT_ERR_INVALID, "nrtOccludedBatch: occlusion queries run on the triangle WideNode kernel only");
+  const bool use_wide = (c->wide || spheres || any_hit) && !count && c->d_wide;
   if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
   if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles);
   if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind);
@@ -608,6 +610,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.range1 = opt->prim_ids_range[1];
   a.skip_prim = opt->skip_prim_id;
   a.cull_back_face = opt->cull_back_face ? 1u : 0u;
+  a.any_hit = any_hit ? 1u : 0u;
   // prim ids are < num_faces: nothing can be rejected by these options -> the kernel variant without the id tests
   a.plain_options = (opt->prim_ids_range[0] == 0u && opt->prim_ids_range[1] >= c->num_faces && opt->skip_prim_id >= c->num_faces &&
                      !opt->cull_back_face) ? 1u : 0u;
@@ -690,6 +693,28 @@ static nrt_status traverse_count(nrt_ctx *c, const typename Wire<T>::Ray *d_rays
   return NRT_OK;
 }
 
+template <typename T>
+static nrt_status occluded_host(nrt_ctx *c, const typename Wire<T>::Ray *rays, uint64_t n, const nrt_trace_options *opt, uint8_t *mask) {
+  if (!c) return NRT_ERR_INVALID;
+  if (n == 0) return NRT_OK;
+  if (!rays || !mask) return fail(c, NRT_ERR_INVALID, "nrtOccludedBatch: NULL rays/mask");
+  typedef typename Wire<T>::Ray Ray;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t kMaxChunk = 1ull << 26;
+  for (uint64_t off = 0; off < n; off += kMaxChunk) {
+    const uint64_t m = std::min(kMaxChunk, n - off);
+    nrt_status st;
+    if ((st = ensure(c, c->st_rays, m * sizeof(Ray)))) return st;
+    if ((st = ensure(c, c->st_mask, m))) return st;
+    HIPCHK(c, hipMemcpyAsync(c->st_rays.p, rays + off, m * sizeof(Ray), hipMemcpyHostToDevice, c->stream));
+    st = traverse_device<T>(c, (const Ray *)c->st_rays.p, m, opt, nullptr, (uint8_t *)c->st_mask.p, c->stream, false, true, nullptr, true);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(mask + off, c->st_mask.p, m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return NRT_OK;
+}
+
 extern "C" {
 
 nrt_status nrtSetMesh_f32(nrt_ctx *c, const float *v, size_t stride, const uint32_t *f, uint32_t nf) {
@@ -732,6 +757,23 @@ nrt_status nrtTraverseBatchCylinders_f32(nrt_ctx *c, const nrt_ray_f32 *rays, ui
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return NRT_OK;
+}
+
+nrt_status nrtOccludedBatch_f32(nrt_ctx *c, const nrt_ray_f32 *r, uint64_t n, const nrt_trace_options *o, uint8_t *m) {
+  return occluded_host<float>(c, r, n, o, m);
+}
+nrt_status nrtOccludedBatch_f64(nrt_ctx *c, const nrt_ray_f64 *r, uint64_t n, const nrt_trace_options *o, uint8_t *m) {
+  return occluded_host<double>(c, r, n, o, m);
+}
+nrt_status nrtOccludedBatchDevice_f32(nrt_ctx *c, const nrt_ray_f32 *r, uint64_t n, const nrt_trace_options *o, uint8_t *m, void *s) {
+  if (!c) return NRT_ERR_INVALID;
+  if (n && !m) return fail(c, NRT_ERR_INVALID, "nrtOccludedBatchDevice: NULL mask");
+  return traverse_device<float>(c, r, n, o, nullptr, m, (hipStream_t)s, false, true, nullptr, true);
+}
+nrt_status nrtOccludedBatchDevice_f64(nrt_ctx *c, const nrt_ray_f64 *r, uint64_t n, const nrt_trace_options *o, uint8_t *m, void *s) {
+  if (!c) return NRT_ERR_INVALID;
+  if (n && !m) return fail(c, NRT_ERR_INVALID, "nrtOccludedBatchDevice: NULL mask");
+  return traverse_device<double>(c, r, n, o, nullptr, m, (hipStream_t)s, false, true, nullptr, true);
 }
 
 nrt_status nrtSetSpheres_f32(nrt_ctx *c, const float *centers, const float *radii, uint32_t n) {

@@ -137,6 +137,7 @@ struct TraverseArgs {
   uint32_t num_rays;
   uint32_t range0, range1, skip_prim; // BVHTraceOptions
   uint32_t cull_back_face;
+  uint32_t any_hit;       // occlusion query (opt-in extension): a ray stops at the first primitive it accepts
   uint32_t plain_options; // the options above cannot reject any primitive of this tree (host-checked)
   uint32_t *spill;        // [spill_levels][spill_stride] overflow stack, may be null
   T *spill_tmin;          // same shape, entry t_min (wide kernel)

@@ -819,7 +819,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
     }                                                   \
     h_.t = hit_ ? L.hit_t : L.max_t;                    \
     h_.prim_id = hit_ ? L.prim : kInvalid;              \
-    store_hit_nt<T>(a.hits + rid, h_);                  \
+    if (a.hits) store_hit_nt<T>(a.hits + rid, h_);      \
     if (a.mask) a.mask[rid] = hit_ ? (KIND == kPrimCylinders ? (uint8_t)(1u | (L.cap << 1)) : (uint8_t)1) : (uint8_t)0; \
   } while (0)
 
@@ -970,6 +970,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
             tri_test<T>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull);
         }
       }
+      // occlusion query: any accepted primitive settles the ray — drop what is left of its stack
+      if (a.any_hit) sp = (state == W_LEAF && L.hit_t < L.max_t) ? 0 : sp;
       state = (state == W_LEAF) ? W_POP : state;
     }
   }

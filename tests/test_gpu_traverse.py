@@ -263,3 +263,31 @@ def test_contexts_release_their_device_memory():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, "leaked %.1f MiB over 25 cycles" % ((free0 - free1) / 2**20)
+
+
+@pytest.mark.parametrize("real", [np.float32, np.float64])
+def test_occlusion_queries_equal_the_closest_hit_flags(real, c1_mesh):
+    """Opt-in extension: nrtOccludedBatch* stops a ray at the first accepted primitive; its flags must be exactly the hit
+    flags of the closest-hit traversal — camera, shadow and bounce rays, with and without restrictive trace options."""
+    import torch
+
+    for (v, f), (w, h) in ((c1_mesh, (256, 256)), (scenes.plane(200, 100), (480, 270))):
+        a = BVHAccel(real)
+        assert a.Build(f.shape[0], TriangleMesh(v.astype(real), f))
+        rays1 = scenes.camera_rays(w, h)
+        a32 = BVHAccel(np.float32)
+        assert a32.Build(f.shape[0], TriangleMesh(v, f))
+        h1, m1 = a32.TraverseBatch(rays1)
+        sets = [rays1, scenes.secondary_rays("shadow", v, f, rays1, h1, m1), scenes.secondary_rays("bounce", v, f, rays1, h1, m1)]
+        for rays in sets:
+            if real == np.float64:
+                rays = widen_rays(rays)
+            for o in (None, trace_options(cull=True), trace_options(range_=(10, f.shape[0] // 2), skip=11)):
+                _, m = a.TraverseBatch(rays, o)
+                occ = a.OccludedBatch(rays, o)
+                assert np.array_equal(occ, m)
+        d = torch.from_numpy(np.ascontiguousarray(rays).view(np.uint8)).cuda()
+        dm = torch.zeros(rays.shape[0], dtype=torch.uint8, device="cuda")
+        a.OccludedBatchDevice(d, dm)
+        torch.cuda.synchronize()
+        assert np.array_equal(dm.cpu().numpy(), a.TraverseBatch(rays)[1])
