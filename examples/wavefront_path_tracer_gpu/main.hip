@@ -261,7 +261,7 @@ int main(int argc, char **argv) {
   float *d_verts, *d_contrib, *d_image;
   unsigned int *d_faces;
   Ray *d_rays, *d_shadow;
-  Hit *d_hits, *d_shits;
+  Hit *d_hits;
   unsigned char *d_mask, *d_smask;
   PathState *d_paths;
   hipStream_t stream;
@@ -271,7 +271,6 @@ int main(int argc, char **argv) {
   CHECK(hipMalloc(&d_rays, (size_t)n * sizeof(Ray)));
   CHECK(hipMalloc(&d_shadow, (size_t)n * sizeof(Ray)));
   CHECK(hipMalloc(&d_hits, (size_t)n * sizeof(Hit)));
-  CHECK(hipMalloc(&d_shits, (size_t)n * sizeof(Hit)));
   CHECK(hipMalloc(&d_mask, n));
   CHECK(hipMalloc(&d_smask, n));
   CHECK(hipMalloc(&d_paths, (size_t)n * sizeof(PathState)));
@@ -296,7 +295,8 @@ int main(int argc, char **argv) {
         }
         hipLaunchKernelGGL(k_shade, grid, block, 0, stream, n, spp, d, depth, d_verts, d_faces, d_rays, d_hits, d_mask, d_paths, d_shadow,
                            d_contrib, d_image);
-        if (!Trace(accel, d_shadow, n, d_shits, d_smask, stream)) return 1;
+        // shadow rays only ask "is anything in the way?": the opt-in occlusion query (same flags, early exit)
+        if (!accel.OccludedBatchDevice(reinterpret_cast<const nanort::Ray<float> *>(d_shadow), n, d_smask, stream)) return 1;
         hipLaunchKernelGGL(k_resolve_shadows, grid, block, 0, stream, n, spp, d_smask, d_contrib, d_image);
         rays_traced += 2ull * n;
       }

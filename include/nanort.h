@@ -900,6 +900,9 @@ struct HipApi<float> {
     return nrtTraverseBatchDevice_f32(c, r, n, o, h, m, s);
   }
   static nrt_status Occluded(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m) { return nrtOccludedBatch_f32(c, r, n, o, m); }
+  static nrt_status OccludedDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m, void *s) {
+    return nrtOccludedBatchDevice_f32(c, r, n, o, m, s);
+  }
 };
 template <>
 struct HipApi<double> {
@@ -918,6 +921,9 @@ struct HipApi<double> {
     return nrtTraverseBatchDevice_f64(c, r, n, o, h, m, s);
   }
   static nrt_status Occluded(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m) { return nrtOccludedBatch_f64(c, r, n, o, m); }
+  static nrt_status OccludedDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m, void *s) {
+    return nrtOccludedBatchDevice_f64(c, r, n, o, m, s);
+  }
 };
 struct CtxDeleter {
   void operator()(nrt_ctx *c) const { nrtDestroy(c); }
@@ -1129,6 +1135,22 @@ class BVHAccel {
     nrt_trace_options o;
     std::memcpy(&o, &options, sizeof(o));
     if (Api::Occluded(ctx_.get(), reinterpret_cast<const typename Api::RayPod *>(rays), num_rays, &o, occluded_out) != NRT_OK) {
+      backend_error_ = nrtLastError(ctx_.get());
+      return false;
+    }
+    return true;
+  }
+  // ... and with device pointers, asynchronous on `hip_stream` (see TraverseBatchDevice).
+  bool OccludedBatchDevice(const Ray<T> *d_rays, size_t num_rays, unsigned char *d_occluded, void *hip_stream,
+                           const BVHTraceOptions &options = BVHTraceOptions()) const {
+    typedef detail::HipApi<T> Api;
+    if (!ctx_ || device_tree_stale_) {
+      backend_error_ = "OccludedBatchDevice: no tree on the GPU";
+      return false;
+    }
+    nrt_trace_options o;
+    std::memcpy(&o, &options, sizeof(o));
+    if (Api::OccludedDevice(ctx_.get(), reinterpret_cast<const typename Api::RayPod *>(d_rays), num_rays, &o, d_occluded, hip_stream) != NRT_OK) {
       backend_error_ = nrtLastError(ctx_.get());
       return false;
     }
