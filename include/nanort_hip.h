@@ -338,6 +338,8 @@ NRT_API nrt_status nrtSceneCommit(nrt_scene *scene);
 /* The matrices Node::Update derives for node `node_id` (nanosg.h:397-437), valid after nrtSceneCommit: xform,
  * inv_xform, inv_xform33, inv_transpose_xform33 — 16 floats each (nanosg's row-major T[4][4]), 64 in all. */
 NRT_API nrt_status nrtSceneNodeState_f32(nrt_scene *scene, uint32_t node_id, float out[64]);
+/* Scene::GetBoundingBox (nanosg.h:761-769): union of the nodes' world boxes, valid after nrtSceneCommit. */
+NRT_API nrt_status nrtSceneBounds_f32(nrt_scene *scene, float bmin[3], float bmax[3]);
 NRT_API nrt_status nrtSceneTraverseBatch_f32(nrt_scene *scene, const nrt_ray_f32 *rays, uint64_t num_rays,
                                              nrt_scene_hit_f32 *hits_out, uint8_t *hit_mask_out);
 

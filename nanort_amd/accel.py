@@ -336,6 +336,13 @@ class Scene:
         self._check(st)
         return True
 
+    def GetBoundingBox(self):
+        """Scene::GetBoundingBox (reference nanosg.h:761-769): (bmin, bmax) of a committed scene."""
+        bmin = np.zeros(3, dtype=np.float32)
+        bmax = np.zeros(3, dtype=np.float32)
+        self._check(self._L.nrtSceneBounds_f32(self._h, _p(bmin), _p(bmax)))
+        return bmin, bmax
+
     def NodeState(self, node_id):
         """xform, inv_xform, inv_xform33, inv_transpose_xform33 of a committed node (reference nanosg.h:397-437)."""
         out = np.zeros(64, dtype=np.float32)

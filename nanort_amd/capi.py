@@ -26,7 +26,7 @@ SYMBOLS = [
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
     "nrtLastTraverseMs", "nrtLastBuildMs", "nrtDebugCounters",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
-    "nrtSceneTraverseBatch_f32",
+    "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32",
 ]
 
 
@@ -126,6 +126,8 @@ def lib():
     L.nrtSceneNodeState_f32.argtypes = [vp, u32, vp]
     L.nrtSceneNodeState_f32.restype = i32
     L.nrtSceneCommit.restype = i32
+    L.nrtSceneBounds_f32.argtypes = [vp, vp, vp]
+    L.nrtSceneBounds_f32.restype = i32
     L.nrtSceneTraverseBatch_f32.argtypes = [vp, vp, u64, vp, vp]
     L.nrtSceneTraverseBatch_f32.restype = i32
     L.nrtLastTraverseMs.argtypes = [vp]

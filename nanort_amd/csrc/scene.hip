@@ -7,11 +7,13 @@
 //                    (the listing does not depend on the shape of the reference's top-level BVH: every
 //                    ancestor box contains the leaf box and the slab arithmetic is monotone, so it is a scan
 //                    over the node table);
-//   for list position j (front to back) and node k:
-//     k_scene_gather   rays whose j-th entry is node k and that survive the early cull
-//                      (t_nearest < t_min, nanosg.h:795) -> compacted, transformed into the node's space;
-//     k_traverse_wide  the single-level kernel, unchanged, over node k's own tree (nrtTraverseBatchDevice);
-//     k_scene_apply    world-space distance of each local hit, strict-nearer update of the ray's result.
+//   for list position j (front to back) — one host synchronisation per round, independent of the number of nodes:
+//     k_scene_count    per node: how many rays have it as their j-th entry and survive the early cull
+//                      (t_nearest < t_min, nanosg.h:795);
+//     k_scene_gather   those rays, compacted into one segment per node and transformed into the node's space;
+//     for every node with a non-empty segment:
+//       k_traverse_wide  the single-level kernel, unchanged, over the node's own tree (nrtTraverseBatchDevice);
+//       k_scene_apply    world-space distance of each local hit, strict-nearer update of the ray's result.
 //
 // The per-node arithmetic (Matrix::Mult / Inverse / MultV, XformBoundingBox, the two slab tests) follows the
 // reference operation for operation; this file is compiled with the same no-contraction / IEEE flags.
@@ -124,26 +126,69 @@ __global__ __launch_bounds__(256) void k_scene_list(const nrt_ray_f32 *__restric
   if (cnt) atomicMax(max_count, cnt);
 }
 
+// Does ray i visit its j-th listed node in round j?  (early cull, nanosg.h:795).  A ray has ONE node at list position j,
+// so within a round no ray is handled twice and best_t[i] only changes through the ray's own node: the decisions of a
+// whole round can be taken up front, for all nodes at once.
+__device__ inline bool round_take(uint32_t i, uint32_t n, uint32_t j, const float *__restrict__ list_t,
+                                  const uint32_t *__restrict__ list_node, const uint32_t *__restrict__ count,
+                                  const float *__restrict__ best_t, uint32_t &node) {
+  node = 0xFFFFFFFFu;
+  if (i >= n || j >= count[i]) return false;
+  if (best_t[i] < list_t[(size_t)j * n + i]) return false;
+  node = list_node[(size_t)j * n + i];
+  return true;
+}
+
+// One atomic per (wave, distinct node): lanes of a wave mostly share a node.  Returns the lane's rank among the lanes
+// of its wave that hold the same node, and through `base` what the group's leader got back from the atomic.
+__device__ inline uint32_t wave_group_add(bool take, uint32_t node, uint32_t *__restrict__ counters, uint32_t &base) {
+  const unsigned lane = threadIdx.x & 63u;
+  uint32_t rank = 0;
+  base = 0;
+  unsigned long long todo = __ballot(take);
+  while (todo) {
+    const int leader = __builtin_ctzll(todo);
+    const uint32_t lnode = __shfl(node, leader);
+    const unsigned long long grp = __ballot(take && node == lnode);
+    uint32_t b = 0;
+    if ((int)lane == leader) b = atomicAdd(&counters[lnode], (uint32_t)__builtin_popcountll(grp));
+    b = __shfl(b, leader);
+    if (take && node == lnode) {
+      base = b;
+      rank = (uint32_t)__builtin_popcountll(grp & ((1ull << lane) - 1ull));
+    }
+    todo &= ~grp;
+  }
+  return rank;
+}
+
+// round j, step 1: how many rays go to each node
+__global__ __launch_bounds__(256) void k_scene_count(uint32_t n, uint32_t j, const float *__restrict__ list_t,
+                                                     const uint32_t *__restrict__ list_node,
+                                                     const uint32_t *__restrict__ count, const float *__restrict__ best_t,
+                                                     uint32_t *__restrict__ node_count) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  uint32_t node, base;
+  const bool take = round_take(i, n, j, list_t, list_node, count, best_t, node);
+  wave_group_add(take, node, node_count, base);
+}
+
+// round j, step 2: compact the rays of every node into its segment [node_offset[k], node_offset[k] + node_count[k]) and
+// transform them into the node's space.  node_cursor starts at zero.
 __global__ __launch_bounds__(256) void k_scene_gather(const nrt_ray_f32 *__restrict__ rays, uint32_t n, uint32_t j,
-                                                      uint32_t node, const NodeDev *__restrict__ nodes,
-                                                      const float *__restrict__ list_t,
+                                                      const NodeDev *__restrict__ nodes, const float *__restrict__ list_t,
                                                       const uint32_t *__restrict__ list_node,
                                                       const uint32_t *__restrict__ count,
-                                                      const float *__restrict__ best_t, uint32_t *__restrict__ sel_count,
-                                                      uint32_t *__restrict__ sel_index, nrt_ray_f32 *__restrict__ local_rays) {
+                                                      const float *__restrict__ best_t,
+                                                      const uint32_t *__restrict__ node_offset,
+                                                      uint32_t *__restrict__ node_cursor, uint32_t *__restrict__ sel_index,
+                                                      nrt_ray_f32 *__restrict__ local_rays) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  bool take = false;
-  if (i < n && j < count[i] && list_node[(size_t)j * n + i] == node) {
-    take = !(best_t[i] < list_t[(size_t)j * n + i]); // early cull, nanosg.h:795
-  }
-  const unsigned long long m = __ballot(take);
-  if (m == 0ull) return;
-  const unsigned lane = threadIdx.x & 63u;
-  uint32_t base = 0;
-  if (lane == (unsigned)__builtin_ctzll(m)) base = atomicAdd(sel_count, (uint32_t)__builtin_popcountll(m));
-  base = __shfl(base, __builtin_ctzll(m));
+  uint32_t node, base;
+  const bool take = round_take(i, n, j, list_t, list_node, count, best_t, node);
+  const uint32_t rank = wave_group_add(take, node, node_cursor, base);
   if (!take) return;
-  const uint32_t slot = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+  const uint32_t slot = node_offset[node] + base + rank;
   const nrt_ray_f32 r = rays[i];
   const NodeDev &nd = nodes[node];
   nrt_ray_f32 lr;
@@ -157,15 +202,14 @@ __global__ __launch_bounds__(256) void k_scene_gather(const nrt_ray_f32 *__restr
 }
 
 __global__ __launch_bounds__(256) void k_scene_apply(const nrt_ray_f32 *__restrict__ rays, uint32_t node,
-                                                     const NodeDev *__restrict__ nodes,
-                                                     const uint32_t *__restrict__ sel_count,
+                                                     const NodeDev *__restrict__ nodes, uint32_t sel_count,
                                                      const uint32_t *__restrict__ sel_index,
                                                      const nrt_ray_f32 *__restrict__ local_rays,
                                                      const nrt_hit_f32 *__restrict__ local_hits,
                                                      const uint8_t *__restrict__ local_mask, float *__restrict__ best_t,
                                                      nrt_scene_hit_f32 *__restrict__ best) {
   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-  if (s >= *sel_count || !local_mask[s]) return;
+  if (s >= sel_count || !local_mask[s]) return;
   const uint32_t i = sel_index[s];
   const nrt_ray_f32 lr = local_rays[s];
   const nrt_hit_f32 lh = local_hits[s];
@@ -292,7 +336,8 @@ struct nrt_scene {
   std::vector<NodeDev> host_nodes;
   bool committed = false;
   nrt::DevBuf d_nodes, d_rays, d_list_t, d_list_node, d_count, d_best_t, d_best, d_sel_index, d_local_rays, d_local_hits,
-      d_local_mask, d_mask, d_scalars; // d_scalars: [0] max_count, [1] sel_count
+      d_local_mask, d_mask, d_scalars, d_node_counters; // d_scalars: [0] max_count
+  std::vector<uint32_t> h_node_counters;
 };
 
 static nrt_status sfail(nrt_scene *s, nrt_status st, const char *fmt, ...) {
@@ -340,7 +385,7 @@ void nrtSceneDestroy(nrt_scene *s) {
   (void)hipStreamSynchronize(s->stream);
   nrt::DevBuf *bufs[] = {&s->d_nodes,     &s->d_rays,       &s->d_list_t,     &s->d_list_node,  &s->d_count,
                          &s->d_best_t,    &s->d_best,       &s->d_sel_index,  &s->d_local_rays, &s->d_local_hits,
-                         &s->d_local_mask, &s->d_mask,       &s->d_scalars};
+                         &s->d_local_mask, &s->d_mask,       &s->d_scalars,    &s->d_node_counters};
   for (nrt::DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   (void)hipStreamDestroy(s->stream);
@@ -384,6 +429,23 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
   return NRT_OK;
 }
 
+// Scene::GetBoundingBox (nanosg.h:761-769): the root box of the top-level tree, i.e. the plain union of the nodes'
+// world boxes (nanort.h:1546-1567 pads nothing).
+nrt_status nrtSceneBounds_f32(nrt_scene *s, float bmin[3], float bmax[3]) {
+  if (!s || !bmin || !bmax) return NRT_ERR_INVALID;
+  if (!s->committed) return sfail(s, NRT_ERR_INVALID, "nrtSceneBounds: commit the scene first");
+  for (int k = 0; k < 3; k++) {
+    bmin[k] = s->host_nodes[0].xbmin[k];
+    bmax[k] = s->host_nodes[0].xbmax[k];
+  }
+  for (size_t i = 1; i < s->host_nodes.size(); i++)
+    for (int k = 0; k < 3; k++) {
+      bmin[k] = std::min(bmin[k], s->host_nodes[i].xbmin[k]);
+      bmax[k] = std::max(bmax[k], s->host_nodes[i].xbmax[k]);
+    }
+  return NRT_OK;
+}
+
 // What Node::Update derives from the local transform (nanosg.h:397-437), for callers that finish the
 // reference's Intersection record (P, Ns, Ng) on the host: xform, inv_xform, inv_xform33 and
 // inv_transpose_xform33 = transpose(inv_xform33) (nanosg.h:430-432), 16 floats each, row-major T[4][4].
@@ -422,7 +484,7 @@ nrt_status nrtSceneTraverseBatch_f32(nrt_scene *s, const nrt_ray_f32 *rays, uint
   SCHK(s, nrt::devbuf_ensure(&s->d_local_mask, (size_t)n));
   SCHK(s, nrt::devbuf_ensure(&s->d_mask, (size_t)n));
   SCHK(s, nrt::devbuf_ensure(&s->d_scalars, 64));
-  uint32_t *d_max_count = (uint32_t *)s->d_scalars.p, *d_sel_count = d_max_count + 1;
+  uint32_t *d_max_count = (uint32_t *)s->d_scalars.p;
   const NodeDev *d_nodes = (const NodeDev *)s->d_nodes.p;
   const nrt_ray_f32 *d_rays = (const nrt_ray_f32 *)s->d_rays.p;
   const unsigned grid = (n + 255u) / 256u;
@@ -437,26 +499,44 @@ nrt_status nrtSceneTraverseBatch_f32(nrt_scene *s, const nrt_ray_f32 *rays, uint
   SCHK(s, hipMemcpyAsync(&max_count, d_max_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
   SCHK(s, hipStreamSynchronize(s->stream));
 
+  // per-node counters of a round: [0, N) counts, [N, 2N) segment offsets, [2N, 3N) gather cursors
+  SCHK(s, nrt::devbuf_ensure(&s->d_node_counters, (size_t)3 * num_nodes * sizeof(uint32_t)));
+  uint32_t *d_node_count = (uint32_t *)s->d_node_counters.p, *d_node_offset = d_node_count + num_nodes,
+           *d_node_cursor = d_node_offset + num_nodes;
+  s->h_node_counters.resize((size_t)3 * num_nodes);
+  uint32_t *h_count = s->h_node_counters.data(), *h_offset = h_count + num_nodes;
   for (uint32_t j = 0; j < max_count; j++) {
+    SCHK(s, hipMemsetAsync(d_node_count, 0, (size_t)3 * num_nodes * sizeof(uint32_t), s->stream));
+    hipLaunchKernelGGL(k_scene_count, dim3(grid), dim3(256), 0, s->stream, n, j, (const float *)s->d_list_t.p,
+                       (const uint32_t *)s->d_list_node.p, (const uint32_t *)s->d_count.p, (const float *)s->d_best_t.p,
+                       d_node_count);
+    SCHK(s, hipGetLastError());
+    SCHK(s, hipMemcpyAsync(h_count, d_node_count, (size_t)num_nodes * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    SCHK(s, hipStreamSynchronize(s->stream)); // the only host round trip of the round
+    uint32_t total = 0;
     for (uint32_t k = 0; k < num_nodes; k++) {
-      SCHK(s, hipMemsetAsync(d_sel_count, 0, sizeof(uint32_t), s->stream));
-      hipLaunchKernelGGL(k_scene_gather, dim3(grid), dim3(256), 0, s->stream, d_rays, n, j, k, d_nodes,
-                         (const float *)s->d_list_t.p, (const uint32_t *)s->d_list_node.p, (const uint32_t *)s->d_count.p,
-                         (const float *)s->d_best_t.p, d_sel_count, (uint32_t *)s->d_sel_index.p,
-                         (nrt_ray_f32 *)s->d_local_rays.p);
-      SCHK(s, hipGetLastError());
-      uint32_t m = 0;
-      SCHK(s, hipMemcpyAsync(&m, d_sel_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-      SCHK(s, hipStreamSynchronize(s->stream));
+      h_offset[k] = total;
+      total += h_count[k];
+    }
+    if (total == 0) continue;
+    SCHK(s, hipMemcpyAsync(d_node_offset, h_offset, (size_t)num_nodes * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_scene_gather, dim3(grid), dim3(256), 0, s->stream, d_rays, n, j, d_nodes, (const float *)s->d_list_t.p,
+                       (const uint32_t *)s->d_list_node.p, (const uint32_t *)s->d_count.p, (const float *)s->d_best_t.p,
+                       (const uint32_t *)d_node_offset, d_node_cursor, (uint32_t *)s->d_sel_index.p,
+                       (nrt_ray_f32 *)s->d_local_rays.p);
+    SCHK(s, hipGetLastError());
+    for (uint32_t k = 0; k < num_nodes; k++) {
+      const uint32_t m = h_count[k], off = h_offset[k];
       if (m == 0) continue;
+      const nrt_ray_f32 *lr = (const nrt_ray_f32 *)s->d_local_rays.p + off;
+      nrt_hit_f32 *lh = (nrt_hit_f32 *)s->d_local_hits.p + off;
+      uint8_t *lm = (uint8_t *)s->d_local_mask.p + off;
       // the single-level kernel over node k's own tree, default trace options (nanosg.h:817)
-      if (nrtTraverseBatchDevice_f32(s->insts[k].mesh, (const nrt_ray_f32 *)s->d_local_rays.p, m, nullptr,
-                                     (nrt_hit_f32 *)s->d_local_hits.p, (uint8_t *)s->d_local_mask.p, s->stream) != NRT_OK)
+      if (nrtTraverseBatchDevice_f32(s->insts[k].mesh, lr, m, nullptr, lh, lm, s->stream) != NRT_OK)
         return sfail(s, NRT_ERR_DEVICE, "nrtSceneTraverseBatch: node %u: %s", k, nrtLastError(s->insts[k].mesh));
-      hipLaunchKernelGGL(k_scene_apply, dim3((m + 255u) / 256u), dim3(256), 0, s->stream, d_rays, k, d_nodes, d_sel_count,
-                         (const uint32_t *)s->d_sel_index.p, (const nrt_ray_f32 *)s->d_local_rays.p,
-                         (const nrt_hit_f32 *)s->d_local_hits.p, (const uint8_t *)s->d_local_mask.p, (float *)s->d_best_t.p,
-                         (nrt_scene_hit_f32 *)s->d_best.p);
+      hipLaunchKernelGGL(k_scene_apply, dim3((m + 255u) / 256u), dim3(256), 0, s->stream, d_rays, k, d_nodes, m,
+                         (const uint32_t *)s->d_sel_index.p + off, lr, (const nrt_hit_f32 *)lh, (const uint8_t *)lm,
+                         (float *)s->d_best_t.p, (nrt_scene_hit_f32 *)s->d_best.p);
       SCHK(s, hipGetLastError());
     }
   }

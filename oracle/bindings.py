@@ -267,6 +267,7 @@ class SceneReference:
         L.refsg_commit.restype = ctypes.c_int
         L.refsg_node_state.argtypes = [vp, u32, vp]
         L.refsg_traverse.argtypes = [vp, vp, u64, ctypes.c_int, vp, vp]
+        L.refsg_bounds.argtypes = [vp, vp, vp]
         self.L = L
         self.h = L.refsg_create()
         self.n = 0
@@ -292,6 +293,12 @@ class SceneReference:
         self.L.refsg_node_state(self.h, i, _p(out))
         return {"xbmin": out[0:3], "xbmax": out[3:6], "inv_xform": out[6:22].reshape(4, 4),
                 "inv_xform33": out[22:38].reshape(4, 4), "xform": out[38:54].reshape(4, 4)}
+
+    def bounds(self):
+        bmin = np.zeros(3, dtype=np.float32)
+        bmax = np.zeros(3, dtype=np.float32)
+        self.L.refsg_bounds(self.h, _p(bmin), _p(bmax))
+        return bmin, bmax
 
     def traverse(self, rays, cull_back_face=False):
         rays = np.ascontiguousarray(rays, dtype=ray_dtype(np.float32))

@@ -83,6 +83,9 @@ void refsg_node_state(void *h, uint32_t node, float *out54) {
   memcpy(out54 + 38, n.xform_, 64);
 }
 
+// Scene::GetBoundingBox (nanosg.h:761-769) after Commit().
+void refsg_bounds(void *h, float bmin[3], float bmax[3]) { static_cast<RefScene *>(h)->scene.GetBoundingBox(bmin, bmax); }
+
 // hits_out: {t, u, v, prim_id(u32), node_id(u32)} = 20 bytes per ray
 void refsg_traverse(void *h, const void *rays, uint64_t n, int cull_back_face, void *hits_out, uint8_t *mask) {
   RefScene *s = static_cast<RefScene *>(h);

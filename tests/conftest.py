@@ -18,6 +18,7 @@ def _ensure_built():
     need = [
         capi.LIB_PATH,
         os.path.join(ROOT, "nanort_amd", "lib", "libnrt_scenes.so"),
+        os.path.join(ROOT, "nanort_amd", "lib", "libnanort_embree.so"),
         os.path.join(ROOT, "oracle", "liboracle.so"),
     ]
     if not all(os.path.exists(p) for p in need):
