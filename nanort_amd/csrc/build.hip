@@ -14,7 +14,10 @@
 //                    (one wave per node, lane == bin, shuffle prefix/suffix
 //                    sweeps of the SAH cost), k_partition (stable, ballot-rank
 //                    scatter of the primitive records into the other buffer),
-//                    k_children.
+//                    k_level_setup (children of the level just partitioned +
+//                    the next level's active list).  Four kernels per level:
+//                    bins and accumulators are handed on clean by their
+//                    consumers (clean_bins) instead of being re-initialised.
 //   SUBTREE PHASE    one wave per node with <= kSmall primitives builds the
 //                    whole subtree out of LDS (lane == split candidate).
 //   RELAYOUT         subtree sizes bottom-up, DFS pre-order indices top-down,
@@ -346,8 +349,37 @@ __global__ __launch_bounds__(256) void k_prim_records(const T *__restrict__ vert
 }
 
 template <typename T>
-__global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info, uint32_t top_cap) {
+struct GBins { // per active node, integer-ordered, accumulated with global atomics
+  uint32_t count[3][kMaxBins];
+  typename Ord<T>::U bmin[3][kMaxBins][3];
+  typename Ord<T>::U bmax[3][kMaxBins][3];
+};
+
+// Bins and child accumulators are kept CLEAN between uses instead of being re-initialised by a kernel per level: whoever
+// consumes slot `a` of a level with A active nodes resets slots a and a + A (k_split: the bins; k_level_setup: the child
+// accumulators), so slots [0, 2A) — all the next level can use — are clean whatever the memory held before; slot 0 is
+// reset by k_init_scene.
+template <typename T>
+__device__ __forceinline__ void clean_bins(GBins<T> *g, int k, unsigned bin) {
+  g->count[k][bin] = 0;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    g->bmin[k][bin][d] = Ord<T>::highest();
+    g->bmax[k][bin][d] = Ord<T>::lowest();
+  }
+}
+template <typename T>
+__device__ __forceinline__ void clean_acc(BoundsAcc<T> *acc) {
+  typedef typename Ord<T>::U U;
+#pragma unroll
+  for (int j = 0; j < 12; j++) acc->v[j] = (j % 6 < 3) ? (U)Ord<T>::highest() : (U)Ord<T>::lowest();
+}
+
+template <typename T>
+__global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info, uint32_t top_cap, GBins<T> *gbins, BoundsAcc<T> *child_acc) {
   if (threadIdx.x < 12) scene->v[threadIdx.x] = (threadIdx.x % 6 < 3) ? Ord<T>::highest() : Ord<T>::lowest();
+  for (int k = 0; k < 3; k++) clean_bins<T>(&gbins[0], k, threadIdx.x); // 64 threads == kMaxBins
+  if (threadIdx.x < 2) clean_acc<T>(&child_acc[threadIdx.x]);
   if (threadIdx.x == 0) {
     info->num_active = 0;
     info->num_chunks = 0;
@@ -546,9 +578,69 @@ __global__ __launch_bounds__(256) void k_gather_records(const PrimRec<T> *__rest
 
 // One block: compacts the SPLIT nodes among top[cand_begin, cand_end) into the
 // active list (in order) and assigns each its chunks.
+// The two children of active node `a` of the level just partitioned: ranges from the split, boxes from the accumulators
+// k_partition reduced into (then reset, see clean_bins).
+template <typename T>
+__device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *active, BoundsAcc<T> *child_acc, uint32_t a,
+                                              uint32_t num_active, uint32_t max_active, uint32_t max_depth, uint32_t dst_buf,
+                                              uint32_t *small_list, LevelInfo *info) {
+  const TopNode<T> p = top[active[a]];
+  for (uint32_t c = 0; c < 2; c++) {
+    TopNode<T> t;
+    BoundsAcc<T> &acc = child_acc[2 * a + c];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      t.bmin[k] = Ord<T>::dec(acc.v[k]);
+      t.bmax[k] = Ord<T>::dec(acc.v[3 + k]);
+      t.cmin[k] = Ord<T>::dec(acc.v[6 + k]);
+      t.cmax[k] = Ord<T>::dec(acc.v[9 + k]);
+    }
+    clean_acc<T>(&acc);
+    if (a + num_active < max_active) clean_acc<T>(&child_acc[2 * (a + num_active) + c]);
+    t.l = c == 0 ? p.l : p.l + p.nleft;
+    t.r = c == 0 ? p.l + p.nleft : p.r;
+    t.depth = p.depth + 1;
+    t.kind = classify<T>(t.r - t.l, t.depth, max_depth);
+    t.axis = 0;
+    t.split_bin = kMedian;
+    t.nleft = 0;
+    t.child0 = 0;
+    t.size = 1;
+    t.dfs = 0;
+    t.buf = dst_buf;
+    t.chunk_base = 0;
+    t.nchunks = 0;
+    const uint32_t ci = p.child0 + c;
+    top[ci] = t;
+    if (t.kind == KIND_SMALL) small_list[atomicAdd(&info->num_small, 1u)] = ci;
+  }
+}
+
+// Wide levels (more active nodes than one block has threads) create their children with a grid of their own; narrow levels
+// do it at the head of k_level_setup and save the launch.
+template <typename T>
+__global__ __launch_bounds__(256) void k_children(TopNode<T> *top, const uint32_t *__restrict__ active, BoundsAcc<T> *child_acc,
+                                                  uint32_t max_active, uint32_t max_depth, uint32_t dst_buf,
+                                                  uint32_t *small_list, LevelInfo *info) {
+  const uint32_t a = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t num_active = info->num_active;
+  if (a >= num_active) return;
+  make_children<T>(top, active, child_acc, a, num_active, max_active, max_depth, dst_buf, small_list, info);
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void k_level_setup(TopNode<T> *top, uint32_t *active, uint32_t *chunk_base,
-                                                       LevelInfo *info) {
+                                                       LevelInfo *info, BoundsAcc<T> *child_acc, uint32_t max_active,
+                                                       uint32_t max_depth, uint32_t dst_buf, uint32_t *small_list,
+                                                       int with_children) {
+  // phase A: finish the previous level — its active list is still in `active` — by creating its children
+  if (with_children) {
+    const uint32_t prev_active = info->num_active;
+    for (uint32_t a = threadIdx.x; a < prev_active; a += 1024u)
+      make_children<T>(top, active, child_acc, a, prev_active, max_active, max_depth, dst_buf, small_list, info);
+    __syncthreads(); // (block-wide: the children are visible to the scan below, and `active` may be rewritten)
+  }
+  // phase B: the new level's active list and chunk ranges
   const uint32_t cand_begin = info->cand_begin, cand_end = info->cand_end;
   __shared__ uint32_t s_wave[2][16];
   __shared__ uint32_t s_carry[2];
@@ -614,33 +706,6 @@ __global__ __launch_bounds__(1024) void k_level_setup(TopNode<T> *top, uint32_t 
   }
 }
 
-template <typename T>
-struct GBins { // per active node, integer-ordered, accumulated with global atomics
-  uint32_t count[3][kMaxBins];
-  typename Ord<T>::U bmin[3][kMaxBins][3];
-  typename Ord<T>::U bmax[3][kMaxBins][3];
-};
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_init_level(GBins<T> *gbins, BoundsAcc<T> *child_acc, const LevelInfo *info) {
-  typedef typename Ord<T>::U U;
-  const uint32_t a = blockIdx.x;
-  if (a >= info->num_active) return;
-  GBins<T> *g = &gbins[a];
-  for (int i = threadIdx.x; i < 3 * kMaxBins; i += 256) {
-    const int k = i / kMaxBins, b = i % kMaxBins;
-    g->count[k][b] = 0;
-    for (int d = 0; d < 3; d++) {
-      g->bmin[k][b][d] = Ord<T>::highest();
-      g->bmax[k][b][d] = Ord<T>::lowest();
-    }
-  }
-  if (threadIdx.x < 24) {
-    const int c = threadIdx.x / 12, j = threadIdx.x % 12;
-    child_acc[2 * a + c].v[j] = (j % 6 < 3) ? (U)Ord<T>::highest() : (U)Ord<T>::lowest();
-  }
-}
-
 __device__ __forceinline__ uint32_t find_task(const uint32_t *chunk_base, uint32_t num_active, uint32_t chunk) {
   // last a with chunk_base[a] <= chunk
   uint32_t lo = 0, hi = num_active;
@@ -689,22 +754,65 @@ __global__ __launch_bounds__(256) void k_bin(const TopNode<T> *__restrict__ top,
     lo[k] = nd.cmin[k];
     sc[k] = bin_scale<T>(nd.cmin[k], nd.cmax[k], K);
   }
-  for (uint32_t p = begin + threadIdx.x; p < end; p += 256u) {
-    const PrimRec<T> r = recs[p];
-    U emin[3], emax[3];
+  // Each lane takes 8 CONSECUTIVE primitives and merges runs that fall into the same bin in registers before touching LDS.
+  // Meshes arrive spatially coherent (neighbouring triangles are neighbours in the array), so at the top levels — few
+  // nodes, wide bins — whole tiles land in one or two bins of an axis and every LDS atomic of a wave would hit the same
+  // address (serialised 64 ways).  Run merging cuts those atomics 8x there and costs a compare per axis where the input
+  // is incoherent (deep levels).
+  static_assert(kTile == 256 * 8, "k_bin: 8 primitives per lane");
+  {
+    int pb[3] = {-1, -1, -1};
+    uint32_t pc[3] = {0, 0, 0};
+    U pmin[3][3], pmax[3][3];
+    const uint32_t p0 = begin + threadIdx.x * 8u;
+    for (uint32_t it = 0; it < 8u; it++) {
+      const uint32_t p = p0 + it;
+      if (p >= end) break;
+      const PrimRec<T> r = recs[p];
+      U emin[3], emax[3];
 #pragma unroll
-    for (int d = 0; d < 3; d++) {
-      emin[d] = Ord<T>::enc(r.bmin[d]);
-      emax[d] = Ord<T>::enc(r.bmax[d]);
+      for (int d = 0; d < 3; d++) {
+        emin[d] = Ord<T>::enc(r.bmin[d]);
+        emax[d] = Ord<T>::enc(r.bmax[d]);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int b = bin_of<T>(r.c[k], lo[k], sc[k], K);
+        if (b == pb[k]) {
+          pc[k]++;
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            pmin[k][d] = emin[d] < pmin[k][d] ? emin[d] : pmin[k][d];
+            pmax[k][d] = emax[d] > pmax[k][d] ? emax[d] : pmax[k][d];
+          }
+        } else {
+          if (pb[k] >= 0) {
+            atomicAdd(&s_cnt[k][pb[k]], pc[k]);
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+              atomicMin(&s_min[k][pb[k]][d], pmin[k][d]);
+              atomicMax(&s_max[k][pb[k]][d], pmax[k][d]);
+            }
+          }
+          pb[k] = b;
+          pc[k] = 1;
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            pmin[k][d] = emin[d];
+            pmax[k][d] = emax[d];
+          }
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      const int b = bin_of<T>(r.c[k], lo[k], sc[k], K);
-      atomicAdd(&s_cnt[k][b], 1u);
+      if (pb[k] >= 0) {
+        atomicAdd(&s_cnt[k][pb[k]], pc[k]);
 #pragma unroll
-      for (int d = 0; d < 3; d++) {
-        atomicMin(&s_min[k][b][d], emin[d]);
-        atomicMax(&s_max[k][b][d], emax[d]);
+        for (int d = 0; d < 3; d++) {
+          atomicMin(&s_min[k][pb[k]][d], pmin[k][d]);
+          atomicMax(&s_max[k][pb[k]][d], pmax[k][d]);
+        }
       }
     }
   }
@@ -729,15 +837,16 @@ __global__ __launch_bounds__(256) void k_bin(const TopNode<T> *__restrict__ top,
 // FindCutFromBinBuffer (nanort.h:1393-1422), argmin over 3 x (K-1) candidates.
 template <typename T>
 __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *__restrict__ active,
-                                              const GBins<T> *__restrict__ gbins, int K,
+                                              GBins<T> *gbins, int K,
                                               const uint32_t *__restrict__ chunk_hist, uint32_t *chunk_left_base,
-                                              const LevelInfo *info) {
+                                              const LevelInfo *info, uint32_t max_active) {
   const uint32_t a = blockIdx.x;
-  if (a >= info->num_active) return;
+  const uint32_t num_active = info->num_active;
+  if (a >= num_active) return;
   const uint32_t next_top_base = info->child_base;
   const unsigned lane = threadIdx.x;
   TopNode<T> &nd = top[active[a]];
-  const GBins<T> &g = gbins[a];
+  GBins<T> &g = gbins[a];
   T best_cost = Lim<T>::inf();
   int best_axis = 0;
   uint32_t best_bin = kMedian, best_nl = 0;
@@ -759,6 +868,8 @@ __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *_
         }
       }
     }
+    clean_bins<T>(&g, k, lane); // consumed: leave the slot clean for the next level (see clean_bins)
+    if (a + num_active < max_active) clean_bins<T>(&gbins[a + num_active], k, lane);
     // inclusive prefix over lanes 0..lane
     uint32_t pc = cnt;
     T pmn[3] = {mn[0], mn[1], mn[2]}, pmx[3] = {mx[0], mx[1], mx[2]};
@@ -990,43 +1101,6 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
       atomicMin(&child_acc[2 * a + s].v[j], s_acc[s][j]);
     else
       atomicMax(&child_acc[2 * a + s].v[j], s_acc[s][j]);
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_children(TopNode<T> *top, const uint32_t *__restrict__ active,
-                                                  const BoundsAcc<T> *__restrict__ child_acc,
-                                                  uint32_t max_depth, uint32_t dst_buf, uint32_t *small_list,
-                                                  LevelInfo *info) {
-  const uint32_t a = blockIdx.x * 256u + threadIdx.x;
-  if (a >= info->num_active) return;
-  const TopNode<T> p = top[active[a]];
-  for (uint32_t c = 0; c < 2; c++) {
-    TopNode<T> t;
-    const BoundsAcc<T> &acc = child_acc[2 * a + c];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      t.bmin[k] = Ord<T>::dec(acc.v[k]);
-      t.bmax[k] = Ord<T>::dec(acc.v[3 + k]);
-      t.cmin[k] = Ord<T>::dec(acc.v[6 + k]);
-      t.cmax[k] = Ord<T>::dec(acc.v[9 + k]);
-    }
-    t.l = c == 0 ? p.l : p.l + p.nleft;
-    t.r = c == 0 ? p.l + p.nleft : p.r;
-    t.depth = p.depth + 1;
-    t.kind = classify<T>(t.r - t.l, t.depth, max_depth);
-    t.axis = 0;
-    t.split_bin = kMedian;
-    t.nleft = 0;
-    t.child0 = 0;
-    t.size = 1;
-    t.dfs = 0;
-    t.buf = dst_buf;
-    t.chunk_base = 0;
-    t.nchunks = 0;
-    const uint32_t ci = p.child0 + c;
-    top[ci] = t;
-    if (t.kind == KIND_SMALL) small_list[atomicAdd(&info->num_small, 1u)] = ci;
   }
 }
 
@@ -1521,7 +1595,7 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     LevelInfo *info = (LevelInfo *)(base + plan.off_info);
     uint32_t *indices = (uint32_t *)indices_buf->p;
 
-    hipLaunchKernelGGL((k_init_scene<T>), dim3(1), dim3(64), 0, s, scene, info, (uint32_t)plan.max_top);
+    hipLaunchKernelGGL((k_init_scene<T>), dim3(1), dim3(64), 0, s, scene, info, (uint32_t)plan.max_top, gbins, child_acc);
     {
       unsigned grid = (unsigned)std::min<size_t>(((size_t)n + 255) / 256, 2048);
       hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, d_radii, cylinders, n, recs[0], scene);
@@ -1555,7 +1629,15 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     int next_check = (n <= (uint32_t)kSmall) ? 0 : expect + 2;
     bool overflow = false;
     for (int level = 0;; level++) {
-      hipLaunchKernelGGL((k_level_setup<T>), dim3(1), dim3(1024), 0, s, top, active, chunk_base, info);
+      // children of the level partitioned last (their records are in recs[cur]): inside k_level_setup while a level
+      // cannot have more than 1024 active nodes, by a grid of their own below that
+      const size_t prev_max = level == 0 ? 0 : (level - 1 < 31 ? std::min<size_t>((size_t)1 << (level - 1), plan.max_active) : plan.max_active);
+      const bool wide = prev_max > 1024;
+      if (wide)
+        hipLaunchKernelGGL((k_children<T>), dim3((unsigned)((prev_max + 255) / 256)), dim3(256), 0, s, top, active, child_acc,
+                           (uint32_t)plan.max_active, max_depth, (uint32_t)cur, small_list, info);
+      hipLaunchKernelGGL((k_level_setup<T>), dim3(1), dim3(1024), 0, s, top, active, chunk_base, info, child_acc,
+                         (uint32_t)plan.max_active, max_depth, (uint32_t)cur, small_list, wide ? 0 : 1);
       if (level >= next_check) {
         BCHK(hipMemcpyAsync(&h, info, offsetof(LevelInfo, level_begin), hipMemcpyDeviceToHost, s));
         BCHK(hipStreamSynchronize(s));
@@ -1568,15 +1650,12 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
       }
       const size_t a_max = level < 31 ? std::min<size_t>((size_t)1 << level, plan.max_active) : plan.max_active;
       const size_t c_max = std::min<size_t>((size_t)n / kTile + a_max + 1, plan.max_chunks);
-      hipLaunchKernelGGL((k_init_level<T>), dim3((unsigned)a_max), dim3(256), 0, s, gbins, child_acc, info);
       hipLaunchKernelGGL((k_bin<T>), dim3((unsigned)c_max), dim3(256), 0, s, top, active, chunk_base, info, recs[cur],
                          K, gbins, chunk_hist);
       hipLaunchKernelGGL((k_split<T>), dim3((unsigned)a_max), dim3(64), 0, s, top, active, gbins, K, chunk_hist,
-                         chunk_left, info);
+                         chunk_left, info, (uint32_t)plan.max_active);
       hipLaunchKernelGGL((k_partition<T>), dim3((unsigned)c_max), dim3(256), 0, s, top, active, chunk_base, info,
                          chunk_left, recs[cur], recs[1 - cur], K, child_acc);
-      hipLaunchKernelGGL((k_children<T>), dim3((unsigned)((a_max + 255) / 256)), dim3(256), 0, s, top, active,
-                         child_acc, max_depth, (uint32_t)(1 - cur), small_list, info);
       BCHK(hipGetLastError());
       cur = 1 - cur;
     }
