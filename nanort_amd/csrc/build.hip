@@ -269,6 +269,11 @@ __device__ __forceinline__ T wave_max(T x) {
 // ---------------------------------------------------------------------------
 // primitive records + scene bounds
 // ---------------------------------------------------------------------------
+template <typename E>
+struct __attribute__((packed, aligned(4))) Vec3Of { // three consecutive elements of a tight xyz / ijk array (element-aligned only)
+  E x, y, z;
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_prim_records(const T *__restrict__ verts,
                                                       const uint32_t *__restrict__ faces,
@@ -288,16 +293,20 @@ __global__ __launch_bounds__(256) void k_prim_records(const T *__restrict__ vert
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     PrimRec<T> r;
     const T third = T(1) / T(3);
-    uint32_t f0 = 0, f1 = 0, f2 = 0;
+    // three indices, then three vertices, each as ONE 12/24-byte load (dword-aligned vectors) instead of nine scalar gathers
+    Vec3Of<uint32_t> f = {0, 0, 0};
+    Vec3Of<T> v0 = {T(0), T(0), T(0)}, v1 = v0, v2 = v0;
     if (faces) {
-      f0 = faces[3 * (size_t)i];
-      f1 = faces[3 * (size_t)i + 1];
-      f2 = faces[3 * (size_t)i + 2];
+      f = *reinterpret_cast<const Vec3Of<uint32_t> *>(faces + 3 * (size_t)i);
+      v0 = *reinterpret_cast<const Vec3Of<T> *>(verts + 3 * (size_t)f.x);
+      v1 = *reinterpret_cast<const Vec3Of<T> *>(verts + 3 * (size_t)f.y);
+      v2 = *reinterpret_cast<const Vec3Of<T> *>(verts + 3 * (size_t)f.z);
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       if (faces) { // triangles
-        const T p0 = verts[3 * (size_t)f0 + k], p1 = verts[3 * (size_t)f1 + k], p2 = verts[3 * (size_t)f2 + k];
+        const T p0 = k == 0 ? v0.x : (k == 1 ? v0.y : v0.z), p1 = k == 0 ? v1.x : (k == 1 ? v1.y : v1.z),
+                p2 = k == 0 ? v2.x : (k == 1 ? v2.y : v2.z);
         r.bmin[k] = tmin(p0, tmin(p1, p2)); // nanort.h:967-968
         r.bmax[k] = tmax(p0, tmax(p1, p2));
         r.c[k] = ((p0 + p1) + p2) * third; // nanort.h:970
