@@ -1119,17 +1119,51 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
 // Pending high-side child of the per-wave subtree builder.
 template <typename T>
 struct SubPending {
-  T bmin[3], bmax[3]; // its AABB, known from the parent's bins
+  T bmin[3], bmax[3]; // its AABB (from the parent's bins, or reduced during the parent's median partition)
+  T cmin[3], cmax[3]; // its centroid bounds (reduced during the parent's partition)
   uint16_t lo, hi, parent;
-  uint16_t flags;     // bit 0: AABB is not known (median split) and must be reduced
+  uint16_t buf;       // which of the two permutation buffers holds [lo, hi)
   uint32_t depth;
 };
 
-// One wave per node of <= kSmall primitives: records in LDS, a 16-bit permutation that is
-// partitioned in place, LDS bin reduction (3 axes x K <= 16 bins, ds_min/ds_max on
-// integer-ordered keys), lane == (axis, bin) prefix/suffix sweeps inside 16-lane groups.
-// The low-side child is processed next (so it is numbered parent + 1, pre-order); the
-// high-side child waits on an LDS stack together with its AABB.
+// Wave-uniform broadcast of lane `src` (an SGPR): v_readlane, no LDS crossbar round trip.
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t x, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)x, src); }
+__device__ __forceinline__ float lane_bcast(float x, int src) {
+  return __builtin_bit_cast(float, lane_bcast(__builtin_bit_cast(uint32_t, x), src));
+}
+__device__ __forceinline__ double lane_bcast(double x, int src) {
+  const unsigned long long v = __builtin_bit_cast(unsigned long long, x);
+  const uint32_t lo = lane_bcast((uint32_t)v, src), hi = lane_bcast((uint32_t)(v >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// All-reduce min / max whose result is wave-uniform: 4 DPP steps leave every lane with its row's value, the four rows
+// are then combined through scalar registers.
+template <typename T>
+__device__ __forceinline__ T wave_min_u(T x) {
+  x = tmin(x, dpp_mov<0xB1>(x, x));
+  x = tmin(x, dpp_mov<0x4E>(x, x));
+  x = tmin(x, dpp_mov<0x141>(x, x));
+  x = tmin(x, dpp_mov<0x140>(x, x));
+  return tmin(tmin(lane_bcast(x, 0), lane_bcast(x, 16)), tmin(lane_bcast(x, 32), lane_bcast(x, 48)));
+}
+template <typename T>
+__device__ __forceinline__ T wave_max_u(T x) {
+  x = tmax(x, dpp_mov<0xB1>(x, x));
+  x = tmax(x, dpp_mov<0x4E>(x, x));
+  x = tmax(x, dpp_mov<0x141>(x, x));
+  x = tmax(x, dpp_mov<0x140>(x, x));
+  return tmax(tmax(lane_bcast(x, 0), lane_bcast(x, 16)), tmax(lane_bcast(x, 32), lane_bcast(x, 48)));
+}
+
+// One wave per node of <= kSmall primitives: records in LDS, a 16-bit permutation ping-ponged between two
+// buffers by the stable partition, LDS bin reduction (3 axes x K <= 16 bins, ds_min/ds_max on integer-ordered
+// keys), lane == (axis, bin) prefix/suffix sweeps inside 16-lane groups.  The low-side child is processed next
+// (so it is numbered parent + 1, pre-order); the high-side child waits on an LDS stack with its AABB and
+// centroid bounds.  A node costs a chain of dependent LDS round trips, not arithmetic, so the chain is kept
+// short: each lane keeps its first element (all of a node of <= 64 primitives) in registers across the binning
+// and partition passes; a child's centroid bounds (and, after a median split, its AABB) are reduced in the
+// parent's partition pass instead of a pass of its own; the bins are reset by the lanes that read them; wave
+// reductions and the winner's broadcast go through DPP and scalar registers.  Two barriers per inner node.
 template <typename T>
 __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t *__restrict__ small_list,
                                                 const PrimRec<T> *__restrict__ recs0,
@@ -1154,18 +1188,30 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
     s_rec[i] = src[i];
     s_perm[0][i] = (uint16_t)i;
   }
+  if (lane < 3 * kSmallBins) { // bins start clean and are handed on clean by their readers
+    const int k = (int)lane / kSmallBins, bq = (int)lane % kSmallBins;
+    s_cnt[k][bq] = 0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      s_bmin[k][bq][d] = Ord<T>::highest();
+      s_bmax[k][bq][d] = Ord<T>::lowest();
+    }
+  }
   Node *out = scratch_nodes + 2 * (size_t)L;
   uint32_t node_count = 0, leaves = 0, deepest = 0, biggest_leaf = 0;
   int sp = 0;
+  const uint32_t leaf_max = min_leaf > 1u ? min_leaf : 1u;
 
   // current node (wave-uniform)
-  uint32_t lo = 0, hi = n_all, depth = task.depth, parent = 0xFFFFu;
-  bool is_high = false, need_box = false;
-  T mn[3], mx[3];
+  uint32_t lo = 0, hi = n_all, depth = task.depth, parent = 0xFFFFu, pb = 0;
+  bool is_high = false;
+  T mn[3], mx[3], cmn[3], cmx[3];
 #pragma unroll
   for (int d = 0; d < 3; d++) {
     mn[d] = task.bmin[d];
     mx[d] = task.bmax[d];
+    cmn[d] = task.cmin[d];
+    cmx[d] = task.cmax[d];
   }
   __syncthreads();
 
@@ -1175,44 +1221,15 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
     deepest = depth > deepest ? depth : deepest;
     if (is_high && lane == 0) out[parent].data[1] = me;
 
-    const bool leaf = n <= (min_leaf > 1u ? min_leaf : 1u) || depth >= max_depth; // nanort.h:1781-1783
-    // centroid bounds (and the AABB after a median split): one pass + wave reduction
-    T cmn[3], cmx[3];
-    if (!leaf || need_box) {
-      T amn[3], amx[3];
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        cmn[d] = amn[d] = Lim<T>::max();
-        cmx[d] = amx[d] = -Lim<T>::max();
-      }
-      for (uint32_t i = lo + lane; i < hi; i += 64u) {
-        const PrimRec<T> &r = s_rec[s_perm[0][i]];
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          cmn[d] = tmin(cmn[d], r.c[d]);
-          cmx[d] = tmax(cmx[d], r.c[d]);
-          if (need_box) {
-            amn[d] = tmin(amn[d], r.bmin[d]);
-            amx[d] = tmax(amx[d], r.bmax[d]);
-          }
-        }
-      }
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        cmn[d] = wave_min<T>(cmn[d]);
-        cmx[d] = wave_max<T>(cmx[d]);
-        if (need_box) {
-          amn[d] = wave_min<T>(amn[d]);
-          amx[d] = wave_max<T>(amx[d]);
-        }
-      }
-      if (need_box) {
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          mn[d] = amn[d];
-          mx[d] = amx[d];
-        }
-      }
+    const bool leaf = n <= leaf_max || depth >= max_depth; // nanort.h:1781-1783
+    // this lane's first element stays in registers for every pass over the node
+    const uint32_t i_first = lo + lane;
+    const bool have = i_first < hi;
+    uint16_t id0 = 0;
+    PrimRec<T> r0;
+    if (have) {
+      id0 = s_perm[pb][i_first];
+      r0 = s_rec[id0];
     }
 
     Node nd;
@@ -1229,26 +1246,16 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
       nd.data[0] = n;
       nd.data[1] = L + lo;
       if (lane == 0) out[me] = nd;
-      for (uint32_t i = lo + lane; i < hi; i += 64u) indices[L + i] = s_rec[s_perm[0][i]].prim;
+      if (have) indices[L + i_first] = r0.prim;
+      for (uint32_t i = i_first + 64u; i < hi; i += 64u) indices[L + i] = s_rec[s_perm[pb][i]].prim;
       leaves++;
       biggest_leaf = n > biggest_leaf ? n : biggest_leaf;
     } else {
       // ---- LDS bin reduction ------------------------------------------------------------------
-      for (int i = lane; i < 3 * kSmallBins; i += 64) {
-        const int k = i / kSmallBins, b = i % kSmallBins;
-        s_cnt[k][b] = 0;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          s_bmin[k][b][d] = Ord<T>::highest();
-          s_bmax[k][b][d] = Ord<T>::lowest();
-        }
-      }
       T sc[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) sc[k] = bin_scale<T>(cmn[k], cmx[k], K);
-      __syncthreads();
-      for (uint32_t i = lo + lane; i < hi; i += 64u) {
-        const PrimRec<T> &r = s_rec[s_perm[0][i]];
+      auto bin_one = [&](const PrimRec<T> &r) {
         U emin[3], emax[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) {
@@ -1265,7 +1272,9 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
             atomicMax(&s_bmax[k][b][d], emax[d]);
           }
         }
-      }
+      };
+      if (have) bin_one(r0);
+      for (uint32_t i = i_first + 64u; i < hi; i += 64u) bin_one(s_rec[s_perm[pb][i]]);
       __syncthreads();
 
       // ---- lane == (axis, bin): sweeps inside 16-lane groups ----------------------------------------
@@ -1285,6 +1294,12 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
             bmn[d] = Ord<T>::dec(s_bmin[ax][bn][d]);
             bmx[d] = Ord<T>::dec(s_bmax[ax][bn][d]);
           }
+          s_cnt[ax][bn] = 0; // read: hand the bin on clean (made visible by the barrier after the partition)
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            s_bmin[ax][bn][d] = Ord<T>::highest();
+            s_bmax[ax][bn][d] = Ord<T>::lowest();
+          }
         }
       }
       uint32_t pc = cnt, sc_n = cnt; // inclusive prefix / suffix inside the 16-lane row (DPP row shifts)
@@ -1303,39 +1318,43 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
       T cost = Lim<T>::inf();
       if (ax < 3 && bn >= 1 && bn < K && nl > 0 && sc_n > 0)
         cost = T(nl) * half_area<T>(lmn, lmx) + T(sc_n) * half_area<T>(smn, smx);
-      T bc = cost;
-      unsigned who = lane; // lane order == (axis, bin): ties -> lowest axis, then lowest bin
-      for (int off = 32; off > 0; off >>= 1) {
-        const T oc = __shfl_xor(bc, off);
-        const unsigned ow = __shfl_xor(who, off);
-        if (oc < bc || (oc == bc && ow < who)) {
-          bc = oc;
-          who = ow;
-        }
-      }
+      if (!(cost == cost)) cost = Lim<T>::inf(); // a NaN cost never wins
+      // argmin: the smallest cost, ties -> lowest lane; lane order == (axis, bin): lowest axis, then lowest bin
+      const T bc = wave_min_u<T>(cost);
+      const int who = (int)__builtin_ctzll(__ballot(cost == bc));
       int axis = 0;
       uint32_t split_bin = kMedian, nleft = n >> 1;
-      T cl[3], ch[3], rl[3], rh[3]; // children AABBs (valid unless median)
+      T cl[3], ch[3], rl[3], rh[3]; // children AABBs
       // a pathological chain of lopsided SAH splits could outgrow the LDS stack: past kSubStackSafe
       // pending nodes fall back to balanced object-median splits (at most log2(kSmall) more levels)
       if (bc < Lim<T>::inf() && sp < kSubStackSafe) {
-        axis = (int)who >> 4;
-        split_bin = who & 15u;
-        nleft = __shfl(nl, who);
+        axis = who >> 4;
+        split_bin = (uint32_t)who & 15u;
+        nleft = lane_bcast(nl, who);
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          cl[d] = __shfl(lmn[d], who);
-          ch[d] = __shfl(lmx[d], who);
-          rl[d] = __shfl(smn[d], who);
-          rh[d] = __shfl(smx[d], who);
+          cl[d] = lane_bcast(lmn[d], who);
+          ch[d] = lane_bcast(lmx[d], who);
+          rl[d] = lane_bcast(smn[d], who);
+          rh[d] = lane_bcast(smx[d], who);
         }
       } else {
 #pragma unroll
-        for (int d = 0; d < 3; d++) cl[d] = ch[d] = rl[d] = rh[d] = T(0);
+        for (int d = 0; d < 3; d++) {
+          cl[d] = rl[d] = Lim<T>::max();
+          ch[d] = rh[d] = -Lim<T>::max();
+        }
       }
       const bool median = split_bin == kMedian;
 
-      // ---- stable partition of s_perm[0][lo, hi) through s_perm[1] -----------------------------------
+      // ---- stable partition of s_perm[pb][lo, hi) into s_perm[1 - pb], reducing the children's centroid bounds
+      //      (and, after a median split, their AABBs) on the way ----------------------------------------------
+      T ccl[3], cch[3], crl[3], crh[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        ccl[d] = crl[d] = Lim<T>::max();
+        cch[d] = crh[d] = -Lim<T>::max();
+      }
       {
         const T clo = axis == 0 ? cmn[0] : (axis == 1 ? cmn[1] : cmn[2]);
         const T scl = axis == 0 ? sc[0] : (axis == 1 ? sc[1] : sc[2]);
@@ -1343,14 +1362,17 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
         for (uint32_t i0 = lo; i0 < hi; i0 += 64u) {
           const uint32_t i = i0 + lane;
           const bool valid = i < hi;
-          uint16_t id = 0;
+          uint16_t id = id0;
+          PrimRec<T> r = r0;
+          if (valid && i0 != lo) {
+            id = s_perm[pb][i];
+            r = s_rec[id];
+          }
           bool left = false;
           if (valid) {
-            id = s_perm[0][i];
             if (median) {
               left = (i - lo) < nleft;
             } else {
-              const PrimRec<T> &r = s_rec[id];
               const T c = axis == 0 ? r.c[0] : (axis == 1 ? r.c[1] : r.c[2]);
               left = (uint32_t)bin_of<T>(c, clo, scl, K) < split_bin;
             }
@@ -1360,13 +1382,49 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
           if (valid) {
             const uint32_t d = left ? lo + run_l + (uint32_t)__builtin_popcountll(bl & lt)
                                     : lo + nleft + run_r + (uint32_t)__builtin_popcountll(br & lt);
-            s_perm[1][d] = id;
+            s_perm[1 - pb][d] = id;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              if (left) {
+                ccl[k] = tmin(ccl[k], r.c[k]);
+                cch[k] = tmax(cch[k], r.c[k]);
+              } else {
+                crl[k] = tmin(crl[k], r.c[k]);
+                crh[k] = tmax(crh[k], r.c[k]);
+              }
+              if (median) {
+                if (left) {
+                  cl[k] = tmin(cl[k], r.bmin[k]);
+                  ch[k] = tmax(ch[k], r.bmax[k]);
+                } else {
+                  rl[k] = tmin(rl[k], r.bmin[k]);
+                  rh[k] = tmax(rh[k], r.bmax[k]);
+                }
+              }
+            }
           }
           run_l += (uint32_t)__builtin_popcountll(bl);
           run_r += (uint32_t)__builtin_popcountll(br);
         }
-        __syncthreads();
-        for (uint32_t i = lo + lane; i < hi; i += 64u) s_perm[0][i] = s_perm[1][i];
+      }
+      // a child that becomes a leaf needs no centroid bounds
+      const bool low_leaf = nleft <= leaf_max || depth + 1 >= max_depth, high_leaf = n - nleft <= leaf_max || depth + 1 >= max_depth;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        if (!low_leaf) {
+          ccl[d] = wave_min_u<T>(ccl[d]);
+          cch[d] = wave_max_u<T>(cch[d]);
+        }
+        if (!high_leaf) {
+          crl[d] = wave_min_u<T>(crl[d]);
+          crh[d] = wave_max_u<T>(crh[d]);
+        }
+        if (median) {
+          cl[d] = wave_min_u<T>(cl[d]);
+          ch[d] = wave_max_u<T>(ch[d]);
+          rl[d] = wave_min_u<T>(rl[d]);
+          rh[d] = wave_max_u<T>(rh[d]);
+        }
       }
 
       nd.flag = 0;
@@ -1380,11 +1438,13 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
         for (int d = 0; d < 3; d++) {
           e.bmin[d] = rl[d];
           e.bmax[d] = rh[d];
+          e.cmin[d] = crl[d];
+          e.cmax[d] = crh[d];
         }
         e.lo = (uint16_t)(lo + nleft);
         e.hi = (uint16_t)hi;
         e.parent = (uint16_t)me;
-        e.flags = median ? 1 : 0;
+        e.buf = (uint16_t)(1u - pb);
         e.depth = depth + 1;
       }
       sp++;
@@ -1393,14 +1453,16 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
       depth = depth + 1;
       parent = me;
       is_high = false;
-      need_box = median;
+      pb = 1u - pb;
 #pragma unroll
       for (int d = 0; d < 3; d++) {
         mn[d] = cl[d];
         mx[d] = ch[d];
+        cmn[d] = ccl[d];
+        cmx[d] = cch[d];
       }
       descend = true;
-      __syncthreads();
+      __syncthreads(); // the permutation, the reset bins and the stack entry are visible to the next node
     }
     if (!descend) {
       if (sp == 0) break;
@@ -1410,12 +1472,14 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
       hi = e.hi;
       depth = e.depth;
       parent = e.parent;
+      pb = e.buf;
       is_high = true;
-      need_box = (e.flags & 1) != 0;
 #pragma unroll
       for (int d = 0; d < 3; d++) {
         mn[d] = e.bmin[d];
         mx[d] = e.bmax[d];
+        cmn[d] = e.cmin[d];
+        cmx[d] = e.cmax[d];
       }
     }
   }
