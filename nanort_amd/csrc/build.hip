@@ -1136,23 +1136,76 @@ __device__ __forceinline__ double lane_bcast(double x, int src) {
   const uint32_t lo = lane_bcast((uint32_t)v, src), hi = lane_bcast((uint32_t)(v >> 32), src);
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-// All-reduce min / max whose result is wave-uniform: 4 DPP steps leave every lane with its row's value, the four rows
-// are then combined through scalar registers.
+__device__ __forceinline__ unsigned long long lane_bcast(unsigned long long v, int src) {
+  const uint32_t lo = lane_bcast((uint32_t)v, src), hi = lane_bcast((uint32_t)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_mov(unsigned long long old, unsigned long long src) {
+  const uint32_t lo = dpp_u32<CTRL>((uint32_t)old, (uint32_t)src), hi = dpp_u32<CTRL>((uint32_t)(old >> 32), (uint32_t)(src >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+// The subtree kernel is bound by VALU issue (a wave instruction costs the same for 5 active lanes as for 64), so its
+// scans and reductions run on the ORDER-PRESERVING INTEGER IMAGES of the values (Ord<T>): for fp32 the compiler then
+// folds each DPP move into the v_min_u32 / v_max_u32 that consumes it — one instruction per scan step and value where
+// the float form (compare + select on a separately moved operand) takes three.
+template <typename U>
+__device__ __forceinline__ U umin_(U a, U b) {
+  return a < b ? a : b;
+}
+template <typename U>
+__device__ __forceinline__ U umax_(U a, U b) {
+  return a > b ? a : b;
+}
+template <typename T, int CTRL>
+__device__ __forceinline__ void row_scan_step_e(uint32_t &cnt, typename Ord<T>::U mn[3], typename Ord<T>::U mx[3]) {
+  cnt += dpp_mov<CTRL>(0u, cnt);
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    mn[d] = umin_(mn[d], dpp_mov<CTRL>(Ord<T>::highest(), mn[d]));
+    mx[d] = umax_(mx[d], dpp_mov<CTRL>(Ord<T>::lowest(), mx[d]));
+  }
+}
+template <typename T>
+__device__ __forceinline__ void row_prefix_e(uint32_t &cnt, typename Ord<T>::U mn[3], typename Ord<T>::U mx[3]) {
+  row_scan_step_e<T, 0x111>(cnt, mn, mx);
+  row_scan_step_e<T, 0x112>(cnt, mn, mx);
+  row_scan_step_e<T, 0x114>(cnt, mn, mx);
+  row_scan_step_e<T, 0x118>(cnt, mn, mx);
+}
+template <typename T>
+__device__ __forceinline__ void row_suffix_e(uint32_t &cnt, typename Ord<T>::U mn[3], typename Ord<T>::U mx[3]) {
+  row_scan_step_e<T, 0x101>(cnt, mn, mx);
+  row_scan_step_e<T, 0x102>(cnt, mn, mx);
+  row_scan_step_e<T, 0x104>(cnt, mn, mx);
+  row_scan_step_e<T, 0x108>(cnt, mn, mx);
+}
+// All-reduce min / max with a wave-uniform result: 4 DPP steps leave every lane with its row's value (quad_perm
+// [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror; `old` = the identity so that the move folds into the min / max),
+// the four rows are combined through scalar registers.
+template <typename U>
+__device__ __forceinline__ U wave_umin(U x) {
+  x = umin_(x, dpp_mov<0xB1>((U)~(U)0, x));
+  x = umin_(x, dpp_mov<0x4E>((U)~(U)0, x));
+  x = umin_(x, dpp_mov<0x141>((U)~(U)0, x));
+  x = umin_(x, dpp_mov<0x140>((U)~(U)0, x));
+  return umin_(umin_(lane_bcast(x, 0), lane_bcast(x, 16)), umin_(lane_bcast(x, 32), lane_bcast(x, 48)));
+}
+template <typename U>
+__device__ __forceinline__ U wave_umax(U x) {
+  x = umax_(x, dpp_mov<0xB1>((U)0, x));
+  x = umax_(x, dpp_mov<0x4E>((U)0, x));
+  x = umax_(x, dpp_mov<0x141>((U)0, x));
+  x = umax_(x, dpp_mov<0x140>((U)0, x));
+  return umax_(umax_(lane_bcast(x, 0), lane_bcast(x, 16)), umax_(lane_bcast(x, 32), lane_bcast(x, 48)));
+}
 template <typename T>
 __device__ __forceinline__ T wave_min_u(T x) {
-  x = tmin(x, dpp_mov<0xB1>(x, x));
-  x = tmin(x, dpp_mov<0x4E>(x, x));
-  x = tmin(x, dpp_mov<0x141>(x, x));
-  x = tmin(x, dpp_mov<0x140>(x, x));
-  return tmin(tmin(lane_bcast(x, 0), lane_bcast(x, 16)), tmin(lane_bcast(x, 32), lane_bcast(x, 48)));
+  return Ord<T>::dec(wave_umin<typename Ord<T>::U>(Ord<T>::enc(x)));
 }
 template <typename T>
 __device__ __forceinline__ T wave_max_u(T x) {
-  x = tmax(x, dpp_mov<0xB1>(x, x));
-  x = tmax(x, dpp_mov<0x4E>(x, x));
-  x = tmax(x, dpp_mov<0x141>(x, x));
-  x = tmax(x, dpp_mov<0x140>(x, x));
-  return tmax(tmax(lane_bcast(x, 0), lane_bcast(x, 16)), tmax(lane_bcast(x, 32), lane_bcast(x, 48)));
+  return Ord<T>::dec(wave_umax<typename Ord<T>::U>(Ord<T>::enc(x)));
 }
 
 // One wave per node of <= kSmall primitives: records in LDS, a 16-bit permutation ping-ponged between two
@@ -1277,22 +1330,22 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
       for (uint32_t i = i_first + 64u; i < hi; i += 64u) bin_one(s_rec[s_perm[pb][i]]);
       __syncthreads();
 
-      // ---- lane == (axis, bin): sweeps inside 16-lane groups ----------------------------------------
+      // ---- lane == (axis, bin): sweeps inside 16-lane groups, on the integer images ----------------------
       const int ax = (int)lane >> 4, bn = (int)lane & 15;
       uint32_t cnt = 0;
-      T bmn[3], bmx[3];
+      U pmn[3], pmx[3];
 #pragma unroll
       for (int d = 0; d < 3; d++) {
-        bmn[d] = Lim<T>::max();
-        bmx[d] = -Lim<T>::max();
+        pmn[d] = Ord<T>::highest();
+        pmx[d] = Ord<T>::lowest();
       }
       if (ax < 3 && bn < K) {
         cnt = s_cnt[ax][bn];
         if (cnt) {
 #pragma unroll
           for (int d = 0; d < 3; d++) {
-            bmn[d] = Ord<T>::dec(s_bmin[ax][bn][d]);
-            bmx[d] = Ord<T>::dec(s_bmax[ax][bn][d]);
+            pmn[d] = s_bmin[ax][bn][d];
+            pmx[d] = s_bmax[ax][bn][d];
           }
           s_cnt[ax][bn] = 0; // read: hand the bin on clean (made visible by the barrier after the partition)
 #pragma unroll
@@ -1303,40 +1356,50 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
         }
       }
       uint32_t pc = cnt, sc_n = cnt; // inclusive prefix / suffix inside the 16-lane row (DPP row shifts)
-      T pmn[3] = {bmn[0], bmn[1], bmn[2]}, pmx[3] = {bmx[0], bmx[1], bmx[2]};
-      T smn[3] = {bmn[0], bmn[1], bmn[2]}, smx[3] = {bmx[0], bmx[1], bmx[2]};
-      row_prefix<T>(pc, pmn, pmx);
-      row_suffix<T>(sc_n, smn, smx);
+      U smn[3] = {pmn[0], pmn[1], pmn[2]}, smx[3] = {pmx[0], pmx[1], pmx[2]};
+      row_prefix_e<T>(pc, pmn, pmx);
+      row_suffix_e<T>(sc_n, smn, smx);
       // candidate (ax, s = bn), s in 1..K-1: low side = bins [0, s), high side = bins [s, K)
       const uint32_t nl = dpp_mov<0x111>(0u, pc);
-      T lmn[3], lmx[3];
+      U lmn[3], lmx[3];
 #pragma unroll
       for (int d = 0; d < 3; d++) {
-        lmn[d] = dpp_mov<0x111>(Lim<T>::max(), pmn[d]);
-        lmx[d] = dpp_mov<0x111>(-Lim<T>::max(), pmx[d]);
+        lmn[d] = dpp_mov<0x111>(Ord<T>::highest(), pmn[d]);
+        lmx[d] = dpp_mov<0x111>(Ord<T>::lowest(), pmx[d]);
       }
       T cost = Lim<T>::inf();
-      if (ax < 3 && bn >= 1 && bn < K && nl > 0 && sc_n > 0)
-        cost = T(nl) * half_area<T>(lmn, lmx) + T(sc_n) * half_area<T>(smn, smx);
+      if (ax < 3 && bn >= 1 && bn < K && nl > 0 && sc_n > 0) {
+        T a0[3], a1[3], b0[3], b1[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          a0[d] = Ord<T>::dec(lmn[d]);
+          a1[d] = Ord<T>::dec(lmx[d]);
+          b0[d] = Ord<T>::dec(smn[d]);
+          b1[d] = Ord<T>::dec(smx[d]);
+        }
+        cost = T(nl) * half_area<T>(a0, a1) + T(sc_n) * half_area<T>(b0, b1);
+      }
       if (!(cost == cost)) cost = Lim<T>::inf(); // a NaN cost never wins
       // argmin: the smallest cost, ties -> lowest lane; lane order == (axis, bin): lowest axis, then lowest bin
-      const T bc = wave_min_u<T>(cost);
-      const int who = (int)__builtin_ctzll(__ballot(cost == bc));
+      const U ecost = Ord<T>::enc(cost);
+      const U ebest = wave_umin<U>(ecost);
+      const int who = (int)__builtin_ctzll(__ballot(ecost == ebest));
+      const bool found = ebest < Ord<T>::enc(Lim<T>::inf());
       int axis = 0;
       uint32_t split_bin = kMedian, nleft = n >> 1;
       T cl[3], ch[3], rl[3], rh[3]; // children AABBs
       // a pathological chain of lopsided SAH splits could outgrow the LDS stack: past kSubStackSafe
       // pending nodes fall back to balanced object-median splits (at most log2(kSmall) more levels)
-      if (bc < Lim<T>::inf() && sp < kSubStackSafe) {
+      if (found && sp < kSubStackSafe) {
         axis = who >> 4;
         split_bin = (uint32_t)who & 15u;
         nleft = lane_bcast(nl, who);
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          cl[d] = lane_bcast(lmn[d], who);
-          ch[d] = lane_bcast(lmx[d], who);
-          rl[d] = lane_bcast(smn[d], who);
-          rh[d] = lane_bcast(smx[d], who);
+          cl[d] = Ord<T>::dec(lane_bcast(lmn[d], who));
+          ch[d] = Ord<T>::dec(lane_bcast(lmx[d], who));
+          rl[d] = Ord<T>::dec(lane_bcast(smn[d], who));
+          rh[d] = Ord<T>::dec(lane_bcast(smx[d], who));
         }
       } else {
 #pragma unroll
