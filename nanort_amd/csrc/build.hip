@@ -269,6 +269,134 @@ __device__ __forceinline__ T wave_max(T x) {
 // ---------------------------------------------------------------------------
 // primitive records + scene bounds
 // ---------------------------------------------------------------------------
+// Wave-uniform broadcast of lane `src` (an SGPR): v_readlane, no LDS crossbar round trip.
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t x, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)x, src); }
+__device__ __forceinline__ float lane_bcast(float x, int src) {
+  return __builtin_bit_cast(float, lane_bcast(__builtin_bit_cast(uint32_t, x), src));
+}
+__device__ __forceinline__ double lane_bcast(double x, int src) {
+  const unsigned long long v = __builtin_bit_cast(unsigned long long, x);
+  const uint32_t lo = lane_bcast((uint32_t)v, src), hi = lane_bcast((uint32_t)(v >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned long long lane_bcast(unsigned long long v, int src) {
+  const uint32_t lo = lane_bcast((uint32_t)v, src), hi = lane_bcast((uint32_t)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_mov(unsigned long long old, unsigned long long src) {
+  const uint32_t lo = dpp_u32<CTRL>((uint32_t)old, (uint32_t)src), hi = dpp_u32<CTRL>((uint32_t)(old >> 32), (uint32_t)(src >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+// The subtree kernel is bound by VALU issue (a wave instruction costs the same for 5 active lanes as for 64), so its
+// scans and reductions run on the ORDER-PRESERVING INTEGER IMAGES of the values (Ord<T>): for fp32 the compiler then
+// folds each DPP move into the v_min_u32 / v_max_u32 that consumes it — one instruction per scan step and value where
+// the float form (compare + select on a separately moved operand) takes three.
+template <typename U>
+__device__ __forceinline__ U umin_(U a, U b) {
+  return a < b ? a : b;
+}
+template <typename U>
+__device__ __forceinline__ U umax_(U a, U b) {
+  return a > b ? a : b;
+}
+template <typename T, int CTRL>
+__device__ __forceinline__ void row_scan_step_e(uint32_t &cnt, typename Ord<T>::U mn[3], typename Ord<T>::U mx[3]) {
+  cnt += dpp_mov<CTRL>(0u, cnt);
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    mn[d] = umin_(mn[d], dpp_mov<CTRL>(Ord<T>::highest(), mn[d]));
+    mx[d] = umax_(mx[d], dpp_mov<CTRL>(Ord<T>::lowest(), mx[d]));
+  }
+}
+template <typename T>
+__device__ __forceinline__ void row_prefix_e(uint32_t &cnt, typename Ord<T>::U mn[3], typename Ord<T>::U mx[3]) {
+  row_scan_step_e<T, 0x111>(cnt, mn, mx);
+  row_scan_step_e<T, 0x112>(cnt, mn, mx);
+  row_scan_step_e<T, 0x114>(cnt, mn, mx);
+  row_scan_step_e<T, 0x118>(cnt, mn, mx);
+}
+template <typename T>
+__device__ __forceinline__ void row_suffix_e(uint32_t &cnt, typename Ord<T>::U mn[3], typename Ord<T>::U mx[3]) {
+  row_scan_step_e<T, 0x101>(cnt, mn, mx);
+  row_scan_step_e<T, 0x102>(cnt, mn, mx);
+  row_scan_step_e<T, 0x104>(cnt, mn, mx);
+  row_scan_step_e<T, 0x108>(cnt, mn, mx);
+}
+// All-reduce min / max with a wave-uniform result: 4 DPP steps leave every lane with its row's value (quad_perm
+// [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror; `old` = the identity so that the move folds into the min / max),
+// the four rows are combined through scalar registers.
+template <typename U>
+__device__ __forceinline__ U wave_umin(U x) {
+  x = umin_(x, dpp_mov<0xB1>((U)~(U)0, x));
+  x = umin_(x, dpp_mov<0x4E>((U)~(U)0, x));
+  x = umin_(x, dpp_mov<0x141>((U)~(U)0, x));
+  x = umin_(x, dpp_mov<0x140>((U)~(U)0, x));
+  return umin_(umin_(lane_bcast(x, 0), lane_bcast(x, 16)), umin_(lane_bcast(x, 32), lane_bcast(x, 48)));
+}
+template <typename U>
+__device__ __forceinline__ U wave_umax(U x) {
+  x = umax_(x, dpp_mov<0xB1>((U)0, x));
+  x = umax_(x, dpp_mov<0x4E>((U)0, x));
+  x = umax_(x, dpp_mov<0x141>((U)0, x));
+  x = umax_(x, dpp_mov<0x140>((U)0, x));
+  return umax_(umax_(lane_bcast(x, 0), lane_bcast(x, 16)), umax_(lane_bcast(x, 32), lane_bcast(x, 48)));
+}
+template <typename T>
+__device__ __forceinline__ T wave_min_u(T x) {
+  return Ord<T>::dec(wave_umin<typename Ord<T>::U>(Ord<T>::enc(x)));
+}
+template <typename T>
+__device__ __forceinline__ T wave_max_u(T x) {
+  return Ord<T>::dec(wave_umax<typename Ord<T>::U>(Ord<T>::enc(x)));
+}
+
+// Inclusive scans over all 64 lanes (k_split: lane == bin, up to 64 bins): the row scans above, then each row takes
+// the totals of the rows before (prefix) / after (suffix) it, which travel through scalar registers.
+template <typename U, bool MIN>
+__device__ __forceinline__ U row_carry(U x, U t_a, U t_b, U t_c, unsigned row, bool prefix) {
+  // prefix: t_a, t_b, t_c = totals of rows 0, 1, 2;  suffix: totals of rows 1, 2, 3
+  const U id = MIN ? (U) ~(U)0 : (U)0;
+  auto op = [](U p, U q) { return MIN ? umin_(p, q) : umax_(p, q); };
+  U c;
+  if (prefix)
+    c = row == 0 ? id : (row == 1 ? t_a : (row == 2 ? op(t_a, t_b) : op(op(t_a, t_b), t_c)));
+  else
+    c = row == 3 ? id : (row == 2 ? t_c : (row == 1 ? op(t_b, t_c) : op(op(t_a, t_b), t_c)));
+  return op(x, c);
+}
+template <typename T>
+__device__ __forceinline__ void wave_prefix_e(uint32_t &cnt, typename Ord<T>::U mn[3], typename Ord<T>::U mx[3], unsigned lane) {
+  typedef typename Ord<T>::U U;
+  row_prefix_e<T>(cnt, mn, mx);
+  const unsigned row = lane >> 4;
+  const uint32_t c0 = lane_bcast(cnt, 15), c1 = lane_bcast(cnt, 31), c2 = lane_bcast(cnt, 47);
+  cnt += row == 0 ? 0u : (row == 1 ? c0 : (row == 2 ? c0 + c1 : c0 + c1 + c2));
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    mn[d] = row_carry<U, true>(mn[d], lane_bcast(mn[d], 15), lane_bcast(mn[d], 31), lane_bcast(mn[d], 47), row, true);
+    mx[d] = row_carry<U, false>(mx[d], lane_bcast(mx[d], 15), lane_bcast(mx[d], 31), lane_bcast(mx[d], 47), row, true);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void wave_suffix_e(uint32_t &cnt, typename Ord<T>::U mn[3], typename Ord<T>::U mx[3], unsigned lane) {
+  typedef typename Ord<T>::U U;
+  row_suffix_e<T>(cnt, mn, mx);
+  const unsigned row = lane >> 4;
+  const uint32_t c1 = lane_bcast(cnt, 16), c2 = lane_bcast(cnt, 32), c3 = lane_bcast(cnt, 48);
+  cnt += row == 3 ? 0u : (row == 2 ? c3 : (row == 1 ? c2 + c3 : c1 + c2 + c3));
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    mn[d] = row_carry<U, true>(mn[d], lane_bcast(mn[d], 16), lane_bcast(mn[d], 32), lane_bcast(mn[d], 48), row, false);
+    mx[d] = row_carry<U, false>(mx[d], lane_bcast(mx[d], 16), lane_bcast(mx[d], 32), lane_bcast(mx[d], 48), row, false);
+  }
+}
+// value of lane - 1 (lane 0: `first`): DPP wave_shr:1
+template <typename U>
+__device__ __forceinline__ U wave_shr1(U first, U x) {
+  return dpp_mov<0x138>(first, x);
+}
+
 template <typename E>
 struct __attribute__((packed, aligned(4))) Vec3Of { // three consecutive elements of a tight xyz / ijk array (element-aligned only)
   E x, y, z;
@@ -859,94 +987,57 @@ __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *_
   T best_cost = Lim<T>::inf();
   int best_axis = 0;
   uint32_t best_bin = kMedian, best_nl = 0;
+  typedef typename Ord<T>::U U;
   for (int k = 0; k < 3; k++) {
+    // scans on the integer images (see row_scan_step_e): DPP + scalar registers, no LDS crossbar
     uint32_t cnt = 0;
-    T mn[3], mx[3];
+    U pmn[3], pmx[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-      mn[d] = Lim<T>::max();
-      mx[d] = -Lim<T>::max();
+      pmn[d] = Ord<T>::highest();
+      pmx[d] = Ord<T>::lowest();
     }
     if ((int)lane < K) {
       cnt = g.count[k][lane];
       if (cnt) {
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          mn[d] = Ord<T>::dec(g.bmin[k][lane][d]);
-          mx[d] = Ord<T>::dec(g.bmax[k][lane][d]);
+          pmn[d] = g.bmin[k][lane][d];
+          pmx[d] = g.bmax[k][lane][d];
         }
       }
     }
     clean_bins<T>(&g, k, lane); // consumed: leave the slot clean for the next level (see clean_bins)
     if (a + num_active < max_active) clean_bins<T>(&gbins[a + num_active], k, lane);
-    // inclusive prefix over lanes 0..lane
-    uint32_t pc = cnt;
-    T pmn[3] = {mn[0], mn[1], mn[2]}, pmx[3] = {mx[0], mx[1], mx[2]};
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t tc = __shfl_up(pc, off);
-      T tmn[3], tmx[3];
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        tmn[d] = __shfl_up(pmn[d], off);
-        tmx[d] = __shfl_up(pmx[d], off);
-      }
-      if (lane >= (unsigned)off) {
-        pc += tc;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          pmn[d] = tmin(pmn[d], tmn[d]);
-          pmx[d] = tmax(pmx[d], tmx[d]);
-        }
-      }
-    }
-    // inclusive suffix over lanes lane..63
-    uint32_t sc = cnt;
-    T smn[3] = {mn[0], mn[1], mn[2]}, smx[3] = {mx[0], mx[1], mx[2]};
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t tc = __shfl_down(sc, off);
-      T tmn[3], tmx[3];
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        tmn[d] = __shfl_down(smn[d], off);
-        tmx[d] = __shfl_down(smx[d], off);
-      }
-      if (lane + (unsigned)off < 64u) {
-        sc += tc;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          smn[d] = tmin(smn[d], tmn[d]);
-          smx[d] = tmax(smx[d], tmx[d]);
-        }
-      }
-    }
+    uint32_t pc = cnt, sc = cnt;
+    U smn[3] = {pmn[0], pmn[1], pmn[2]}, smx[3] = {pmx[0], pmx[1], pmx[2]};
+    wave_prefix_e<T>(pc, pmn, pmx, lane); // inclusive over lanes 0..lane
+    wave_suffix_e<T>(sc, smn, smx, lane); // inclusive over lanes lane..63
     // candidate s == lane (1..K-1): left = bins [0, s), right = bins [s, K)
-    const uint32_t nl = __shfl_up(pc, 1);
-    T lmn[3], lmx[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-      lmn[d] = __shfl_up(pmn[d], 1);
-      lmx[d] = __shfl_up(pmx[d], 1);
-    }
+    const uint32_t nl = wave_shr1<uint32_t>(0u, pc);
     T cost = Lim<T>::inf();
-    if (lane >= 1 && (int)lane < K && nl > 0 && sc > 0) {
-      cost = T(nl) * half_area<T>(lmn, lmx) + T(sc) * half_area<T>(smn, smx);
-    }
-    // wave argmin, ties -> lowest lane
-    T c = cost;
-    unsigned who = lane;
-    for (int off = 32; off > 0; off >>= 1) {
-      const T oc = __shfl_xor(c, off);
-      const unsigned ow = __shfl_xor(who, off);
-      if (oc < c || (oc == c && ow < who)) {
-        c = oc;
-        who = ow;
+    {
+      T lmn[3], lmx[3], rmn[3], rmx[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        lmn[d] = Ord<T>::dec(wave_shr1<U>(Ord<T>::highest(), pmn[d]));
+        lmx[d] = Ord<T>::dec(wave_shr1<U>(Ord<T>::lowest(), pmx[d]));
+        rmn[d] = Ord<T>::dec(smn[d]);
+        rmx[d] = Ord<T>::dec(smx[d]);
       }
+      if (lane >= 1 && (int)lane < K && nl > 0 && sc > 0) cost = T(nl) * half_area<T>(lmn, lmx) + T(sc) * half_area<T>(rmn, rmx);
     }
+    if (!(cost == cost)) cost = Lim<T>::inf(); // a NaN cost never wins
+    // wave argmin, ties -> lowest lane
+    const U ecost = Ord<T>::enc(cost);
+    const U ebest = wave_umin<U>(ecost);
+    const T c = Ord<T>::dec(ebest);
+    const int who = (int)__builtin_ctzll(__ballot(ecost == ebest));
     if (c < best_cost) { // ties -> lowest axis
       best_cost = c;
       best_axis = k;
-      best_bin = who;
-      best_nl = __shfl(nl, who);
+      best_bin = (uint32_t)who;
+      best_nl = lane_bcast(nl, who);
     }
   }
   const uint32_t n = nd.r - nd.l;
@@ -1125,88 +1216,6 @@ struct SubPending {
   uint16_t buf;       // which of the two permutation buffers holds [lo, hi)
   uint32_t depth;
 };
-
-// Wave-uniform broadcast of lane `src` (an SGPR): v_readlane, no LDS crossbar round trip.
-__device__ __forceinline__ uint32_t lane_bcast(uint32_t x, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)x, src); }
-__device__ __forceinline__ float lane_bcast(float x, int src) {
-  return __builtin_bit_cast(float, lane_bcast(__builtin_bit_cast(uint32_t, x), src));
-}
-__device__ __forceinline__ double lane_bcast(double x, int src) {
-  const unsigned long long v = __builtin_bit_cast(unsigned long long, x);
-  const uint32_t lo = lane_bcast((uint32_t)v, src), hi = lane_bcast((uint32_t)(v >> 32), src);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ unsigned long long lane_bcast(unsigned long long v, int src) {
-  const uint32_t lo = lane_bcast((uint32_t)v, src), hi = lane_bcast((uint32_t)(v >> 32), src);
-  return ((unsigned long long)hi << 32) | lo;
-}
-template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_mov(unsigned long long old, unsigned long long src) {
-  const uint32_t lo = dpp_u32<CTRL>((uint32_t)old, (uint32_t)src), hi = dpp_u32<CTRL>((uint32_t)(old >> 32), (uint32_t)(src >> 32));
-  return ((unsigned long long)hi << 32) | lo;
-}
-// The subtree kernel is bound by VALU issue (a wave instruction costs the same for 5 active lanes as for 64), so its
-// scans and reductions run on the ORDER-PRESERVING INTEGER IMAGES of the values (Ord<T>): for fp32 the compiler then
-// folds each DPP move into the v_min_u32 / v_max_u32 that consumes it — one instruction per scan step and value where
-// the float form (compare + select on a separately moved operand) takes three.
-template <typename U>
-__device__ __forceinline__ U umin_(U a, U b) {
-  return a < b ? a : b;
-}
-template <typename U>
-__device__ __forceinline__ U umax_(U a, U b) {
-  return a > b ? a : b;
-}
-template <typename T, int CTRL>
-__device__ __forceinline__ void row_scan_step_e(uint32_t &cnt, typename Ord<T>::U mn[3], typename Ord<T>::U mx[3]) {
-  cnt += dpp_mov<CTRL>(0u, cnt);
-#pragma unroll
-  for (int d = 0; d < 3; d++) {
-    mn[d] = umin_(mn[d], dpp_mov<CTRL>(Ord<T>::highest(), mn[d]));
-    mx[d] = umax_(mx[d], dpp_mov<CTRL>(Ord<T>::lowest(), mx[d]));
-  }
-}
-template <typename T>
-__device__ __forceinline__ void row_prefix_e(uint32_t &cnt, typename Ord<T>::U mn[3], typename Ord<T>::U mx[3]) {
-  row_scan_step_e<T, 0x111>(cnt, mn, mx);
-  row_scan_step_e<T, 0x112>(cnt, mn, mx);
-  row_scan_step_e<T, 0x114>(cnt, mn, mx);
-  row_scan_step_e<T, 0x118>(cnt, mn, mx);
-}
-template <typename T>
-__device__ __forceinline__ void row_suffix_e(uint32_t &cnt, typename Ord<T>::U mn[3], typename Ord<T>::U mx[3]) {
-  row_scan_step_e<T, 0x101>(cnt, mn, mx);
-  row_scan_step_e<T, 0x102>(cnt, mn, mx);
-  row_scan_step_e<T, 0x104>(cnt, mn, mx);
-  row_scan_step_e<T, 0x108>(cnt, mn, mx);
-}
-// All-reduce min / max with a wave-uniform result: 4 DPP steps leave every lane with its row's value (quad_perm
-// [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror; `old` = the identity so that the move folds into the min / max),
-// the four rows are combined through scalar registers.
-template <typename U>
-__device__ __forceinline__ U wave_umin(U x) {
-  x = umin_(x, dpp_mov<0xB1>((U)~(U)0, x));
-  x = umin_(x, dpp_mov<0x4E>((U)~(U)0, x));
-  x = umin_(x, dpp_mov<0x141>((U)~(U)0, x));
-  x = umin_(x, dpp_mov<0x140>((U)~(U)0, x));
-  return umin_(umin_(lane_bcast(x, 0), lane_bcast(x, 16)), umin_(lane_bcast(x, 32), lane_bcast(x, 48)));
-}
-template <typename U>
-__device__ __forceinline__ U wave_umax(U x) {
-  x = umax_(x, dpp_mov<0xB1>((U)0, x));
-  x = umax_(x, dpp_mov<0x4E>((U)0, x));
-  x = umax_(x, dpp_mov<0x141>((U)0, x));
-  x = umax_(x, dpp_mov<0x140>((U)0, x));
-  return umax_(umax_(lane_bcast(x, 0), lane_bcast(x, 16)), umax_(lane_bcast(x, 32), lane_bcast(x, 48)));
-}
-template <typename T>
-__device__ __forceinline__ T wave_min_u(T x) {
-  return Ord<T>::dec(wave_umin<typename Ord<T>::U>(Ord<T>::enc(x)));
-}
-template <typename T>
-__device__ __forceinline__ T wave_max_u(T x) {
-  return Ord<T>::dec(wave_umax<typename Ord<T>::U>(Ord<T>::enc(x)));
-}
 
 // One wave per node of <= kSmall primitives: records in LDS, a 16-bit permutation ping-ponged between two
 // buffers by the stable partition, LDS bin reduction (3 axes x K <= 16 bins, ds_min/ds_max on integer-ordered
