@@ -1054,8 +1054,18 @@ __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *_
         const uint32_t start = j * kTile, len = (n - start < (uint32_t)kTile) ? n - start : kTile;
         left = best_nl > start ? (best_nl - start < len ? best_nl - start : len) : 0;
       } else {
-        const uint32_t *h = chunk_hist + (size_t)(cb + j) * (3 * kMaxBins) + best_axis * kMaxBins;
-        for (uint32_t b = 0; b < best_bin; b++) left += h[b];
+        // all 64 counts of the winning axis as 16 independent 16-byte loads (one latency), masked to bins < best_bin —
+        // a loop over best_bin single loads costs best_bin latencies and was most of this kernel
+        const uint4 *h4 = reinterpret_cast<const uint4 *>(chunk_hist + (size_t)(cb + j) * (3 * kMaxBins) + best_axis * kMaxBins);
+        uint4 hv[kMaxBins / 4];
+#pragma unroll
+        for (int q = 0; q < kMaxBins / 4; q++) hv[q] = h4[q];
+#pragma unroll
+        for (int q = 0; q < kMaxBins / 4; q++) {
+          const uint32_t b0 = 4u * (uint32_t)q;
+          left += (b0 < best_bin ? hv[q].x : 0u) + (b0 + 1u < best_bin ? hv[q].y : 0u) + (b0 + 2u < best_bin ? hv[q].z : 0u) +
+                  (b0 + 3u < best_bin ? hv[q].w : 0u);
+        }
       }
     }
     uint32_t inc = left;
