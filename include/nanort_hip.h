@@ -343,6 +343,12 @@ NRT_API nrt_status nrtSceneBounds_f32(nrt_scene *scene, float bmin[3], float bma
 NRT_API nrt_status nrtSceneTraverseBatch_f32(nrt_scene *scene, const nrt_ray_f32 *rays, uint64_t num_rays,
                                              nrt_scene_hit_f32 *hits_out, uint8_t *hit_mask_out);
 
+/* The same traversal with rays and results resident in HBM (device pointers; d_mask_out may be NULL): no PCIe traffic.
+ * The call is still SYNCHRONOUS — it reads one small counter array back per list position to size the per-node
+ * launches — and runs on the scene's own stream: the caller makes sure `d_rays` is complete before calling. */
+NRT_API nrt_status nrtSceneTraverseBatchDevice_f32(nrt_scene *scene, const nrt_ray_f32 *d_rays, uint64_t num_rays,
+                                                   nrt_scene_hit_f32 *d_hits_out, uint8_t *d_mask_out);
+
 #ifdef __cplusplus
 }
 #endif

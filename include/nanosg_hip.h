@@ -94,6 +94,18 @@ class BatchTracer {
     return true;
   }
 
+  // For callers that keep their ray waves in HBM: device pointers in and out, compact records {t, u, v, prim_id, node_id}
+  // (every record is written: a miss carries t = ray.max_t and ids 0xFFFFFFFF), optional hit flags.  The rest of the
+  // reference's Intersection record (P, Ns, Ng) is the shader's business on the device.  Synchronous.
+  bool TraverseDevice(const nanort::Ray<float> *d_rays, size_t num_rays, nrt_scene_hit_f32 *d_hits, unsigned char *d_hit_flags = NULL) {
+    if (!handle_) return false;
+    if (nrtSceneTraverseBatchDevice_f32(handle_, reinterpret_cast<const nrt_ray_f32 *>(d_rays), num_rays, d_hits, d_hit_flags) != NRT_OK) {
+      error_ = nrtSceneLastError(handle_);
+      return false;
+    }
+    return true;
+  }
+
  private:
   struct NodeState {
     float m[64];  // xform, inv_xform, inv_xform33, inv_transpose_xform33 (nrtSceneNodeState_f32)

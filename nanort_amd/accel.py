@@ -358,3 +358,16 @@ class Scene:
         mask = np.zeros((rays.shape[0],), dtype=np.uint8)
         self._check(self._L.nrtSceneTraverseBatch_f32(self._h, _p(rays), rays.shape[0], _p(hits), _p(mask)))
         return hits, mask
+
+    def TraverseBatchDevice(self, d_rays, d_hits, d_mask=None):
+        """Rays and results in HBM: torch uint8 tensors holding RAY_F32 records in, SCENE_HIT_F32 records (20 B) and the
+        optional hit flags out.  Synchronous (see nrtSceneTraverseBatchDevice_f32); waits for torch's current stream first."""
+        import torch
+
+        from .wire import RAY_F32, SCENE_HIT_F32
+
+        n = d_rays.numel() // RAY_F32.itemsize
+        assert d_rays.is_cuda and d_hits.is_cuda and d_hits.numel() >= n * SCENE_HIT_F32.itemsize
+        torch.cuda.current_stream().synchronize()
+        self._check(self._L.nrtSceneTraverseBatchDevice_f32(self._h, d_rays.data_ptr(), n, d_hits.data_ptr(),
+                                                            d_mask.data_ptr() if d_mask is not None else None))

@@ -26,7 +26,7 @@ SYMBOLS = [
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
     "nrtLastTraverseMs", "nrtLastBuildMs", "nrtDebugCounters",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
-    "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32",
+    "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32",
 ]
 
 
@@ -130,6 +130,8 @@ def lib():
     L.nrtSceneBounds_f32.restype = i32
     L.nrtSceneTraverseBatch_f32.argtypes = [vp, vp, u64, vp, vp]
     L.nrtSceneTraverseBatch_f32.restype = i32
+    L.nrtSceneTraverseBatchDevice_f32.argtypes = [vp, vp, u64, vp, vp]
+    L.nrtSceneTraverseBatchDevice_f32.restype = i32
     L.nrtLastTraverseMs.argtypes = [vp]
     L.nrtLastTraverseMs.restype = ctypes.c_float
     L.nrtLastBuildMs.argtypes = [vp]

@@ -462,8 +462,12 @@ nrt_status nrtSceneNodeState_f32(nrt_scene *s, uint32_t node_id, float out[64]) 
   return NRT_OK;
 }
 
-nrt_status nrtSceneTraverseBatch_f32(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t n64, nrt_scene_hit_f32 *hits_out,
-                                     uint8_t *mask_out) {
+} // extern "C"
+
+// `device` = rays / hits_out / mask_out are device pointers (no PCIe traffic); the call itself stays synchronous: it
+// reads one counter array back per list position to size the per-node launches.
+static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t n64, nrt_scene_hit_f32 *hits_out,
+                                 uint8_t *mask_out, bool device) {
   if (!s) return NRT_ERR_INVALID;
   if (!s->committed) return sfail(s, NRT_ERR_INVALID, "nrtSceneTraverseBatch: commit the scene first");
   if (n64 == 0) return NRT_OK;
@@ -472,28 +476,30 @@ nrt_status nrtSceneTraverseBatch_f32(nrt_scene *s, const nrt_ray_f32 *rays, uint
   const uint32_t n = (uint32_t)n64, num_nodes = (uint32_t)s->insts.size();
   const uint32_t cap = std::min<uint32_t>(kMaxList, num_nodes);
   SCHK(s, hipSetDevice(s->device));
-  SCHK(s, nrt::devbuf_ensure(&s->d_rays, (size_t)n * sizeof(nrt_ray_f32)));
+  if (!device) SCHK(s, nrt::devbuf_ensure(&s->d_rays, (size_t)n * sizeof(nrt_ray_f32)));
   SCHK(s, nrt::devbuf_ensure(&s->d_list_t, (size_t)cap * n * sizeof(float)));
   SCHK(s, nrt::devbuf_ensure(&s->d_list_node, (size_t)cap * n * sizeof(uint32_t)));
   SCHK(s, nrt::devbuf_ensure(&s->d_count, (size_t)n * sizeof(uint32_t)));
   SCHK(s, nrt::devbuf_ensure(&s->d_best_t, (size_t)n * sizeof(float)));
-  SCHK(s, nrt::devbuf_ensure(&s->d_best, (size_t)n * sizeof(nrt_scene_hit_f32)));
+  if (!device) SCHK(s, nrt::devbuf_ensure(&s->d_best, (size_t)n * sizeof(nrt_scene_hit_f32)));
   SCHK(s, nrt::devbuf_ensure(&s->d_sel_index, (size_t)n * sizeof(uint32_t)));
   SCHK(s, nrt::devbuf_ensure(&s->d_local_rays, (size_t)n * sizeof(nrt_ray_f32)));
   SCHK(s, nrt::devbuf_ensure(&s->d_local_hits, (size_t)n * sizeof(nrt_hit_f32)));
   SCHK(s, nrt::devbuf_ensure(&s->d_local_mask, (size_t)n));
-  SCHK(s, nrt::devbuf_ensure(&s->d_mask, (size_t)n));
+  if (!device || !mask_out) SCHK(s, nrt::devbuf_ensure(&s->d_mask, (size_t)n));
   SCHK(s, nrt::devbuf_ensure(&s->d_scalars, 64));
   uint32_t *d_max_count = (uint32_t *)s->d_scalars.p;
   const NodeDev *d_nodes = (const NodeDev *)s->d_nodes.p;
-  const nrt_ray_f32 *d_rays = (const nrt_ray_f32 *)s->d_rays.p;
+  const nrt_ray_f32 *d_rays = device ? rays : (const nrt_ray_f32 *)s->d_rays.p;
+  nrt_scene_hit_f32 *d_best = device ? hits_out : (nrt_scene_hit_f32 *)s->d_best.p;
+  uint8_t *d_mask = (device && mask_out) ? mask_out : (uint8_t *)s->d_mask.p;
   const unsigned grid = (n + 255u) / 256u;
 
-  SCHK(s, hipMemcpyAsync(s->d_rays.p, rays, (size_t)n * sizeof(nrt_ray_f32), hipMemcpyHostToDevice, s->stream));
+  if (!device) SCHK(s, hipMemcpyAsync(s->d_rays.p, rays, (size_t)n * sizeof(nrt_ray_f32), hipMemcpyHostToDevice, s->stream));
   SCHK(s, hipMemsetAsync(s->d_scalars.p, 0, 64, s->stream));
   hipLaunchKernelGGL(k_scene_list, dim3(grid), dim3(256), 0, s->stream, d_rays, n, d_nodes, num_nodes, cap,
                      (float *)s->d_list_t.p, (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p, (float *)s->d_best_t.p,
-                     (nrt_scene_hit_f32 *)s->d_best.p, d_max_count);
+                     d_best, d_max_count);
   SCHK(s, hipGetLastError());
   uint32_t max_count = 0;
   SCHK(s, hipMemcpyAsync(&max_count, d_max_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -536,16 +542,32 @@ nrt_status nrtSceneTraverseBatch_f32(nrt_scene *s, const nrt_ray_f32 *rays, uint
         return sfail(s, NRT_ERR_DEVICE, "nrtSceneTraverseBatch: node %u: %s", k, nrtLastError(s->insts[k].mesh));
       hipLaunchKernelGGL(k_scene_apply, dim3((m + 255u) / 256u), dim3(256), 0, s->stream, d_rays, k, d_nodes, m,
                          (const uint32_t *)s->d_sel_index.p + off, lr, (const nrt_hit_f32 *)lh, (const uint8_t *)lm,
-                         (float *)s->d_best_t.p, (nrt_scene_hit_f32 *)s->d_best.p);
+                         (float *)s->d_best_t.p, d_best);
       SCHK(s, hipGetLastError());
     }
   }
-  hipLaunchKernelGGL(k_scene_mask, dim3(grid), dim3(256), 0, s->stream, (const float *)s->d_best_t.p, n, (uint8_t *)s->d_mask.p);
-  SCHK(s, hipGetLastError());
-  SCHK(s, hipMemcpyAsync(hits_out, s->d_best.p, (size_t)n * sizeof(nrt_scene_hit_f32), hipMemcpyDeviceToHost, s->stream));
-  if (mask_out) SCHK(s, hipMemcpyAsync(mask_out, s->d_mask.p, (size_t)n, hipMemcpyDeviceToHost, s->stream));
+  if (!device || mask_out) {
+    hipLaunchKernelGGL(k_scene_mask, dim3(grid), dim3(256), 0, s->stream, (const float *)s->d_best_t.p, n, d_mask);
+    SCHK(s, hipGetLastError());
+  }
+  if (!device) {
+    SCHK(s, hipMemcpyAsync(hits_out, s->d_best.p, (size_t)n * sizeof(nrt_scene_hit_f32), hipMemcpyDeviceToHost, s->stream));
+    if (mask_out) SCHK(s, hipMemcpyAsync(mask_out, s->d_mask.p, (size_t)n, hipMemcpyDeviceToHost, s->stream));
+  }
   SCHK(s, hipStreamSynchronize(s->stream));
   return NRT_OK;
+}
+
+extern "C" {
+
+nrt_status nrtSceneTraverseBatch_f32(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t n, nrt_scene_hit_f32 *hits_out,
+                                     uint8_t *mask_out) {
+  return scene_traverse(s, rays, n, hits_out, mask_out, false);
+}
+
+nrt_status nrtSceneTraverseBatchDevice_f32(nrt_scene *s, const nrt_ray_f32 *d_rays, uint64_t n, nrt_scene_hit_f32 *d_hits_out,
+                                           uint8_t *d_mask_out) {
+  return scene_traverse(s, d_rays, n, d_hits_out, d_mask_out, true);
 }
 
 } // extern "C"

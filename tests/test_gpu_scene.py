@@ -156,3 +156,32 @@ def test_nanosg_batch_tracer_addon(tmp_path):
     n0 = hit & (out["node_id"] == 0)
     assert np.allclose(np.linalg.norm(out["Ng"][n0], axis=1), 1.0, atol=1e-5)
     assert set(np.unique(out["node_id"][hit]).tolist()) == {0, 1, 2, 3}
+
+
+def test_device_resident_entry_point_matches_the_host_one():
+    """nrtSceneTraverseBatchDevice_f32: rays and records in HBM, same bytes as the host entry point; the hit-flag array is
+    optional."""
+    import torch
+
+    from nanort_amd.wire import SCENE_HIT_F32
+
+    sc = Scene()
+    keep = []
+    for v, f, x in instances():
+        a = BVHAccel(np.float32)
+        assert a.Build(f.shape[0], TriangleMesh(v, f))
+        keep.append(a)
+        sc.AddNode(a, x)
+    assert sc.Commit()
+    rays = scenes.camera_rays(320, 180)
+    h, m = sc.TraverseBatch(rays)
+    d_rays = torch.from_numpy(rays.view(np.uint8)).cuda()
+    d_hits = torch.zeros(rays.shape[0] * SCENE_HIT_F32.itemsize, dtype=torch.uint8, device="cuda")
+    d_mask = torch.zeros(rays.shape[0], dtype=torch.uint8, device="cuda")
+    sc.TraverseBatchDevice(d_rays, d_hits, d_mask)
+    assert d_hits.cpu().numpy().tobytes() == h.tobytes() and np.array_equal(d_mask.cpu().numpy(), m)
+    d_hits.zero_()
+    sc.TraverseBatchDevice(d_rays, d_hits)
+    assert d_hits.cpu().numpy().tobytes() == h.tobytes()
+    bmin, bmax = sc.GetBoundingBox()
+    assert np.all(bmin < bmax)
