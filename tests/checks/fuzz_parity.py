@@ -2,7 +2,7 @@
 meshes built to provoke the edge rules (grid-aligned vertices -> rays through edges and vertices -> exact zeros in the
 edge functions and exact t ties; degenerate and duplicated triangles; axis-parallel, zero, NaN and infinite ray
 components; random trace options), fp32 and fp64, GPU-built trees and adopted oracle-built trees, and the occlusion
-query's flags.  Usage: python tools/fuzz_parity.py [seconds] [seed]"""
+query's flags.  Usage: python tests/checks/fuzz_parity.py [seconds] [seed]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')

@@ -3,7 +3,7 @@ scenes, GPU vs the CPU restatements on the SAME node arrays.  Spheres: t / prim_
 1e-6 (double atan2 / acos); cylinders: every field bit for bit (NaNs included); scenes: every field bit for bit, with
 random node transforms (rotation, non-uniform and mirrored scale, translation, nearly flat), up to 90 nodes (more than
 nanosg's 64-entry list), shared meshes, coincident instances and bounded ray intervals.
-Usage: python tools/fuzz_prims_scenes.py [seconds] [seed]"""
+Usage: python tests/checks/fuzz_prims_scenes.py [seconds] [seed]"""
 import sys
 import time
 

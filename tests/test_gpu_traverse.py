@@ -296,20 +296,20 @@ def test_occlusion_queries_equal_the_closest_hit_flags(real, c1_mesh):
 
 
 def test_randomised_parity_soak_short():
-    """tools/fuzz_parity.py for a few seconds: random grid-aligned / flat / smooth meshes with duplicated and degenerate
+    """tests/checks/fuzz_parity.py for a few seconds: random grid-aligned / flat / smooth meshes with duplicated and degenerate
     triangles, hostile rays, random trace options, fp32 and fp64, built and adopted trees, closest-hit and occlusion
     queries — GPU == oracle on the same node array, bit for bit.  (Round 1 ran it for 250 s: 11 140 rounds, 44.6 M rays.)"""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "8", "7"], cwd=root, stdout=subprocess.PIPE,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "checks", "fuzz_parity.py"), "8", "7"], cwd=root, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:]
 
 
 def test_randomised_primitive_and_scene_soak_short():
-    """tools/fuzz_prims_scenes.py for a few seconds: random sphere / cylinder sets (zero, negative, denormal and huge radii,
+    """tests/checks/fuzz_prims_scenes.py for a few seconds: random sphere / cylinder sets (zero, negative, denormal and huge radii,
     zero-length and lattice-aligned cylinders, caps on and off, random build options and prim_ids_range) and random
     two-level scenes (rotated, mirrored, nearly flat, duplicated instances, up to 90 nodes) under hostile rays — GPU ==
     the restatements on the same node arrays.  (Round 1 ran it for 90 s: 5 573 rounds, 18.6 M rays.)"""
@@ -318,6 +318,6 @@ def test_randomised_primitive_and_scene_soak_short():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_prims_scenes.py"), "8", "5"], cwd=root, stdout=subprocess.PIPE,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "checks", "fuzz_prims_scenes.py"), "8", "5"], cwd=root, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:]
