@@ -1226,13 +1226,16 @@ class BVHAccel {
       device_tree_stale_ = false;
     }
     if (num_rays == 0) return true;
-    // Grow-only byte staging owned by the accel (PODs: no per-element construction, and no fresh pages to fault in on
-    // every wave); the caller's mask array is used directly when there is one.
+    // Grow-only byte staging owned by the accel, page-locked when the backend can provide it (the device-to-host copy
+    // then runs at PCIe speed; PODs: no per-element construction, no fresh pages to fault in on every wave); the caller's
+    // mask array is used directly when there is one.
     typedef typename Api::HitPod HitPod;
-    if (stage_hits_.size() < num_rays * sizeof(HitPod)) stage_hits_.resize(num_rays * sizeof(HitPod));
-    if (!hit_out && stage_mask_.size() < num_rays) stage_mask_.resize(num_rays);
-    HitPod *tmp = reinterpret_cast<HitPod *>(&stage_hits_[0]);
-    unsigned char *mask = hit_out ? hit_out : &stage_mask_[0];
+    HitPod *tmp = static_cast<HitPod *>(StageEnsure(&stage_hits_, &stage_hits_cap_, num_rays * sizeof(HitPod)));
+    unsigned char *mask = hit_out ? hit_out : static_cast<unsigned char *>(StageEnsure(&stage_mask_, &stage_mask_cap_, num_rays));
+    if (!tmp || !mask) {
+      backend_error_ = "TraverseBatch: out of host memory for the staging buffers";
+      return false;
+    }
     nrt_trace_options o;
     std::memcpy(&o, &options, sizeof(o));
     if (Api::Traverse(ctx_.get(), reinterpret_cast<const typename Api::RayPod *>(rays), num_rays, &o, tmp, mask) != NRT_OK) {
@@ -1502,7 +1505,26 @@ class BVHAccel {
   const float *cyl_endpoints_ = NULL;  // cylinder primitive: what Build() was given
   const float *cyl_radii_ = NULL;
   mutable bool cyl_test_cap_ = true;
-  mutable std::vector<unsigned char> stage_hits_, stage_mask_;  // TraverseBatch staging (grow-only)
+  // TraverseBatch staging (grow-only): pinned through nrtHostAlloc, plain malloc if that fails
+  mutable std::shared_ptr<void> stage_hits_, stage_mask_;
+  mutable size_t stage_hits_cap_ = 0, stage_mask_cap_ = 0;
+  static void StageFreePinned(void *p) { nrtHostFree(p); }
+  static void *StageEnsure(std::shared_ptr<void> *buf, size_t *cap, size_t bytes) {
+    if (bytes <= *cap && buf->get()) return buf->get();
+    const size_t want = bytes + bytes / 4;
+    void *p = NULL;
+    buf->reset();
+    *cap = 0;
+    if (nrtHostAlloc(want, &p) == NRT_OK && p) {
+      buf->reset(p, StageFreePinned);
+    } else {
+      p = std::malloc(want);
+      if (!p) return NULL;
+      buf->reset(p, std::free);
+    }
+    *cap = want;
+    return p;
+  }
   mutable std::string backend_error_;
 #endif
 };

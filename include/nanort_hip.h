@@ -177,6 +177,12 @@ NRT_API const char *nrtLastError(const nrt_ctx *ctx);
 /* Library / device identification, e.g. "libnanort_hip gfx950 ...". */
 NRT_API const char *nrtVersion(void);
 
+/* Page-locked (pinned) host memory, for callers that do not link HIP themselves: ray / hit arrays allocated here make
+ * the copies inside the host entry points (nrtTraverseBatch_*, nrtSceneTraverseBatch_f32, ...) run at PCIe speed instead of
+ * being staged through the runtime's bounce buffers.  No reference counterpart.  nrtHostFree(NULL) is a no-op. */
+NRT_API nrt_status nrtHostAlloc(size_t bytes, void **out);
+NRT_API void nrtHostFree(void *p);
+
 /* ---- mesh: replaces the TriangleMesh / TriangleSAHPred / TriangleIntersector
  * constructors (nanort.h:866-873, 925-930, 1032-1039) ----------------------
  * vertices are read through `vertex_stride_bytes` exactly like

@@ -24,7 +24,7 @@ SYMBOLS = [
     "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64",
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
-    "nrtLastTraverseMs", "nrtLastBuildMs", "nrtDebugCounters",
+    "nrtLastTraverseMs", "nrtLastBuildMs", "nrtDebugCounters", "nrtHostAlloc", "nrtHostFree",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
     "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32",
 ]
@@ -132,6 +132,10 @@ def lib():
     L.nrtSceneTraverseBatch_f32.restype = i32
     L.nrtSceneTraverseBatchDevice_f32.argtypes = [vp, vp, u64, vp, vp]
     L.nrtSceneTraverseBatchDevice_f32.restype = i32
+    L.nrtHostAlloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.nrtHostAlloc.restype = i32
+    L.nrtHostFree.argtypes = [vp]
+    L.nrtHostFree.restype = None
     L.nrtLastTraverseMs.argtypes = [vp]
     L.nrtLastTraverseMs.restype = ctypes.c_float
     L.nrtLastBuildMs.argtypes = [vp]

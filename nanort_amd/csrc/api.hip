@@ -163,6 +163,23 @@ extern "C" {
 
 const char *nrtVersion(void) { return "libnanort_hip 0.1 (gfx950, HIP)"; }
 
+// Page-locked host memory for ray / hit buffers handed to the host entry points: the copies then run at PCIe speed
+// (pageable memory is staged by the runtime at roughly half of it) — for callers that do not link HIP themselves.
+nrt_status nrtHostAlloc(size_t bytes, void **out) {
+  if (!out) return fail(nullptr, NRT_ERR_INVALID, "nrtHostAlloc: out == NULL");
+  *out = nullptr;
+  if (bytes == 0) return NRT_OK;
+  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return fail(nullptr, NRT_ERR_DEVICE, "nrtHostAlloc: hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return NRT_OK;
+}
+void nrtHostFree(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
 nrt_status nrtCreate(int device, nrt_ctx **out) {
   if (!out) return fail(nullptr, NRT_ERR_INVALID, "nrtCreate: out == NULL");
   *out = nullptr;

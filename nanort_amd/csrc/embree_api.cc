@@ -45,6 +45,40 @@ struct Mesh {
   }
 };
 
+// Grow-only host staging for a query's rays / records: page-locked when the backend can provide it (the copies of
+// nrtSceneTraverseBatch_f32 then run at PCIe speed), plain malloc otherwise.
+struct HostBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  void *ensure(size_t bytes) {
+    if (bytes <= cap && p) return p;
+    release();
+    const size_t want = bytes + bytes / 4;
+    void *q = nullptr;
+    if (nrtHostAlloc(want, &q) == NRT_OK && q) {
+      p = q;
+      pinned = true;
+    } else {
+      p = malloc(want);
+      pinned = false;
+    }
+    cap = p ? want : 0;
+    return p;
+  }
+  void release() {
+    if (p) {
+      if (pinned)
+        nrtHostFree(p);
+      else
+        free(p);
+    }
+    p = nullptr;
+    cap = 0;
+  }
+  ~HostBuf() { release(); }
+};
+
 struct Scene {
   Device *device = nullptr;
   std::map<uint32_t, Mesh *> meshes;  // by geometry id; iteration order = node order, as in the reference (:321-329)
@@ -52,9 +86,7 @@ struct Scene {
   nrt_scene *scene = nullptr;
   bool committed = false;
   std::mutex mu;  // the staging buffers below and the nrt_scene are used by one query at a time
-  std::vector<nrt_ray_f32> rays;
-  std::vector<nrt_scene_hit_f32> hits;
-  std::vector<uint8_t> mask;
+  HostBuf rays, hits, mask;
   ~Scene() {
     if (scene) nrtSceneDestroy(scene);
     for (auto &kv : meshes) delete kv.second;
@@ -170,16 +202,25 @@ void trace(Scene *s, size_t n, bool occluded, Get get) {
   std::lock_guard<std::mutex> lk(s->mu);
   bool ok = s->committed;
   if (!ok) report(s->device, RTC_INVALID_OPERATION, "rtcIntersect/rtcOccluded: the scene is not committed");
+  nrt_ray_f32 *rays = nullptr;
+  nrt_scene_hit_f32 *hits = nullptr;
+  uint8_t *mask = nullptr;
   if (ok) {
-    s->rays.resize(n);
-    s->hits.resize(n);
-    s->mask.resize(n);
+    rays = static_cast<nrt_ray_f32 *>(s->rays.ensure(n * sizeof(nrt_ray_f32)));
+    hits = static_cast<nrt_scene_hit_f32 *>(s->hits.ensure(n * sizeof(nrt_scene_hit_f32)));
+    mask = static_cast<uint8_t *>(s->mask.ensure(n));
+    if (!rays || !hits || !mask) {
+      report(s->device, RTC_OUT_OF_MEMORY, "rtcIntersect/rtcOccluded: no host memory for %zu rays", n);
+      ok = false;
+    }
+  }
+  if (ok) {
     // A 1920x1080 stream is 200 MB of RTCRay records: converting it on one core costs more than the traversal.  A small
     // fixed team (not the OpenMP default, which on a many-core host starves the HIP runtime's own threads).
 #pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n > kParallelMin)
     for (size_t i = 0; i < n; i++) {
       const RTCRay *r = get(i);
-      nrt_ray_f32 &o = s->rays[i];
+      nrt_ray_f32 &o = rays[i];
       for (int k = 0; k < 3; k++) {
         o.org[k] = r->org[k];
         o.dir[k] = r->dir[k];
@@ -188,7 +229,7 @@ void trace(Scene *s, size_t n, bool occluded, Get get) {
       o.max_t = r->tfar;
       o.type = 0u;  // RAY_TYPE_NONE: the reference's Ray default, not read by traversal
     }
-    if (nrtSceneTraverseBatch_f32(s->scene, s->rays.data(), n, s->hits.data(), s->mask.data()) != NRT_OK) {
+    if (nrtSceneTraverseBatch_f32(s->scene, rays, n, hits, mask) != NRT_OK) {
       report(s->device, RTC_UNKNOWN_ERROR, "rtcIntersect/rtcOccluded: %s", nrtSceneLastError(s->scene));
       ok = false;
     }
@@ -196,13 +237,13 @@ void trace(Scene *s, size_t n, bool occluded, Get get) {
 #pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n > kParallelMin)
   for (size_t i = 0; i < n; i++) {
     RTCRay *r = get(i);
-    const bool hit = ok && s->mask[i] != 0;
+    const bool hit = ok && mask[i] != 0;
     if (occluded) {
       if (hit) r->geomID = 0;
       continue;
     }
     if (hit) {  // nanort-embree.cc:541-548
-      const nrt_scene_hit_f32 &h = s->hits[i];
+      const nrt_scene_hit_f32 &h = hits[i];
       r->tfar = h.t;
       r->u = h.u;
       r->v = h.v;
