@@ -18,10 +18,11 @@
  *     memory; "Device" entry points take device pointers (HBM-resident
  *     buffers, e.g. torch tensors) and a hipStream_t passed as void*;
  *   - one nrt_ctx per BVHAccel object; a context is bound to one GPU.  The
- *     primitive / build / tree calls and the host-buffer traversal calls are
- *     not re-entrant on one context (like BVHAccel::Build, nanort.h:1892);
- *     the Device traversal calls are: they may be issued from several host
- *     threads and on several streams at once, and launches on different
+ *     primitive / build / tree calls are not re-entrant on one context (like
+ *     BVHAccel::Build, nanort.h:1892).  The traversal calls may be issued
+ *     from several host threads: the host-buffer ones share the context's
+ *     staging buffers and are served one at a time; the Device ones run
+ *     concurrently, on several streams at once, and launches on different
  *     streams overlap on the GPU (each launch owns its scratch until it
  *     completes).  Distinct contexts may be used from distinct host threads.
  *

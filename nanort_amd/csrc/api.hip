@@ -98,6 +98,7 @@ struct nrt_ctx {
   LaunchSlot slots[kSlots];
   unsigned next_victim = 0;
   std::mutex launch_mutex; // slot selection + launch (nrtTraverseBatchDevice may be called from several host threads)
+  std::mutex host_mutex;   // the host-buffer traversal calls share one set of staging buffers: one at a time
   unsigned long long *d_counters = nullptr;  // 8 x u64 (counting pass / profiling instantiation only)
   DevBuf st_rays, st_hits, st_mask;
 
@@ -674,6 +675,7 @@ static nrt_status traverse_host(nrt_ctx *c, const typename Wire<T>::Ray *rays, u
   if (!rays || !hits) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatch: NULL rays/hits");
   typedef typename Wire<T>::Ray Ray;
   typedef typename Wire<T>::Hit Hit;
+  std::lock_guard<std::mutex> host_lock(c->host_mutex);
   HIPCHK(c, hipSetDevice(c->device));
   const uint64_t kMaxChunk = 1ull << 26; // rays per launch (keeps staging bounded)
   for (uint64_t off = 0; off < n; off += kMaxChunk) {
@@ -716,6 +718,7 @@ static nrt_status occluded_host(nrt_ctx *c, const typename Wire<T>::Ray *rays, u
   if (n == 0) return NRT_OK;
   if (!rays || !mask) return fail(c, NRT_ERR_INVALID, "nrtOccludedBatch: NULL rays/mask");
   typedef typename Wire<T>::Ray Ray;
+  std::lock_guard<std::mutex> host_lock(c->host_mutex);
   HIPCHK(c, hipSetDevice(c->device));
   const uint64_t kMaxChunk = 1ull << 26;
   for (uint64_t off = 0; off < n; off += kMaxChunk) {
@@ -757,6 +760,7 @@ nrt_status nrtTraverseBatchCylinders_f32(nrt_ctx *c, const nrt_ray_f32 *rays, ui
   if (!c) return NRT_ERR_INVALID;
   if (n == 0) return NRT_OK;
   if (!rays || !hits) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchCylinders: NULL rays/hits");
+  std::lock_guard<std::mutex> host_lock(c->host_mutex);
   HIPCHK(c, hipSetDevice(c->device));
   const uint64_t kMaxChunk = 1ull << 26;
   for (uint64_t off = 0; off < n; off += kMaxChunk) {

@@ -321,3 +321,30 @@ def test_randomised_primitive_and_scene_soak_short():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "checks", "fuzz_prims_scenes.py"), "8", "5"], cwd=root, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:]
+
+
+def test_host_entry_point_from_several_threads(c1):
+    """nrtTraverseBatch (host buffers) issued from four host threads on ONE context: the calls share the context's staging
+    buffers and are served one at a time — every result equals the single-threaded one."""
+    import threading
+
+    v, f, nodes, idx, a = c1
+    batches = [scenes.camera_rays(200 + 8 * k, 100) for k in range(4)]
+    want = [a.TraverseBatch(r) for r in batches]
+    got = [None] * 4
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(6):
+                got[k] = a.TraverseBatch(batches[k])
+                assert got[k][0].tobytes() == want[k][0].tobytes() and np.array_equal(got[k][1], want[k][1])
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
