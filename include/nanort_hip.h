@@ -325,7 +325,9 @@ NRT_API int nrtDebugCounters(nrt_ctx *ctx, unsigned long long *out8);
  * cull `t_nearest < t_min`; the local ray carries the default [0, FLT_MAX] interval and default
  * trace options (the world ray's interval and the cull flag never reach the per-node Traverse);
  * the reported t is the WORLD distance |xform(P_local) - org| and a node replaces the current hit
- * only when strictly nearer.  A node is a built nrt_ctx (f32) plus nanosg's T[4][4] local transform
+ * only when strictly nearer.  Nodes entered at exactly the same distance are visited in node order (the
+ * reference: in the order its std::priority_queue pops them), which only shows when several COINCIDENT
+ * instances produce the same hit record: either may be named in node_id.  A node is a built nrt_ctx (f32) plus nanosg's T[4][4] local transform
  * (row 3 = translation, nanosg.h:232-240); the mesh contexts must outlive the scene. */
 typedef struct nrt_scene nrt_scene;
 typedef struct {
