@@ -1,6 +1,6 @@
 """Short runs of the CPU soaks that pin the checkers on the unmodified reference (tests/checks/fuzz_oracle_vs_reference.py,
 fuzz_prim_oracles_vs_reference.py): random hostile inputs, every record bit for bit.  Only where the reference-built
-libraries exist (the build container); the long runs of round 1 covered 43 M + 1.7 M rays."""
+libraries exist (the build container); the long runs of round 1 covered 43 M + 6.9 M rays."""
 import os
 import subprocess
 import sys
