@@ -21,3 +21,11 @@ def test_restatements_equal_the_reference_on_random_hostile_inputs(script, token
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", script), "8", "3"], cwd=ROOT, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and token in r.stdout, r.stdout[-2000:]
+
+
+def test_header_host_path_equals_the_restatement_on_random_hostile_inputs():
+    """include/nanort.h without the GPU backend (its own builder + per-ray Traverse) against the restatement walking the
+    header's own tree: tests/checks/fuzz_header_host_path.py for a few seconds (round 1: 22.7 M rays, no difference)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "fuzz_header_host_path.py"), "8", "5"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "header host path == restatement" in r.stdout, r.stdout[-2000:]
