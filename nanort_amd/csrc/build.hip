@@ -56,6 +56,7 @@ constexpr int kTile = 2048;     // primitives per top-phase chunk (256 threads x
 constexpr int kMaxBins = 64;    // top phase: lane == bin
 constexpr int kSmallBins = 16;  // subtree phase: 3 x 15 candidates == 45 lanes
 constexpr uint32_t kMedian = 0xFFFFFFFFu;
+constexpr int kSceneReplicas = 16; // k_prim_records spreads its per-block atomics on the scene bounds over this many copies
 constexpr int kSubStack = 48;     // pending high-side children per subtree wave (LDS)
 constexpr int kSubStackSafe = 36; // above this many, splits are forced to the object median (depth <= log2 n more)
 
@@ -477,11 +478,14 @@ __global__ __launch_bounds__(256) void k_prim_records(const T *__restrict__ vert
     }
   }
   __syncthreads();
+  // 2048 blocks hammering the same 12 words with device-scope atomics serialise at the memory side (~40 us of this
+  // kernel's 60): each block reduces into one of kSceneReplicas copies, combined by combine_scene() before use
+  BoundsAcc<T> *rep = scene + 1 + (blockIdx.x % kSceneReplicas);
   if (threadIdx.x < 12) {
     if (threadIdx.x % 6 < 3)
-      atomicMin(&scene->v[threadIdx.x], s_acc[threadIdx.x]);
+      atomicMin(&rep->v[threadIdx.x], s_acc[threadIdx.x]);
     else
-      atomicMax(&scene->v[threadIdx.x], s_acc[threadIdx.x]);
+      atomicMax(&rep->v[threadIdx.x], s_acc[threadIdx.x]);
   }
 }
 
@@ -514,7 +518,8 @@ __device__ __forceinline__ void clean_acc(BoundsAcc<T> *acc) {
 
 template <typename T>
 __global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info, uint32_t top_cap, GBins<T> *gbins, BoundsAcc<T> *child_acc) {
-  if (threadIdx.x < 12) scene->v[threadIdx.x] = (threadIdx.x % 6 < 3) ? Ord<T>::highest() : Ord<T>::lowest();
+  if (threadIdx.x < 12)
+    for (int r = 0; r <= kSceneReplicas; r++) scene[r].v[threadIdx.x] = (threadIdx.x % 6 < 3) ? Ord<T>::highest() : Ord<T>::lowest();
   for (int k = 0; k < 3; k++) clean_bins<T>(&gbins[0], k, threadIdx.x); // 64 threads == kMaxBins
   if (threadIdx.x < 2) clean_acc<T>(&child_acc[threadIdx.x]);
   if (threadIdx.x == 0) {
@@ -544,9 +549,26 @@ __device__ __forceinline__ uint32_t classify(uint32_t n, uint32_t depth, uint32_
   return KIND_SPLIT;
 }
 
+// scene[0] <- min / max over the replicas k_prim_records reduced into (idempotent); called by threads 0..11 of one block
 template <typename T>
-__global__ void k_make_root(const BoundsAcc<T> *scene, uint32_t n, uint32_t max_depth, uint32_t buf, TopNode<T> *top,
+__device__ __forceinline__ void combine_scene(BoundsAcc<T> *scene, unsigned j) {
+  typename Ord<T>::U x = scene[0].v[j];
+  for (int r = 1; r <= kSceneReplicas; r++) {
+    const typename Ord<T>::U y = scene[r].v[j];
+    x = (j % 6 < 3) ? (y < x ? y : x) : (y > x ? y : x);
+  }
+  scene[0].v[j] = x;
+}
+template <typename T>
+__global__ void k_combine_scene(BoundsAcc<T> *scene) {
+  if (threadIdx.x < 12) combine_scene<T>(scene, threadIdx.x);
+}
+
+template <typename T>
+__global__ void k_make_root(BoundsAcc<T> *scene, uint32_t n, uint32_t max_depth, uint32_t buf, TopNode<T> *top,
                             uint32_t *small_list, LevelInfo *info) {
+  if (threadIdx.x < 12) combine_scene<T>(scene, threadIdx.x);
+  __syncthreads();
   if (threadIdx.x != 0) return;
   TopNode<T> t;
 #pragma unroll
@@ -1702,7 +1724,7 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
     off_chunk_hist = take(max_chunks * 3 * kMaxBins * sizeof(uint32_t));
     off_chunk_left = take(max_chunks * sizeof(uint32_t));
     off_small = take((max_top + 1) * sizeof(uint32_t));
-    off_scene = take(sizeof(BoundsAcc<T>));
+    off_scene = take((1 + kSceneReplicas) * sizeof(BoundsAcc<T>));
     off_info = take(sizeof(LevelInfo));
     // Morton sort: keys/values ping-pong (4 x n u32) + digit-major block histograms
     sort_blocks = ((size_t)n + kSortTile - 1) / kSortTile;
@@ -1761,6 +1783,7 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
       uint32_t *vals[2] = {keys[1] + (size_t)n, keys[1] + 2 * (size_t)n};
       uint32_t *block_hist = keys[1] + 3 * (size_t)n;
       const unsigned nb = (unsigned)plan.sort_blocks;
+      hipLaunchKernelGGL((k_combine_scene<T>), dim3(1), dim3(64), 0, s, scene);
       hipLaunchKernelGGL((k_morton_keys<T>), dim3((n + 255) / 256), dim3(256), 0, s, recs[0], n, scene, keys[0], vals[0]);
       int pp = 0;
       for (int shift = 0; shift < 32; shift += 8) {
