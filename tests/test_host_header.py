@@ -581,3 +581,29 @@ def test_unmodified_nanosg_over_this_header_equals_over_the_reference_header(tmp
         assert np.array_equal(rh["u"][q], mh["u"][q], equal_nan=True) and np.array_equal(rh["v"][q], mh["v"][q], equal_nan=True)
         total += n
     assert total == 21000
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "examples", "vrcamera", "main.cc")), reason="reference tree not present")
+@pytest.mark.parametrize("example,inputs,outputs", [
+    ("curves_primitive", (), ("render.png",)),  # a third custom primitive (Bezier curves) through the generic templates
+    ("vrcamera", ("cornellbox_suzanne_vr.obj", "cornellbox_suzanne_vr.mtl"), ("render.exr", "render.data")),  # stereo panorama of its own scene
+])
+def test_more_reference_examples_write_the_same_images(tmp_path, example, inputs, outputs):
+    """Two more of the reference's demos, unchanged, against both headers: byte-identical output files."""
+    import shutil
+
+    src = os.path.join(REFERENCE, "examples", example)
+    res = {}
+    for tag, inc in (("ref", REFERENCE), ("mine", INC)):
+        d = tmp_path / tag
+        d.mkdir()
+        exe = d / example
+        extra = [os.path.join(src, "tiny_obj_loader.cc")] if os.path.exists(os.path.join(src, "tiny_obj_loader.cc")) else []
+        cxx(["-O2", "-w", "-fopenmp", "-I", inc, "-I", src, "-I", os.path.join(REFERENCE, "examples", "common"), os.path.join(src, "main.cc")] + extra + ["-o", str(exe)])
+        for f in inputs:
+            shutil.copy(os.path.join(src, f), str(d / f))
+        r = subprocess.run([str(exe)], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:]
+        res[tag] = {f: open(str(d / f), "rb").read() for f in outputs}
+    for f in outputs:
+        assert res["ref"][f] == res["mine"][f] and len(res["ref"][f]) > 1000, f
