@@ -1453,6 +1453,8 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
 
       // ---- stable partition of s_perm[pb][lo, hi) into s_perm[1 - pb], reducing the children's centroid bounds
       //      (and, after a median split, their AABBs) on the way ----------------------------------------------
+      const bool low_leaf = nleft <= leaf_max || depth + 1 >= max_depth, high_leaf = n - nleft <= leaf_max || depth + 1 >= max_depth;
+      const bool both_leaves = low_leaf && high_leaf; // the common case at the bottom: finished here, no trip through the stack
       T ccl[3], cch[3], crl[3], crh[3];
 #pragma unroll
       for (int d = 0; d < 3; d++) {
@@ -1487,6 +1489,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
             const uint32_t d = left ? lo + run_l + (uint32_t)__builtin_popcountll(bl & lt)
                                     : lo + nleft + run_r + (uint32_t)__builtin_popcountll(br & lt);
             s_perm[1 - pb][d] = id;
+            if (both_leaves) indices[L + d] = r.prim; // the leaves' index slots, in partition order
 #pragma unroll
             for (int k = 0; k < 3; k++) {
               if (left) {
@@ -1511,8 +1514,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
           run_r += (uint32_t)__builtin_popcountll(br);
         }
       }
-      // a child that becomes a leaf needs no centroid bounds
-      const bool low_leaf = nleft <= leaf_max || depth + 1 >= max_depth, high_leaf = n - nleft <= leaf_max || depth + 1 >= max_depth;
+      // (a child that becomes a leaf needs no centroid bounds)
 #pragma unroll
       for (int d = 0; d < 3; d++) {
         if (!low_leaf) {
@@ -1535,6 +1537,38 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
       nd.axis = axis;
       nd.data[0] = me + 1; // low-side child follows its parent (pre-order)
       nd.data[1] = 0;      // patched when the high-side child is emitted
+      if (both_leaves) {
+        // both children are leaves: emit the three nodes now (pre-order: parent, low leaf, high leaf)
+        nd.data[1] = me + 2;
+        if (lane == 0) {
+          out[me] = nd;
+          Node lf;
+          lf.flag = 1;
+          lf.axis = 0;
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            lf.bmin[d] = cl[d];
+            lf.bmax[d] = ch[d];
+          }
+          lf.data[0] = nleft;
+          lf.data[1] = L + lo;
+          out[me + 1] = lf;
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            lf.bmin[d] = rl[d];
+            lf.bmax[d] = rh[d];
+          }
+          lf.data[0] = n - nleft;
+          lf.data[1] = L + lo + nleft;
+          out[me + 2] = lf;
+        }
+        node_count += 2;
+        leaves += 2;
+        deepest = depth + 1 > deepest ? depth + 1 : deepest;
+        const uint32_t big = nleft > n - nleft ? nleft : n - nleft;
+        biggest_leaf = big > biggest_leaf ? big : biggest_leaf;
+        __syncthreads(); // the reset bins are visible to the next node
+      } else {
       if (lane == 0) {
         out[me] = nd;
         SubPending<T> &e = s_stack[sp];
@@ -1567,6 +1601,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
       }
       descend = true;
       __syncthreads(); // the permutation, the reset bins and the stack entry are visible to the next node
+      }
     }
     if (!descend) {
       if (sp == 0) break;
