@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
             const uint32_t d = left ? lo + run_l + (uint32_t)__builtin_popcountll(bl & lt)
                                     : lo + nleft + run_r + (uint32_t)__builtin_popcountll(br & lt);
             s_perm[1 - pb][d] = id;
-            if (both_leaves) indices[L + d] = r.prim; // the leaves' index slots, in partition order
+            if (both_leaves || (low_leaf && left)) indices[L + d] = r.prim; // index slots of the leaves emitted below, in partition order
 #pragma unroll
             for (int k = 0; k < 3; k++) {
               if (left) {
@@ -1568,6 +1568,41 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
         const uint32_t big = nleft > n - nleft ? nleft : n - nleft;
         biggest_leaf = big > biggest_leaf ? big : biggest_leaf;
         __syncthreads(); // the reset bins are visible to the next node
+      } else if (low_leaf) {
+        // the low child is a leaf, the high one is not: emit the leaf (node me + 1) and continue with the high child
+        // right away (it is node me + 2; the loop head patches the parent's data[1]) — no stack entry
+        if (lane == 0) {
+          out[me] = nd;
+          Node lf;
+          lf.flag = 1;
+          lf.axis = 0;
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            lf.bmin[d] = cl[d];
+            lf.bmax[d] = ch[d];
+          }
+          lf.data[0] = nleft;
+          lf.data[1] = L + lo;
+          out[me + 1] = lf;
+        }
+        node_count += 1;
+        leaves += 1;
+        deepest = depth + 1 > deepest ? depth + 1 : deepest;
+        biggest_leaf = nleft > biggest_leaf ? nleft : biggest_leaf;
+        lo = lo + nleft;
+        depth = depth + 1;
+        parent = me;
+        is_high = true;
+        pb = 1u - pb;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          mn[d] = rl[d];
+          mx[d] = rh[d];
+          cmn[d] = crl[d];
+          cmx[d] = crh[d];
+        }
+        descend = true;
+        __syncthreads(); // the permutation and the reset bins are visible to the next node
       } else {
       if (lane == 0) {
         out[me] = nd;
