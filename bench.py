@@ -1,44 +1,51 @@
 #!/usr/bin/env python3
 """bench.py — the headline measurement of the hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|C4|C4tile|C5] [--mesh file.ply|.obj]
 
-Metric (BASELINE.json): Mrays/s (primary + 1-bounce) at 1920x1080 on the
-1M-triangle mesh; BVH build ms.  Workload = config C3 of SURVEY.md §8(d):
-Plane(1000,500) (exactly 1 000 000 triangles), fp32, objrender camera.
+Metric (BASELINE.json): Mrays/s (primary + 1-bounce) at 1920x1080 on the 1M-triangle mesh; BVH build ms.
+Default workload = config C3 of SURVEY.md §8(d): Plane(1000,500) (exactly 1 000 000 triangles), fp32, objrender
+camera.  The other single-GPU configs of BASELINE.json are measured too: untimed, in the `configs` object of the
+default line (C2 stand-in, the C4 4096x512 tile, C5 fp64), or as the headline with `--config`.
 
-One "step" = one pass of the hot path over one batch: wave 1 (W*H primary
-rays) + wave 2 (one cosine-weighted bounce ray per wave-1 hit), both already
-resident in HBM, traced by the batched traversal kernel through the C ABI
-(nrtTraverseBatchDevice_f32) on torch's current stream.  The BVH is built on
-the GPU (nrtBuild_f32) before the timed region; its device time is reported
-as `build_ms` (median of several builds).
+One "step" = one pass of the hot path over one batch: wave 1 (W*H primary rays) + wave 2 (one cosine-weighted
+bounce ray per wave-1 hit), both already resident in HBM, traced by the batched traversal kernel through the C ABI
+(nrtTraverseBatchDevice_*) on torch's current stream.  The BVH is built on the GPU (nrtBuild_*) before the timed
+region; its device time is reported as `build_ms` (median of several builds).
 
-N > 1 (weak scaling): the image grows to 1920 x (1080*N) and rank r traces the
-interleaved rows y = r (mod N), i.e. 1920x1080 rays per GPU, over its own
-replica of the BVH (deterministic build, no broadcast).  The wave-1 hit
-records are gathered to rank 0 with one RCCL gather per step (grouped send/recv),
-issued asynchronously and double-buffered so it overlaps wave 2 and the next step.
+N > 1: `python bench.py --gpus N` starts N ranks itself (torch.distributed.run, one per GPU, RCCL) when it was not
+launched under a launcher already, and fails loudly when the box has fewer than N GPUs.  Each rank holds a replica
+of the BVH (deterministic GPU build, no broadcast) and traces the interleaved image rows y = rank (mod N); the hit
+records of BOTH waves are gathered to rank 0 (RCCL gather = grouped send/recv over xGMI), asynchronously and
+double-buffered, so the exchange overlaps the following waves.  C2/C3/C5 scale weakly (the image grows to
+W x (H*N): fixed work per GPU); `--config C4` is BASELINE.json's strong-scaling case: Plane(2500,2000) = 10M
+triangles, a fixed 4096x4096 frame cut into N row-interleaved tiles.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel k_traverse<float>: ALGORITHMIC bytes per launch
-                (52 + 40*nodes_visited + 52*tris_tested per ray, SURVEY.md §8d,
-                counted on the tree actually traversed by the kernel's own
-                counting pass) / mean launch duration measured live with HIP
-                events on the launch stream; peak = 8 TB/s HBM3E.
-  cpu_baseline  the UNMODIFIED reference (oracle/_ref, OpenMP, all host cores)
-                on a bounded sample of the same ray buffers; falls back to the
-                single-thread C port (oracle/liboracle.so) when _ref is absent.
-                Carries the parity check of the same run: the GPU's
-                records of the timed waves against the reference on its own tree
-                (1e-5 tolerance, prim ids equal except at exact-t ties) and
-                against the reference over the GPU-built tree (bit-identical).
+  roofline      the dominant kernel (named by the library: nrtLastKernelName).  `hbm`: HBM-side bytes per launch
+                MEASURED IN THIS RUN (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over a 3-step sub-run of this
+                same script, outside the timed region; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+                gfx950) over the launch time -> fraction of the 8 TB/s HBM3E peak.  `valu`: active VALU
+                lane-operations per launch (SQ_THREAD_CYCLES_VALU) over the launch time -> fraction of the vector
+                lane peak (SIMD-32: 2 cycles per wave64 instruction), with lane utilisation and issue-slot occupancy.  `algorithmic`: SURVEY §8(d)'s figure
+                (52 + 40*nodes + 52*tris bytes per ray, counted on the tree actually traversed) — served almost
+                entirely from L1/L2/Infinity Cache, stated as such.  `build`: compulsory bytes of the build
+                (52N + 40*nodes + 4N) over its device time.  The top-level bound/achieved/peak/frac/traffic
+                fields are the HBM figures (every frac <= 1).
+  cpu_baseline  the UNMODIFIED reference (oracle/_ref, OpenMP, host cores) on a bounded sample of the same ray
+                buffers, with the parity check of the same run; falls back to the single-thread C port.
+  configs       (default line only) {Mrays/s, build_ms, parity} for C2, the C4 tile and C5, each with the
+                reference's answer on a bounded sample in the same run.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -47,7 +54,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-WIDTH, HEIGHT = 1920, 1080
+# Vector lane peak: 256 CUs x 4 SIMD-32 x 2.4 GHz max clock.  A wave64 fp32 VALU instruction occupies its SIMD for 2 cycles
+# (MI355X_MICROARCH.md "Wave scheduling"; measured here with tools/ubench/valu_rate.hip -> profiles/r02a_valu_rate.txt:
+# 2.8 cycles per v_fma_f32 / v_mul_f32 at 8 waves per SIMD, and twice that for the packed v_pk_* forms and v_max3/v_min3,
+# i.e. packing saves issue slots, not lane-cycles).
+VALU_LANES_PER_SIMD = 32
+VALU_CYCLES_PER_WAVE_INST = 64 // VALU_LANES_PER_SIMD
+N_XCD = 8  # GRBM_GUI_ACTIVE arrives summed over the XCDs
+CLOCK_GHZ = 2.4
+METRIC = "Mrays/s (primary + 1-bounce) at 1920x1080, 1M-tri mesh; BVH build ms"
+
+CONFIGS = {
+    # name: mesh generator, precision, image, scaling when N > 1
+    "C2": {"mesh": "sphere", "real": "f32", "w": 1920, "h": 1080, "scaling": "weak",
+           "text": "C2 stand-in: closed lumpy sphere 264x132 = 69,168 triangles fp32 (Stanford bun_zipper.ply when --mesh is given)"},
+    "C3": {"mesh": ("plane", 1000, 500), "real": "f32", "w": 1920, "h": 1080, "scaling": "weak",
+           "text": "C3: Plane(1000,500) = 1,000,000 triangles fp32"},
+    "C4": {"mesh": ("plane", 2500, 2000), "real": "f32", "w": 4096, "h": 4096, "scaling": "strong",
+           "text": "C4: Plane(2500,2000) = 10,000,000 triangles fp32, fixed 4096x4096 frame"},
+    "C4tile": {"mesh": ("plane", 2500, 2000), "real": "f32", "w": 4096, "h": 4096, "scaling": "weak", "tile_of": 8,
+               "text": "C4 tile: Plane(2500,2000) = 10,000,000 triangles fp32, one GPU's 4096x512 share (rows y = 0 mod 8) of the 4096x4096 frame"},
+    "C5": {"mesh": ("plane", 1000, 500), "real": "f64", "w": 1920, "h": 1080, "scaling": "weak",
+           "text": "C5: Plane(1000,500) = 1,000,000 triangles, fp64 build + traversal"},
+}
 
 
 def algorithmic_bytes(counters, real_bytes=4):
@@ -55,6 +84,11 @@ def algorithmic_bytes(counters, real_bytes=4):
     if real_bytes == 4:
         return 52 * counters["num_rays"] + 40 * counters["nodes_visited"] + 52 * counters["tris_tested"]
     return 104 * counters["num_rays"] + 64 * counters["nodes_visited"] + 88 * counters["tris_tested"]
+
+
+def build_bytes(num_tris, num_nodes, real_bytes=4):
+    """read the mesh once + write the tree once = N*(12 + 9*sizeof(T)) + nodes*sizeof(BVHNode) + 4N."""
+    return num_tris * (12 + 9 * real_bytes) + num_nodes * (40 if real_bytes == 4 else 64) + 4 * num_tris
 
 
 def parity(ref_hits, ref_mask, gpu_hits, gpu_mask):
@@ -83,7 +117,25 @@ def parity(ref_hits, ref_mask, gpu_hits, gpu_mask):
     }
 
 
-def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, gpu_results=None, budget_s=12.0):
+def bit_identical(h_a, m_a, h_b, m_b):
+    same = np.array_equal(m_a, m_b)
+    for k in ("t", "u", "v", "prim_id"):
+        same = same and h_a[k].tobytes() == h_b[k].tobytes()
+    return bool(same)
+
+
+def host_threads():
+    """Usable host parallelism: the box may expose more logical CPUs than its cgroup quota allows."""
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else max(1, int(int(q) / int(per)))
+    except Exception:
+        quota = None
+    return quota
+
+
+def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, width, gpu_results=None, budget_s=12.0):
     """Reference (or port) timed on the host cores over a bounded sample of the same buffers; with `gpu_results` =
     (hits1, mask1, hits2, mask2) of the GPU also the parity check of the same run."""
     from oracle import bindings as ob
@@ -91,33 +143,27 @@ def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, gpu_results
     total = rays1.shape[0] + rays2.shape[0]
     if ob.reference_available():
         R = ob.Reference(verts, faces)
-        # usable host parallelism: the box may expose more logical CPUs than its cgroup quota allows;
-        # oversubscribing a quota makes OpenMP collapse, so probe a few thread counts and keep the best
-        quota = None
-        try:
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-            quota = None if q == "max" else max(1, int(int(q) / int(per)))
-        except Exception:
-            quota = None
+        # oversubscribing a cgroup quota makes OpenMP collapse, so probe a few thread counts and keep the best
+        quota = host_threads()
         hw = R.max_threads()
         cands = sorted({t for t in ((quota or hw), 2 * (quota or hw), hw) if 1 <= t <= hw})
         ok, st = R.build(parallel=True, threads=cands[0])
         build_ms = st["build_secs"] * 1e3
-        probe = rays1.reshape(-1, WIDTH)[::40].reshape(-1)
+        probe = rays1.reshape(-1, width)[::40].reshape(-1)
         best_t, rate = cands[0], 0.0
         for t in cands:
-            _, _, secs = R.traverse(probe, threads=t, chunk=WIDTH)
+            _, _, secs = R.traverse(probe, threads=t, chunk=width)
             if probe.shape[0] / secs > rate:
                 best_t, rate = t, probe.shape[0] / secs
         frac = min(1.0, budget_s * rate / total)
-        rows1 = max(8, int(rays1.shape[0] // WIDTH * frac))
-        step = max(1, (rays1.shape[0] // WIDTH) // rows1)
-        s1 = rays1.reshape(-1, WIDTH)[::step].reshape(-1)
+        rows1 = max(8, int(rays1.shape[0] // width * frac))
+        step = max(1, (rays1.shape[0] // width) // rows1)
+        s1 = rays1.reshape(-1, width)[::step].reshape(-1)
         s2 = rays2[:: max(1, step)]
         best = 1e30
         for _ in range(2):
-            rh1, rm1, t1 = R.traverse(s1, threads=best_t, chunk=WIDTH)
-            rh2, rm2, t2 = R.traverse(s2, threads=best_t, chunk=WIDTH)
+            rh1, rm1, t1 = R.traverse(s1, threads=best_t, chunk=width)
+            rh2, rm2, t2 = R.traverse(s2, threads=best_t, chunk=width)
             best = min(best, t1 + t2)
         value = (s1.shape[0] + s2.shape[0]) / best / 1e6
         out = {
@@ -129,39 +175,35 @@ def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, gpu_results
                           s1.shape[0], step, s2.shape[0], best_t, cands, hw, quota),
             "build_ms": round(build_ms, 1),
         }
-        if ob.reference_v3_available():  # the same code with -march=x86-64-v3: the stronger timing baseline of SURVEY 8(d)
+        if ob.reference_v3_available() and verts.dtype == np.float32:  # the same code with -march=x86-64-v3: SURVEY 8(d)'s stronger timing baseline
             try:
                 R3 = ob.ReferenceV3(verts, faces)
                 R3.build(parallel=True, threads=cands[0])
-                _, _, t1 = R3.traverse(s1, threads=best_t, chunk=WIDTH)
-                _, _, t2 = R3.traverse(s2, threads=best_t, chunk=WIDTH)
+                _, _, t1 = R3.traverse(s1, threads=best_t, chunk=width)
+                _, _, t2 = R3.traverse(s2, threads=best_t, chunk=width)
                 out["value_march_x86_64_v3"] = round((s1.shape[0] + s2.shape[0]) / (t1 + t2) / 1e6, 4)
             except Exception as e:  # pragma: no cover
                 out["value_march_x86_64_v3"] = None
                 out["v3_error"] = repr(e)
-        # same traversal code over the GPU-built node array: separates "better tree" from "faster traversal"
         if gpu_results is not None:  # reference on ITS tree vs GPU on the GPU-built tree: equal up to exact-t ties in prim_id / u / v
             gh1, gm1, gh2, gm2 = gpu_results
-            W = WIDTH
             out["parity_own_trees"] = {
-                "primary": parity(rh1, rm1, gh1.reshape(-1, W)[::step].reshape(-1), gm1.reshape(-1, W)[::step].reshape(-1)),
+                "primary": parity(rh1, rm1, gh1.reshape(-1, width)[::step].reshape(-1), gm1.reshape(-1, width)[::step].reshape(-1)),
                 "bounce": parity(rh2, rm2, gh2[:: max(1, step)], gm2[:: max(1, step)])}
+        # same traversal code over the GPU-built node array: separates "better tree" from "faster traversal"
         if R.load_tree(gpu_nodes, gpu_indices):
-            th1, tm1, t1 = R.traverse(rays1, threads=best_t, chunk=WIDTH)
-            th2, tm2, t2 = R.traverse(rays2, threads=best_t, chunk=WIDTH)
+            th1, tm1, t1 = R.traverse(rays1, threads=best_t, chunk=width)
+            th2, tm2, t2 = R.traverse(rays2, threads=best_t, chunk=width)
             out["value_on_gpu_built_tree"] = round(total / (t1 + t2) / 1e6, 4)
             if gpu_results is not None:  # same node array: every field must be bit-identical
                 gh1, gm1, gh2, gm2 = gpu_results
-                same = all(np.array_equal(a, b) for a, b in ((tm1, gm1), (tm2, gm2)))
-                for k in ("t", "u", "v", "prim_id"):
-                    same = same and th1[k].tobytes() == gh1[k].tobytes() and th2[k].tobytes() == gh2[k].tobytes()
-                out["parity_same_tree_bit_identical"] = bool(same)
+                out["parity_same_tree_bit_identical"] = bit_identical(th1, tm1, gh1, gm1) and bit_identical(th2, tm2, gh2, gm2)
         return out
     O = ob.Oracle()
     t0 = time.time()
     nodes, idx, _ = O.build(verts, faces)
     build_ms = (time.time() - t0) * 1e3
-    s1 = rays1.reshape(-1, WIDTH)[::54].reshape(-1)
+    s1 = rays1.reshape(-1, width)[::54].reshape(-1)
     t0 = time.time()
     O.traverse(nodes, idx, verts, faces, s1)
     dt = time.time() - t0
@@ -170,12 +212,120 @@ def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, gpu_results
             "build_ms": round(build_ms, 1)}
 
 
+# ---------------------------------------------------------------------------
+# workload set-up (shared by the headline run, the `configs` extras and the PMC child)
+# ---------------------------------------------------------------------------
+def make_mesh(cfg, mesh_path=None):
+    from nanort_amd import scenes
+
+    if cfg["mesh"] == "sphere":
+        if mesh_path:
+            from nanort_amd import meshio
+
+            v, f = meshio.load_mesh(mesh_path)
+            # the C2 camera looks at (0, 5, 0) from z = 20: bring a user mesh into that frame (uniform scale to a 15-unit box)
+            lo, hi = v.min(axis=0), v.max(axis=0)
+            s = np.float32(15.0 / float((hi - lo).max()))
+            v = ((v - (lo + hi) * np.float32(0.5)) * s + np.array([0, 5, 0], np.float32)).astype(np.float32)
+            return np.ascontiguousarray(v), np.ascontiguousarray(f), "user mesh %s (%d triangles)" % (os.path.basename(mesh_path), f.shape[0])
+        v, f = scenes.sphere()
+        return v, f, None
+    _, nx, ny = cfg["mesh"]
+    v, f = scenes.plane(nx, ny)
+    return v, f, None
+
+
+class Workload:
+    """One config on one rank: mesh, GPU-built BVH, wave 1 and wave 2 resident in HBM."""
+
+    def __init__(self, name, rank=0, world=1, device=0, builds=5, mesh_path=None):
+        import torch
+
+        from nanort_amd import BVHAccel, TriangleMesh, scenes
+        from nanort_amd.wire import hit_dtype, ray_dtype, widen_rays
+
+        cfg = CONFIGS[name]
+        self.name, self.cfg, self.rank, self.world, self.torch = name, cfg, rank, world, torch
+        self.real = np.float32 if cfg["real"] == "f32" else np.float64
+        self.rb = 4 if cfg["real"] == "f32" else 8
+        self.RAY, self.HIT = ray_dtype(self.real), hit_dtype(self.real)
+        v32, self.faces, self.mesh_note = make_mesh(cfg, mesh_path)
+        self.verts32 = v32
+        self.verts = v32 if self.real == np.float32 else v32.astype(np.float64)
+        mesh = TriangleMesh(self.verts, self.faces)
+        self.accel = BVHAccel(self.real, device=device)
+        self.build_ms = []
+        for _ in range(max(1, builds)):
+            assert self.accel.Build(mesh.num_faces, mesh)
+            self.build_ms.append(self.accel.LastBuildMs())
+        self.stats = self.accel.GetStatistics()
+        self.num_nodes = int(self.stats["num_leaf_nodes"] + self.stats["num_branch_nodes"])
+        # image rows of this rank: interleaved; weak scaling grows the image, strong scaling cuts a fixed one
+        W, H = cfg["w"], cfg["h"]
+        self.width = W
+        if "tile_of" in cfg:  # one GPU's share of the C4 frame
+            t = cfg["tile_of"]
+            self.h_glob, y0, step, rows = H, rank, t * world, H // (t * world)
+        elif cfg["scaling"] == "strong":
+            if H % world:
+                raise SystemExit("--config %s: %d rows do not split into %d equal tiles" % (name, H, world))
+            self.h_glob, y0, step, rows = H, rank, world, H // world
+        else:
+            self.h_glob, y0, step, rows = H * world, rank, world, H
+        self.rows = rows
+        rays1_f32 = scenes.camera_rays_rows(W, self.h_glob, y0, step, rows)
+        self.rays1 = rays1_f32 if self.real == np.float32 else widen_rays(rays1_f32)
+        self.n1 = self.rays1.shape[0]
+        cuda = torch.device("cuda", device)
+        self.d_rays1 = torch.from_numpy(self.rays1.view(np.uint8)).to(cuda)
+        self.d_hits1 = torch.empty(self.n1 * self.HIT.itemsize, dtype=torch.uint8, device=cuda)
+        self.d_mask1 = torch.empty(self.n1, dtype=torch.uint8, device=cuda)
+        self.accel.TraverseBatchDevice(self.d_rays1, self.d_hits1, self.d_mask1)
+        torch.cuda.synchronize()
+        self.hits1 = self.d_hits1.cpu().numpy().view(self.HIT)
+        self.mask1 = self.d_mask1.cpu().numpy()
+        # wave 2 is generated on the host from the wave-1 hits, in fp32 as SURVEY 8(d) defines it (widened for C5);
+        # pixel index of ray i in the global image: row (y0 + step * (i // W)), column i % W
+        from nanort_amd.wire import HIT_F32
+
+        h32 = self.hits1
+        if self.real != np.float32:
+            h32 = np.zeros(self.n1, dtype=HIT_F32)
+            for k in ("t", "u", "v"):
+                h32[k] = self.hits1[k].astype(np.float32)
+            h32["prim_id"] = self.hits1["prim_id"]
+        self.kind2 = "bounce"
+        rays2_f32 = scenes.secondary_rays("bounce", v32, self.faces, rays1_f32, h32, self.mask1, pixel_base=rank * self.n1)
+        self.rays1_f32, self.hits1_f32 = rays1_f32, h32
+        self.rays2 = rays2_f32 if self.real == np.float32 else widen_rays(rays2_f32)
+        self.n2 = self.rays2.shape[0]
+        self.d_rays2 = torch.from_numpy(self.rays2.view(np.uint8)).to(cuda)
+        # wave-2 records are padded to n1 so that every rank's gather slice has the same size
+        self.d_hits2 = torch.empty(max(1, self.n1) * self.HIT.itemsize, dtype=torch.uint8, device=cuda)
+        self.d_mask2 = torch.empty(max(1, self.n1), dtype=torch.uint8, device=cuda)
+
+    def counters(self):
+        c1 = self.accel.TraverseCountDevice(self.d_rays1)
+        c2 = self.accel.TraverseCountDevice(self.d_rays2) if self.n2 else {"num_rays": 0, "nodes_visited": 0, "tris_tested": 0}
+        return c1, c2
+
+    def results(self):
+        self.torch.cuda.synchronize()
+        return (self.d_hits1.cpu().numpy().view(self.HIT), self.d_mask1.cpu().numpy(),
+                self.d_hits2.cpu().numpy().view(self.HIT)[:self.n2], self.d_mask2.cpu().numpy()[:self.n2])
+
+    def describe(self):
+        return "%s; %dx%d objrender-camera primaries + 1 cosine bounce per hit (%d + %d rays per GPU per step)" % (
+            self.mesh_note or self.cfg["text"], self.width, self.rows, self.n1, self.n2)
+
+
 def pipelined(accel, torch, wave1, wave2, steps, rays_per_step, frames_in_flight=2):
     """K steps with `frames_in_flight` independent frames in flight, one stream per frame (one context: every
     launch owns a launch slot).  Same work as the timed region; reported beside it, never as `value`."""
     streams = [torch.cuda.Stream() for _ in range(frames_in_flight)]
     bufs = [(wave1, wave2)] + [tuple((w[0], torch.empty_like(w[1]), torch.empty_like(w[2])) for w in (wave1, wave2))
                                for _ in range(frames_in_flight - 1)]
+
     def run(k):
         for i in range(k):
             w1, w2 = bufs[i % frames_in_flight]
@@ -192,34 +342,257 @@ def pipelined(accel, torch, wave1, wave2, steps, rays_per_step, frames_in_flight
             "ms_per_step": round(dt / steps * 1e3, 4)}
 
 
+# ---------------------------------------------------------------------------
+# hardware counters, collected in the same invocation (outside the timed region)
+# ---------------------------------------------------------------------------
+PMC_PASSES = [
+    ("fetch", "FETCH_SIZE"),
+    ("write", "WRITE_SIZE"),
+    ("sq", "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"),
+    ("tcc", "TCC_HIT_sum TCC_MISS_sum"),
+]
+
+
+def pmc_child(args):
+    """The sub-run the counter passes profile: set-up, then (warmup + steps) x (primary, bounce) launches, nothing else."""
+    import torch
+
+    wl = Workload(args.config, builds=1, mesh_path=args.mesh)
+    for _ in range(args.warmup + args.steps):
+        wl.accel.TraverseBatchDevice(wl.d_rays1, wl.d_hits1, wl.d_mask1)
+        wl.accel.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)
+    torch.cuda.synchronize()
+    print(json.dumps({"pmc_child": True, "kernel": wl.accel.LastKernelName(), "n1": wl.n1, "n2": wl.n2}), flush=True)
+
+
+def _kernel_key(name):
+    return name.replace("void ", "").split("(")[0].replace(" ", "")
+
+
+def pmc_collect(config, mesh_path, kernel_name, keep_dir=None, warmup=1, steps=3):
+    """Run the counter passes (one rocprofv3 --pmc invocation each, kernel trace only, as MI355X_MICROARCH.md
+    prescribes) over `bench.py --pmc-child` and return per-launch means for the primary and the bounce launches of
+    `kernel_name`.  Returns (dict, error string or None)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    want = _kernel_key(kernel_name)
+    tmp = keep_dir or tempfile.mkdtemp(prefix="nrt_pmc_", dir="/tmp")
+    os.makedirs(tmp, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    per = {"primary": {}, "bounce": {}}
+    durs = {"primary": [], "bounce": []}
+    errors = []
+    for tag, counters in PMC_PASSES:
+        out_dir = os.path.join(tmp, tag)
+        cmd = [exe, "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", out_dir, "-o", "p", "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", config, "--steps", str(steps), "--warmup", str(warmup)]
+        if mesh_path:
+            cmd += ["--mesh", mesh_path]
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300, cwd="/tmp")
+        except Exception as e:  # pragma: no cover
+            errors.append("%s: %r" % (tag, e))
+            continue
+        if r.returncode != 0:
+            errors.append("%s: rc %d: %s" % (tag, r.returncode, r.stdout[-300:]))
+            continue
+        rows = []
+        for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+            rows += [x for x in csv.DictReader(open(path)) if _kernel_key(x.get("Kernel_Name", "")) == want]
+        if not rows:
+            errors.append("%s: no counter rows for %s" % (tag, kernel_name))
+            continue
+        ids = sorted({int(x["Dispatch_Id"]) for x in rows})
+        order = {d: k for k, d in enumerate(ids)}  # launch 0 = the set-up's primary wave, then (primary, bounce) pairs
+        acc = {}
+        for x in rows:
+            k = order[int(x["Dispatch_Id"])]
+            if k == 0:
+                continue
+            wave = "primary" if k % 2 == 1 else "bounce"
+            acc.setdefault((wave, x["Counter_Name"], k), 0.0)
+            acc[(wave, x["Counter_Name"], k)] += float(x["Counter_Value"])
+        for (wave, cname, _k), v in acc.items():
+            per[wave].setdefault(cname, []).append(v)
+        for path in glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"), recursive=True):
+            tr = [x for x in csv.DictReader(open(path)) if _kernel_key(x.get("Kernel_Name", "")) == want]
+            tr.sort(key=lambda x: int(x["Start_Timestamp"]))
+            for k, x in enumerate(tr):
+                if k >= 1 and tag == "sq":
+                    durs["primary" if k % 2 == 1 else "bounce"].append((int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) * 1e-3)
+    out = {w: {c: float(np.mean(v)) for c, v in per[w].items()} for w in per}
+    out["profiled_us"] = {w: (float(np.mean(v)) if v else None) for w, v in durs.items()}
+    if not keep_dir:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, ("; ".join(errors) if errors else None)
+
+
+def roofline_from_counters(pmc, k_ms, n_cus):
+    """HBM and VALU rooflines of the primary / bounce launches from the in-run counter means (per launch)."""
+    simds = n_cus * 4
+    lane_peak = simds * VALU_LANES_PER_SIMD * CLOCK_GHZ * 1e9  # lane-operations per second
+    res = {"hbm": None, "valu": None}
+    waves = ("primary", "bounce")
+    if all("FETCH_SIZE" in pmc[w] and "WRITE_SIZE" in pmc[w] for w in waves):
+        # rocprofv3 reports both in KiB; gfx950: FETCH_SIZE counts 128-B read requests as 64 B -> x2 (MI355X_MICROARCH.md §HBM)
+        b = {w: pmc[w]["FETCH_SIZE"] * 1024.0 * 2.0 + pmc[w]["WRITE_SIZE"] * 1024.0 for w in waves}
+        tot_ms = sum(k_ms[w] for w in waves)
+        gbs = sum(b.values()) / (tot_ms * 1e-3) / 1e9
+        res["hbm"] = {"bytes_per_launch": int(sum(b.values()) / 2), "achieved_GBs": round(gbs, 1), "peak_GBs": HBM_PEAK_GBS,
+                      "frac": round(gbs / HBM_PEAK_GBS, 4),
+                      "per_wave_bytes": {w: int(b[w]) for w in waves},
+                      "formula": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024"}
+        if all("TCC_HIT_sum" in pmc[w] for w in waves):
+            h = sum(pmc[w]["TCC_HIT_sum"] for w in waves)
+            m = sum(pmc[w]["TCC_MISS_sum"] for w in waves)
+            res["hbm"]["l2_hit_rate"] = round(h / max(1.0, h + m), 4)
+    if all("SQ_THREAD_CYCLES_VALU" in pmc[w] and "SQ_INSTS_VALU" in pmc[w] for w in waves):
+        per = {}
+        for w in waves:
+            lane_ops, insts = pmc[w]["SQ_THREAD_CYCLES_VALU"], pmc[w]["SQ_INSTS_VALU"]
+            secs = k_ms[w] * 1e-3
+            per[w] = {"lane_ops": int(lane_ops), "wave_insts": int(insts), "frac": round(lane_ops / secs / lane_peak, 4),
+                      "lane_util": round(lane_ops / (64.0 * insts), 4),
+                      # a wave64 instruction holds its SIMD-32 for 2 cycles (packed / 3-input forms longer: a lower bound)
+                      "issue_busy": round(insts * VALU_CYCLES_PER_WAVE_INST / (simds * secs * CLOCK_GHZ * 1e9), 4)}
+            if "SQ_WAIT_ANY" in pmc[w] and pmc[w].get("SQ_WAVE_CYCLES"):
+                per[w]["wait_frac_of_wave_cycles"] = round(pmc[w]["SQ_WAIT_ANY"] / pmc[w]["SQ_WAVE_CYCLES"], 4)
+            if "SQ_LDS_BANK_CONFLICT" in pmc[w]:
+                per[w]["lds_bank_conflict_cycles"] = int(pmc[w]["SQ_LDS_BANK_CONFLICT"])
+            if pmc[w].get("GRBM_GUI_ACTIVE") and pmc.get("profiled_us", {}).get(w):
+                per[w]["effective_clock_GHz_under_profiler"] = round(pmc[w]["GRBM_GUI_ACTIVE"] / N_XCD / (pmc["profiled_us"][w] * 1e3), 3)
+        tot_ops = sum(per[w]["lane_ops"] for w in waves)
+        tot_s = sum(k_ms[w] for w in waves) * 1e-3
+        res["valu"] = {"lane_ops_per_launch": int(tot_ops / 2), "achieved_Tlaneops": round(tot_ops / tot_s / 1e12, 3),
+                       "peak_Tlaneops": round(lane_peak / 1e12, 2),
+                       "peak_definition": "%d CUs x 4 SIMDs x %d lanes x %.1f GHz (max clock)" % (n_cus, VALU_LANES_PER_SIMD, CLOCK_GHZ),
+                       "frac": round(tot_ops / tot_s / lane_peak, 4),
+                       "lane_util": round(tot_ops / (64.0 * sum(per[w]["wave_insts"] for w in waves)), 4),
+                       "issue_busy": round(sum(per[w]["wave_insts"] for w in waves) * VALU_CYCLES_PER_WAVE_INST / (simds * tot_s * CLOCK_GHZ * 1e9), 4),
+                       "per_wave": per}
+    return res
+
+
+# ---------------------------------------------------------------------------
+# untimed extras: the other single-GPU configs of BASELINE.json
+# ---------------------------------------------------------------------------
+def measure_config(name, mesh_path=None, reps=5, parity_rays=200_000):
+    """{Mrays/s, build_ms, parity} for one config on GPU 0, with the reference's answer on a bounded sample."""
+    import torch
+
+    wl = Workload(name, builds=3, mesh_path=mesh_path)
+    a = wl.accel
+    t1, t2 = [], []
+    for _ in range(reps):
+        a.TraverseBatchDevice(wl.d_rays1, wl.d_hits1, wl.d_mask1)
+        t1.append(a.LastTraverseMs())
+        a.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)
+        t2.append(a.LastTraverseMs())
+    ms1, ms2 = float(np.median(t1)), float(np.median(t2))
+    out = {"workload": wl.describe(), "dtype": wl.cfg["real"], "value": round((wl.n1 + wl.n2) / (ms1 + ms2) / 1e3, 1), "unit": "Mrays/s",
+           "primary_ms": round(ms1, 4), "bounce_ms": round(ms2, 4), "primary_Mrays_s": round(wl.n1 / ms1 / 1e3, 1),
+           "build_ms": round(float(np.median(wl.build_ms)), 4), "kernel": a.LastKernelName(),
+           "bvh": {"nodes": wl.num_nodes, "max_depth": int(wl.stats["max_tree_depth"])},
+           "roofline_build": {"bytes": int(build_bytes(wl.faces.shape[0], wl.num_nodes, wl.rb)),
+                              "frac": round(build_bytes(wl.faces.shape[0], wl.num_nodes, wl.rb) / (float(np.median(wl.build_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+    try:
+        from oracle import bindings as ob
+
+        gh1, gm1, gh2, gm2 = wl.results()
+        nodes, indices = a.GetTree()
+        if ob.reference_available():
+            R = ob.Reference(wl.verts, wl.faces)
+            threads = host_threads() or 0
+            # (a) the reference's Traverse over the GPU-built node array: every field bit-identical
+            s1 = max(1, wl.n1 // parity_rays)
+            s2 = max(1, wl.n2 // parity_rays)
+            p = {"kind": "reference"}
+            if R.load_tree(nodes, indices):
+                th1, tm1, _ = R.traverse(wl.rays1[::s1], threads=threads, chunk=4096)
+                th2, tm2, _ = R.traverse(wl.rays2[::s2], threads=threads, chunk=4096)
+                p["same_tree_bit_identical"] = bit_identical(th1, tm1, gh1[::s1], gm1[::s1]) and bit_identical(th2, tm2, gh2[::s2], gm2[::s2])
+                p["same_tree_rays"] = int(th1.shape[0] + th2.shape[0])
+            # (b) the reference on its own tree (its own Build): equal up to exact-t ties
+            ok, st = R.build(parallel=True, threads=threads)
+            s1b = max(1, wl.n1 // (parity_rays // 10))
+            rh1, rm1, _ = R.traverse(wl.rays1[::s1b], threads=threads, chunk=4096)
+            p["own_trees"] = parity(rh1, rm1, gh1[::s1b], gm1[::s1b])
+            p["reference_tree"] = {"nodes": int(st["num_leaf_nodes"] + st["num_branch_nodes"]), "max_depth": int(st["max_tree_depth"]),
+                                   "build_ms": round(st["build_secs"] * 1e3, 1)}
+        else:
+            O = ob.Oracle()
+            s1 = max(1, wl.n1 // 20000)
+            oh, om = O.traverse(nodes, indices, wl.verts, wl.faces, wl.rays1[::s1])
+            p = {"kind": "port", "same_tree_bit_identical": bit_identical(oh, om, gh1[::s1], gm1[::s1]), "same_tree_rays": int(oh.shape[0])}
+        out["parity"] = p
+    except Exception as e:  # pragma: no cover
+        out["parity"] = {"error": repr(e)}
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------
+def self_spawn(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) and relay their output."""
+    import torch
+
+    shared = os.environ.get("NRT_BENCH_TEST_SHARED_GPU") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and not shared:
+        sys.stderr.write("bench.py: --gpus %d requested but this box exposes %d GPU(s); refusing to report a %d-GPU line "
+                         "from fewer devices\n" % (args.gpus, have, args.gpus))
+        return 2
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
+    ap.add_argument("--mesh", default=None, help="C2: a .ply / .obj triangle mesh (e.g. Stanford bun_zipper.ply) instead of the procedural stand-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--builds", type=int, default=5)
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras (2 frames in flight, primary+shadow): use for rocprofv3 runs, so that the "
                          "kernel statistics hold the timed region's launches only")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (roofline.hbm/valu fall back to the committed file)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the untimed measurements of the other single-GPU configs")
+    ap.add_argument("--pmc-dir", default=None, help="keep the raw rocprofv3 counter CSVs here")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.mesh and args.config != "C2":
+        raise SystemExit("--mesh applies to --config C2")
+
+    if args.pmc_child:
+        return pmc_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args, sys.argv[1:]))
 
     import torch
-
-    from nanort_amd import BVHAccel, TriangleMesh, scenes
-    from nanort_amd.wire import HIT_F32, RAY_F32
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     # Test hook (tests/test_bench_multi.py): NRT_BENCH_TEST_SHARED_GPU=1 lets N ranks share GPU 0 so that the N > 1
     # control flow can be run on a one-GPU box; RCCL cannot put two ranks on one device, so the collectives then go
     # through gloo with CPU staging.  Never set by the driver: its numbers come from one rank per GPU over RCCL.
     shared = world > 1 and os.environ.get("NRT_BENCH_TEST_SHARED_GPU") == "1"
     if shared:
         local_rank = 0
+    if world > 1 and not shared and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -231,81 +604,63 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     comm_dev = "cpu" if shared else "cuda"
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
-    # ---- mesh + BVH (replicated per rank, deterministic) ----------------------
-    verts, faces = scenes.plane(1000, 500)
-    mesh = TriangleMesh(verts, faces)
-    accel = BVHAccel(np.float32, device=local_rank)
-    build_ms = []
-    for _ in range(max(1, args.builds)):
-        assert accel.Build(mesh.num_faces, mesh)
-        build_ms.append(accel.LastBuildMs())
-    stats = accel.GetStatistics()
-
-    # ---- rays: wave 1 (this rank's interleaved rows), wave 2 from its hits --------
-    H_glob = HEIGHT * world
-    rays1 = scenes.camera_rays_rows(WIDTH, H_glob, rank, world, HEIGHT)
-    n1 = rays1.shape[0]
-    d_rays1 = torch.from_numpy(rays1.view(np.uint8)).cuda()
-    d_hits1 = torch.empty(n1 * HIT_F32.itemsize, dtype=torch.uint8, device="cuda")
-    d_mask1 = torch.empty(n1, dtype=torch.uint8, device="cuda")
-    accel.TraverseBatchDevice(d_rays1, d_hits1, d_mask1)
-    torch.cuda.synchronize()
-    hits1 = d_hits1.cpu().numpy().view(HIT_F32)
-    mask1 = d_mask1.cpu().numpy()
-    # pixel index of ray i in the global image: row (rank + world * (i // W)), column i % W
-    rays2 = scenes.secondary_rays("bounce", verts, faces, rays1, hits1, mask1, pixel_base=rank * n1)
-    n2 = rays2.shape[0]
-    d_rays2 = torch.from_numpy(rays2.view(np.uint8)).cuda()
-    d_hits2 = torch.empty(max(1, n2) * HIT_F32.itemsize, dtype=torch.uint8, device="cuda")
-    d_mask2 = torch.empty(max(1, n2), dtype=torch.uint8, device="cuda")
-    # rank 0 assembles the frame: it receives every rank's records over its 7 direct xGMI links at once (33 MB each),
-    # the other ranks only send.  The records are double-buffered so that the gather of step k (RCCL, its own stream)
-    # overlaps wave 2 of step k and all of step k+1; it is waited for before its buffers are reused.
-    hit_bufs = [d_hits1, torch.empty_like(d_hits1)] if world > 1 else [d_hits1]
     from nanort_amd import dist as nd
+    from nanort_amd import scenes
 
-    proto = torch.empty(0, dtype=torch.uint8, device=comm_dev)
-    gathered = [None, None]
+    wl = Workload(args.config, rank, world, local_rank, args.builds, args.mesh)
+    accel, n1, n2 = wl.accel, wl.n1, wl.n2
+    HIT = wl.HIT
+    # rank 0 assembles the frame: it receives every rank's records over its 7 direct xGMI links at once (33 MB each per
+    # wave), the other ranks only send.  The records of BOTH waves are double-buffered so that the gather of wave 1
+    # (RCCL, its own stream) overlaps wave 2 of the same step and the gather of wave 2 overlaps the next step; a gather
+    # is waited for before its buffers are reused.
+    nbuf = 2 if world > 1 else 1
+    hit_bufs1 = [wl.d_hits1] + [torch.empty_like(wl.d_hits1) for _ in range(nbuf - 1)]
+    hit_bufs2 = [wl.d_hits2] + [torch.empty_like(wl.d_hits2) for _ in range(nbuf - 1)]
+    gathered1 = gathered2 = [None, None]
     if world > 1 and rank == 0:
-        gathered = [torch.empty(world * n1 * HIT_F32.itemsize, dtype=torch.uint8, device=comm_dev) for _ in range(2)]
-    del proto
-    pending = [None, None]
+        gathered1 = [torch.empty(world * n1 * HIT.itemsize, dtype=torch.uint8, device=comm_dev) for _ in range(2)]
+        gathered2 = [torch.empty(world * n1 * HIT.itemsize, dtype=torch.uint8, device=comm_dev) for _ in range(2)]
+    pending = [[None, None], [None, None]]  # [wave][buffer]
 
     # ---- work counters -> algorithmic bytes per launch ---------------------------
-    c1 = accel.TraverseCountDevice(d_rays1)
-    c2 = accel.TraverseCountDevice(d_rays2)
-    bytes1, bytes2 = algorithmic_bytes(c1), algorithmic_bytes(c2)
+    c1, c2 = wl.counters()
+    bytes1, bytes2 = algorithmic_bytes(c1, wl.rb), algorithmic_bytes(c2, wl.rb)
 
     step_no = [0]
 
     def step(ev=None):
-        b = step_no[0] % len(hit_bufs)
+        b = step_no[0] % nbuf
         step_no[0] += 1
-        if world > 1 and pending[b] is not None:
-            pending[b].wait()  # the gather that last used this buffer pair (two steps ago)
-            pending[b] = None
+        if world > 1:
+            for w in (0, 1):
+                if pending[w][b] is not None:
+                    pending[w][b].wait()  # the gathers that last used this buffer pair (two steps ago)
+                    pending[w][b] = None
         if ev is not None:
             ev[0].record()
-        accel.TraverseBatchDevice(d_rays1, hit_bufs[b], d_mask1)
+        accel.TraverseBatchDevice(wl.d_rays1, hit_bufs1[b], wl.d_mask1)
         if ev is not None:
             ev[1].record()
         if world > 1:
-            src = hit_bufs[b].cpu() if shared else hit_bufs[b]  # (test hook: staged through the host for gloo)
-            _, pending[b] = nd.gather_hit_records(src, world, rank, dist, out=gathered[b], async_op=True)
+            src = hit_bufs1[b].cpu() if shared else hit_bufs1[b]  # (test hook: staged through the host for gloo)
+            _, pending[0][b] = nd.gather_hit_records(src, world, rank, dist, out=gathered1[b], async_op=True)
         if ev is not None:
             ev[2].record()
-        accel.TraverseBatchDevice(d_rays2, d_hits2, d_mask2)
+        accel.TraverseBatchDevice(wl.d_rays2, hit_bufs2[b], wl.d_mask2)
         if ev is not None:
             ev[3].record()
+        if world > 1:
+            src = hit_bufs2[b].cpu() if shared else hit_bufs2[b]
+            _, pending[1][b] = nd.gather_hit_records(src, world, rank, dist, out=gathered2[b], async_op=True)
 
     def drain():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        for w in (0, 1):
+            for b in range(2):
+                if pending[w][b] is not None:
+                    pending[w][b].wait()
+                    pending[w][b] = None
 
     for _ in range(args.warmup):
         step()
@@ -322,34 +677,101 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    kernel_name = accel.LastKernelName()
 
     k_ms1 = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     k_ms2 = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
     rays_per_step = n1 + n2
+    per_rank = None
+    gather_ms = None
     if world > 1:
-        t = torch.tensor([dt, float(rays_per_step), float(bytes1 + bytes2), k_ms1 + k_ms2], dtype=torch.float64,
-                         device=comm_dev)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0])
-        total_rays = float(tsum[1])
+        # a blocking gather of one wave's records, timed on its own (outside the timed region)
+        g0 = time.perf_counter()
+        src = hit_bufs1[0].cpu() if shared else hit_bufs1[0]
+        _, wk = nd.gather_hit_records(src, world, rank, dist, out=gathered1[0], async_op=True)
+        wk.wait()
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        t = torch.tensor([dt, float(rays_per_step), float(bytes1 + bytes2), k_ms1, k_ms2, gather_ms], dtype=torch.float64, device=comm_dev)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        allt = torch.stack(allt).cpu().numpy()
+        dt = float(allt[:, 0].max())
+        total_rays = float(allt[:, 1].sum())
+        per_rank = {"wall_ms_per_step": [round(float(x) / args.steps * 1e3, 4) for x in allt[:, 0]],
+                    "primary_kernel_ms": [round(float(x), 4) for x in allt[:, 3]],
+                    "bounce_kernel_ms": [round(float(x), 4) for x in allt[:, 4]],
+                    "kernel_ms_max": round(float((allt[:, 3] + allt[:, 4]).max()), 4),
+                    "kernel_ms_min": round(float((allt[:, 3] + allt[:, 4]).min()), 4),
+                    "gather_ms_one_wave_blocking": [round(float(x), 4) for x in allt[:, 5]]}
+        agg_bytes = float(allt[:, 2].sum())
+        agg_ms = float((allt[:, 3] + allt[:, 4]).max())
     else:
         total_rays = float(rays_per_step)
+        agg_bytes = float(bytes1 + bytes2)
+        agg_ms = k_ms1 + k_ms2
 
     if rank == 0:
         value = total_rays * args.steps / dt / 1e6
-        achieved = (bytes1 + bytes2) / ((k_ms1 + k_ms2) * 1e-3) / 1e9  # GB/s, this rank's two launches
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic_c3.json")
-        if os.path.exists(tf):
+        k_ms = {"primary": k_ms1, "bounce": k_ms2}
+        alg_gbs = agg_bytes / (agg_ms * 1e-3) / 1e9  # all ranks' algorithmic bytes over the slowest rank's two launches
+        build_ms = float(np.median(wl.build_ms))
+        bbytes = build_bytes(wl.faces.shape[0], wl.num_nodes, wl.rb)
+        roof = {
+            "kernel": kernel_name,
+            "limiting": "latency (per-ray dependent chain node fetch -> slab test -> next fetch; waves wait on L1/L2 about half of their "
+                        "cycles) with the vector ALUs a third busy and HBM far from saturated: see valu / hbm; no MFMA in this path",
+            "launch_ms": round((k_ms1 + k_ms2) / 2, 4),
+            "algorithmic": {"bytes_per_launch": int((bytes1 + bytes2) // 2), "GBs": round(alg_gbs, 1),
+                            "x_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4), "served_from_cache": True,
+                            "note": "SURVEY 8(d) bytes the reference's loop would touch (52 + 40*nodes + 52*tris per ray, counted by the "
+                                    "kernel's own counting pass on the tree traversed); they are served by L1/L2/Infinity Cache, so this "
+                                    "is not a bandwidth claim and may exceed the HBM peak"},
+            "build": {"bytes": int(bbytes), "ms": round(build_ms, 4), "GBs": round(bbytes / (build_ms * 1e-3) / 1e9, 1),
+                      "frac": round(bbytes / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                      "note": "compulsory traffic 52N + 40*nodes + 4N (SURVEY 8d) over the build's device time"},
+            "per_wave": {
+                "primary": {"ms": round(k_ms1, 4), "rays": n1, "nodes_per_ray": round(c1["nodes_visited"] / n1, 2),
+                            "tris_per_ray": round(c1["tris_tested"] / n1, 2), "algorithmic_bytes": int(bytes1)},
+                "bounce": {"ms": round(k_ms2, 4), "rays": n2, "nodes_per_ray": round(c2["nodes_visited"] / max(1, n2), 2),
+                           "tris_per_ray": round(c2["tris_tested"] / max(1, n2), 2), "algorithmic_bytes": int(bytes2)},
+            },
+        }
+        # hardware counters of this run (rank 0's GPU; every rank runs the same kernel on the same kind of rows)
+        pmc, pmc_err, source = None, None, None
+        if not args.no_pmc and not shared:
+            keep = args.pmc_dir and os.path.abspath(args.pmc_dir)
+            pmc, pmc_err = pmc_collect(args.config, args.mesh, kernel_name, keep_dir=keep)
+        n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        if pmc is not None:
+            r = roofline_from_counters(pmc, k_ms, n_cus)
+            if r["hbm"]:
+                roof["hbm"], source = r["hbm"], "in-run rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; 3 steps of the same workload)"
+            if r["valu"]:
+                roof["valu"] = r["valu"]
+        if pmc_err:
+            roof["pmc_error"] = pmc_err
+        if "hbm" not in roof and args.config == "C3":
+            tf = os.path.join(ROOT, "profiles", "traffic_c3.json")
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                traffic = float(json.load(open(tf)).get("hbm_bytes_per_launch"))
+                gbs = traffic / ((k_ms1 + k_ms2) / 2 * 1e-3) / 1e9
+                roof["hbm"] = {"bytes_per_launch": int(traffic), "achieved_GBs": round(gbs, 1), "peak_GBs": HBM_PEAK_GBS,
+                               "frac": round(gbs / HBM_PEAK_GBS, 4)}
+                source = "stale-file"
             except Exception:
-                traffic = None
+                pass
+        hb = roof.get("hbm")
+        roof.update({"bound": "hbm", "achieved": hb["achieved_GBs"] if hb else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": hb["frac"] if hb else None, "traffic": hb["bytes_per_launch"] if hb else None, "traffic_source": source})
+        cfg = wl.cfg
+        par = "replicated BVH, interleaved image rows per GPU"
+        if world > 1:
+            par += (", RCCL gather of both waves' hit records to rank 0 (send/recv over xGMI), double-buffered and overlapped with "
+                    "the following waves; %s" % ("strong scaling: fixed %dx%d frame cut into %d row-interleaved tiles" % (cfg["w"], cfg["h"], world)
+                                                 if cfg["scaling"] == "strong" else "weak scaling: %dx%d rays per GPU" % (cfg["w"], wl.rows)))
         out = {
-            "metric": "Mrays/s (primary + 1-bounce) at 1920x1080, 1M-tri mesh; BVH build ms",
+            "metric": METRIC,
             "value": round(value, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -357,47 +779,30 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": cfg["scaling"] if "tile_of" not in cfg else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "C3: Plane(1000,500) = 1,000,000 triangles fp32; %dx%d objrender-camera primaries "
-                            "+ 1 cosine bounce per hit (%d + %d rays per GPU per step)" % (WIDTH, HEIGHT, n1, n2),
-                "parallelism": "replicated BVH, interleaved image rows per GPU%s" % (
-                    ", RCCL gather of the wave-1 hit records to rank 0 (send/recv over xGMI), double-buffered and overlapped with the following waves" if world > 1 else ""),
-                "rays_per_step": int(total_rays),
-            },
-            "build_ms": round(float(np.median(build_ms)), 4),
-            "bvh": {"nodes": int(stats["num_leaf_nodes"] + stats["num_branch_nodes"]),
-                    "max_depth": int(stats["max_tree_depth"])},
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "nrt::k_traverse_wide<float,10>",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": int((bytes1 + bytes2) // 2),
-                "launch_ms": round((k_ms1 + k_ms2) / 2, 4),
-                "per_wave": {
-                    "primary": {"ms": round(k_ms1, 4), "rays": n1, "nodes_per_ray": round(c1["nodes_visited"] / n1, 2),
-                                "tris_per_ray": round(c1["tris_tested"] / n1, 2), "bytes": int(bytes1)},
-                    "bounce": {"ms": round(k_ms2, 4), "rays": n2,
-                               "nodes_per_ray": round(c2["nodes_visited"] / max(1, n2), 2),
-                               "tris_per_ray": round(c2["tris_tested"] / max(1, n2), 2), "bytes": int(bytes2)},
-                },
-            },
+            "dtype": cfg["real"],
+            "data": "synthetic" if not wl.mesh_note else "user mesh, synthetic rays",
+            "config": {"name": args.config, "workload": wl.describe(), "parallelism": par, "rays_per_step": int(total_rays)},
+            "build_ms": round(build_ms, 4),
+            "bvh": {"nodes": wl.num_nodes, "max_depth": int(wl.stats["max_tree_depth"])},
+            "roofline": roof,
         }
+        if world > 1:
+            out["multi_gpu"] = dict(per_rank, rccl_ranks=world, backend="gloo (test hook)" if shared else "nccl (RCCL)",
+                                    gathered_bytes_per_step=int(2 * world * n1 * HIT.itemsize))
         if world == 1 and not args.no_extras:
             # extras, outside the timed region: (a) the same K steps with two frames in flight (steps alternate
             # between two streams; a launch's drain tail is filled by the next frame's rays), (b) SURVEY 8(d)'s
             # primary + shadow pair
-            out["pipelined"] = pipelined(accel, torch, (d_rays1, d_hits1, d_mask1), (d_rays2, d_hits2, d_mask2), args.steps, n1 + n2)
-            rays_s = scenes.secondary_rays("shadow", verts, faces, rays1, hits1, mask1)
+            out["pipelined"] = pipelined(accel, torch, (wl.d_rays1, wl.d_hits1, wl.d_mask1), (wl.d_rays2, wl.d_hits2, wl.d_mask2), args.steps, n1 + n2)
+            rays_s = scenes.secondary_rays("shadow", wl.verts32, wl.faces, wl.rays1_f32, wl.hits1_f32, wl.mask1)
+            if wl.real != np.float32:
+                from nanort_amd.wire import widen_rays
+
+                rays_s = widen_rays(rays_s)
             d_rs = torch.from_numpy(rays_s.view(np.uint8)).cuda()
-            d_hs = torch.empty(max(1, rays_s.shape[0]) * HIT_F32.itemsize, dtype=torch.uint8, device="cuda")
+            d_hs = torch.empty(max(1, rays_s.shape[0]) * HIT.itemsize, dtype=torch.uint8, device="cuda")
             ts = []
             for _ in range(5):
                 accel.TraverseBatchDevice(d_rs, d_hs)
@@ -405,12 +810,23 @@ def main():
             ms_s = float(np.median(ts))
             out["primary_plus_shadow"] = {"value": round((n1 + rays_s.shape[0]) / (k_ms1 + ms_s) / 1e3, 1), "unit": "Mrays/s",
                                           "shadow_ms": round(ms_s, 4), "shadow_rays": int(rays_s.shape[0])}
+            del d_rs, d_hs
         if world == 1 and not args.no_cpu_baseline:
             nodes, indices = accel.GetTree()
-            torch.cuda.synchronize()
-            gpu_results = (d_hits1.cpu().numpy().view(HIT_F32), d_mask1.cpu().numpy(), d_hits2.cpu().numpy().view(HIT_F32)[:n2],
-                           d_mask2.cpu().numpy()[:n2])
-            out["cpu_baseline"] = cpu_baseline(verts, faces, rays1, rays2, nodes, indices, gpu_results)
+            # the timed region's own output buffers
+            accel.TraverseBatchDevice(wl.d_rays1, wl.d_hits1, wl.d_mask1)
+            accel.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)
+            budget = 12.0 if args.config in ("C3", "C2") else 6.0
+            out["cpu_baseline"] = cpu_baseline(wl.verts, wl.faces, wl.rays1, wl.rays2, nodes, indices, wl.width, wl.results(), budget_s=budget)
+        if world == 1 and not args.no_configs and args.config == "C3":
+            del wl
+            torch.cuda.empty_cache()
+            out["configs"] = {}
+            for name in ("C2", "C4tile", "C5"):
+                try:
+                    out["configs"][name] = measure_config(name)
+                except Exception as e:  # pragma: no cover
+                    out["configs"][name] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -311,6 +311,10 @@ NRT_API nrt_status nrtTraverseCountDevice_f64(nrt_ctx *ctx, const nrt_ray_f64 *d
  * Synchronises with that work. */
 NRT_API float nrtLastTraverseMs(nrt_ctx *ctx);
 NRT_API float nrtLastBuildMs(nrt_ctx *ctx);
+/* Name of the traversal kernel variant the most recent traversal launch of this context used, spelled as
+ * rocprofv3 prints it without the argument list (static storage; "" before the first launch).  bench.py
+ * reports it in `roofline.kernel` and matches the counter rows of its PMC passes against it. */
+NRT_API const char *nrtLastKernelName(const nrt_ctx *ctx);
 /* Profiling aid: loop-occupancy counters of the last traversal launched with the environment variable
  * NRT_DEBUG bit 32 set (a separately instantiated, slower kernel).  out8[0..6] = phase-1 wave iterations,
  * sum of active lanes, sum of lanes walking inner nodes, phase-2 iterations, sum of lanes testing a

@@ -170,6 +170,10 @@ class BVHAccel:
     def LastTraverseMs(self):
         return float(self._L.nrtLastTraverseMs(self._h))
 
+    def LastKernelName(self):
+        """The traversal kernel variant the most recent launch used (as rocprofv3 names it)."""
+        return self._L.nrtLastKernelName(self._h).decode()
+
     def _tree_size(self):
         nn, ni = ctypes.c_uint64(0), ctypes.c_uint64(0)
         self._check(self._L.nrtTreeSize(self._h, ctypes.byref(nn), ctypes.byref(ni)))

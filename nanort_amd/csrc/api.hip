@@ -23,7 +23,7 @@ hipError_t launch_traverse(const TraverseArgs<T> &, unsigned grid, bool count, i
 template <typename T>
 int traverse_blocks_per_cu(int lds_stack);
 template <typename T>
-hipError_t launch_traverse_wide(const TraverseArgs<T> &, unsigned grid, int lds_stack, int prim_kind, hipStream_t);
+hipError_t launch_traverse_wide(const TraverseArgs<T> &, unsigned grid, int lds_stack, int prim_kind, hipStream_t, const char **name_out);
 template <typename T>
 int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind);
 template <typename T>
@@ -91,6 +91,7 @@ struct nrt_ctx {
     DevBuf spill, spill_tmin;
     DevBuf cyl_hits, cyl_bits;    // cylinder kind: compact records + {hit, cap} bits between the traversal and its post pass
     hipEvent_t done = nullptr;    // recorded after the slot's last launch
+    hipEvent_t t0 = nullptr, t1 = nullptr; // timing of the slot's last launch (per slot: launches on different streams overlap)
     hipStream_t stream = nullptr; // stream of that launch
     bool used = false;
   };
@@ -113,8 +114,10 @@ struct nrt_ctx {
   int wide = 1, wide_stack = 10; // production path: WideNode kernel (env NRT_WIDE=0 selects the binary kernel)
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
 
-  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr;
-  bool have_traverse_time = false, have_build_time = false;
+  hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;
+  int last_timed_slot = -1; // slot of the most recent timed traversal launch (nrtLastTraverseMs)
+  bool have_build_time = false;
+  const char *last_kernel = ""; // variant of the most recent traversal launch (nrtLastKernelName)
 };
 
 static nrt_status fail(nrt_ctx *c, nrt_status st, const char *fmt, ...) {
@@ -141,6 +144,20 @@ static nrt_status fail(nrt_ctx *c, nrt_status st, const char *fmt, ...) {
 static nrt_status ensure(nrt_ctx *c, DevBuf &b, size_t bytes) {
   HIPCHK(c, devbuf_ensure(&b, bytes));
   return NRT_OK;
+}
+
+// Every call that rewrites the tree or the primitive buffers in place (nrtSetMesh / nrtSetSpheres / nrtSetCylinders /
+// nrtSetTree / nrtBuild) first waits for the traversal launches still in flight on the CALLER's streams: they read
+// b_nodes / b_tris / b_wide, which the rebuild reuses without reallocating (a per-frame "trace asynchronously on my
+// stream, then rebuild" loop is therefore safe without a synchronisation of the caller's own).
+static hipError_t wait_for_launches(nrt_ctx *c) {
+  std::lock_guard<std::mutex> lock(c->launch_mutex);
+  for (nrt_ctx::LaunchSlot &sl : c->slots)
+    if (sl.used && sl.done) {
+      const hipError_t e = hipEventSynchronize(sl.done);
+      if (e != hipSuccess) return e;
+    }
+  return hipStreamSynchronize(c->stream);
 }
 
 // Forget the current tree (the buffers stay allocated for the next one).
@@ -195,7 +212,6 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   c->device = device;
   if ((e = hipSetDevice(device)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipEventCreate(&c->ev_t0)) != hipSuccess || (e = hipEventCreate(&c->ev_t1)) != hipSuccess ||
       (e = hipEventCreate(&c->ev_b0)) != hipSuccess || (e = hipEventCreate(&c->ev_b1)) != hipSuccess ||
       (e = hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) {
     fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
@@ -205,7 +221,8 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   for (nrt_ctx::LaunchSlot &sl : c->slots) {
     if ((e = hipMalloc((void **)&sl.d_cursor, 2 * kCursorStrideWords * 4 * kMaxParts)) != hipSuccess ||
         (e = hipMemset(sl.d_cursor, 0, 2 * kCursorStrideWords * 4 * kMaxParts)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreate(&sl.t0)) != hipSuccess || (e = hipEventCreate(&sl.t1)) != hipSuccess) {
       fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
       nrtDestroy(c);
       return NRT_ERR_DEVICE;
@@ -248,6 +265,8 @@ void nrtDestroy(nrt_ctx *c) {
     if (sl.cyl_hits.p) (void)hipFree(sl.cyl_hits.p);
     if (sl.cyl_bits.p) (void)hipFree(sl.cyl_bits.p);
     if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.t0) (void)hipEventDestroy(sl.t0);
+    if (sl.t1) (void)hipEventDestroy(sl.t1);
   }
   free_tree(c);
   free_mesh(c);
@@ -255,7 +274,7 @@ void nrtDestroy(nrt_ctx *c) {
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->d_counters) (void)hipFree(c->d_counters);
-  hipEvent_t evs[] = {c->ev_t0, c->ev_t1, c->ev_b0, c->ev_b1};
+  hipEvent_t evs[] = {c->ev_b0, c->ev_b1};
   for (hipEvent_t ev : evs)
     if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -280,7 +299,7 @@ static nrt_status set_mesh(nrt_ctx *c, const T *vertices, size_t stride, const u
   if (stride < 3 * sizeof(T) && num_faces)
     return fail(c, NRT_ERR_INVALID, "nrtSetMesh: vertex stride %zu < %zu", stride, 3 * sizeof(T));
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, wait_for_launches(c));
   free_tree(c);
   free_mesh(c);
   c->prec = (int)sizeof(T);
@@ -324,7 +343,7 @@ static nrt_status set_spheres(nrt_ctx *c, const T *centers, const T *radii, uint
     return fail(c, NRT_ERR_PRECISION, "nrtSetSpheres: context already holds %s primitives", c->prec == 4 ? "f32" : "f64");
   if (n && (!centers || !radii)) return fail(c, NRT_ERR_INVALID, "nrtSetSpheres: NULL pointer");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, wait_for_launches(c));
   free_tree(c);
   free_mesh(c);
   c->prec = (int)sizeof(T);
@@ -348,7 +367,7 @@ static nrt_status set_cylinders(nrt_ctx *c, const float *endpoints, const float 
   if (n && (!endpoints || !radii)) return fail(c, NRT_ERR_INVALID, "nrtSetCylinders: NULL pointer");
   if (n >= 0x40000000u) return fail(c, NRT_ERR_INVALID, "nrtSetCylinders: too many cylinders");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, wait_for_launches(c));
   free_tree(c);
   free_mesh(c);
   c->prec = 4;
@@ -442,7 +461,7 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
     }
   }
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, wait_for_launches(c));
   free_tree(c);
   c->num_nodes = num_nodes;
   c->num_indices = num_indices;
@@ -496,7 +515,7 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   }
   if (bin_size < 2) return fail(c, NRT_ERR_INVALID, "nrtBuild: bin_size must be > 1 (nanort.h:1905)");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, wait_for_launches(c));
   free_tree(c);
   BuildResult res;
   std::string err;
@@ -648,17 +667,19 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.leaf_min = c->leaf_min;
 
   if (count || (c->debug_flags & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s));
-  if (timed) HIPCHK(c, hipEventRecord(c->ev_t0, s));
-  if (use_wide)
-    HIPCHK(c, launch_traverse_wide<T>(a, grid, c->wide_stack, c->prim_kind, s));
-  else
+  if (timed) HIPCHK(c, hipEventRecord(slot->t0, s));
+  if (use_wide) {
+    HIPCHK(c, launch_traverse_wide<T>(a, grid, c->wide_stack, c->prim_kind, s, &c->last_kernel));
+  } else {
     HIPCHK(c, launch_traverse<T>(a, grid, count, c->lds_stack, s));
+    c->last_kernel = sizeof(T) == 4 ? "nrt::k_traverse<float>" : "nrt::k_traverse<double>";
+  }
   if (d_cyl_hits)
     HIPCHK(c, launch_cylinder_post((const nrt_ray_f32 *)d_rays, (const nrt_hit_f32 *)slot->cyl_hits.p, (const uint8_t *)slot->cyl_bits.p,
                                    (const float *)c->d_verts, (uint32_t)n, d_cyl_hits, d_mask, s));
   if (timed) {
-    HIPCHK(c, hipEventRecord(c->ev_t1, s));
-    c->have_traverse_time = true;
+    HIPCHK(c, hipEventRecord(slot->t1, s));
+    c->last_timed_slot = (int)(slot - c->slots);
   }
   HIPCHK(c, hipEventRecord(slot->done, s));
   slot->parity ^= 1u;
@@ -857,12 +878,23 @@ nrt_status nrtTraverseCountDevice_f64(nrt_ctx *c, const nrt_ray_f64 *r, uint64_t
 }
 
 float nrtLastTraverseMs(nrt_ctx *c) {
-  if (!c || !c->have_traverse_time) return -1.f;
-  if (hipEventSynchronize(c->ev_t1) != hipSuccess) return -1.f;
+  if (!c) return -1.f;
+  hipEvent_t t0, t1;
+  {
+    std::lock_guard<std::mutex> lock(c->launch_mutex);
+    if (c->last_timed_slot < 0) return -1.f;
+    t0 = c->slots[c->last_timed_slot].t0;
+    t1 = c->slots[c->last_timed_slot].t1;
+  }
+  if (hipEventSynchronize(t1) != hipSuccess) return -1.f;
   float ms = -1.f;
-  if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&ms, t0, t1) != hipSuccess) return -1.f;
   return ms;
 }
+
+// Name of the traversal kernel variant the most recent launch of this context used (as rocprofv3 prints it, without
+// the argument list) — bench.py reports it instead of guessing.
+const char *nrtLastKernelName(const nrt_ctx *c) { return c ? c->last_kernel : ""; }
 
 // Profiling aid (not part of the public header): loop-occupancy counters of the last launch made with
 // NRT_DEBUG bit 32 set.  out[0..6] = it1, act1, trav1, it2, act2, refills, refilled.

@@ -1175,34 +1175,59 @@ int traverse_blocks_per_cu(int lds_stack) {
   return n > 8 ? 8 : n;
 }
 
+// `name_out` (optional) receives the name of the variant launched, as rocprofv3 prints it without the argument list.
+#define NRT_LAUNCH_WIDE(NAME, ...)                                                                  \
+  do {                                                                                                \
+    hipLaunchKernelGGL((k_traverse_wide<__VA_ARGS__>), dim3(grid), dim3(kTraverseBlock), 0, s, args); \
+    if (name_out) *name_out = NAME;                                                                   \
+  } while (0)
+
 template <typename T>
-hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int lds_stack, int prim_kind, hipStream_t s) {
+hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int lds_stack, int prim_kind, hipStream_t s,
+                                const char **name_out) {
+  constexpr bool f32 = sizeof(T) == 4;
   if (prim_kind == kPrimSpheres) { // one instantiation: 10 LDS entries (the caller sizes the overflow stack for it)
-    hipLaunchKernelGGL((k_traverse_wide<T, 10, false, kPrimSpheres>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 1, false>" : "nrt::k_traverse_wide<double, 10, false, 1, false>",
+                    T, 10, false, kPrimSpheres);
     if (args.hits)
       hipLaunchKernelGGL((k_sphere_uv<T>), dim3((args.num_rays + 255u) / 256u), dim3(256), 0, s, args.rays, args.hits,
                          args.centers, args.num_rays);
     return hipGetLastError();
   }
   if (prim_kind == kPrimCylinders) {
-    hipLaunchKernelGGL((k_traverse_wide<T, 10, false, kPrimCylinders>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 2, false>" : "nrt::k_traverse_wide<double, 10, false, 2, false>",
+                    T, 10, false, kPrimCylinders);
     return hipGetLastError();
   }
   switch (lds_stack) {
-    case 8: hipLaunchKernelGGL((k_traverse_wide<T, 8, false, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
-    case 10:
-      if (args.debug_flags & 32u)
-        hipLaunchKernelGGL((k_traverse_wide<T, 10, true, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
-      else if (args.plain_options)
-        hipLaunchKernelGGL((k_traverse_wide<T, 10, false, kPrimTriangles, true>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
-      else
-        hipLaunchKernelGGL((k_traverse_wide<T, 10, false, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+    case 8:
+      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 8, false, 0, false>" : "nrt::k_traverse_wide<double, 8, false, 0, false>",
+                      T, 8, false, kPrimTriangles);
       break;
-    case 12: hipLaunchKernelGGL((k_traverse_wide<T, 12, false, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
-    default: hipLaunchKernelGGL((k_traverse_wide<T, 16, false, kPrimTriangles>), dim3(grid), dim3(kTraverseBlock), 0, s, args); break;
+    case 10:
+      if (args.debug_flags & 32u) {
+        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, true, 0, false>" : "nrt::k_traverse_wide<double, 10, true, 0, false>",
+                        T, 10, true, kPrimTriangles);
+      } else if (args.plain_options) {
+        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true>" : "nrt::k_traverse_wide<double, 10, false, 0, true>",
+                        T, 10, false, kPrimTriangles, true);
+      } else {
+        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, false>" : "nrt::k_traverse_wide<double, 10, false, 0, false>",
+                        T, 10, false, kPrimTriangles);
+      }
+      break;
+    case 12:
+      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 12, false, 0, false>" : "nrt::k_traverse_wide<double, 12, false, 0, false>",
+                      T, 12, false, kPrimTriangles);
+      break;
+    default:
+      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 16, false, 0, false>" : "nrt::k_traverse_wide<double, 16, false, 0, false>",
+                      T, 16, false, kPrimTriangles);
+      break;
   }
   return hipGetLastError();
 }
+#undef NRT_LAUNCH_WIDE
 
 template <typename T>
 int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind) {
@@ -1277,8 +1302,8 @@ hipError_t launch_cylinder_post(const nrt_ray_f32 *rays, const nrt_hit_f32 *comp
 
 template hipError_t launch_traverse<float>(const TraverseArgs<float> &, unsigned, bool, int, hipStream_t);
 template hipError_t launch_traverse<double>(const TraverseArgs<double> &, unsigned, bool, int, hipStream_t);
-template hipError_t launch_traverse_wide<float>(const TraverseArgs<float> &, unsigned, int, int, hipStream_t);
-template hipError_t launch_traverse_wide<double>(const TraverseArgs<double> &, unsigned, int, int, hipStream_t);
+template hipError_t launch_traverse_wide<float>(const TraverseArgs<float> &, unsigned, int, int, hipStream_t, const char **);
+template hipError_t launch_traverse_wide<double>(const TraverseArgs<double> &, unsigned, int, int, hipStream_t, const char **);
 template int traverse_wide_blocks_per_cu<float>(int, int);
 template int traverse_wide_blocks_per_cu<double>(int, int);
 template hipError_t launch_gather_leaf_spheres<float>(const uint32_t *, const float *, const float *, LeafSphere<float> *,
