@@ -320,6 +320,10 @@ NRT_API const char *nrtLastKernelName(const nrt_ctx *ctx);
  * sum of active lanes, sum of lanes walking inner nodes, phase-2 iterations, sum of lanes testing a
  * triangle, refill events, lanes refilled.  Returns 0 on success. */
 NRT_API int nrtDebugCounters(nrt_ctx *ctx, unsigned long long *out8);
+/* Profiling aid: with NRT_DEBUG bit 8192 every wave of a traversal launch records when it started, ran out of rays and
+ * finished (100 MHz realtime ticks, 3 x u64 per wave).  Copies up to `cap` records of the most recent launch; returns
+ * the number of waves of that launch, or -1 (tools/drain_probe.py). */
+NRT_API long nrtDebugWaveClocks(nrt_ctx *ctx, unsigned long long *out, long cap);
 
 /* ---- two-level scenes (instancing): replaces nanosg::Scene<float, M> -----------------------
  * examples/nanosg/nanosg.h — AddNode :682, Commit :700-760 (per-node world AABB / inverse

@@ -80,6 +80,7 @@ struct nrt_ctx {
   uint32_t max_leaf_count = 0, min_leaf_count = 0; // over the leaves of the current tree
   uint32_t packed_leaves = 0;
   uint32_t root_is_branch = 0; // node 0 has flag == 0
+  uint32_t tree_nested = 1;    // every child box lies inside its parent's (always true of trees built here; checked for adopted ones)
   nrt_build_stats stats = {0, 0, 0, 0.f};
 
   // traversal scratch.  Every launch owns one LaunchSlot (work cursors + overflow stacks) until it
@@ -102,6 +103,8 @@ struct nrt_ctx {
   std::mutex host_mutex;   // the host-buffer traversal calls share one set of staging buffers: one at a time
   unsigned long long *d_counters = nullptr;  // 8 x u64 (counting pass / profiling instantiation only)
   DevBuf st_rays, st_hits, st_mask;
+  DevBuf b_wave_clock; // profiling (NRT_DEBUG bit 8192)
+  uint32_t wave_clock_waves = 0;
 
   // traversal tuning (env NRT_LDS_STACK / NRT_REFILL_MIN / NRT_TRAV_MIN / NRT_CHUNK override)
   int lds_stack = kLdsStackDefault;
@@ -112,6 +115,11 @@ struct nrt_ctx {
   unsigned static_pct = 75; // share of a batch handed out statically, percent (env NRT_STATIC_PCT)
   unsigned max_blocks_per_cu = 0; // env NRT_BLOCKS_PER_CU caps the persistent grid
   int wide = 1, wide_stack = 10; // production path: WideNode kernel (env NRT_WIDE=0 selects the binary kernel)
+  // Work splitting in the drain of a launch (traverse.hip, k_traverse_wide<..., SPLIT>): exact, soaked, and MEASURED TO
+  // LOSE on C3 (profiles/r02c_split_*.txt: bounce wave 0.50 -> 0.51-0.59 ms depending on the hand-out policy), because
+  // under the while-while loop every helper adds leaf rounds that stall the very ray it helps.  Off unless NRT_SPLIT=1.
+  int split = 0;
+  unsigned drain_steps = 8, split_busy = 8; // hand-out policy (env NRT_DRAIN_STEPS, NRT_SPLIT_BUSY)
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
 
   hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;
@@ -245,6 +253,9 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   if (const char *e = getenv("NRT_STATIC_PCT")) c->static_pct = (unsigned)std::min(100, std::max(0, atoi(e)));
   if (const char *e = getenv("NRT_BLOCKS_PER_CU")) c->max_blocks_per_cu = (unsigned)std::max(0, atoi(e));
   if (const char *e = getenv("NRT_WIDE")) c->wide = atoi(e) != 0;
+  if (const char *e = getenv("NRT_SPLIT")) c->split = atoi(e) != 0;
+  if (const char *e = getenv("NRT_DRAIN_STEPS")) c->drain_steps = (unsigned)std::max(1, atoi(e));
+  if (const char *e = getenv("NRT_SPLIT_BUSY")) c->split_busy = (unsigned)std::min(64, std::max(0, atoi(e)));
   if (const char *e = getenv("NRT_WIDE_STACK")) {
     int v = atoi(e);
     if (v == 8 || v == 10 || v == 12 || v == 16) c->wide_stack = v;
@@ -270,7 +281,7 @@ void nrtDestroy(nrt_ctx *c) {
   }
   free_tree(c);
   free_mesh(c);
-  DevBuf *bufs[] = {&c->b_verts, &c->b_radii, &c->b_faces, &c->st_rays, &c->st_hits, &c->st_mask, &c->b_nodes, &c->b_indices, &c->b_tris, &c->b_wide, &c->b_wide_scratch, &c->b_build_ws};
+  DevBuf *bufs[] = {&c->b_verts, &c->b_radii, &c->b_faces, &c->st_rays, &c->st_hits, &c->st_mask, &c->b_nodes, &c->b_indices, &c->b_tris, &c->b_wide, &c->b_wide_scratch, &c->b_build_ws, &c->b_wave_clock};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->d_counters) (void)hipFree(c->d_counters);
@@ -434,7 +445,7 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
     if (indices[i] >= c->num_faces)
       return fail(c, NRT_ERR_INVALID, "nrtSetTree: indices[%llu]=%u >= num_faces %u",
                   (unsigned long long)i, indices[i], c->num_faces);
-  uint32_t depth = 0, max_leaf = 0, min_leaf = 0xFFFFFFFFu;
+  uint32_t depth = 0, max_leaf = 0, min_leaf = 0xFFFFFFFFu, nested = 1;
   {
     std::vector<std::pair<uint32_t, uint32_t> > st;
     std::vector<uint8_t> seen(num_nodes, 0);
@@ -450,6 +461,11 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
         if (n.data[0] >= num_nodes || n.data[1] >= num_nodes)
           return fail(c, NRT_ERR_INVALID, "nrtSetTree: node %u child out of range", e.first);
         if (n.axis < 0 || n.axis > 2) return fail(c, NRT_ERR_INVALID, "nrtSetTree: node %u axis %d", e.first, n.axis);
+        for (int ch = 0; ch < 2; ch++) { // do the child boxes lie inside this one?  (true of every tree a builder emits; a
+          const typename Wire<T>::Node &k = nodes[n.data[ch]]; // refit or hand-edited tree may break it: see tree_nested)
+          for (int ax = 0; ax < 3; ax++)
+            if (!(k.bmin[ax] >= n.bmin[ax] && k.bmax[ax] <= n.bmax[ax])) nested = 0;
+        }
         st.push_back(std::make_pair(n.data[1], e.second + 1));
         st.push_back(std::make_pair(n.data[0], e.second + 1));
       } else {
@@ -469,6 +485,7 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
   c->max_leaf_count = max_leaf;
   c->min_leaf_count = min_leaf;
   c->root_is_branch = nodes[0].flag == 0 ? 1u : 0u;
+  c->tree_nested = nested;
   c->num_branch_records = 0;
   for (uint64_t i = 0; i < num_nodes; i++)
     if (nodes[i].flag == 0) c->num_branch_records++;
@@ -532,6 +549,7 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   c->num_branch_records = res.num_branches;
   c->root_is_branch = res.num_nodes > 1 ? 1u : 0u;
   c->min_leaf_count = 1; // the GPU builder never emits an empty leaf
+  c->tree_nested = 1;    // a branch's box is the exact union of its children's
   nrt_status fst = finish_tree<T>(c); // leaf-ordered triangles + WideNode array: part of the build
   if (fst) return fst;
   HIPCHK(c, hipEventRecord(c->ev_b1, c->stream));
@@ -651,6 +669,10 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   // prim ids are < num_faces: nothing can be rejected by these options -> the kernel variant without the id tests
   a.plain_options = (opt->prim_ids_range[0] == 0u && opt->prim_ids_range[1] >= c->num_faces && opt->skip_prim_id >= c->num_faces &&
                      !opt->cull_back_face) ? 1u : 0u;
+  a.split = (c->split && use_wide && c->prim_kind == kPrimTriangles && !any_hit && c->root_is_branch && c->tree_nested) ? 1u : 0u;
+  a.root_test = c->tree_nested ? 0u : 1u;
+  a.drain_steps = c->drain_steps;
+  a.split_busy = c->split_busy;
   a.spill = (uint32_t *)slot->spill.p;
   a.spill_stride = total_threads;
   a.spill_levels = levels;
@@ -661,12 +683,19 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.dyn_begin = static_per_wave * total_waves;
   a.blocks_per_part = grid / parts;
   a.counters = c->d_counters;
+  a.wave_clock = nullptr;
+  if (c->debug_flags & 8192u) { // profiling: per-wave time stamps of this launch (nrtDebugWaveClocks)
+    nrt_status st = ensure(c, c->b_wave_clock, (size_t)total_waves * 3 * sizeof(unsigned long long));
+    if (st) return st;
+    a.wave_clock = (unsigned long long *)c->b_wave_clock.p;
+    c->wave_clock_waves = total_waves;
+  }
   a.chunk = c->chunk;
   a.refill_min = c->refill_min;
   a.trav_min = c->trav_min;
   a.leaf_min = c->leaf_min;
 
-  if (count || (c->debug_flags & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s));
+  if (count || (c->debug_flags & (32u | 4096u))) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s));
   if (timed) HIPCHK(c, hipEventRecord(slot->t0, s));
   if (use_wide) {
     HIPCHK(c, launch_traverse_wide<T>(a, grid, c->wide_stack, c->prim_kind, s, &c->last_kernel));
@@ -903,6 +932,17 @@ int nrtDebugCounters(nrt_ctx *c, unsigned long long *out) {
   if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   return hipMemcpy(out, c->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+
+// Profiling aid (not part of the public header): with NRT_DEBUG bit 8192 every wave of a traversal launch records when
+// it started, ran out of rays and finished (100 MHz realtime ticks).  Copies up to `cap` records (3 x u64 each) of the
+// last launch; returns the number of waves, or -1.
+long nrtDebugWaveClocks(nrt_ctx *c, unsigned long long *out, long cap) {
+  if (!c || !out || !c->b_wave_clock.p) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  const long n = std::min<long>(cap, (long)c->wave_clock_waves);
+  if (hipMemcpy(out, c->b_wave_clock.p, (size_t)n * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (long)c->wave_clock_waves;
 }
 
 float nrtLastBuildMs(nrt_ctx *c) {

@@ -139,6 +139,10 @@ struct TraverseArgs {
   uint32_t cull_back_face;
   uint32_t any_hit;       // occlusion query (opt-in extension): a ray stops at the first primitive it accepts
   uint32_t plain_options; // the options above cannot reject any primitive of this tree (host-checked)
+  uint32_t split;         // work splitting in the drain (triangle closest-hit launches over a tree whose child boxes lie inside their parents')
+  uint32_t drain_steps;   // splitting launches: a round of hand-outs every this many trips through the outer loop once the wave is out of rays
+  uint32_t split_busy;    // ... and only while at most this many lanes of the wave are busy
+  uint32_t root_test;     // node 0's box must be tested before its children (an adopted tree whose child boxes may stick out)
   uint32_t *spill;        // [spill_levels][spill_stride] overflow stack, may be null
   T *spill_tmin;          // same shape, entry t_min (wide kernel)
   uint32_t spill_stride;  // == total threads of the launch
@@ -150,6 +154,7 @@ struct TraverseArgs {
   uint32_t dyn_begin;                // rays [dyn_begin, num_rays) are claimed dynamically (per-partition cursors)
   uint32_t blocks_per_part;          // gridDim.x / num_parts
   unsigned long long *counters;      // 4 x u64 when counting
+  unsigned long long *wave_clock;    // profiling (NRT_DEBUG bit 8192): 3 x u64 per wave {start, out of rays, done}, 100 MHz ticks; else null
   uint32_t chunk;                    // rays claimed per atomic
   uint32_t refill_min;               // refill idle lanes once this many are idle (1..64)
   uint32_t trav_min;                 // leave the inner-node loop when fewer lanes than this are walking

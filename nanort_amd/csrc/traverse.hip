@@ -61,15 +61,25 @@ __device__ __forceinline__ T safe_inverse(T v) {
 // Per-lane traversal state (all registers).
 template <typename T>
 struct Lane {
-  T org[3];
-  T inv[3];
+  // (scalars, not arrays, and no two floats of one kind next to each other: the vectoriser otherwise merges neighbours
+  // into overlapping vector accesses that pin parts of the lane state in scratch memory)
+  T org0, inv0, org1, inv1, org2, inv2;
+  __device__ __forceinline__ T org(int k) const { return k == 0 ? org0 : (k == 1 ? org1 : org2); }
+  __device__ __forceinline__ T inv(int k) const { return k == 0 ? inv0 : (k == 1 ? inv1 : inv2); }
   T min_t, max_t, hit_t; // hit_t == intersector t_ == best so far
   T d0, d1, d2;          // ray direction (sphere / cylinder kinds; dead otherwise)
   uint32_t cap;          // cylinder kind: hit_cap_ of the accepted hit (u, v hold u_param_, v_param_)
-  T Sx, Sy, Sz;
-  T u, v;
+  // (floats and integers alternate on purpose: as neighbours, Sx Sy Sz u v get merged into overlapping two- and
+  // four-float vector accesses by the vectoriser, which then pins all five in scratch memory instead of registers)
+  T Sx;
+  int kx;
+  T Sy;
+  int ky;
+  T Sz;
+  int kz;
+  T u;
   uint32_t prim;
-  int kx, ky, kz;
+  T v;
   int sign0, sign1, sign2; // dir < 0 per axis (scalars: no runtime-indexed array)
 };
 
@@ -79,9 +89,9 @@ __device__ __forceinline__ void lane_init(Lane<T> &L, const typename Wire<T>::Ra
   L.d0 = d0;
   L.d1 = d1;
   L.d2 = d2;
-  L.org[0] = r.org[0];
-  L.org[1] = r.org[1];
-  L.org[2] = r.org[2];
+  L.org0 = r.org[0];
+  L.org1 = r.org[1];
+  L.org2 = r.org[2];
   L.min_t = r.min_t;
   L.max_t = r.max_t;
   L.hit_t = r.max_t; // nanort.h:2494, 2501
@@ -120,9 +130,9 @@ __device__ __forceinline__ void lane_init(Lane<T> &L, const typename Wire<T>::Ra
   L.sign0 = d0 < T(0) ? 1 : 0;
   L.sign1 = d1 < T(0) ? 1 : 0;
   L.sign2 = d2 < T(0) ? 1 : 0;
-  L.inv[0] = safe_inverse<T>(d0);
-  L.inv[1] = safe_inverse<T>(d1);
-  L.inv[2] = safe_inverse<T>(d2);
+  L.inv0 = safe_inverse<T>(d0);
+  L.inv1 = safe_inverse<T>(d1);
+  L.inv2 = safe_inverse<T>(d2);
 }
 
 // IntersectRayAABB (nanort.h:2285-2370); safemin/safemax (nanort.h:1236-1243).
@@ -135,8 +145,8 @@ __device__ __forceinline__ bool slab_test(const Lane<T> &L, const T bmin[3], con
     const int sg = k == 0 ? L.sign0 : (k == 1 ? L.sign1 : L.sign2);
     const T lo = sg ? bmax[k] : bmin[k];
     const T hi = sg ? bmin[k] : bmax[k];
-    const T t0 = (lo - L.org[k]) * L.inv[k];
-    const T t1 = (hi - L.org[k]) * L.inv[k] * mm;
+    const T t0 = (lo - L.org(k)) * L.inv(k);
+    const T t1 = (hi - L.org(k)) * L.inv(k) * mm;
     // safemax(t0, tmin) / safemin(t1, tmax) (nanort.h:1236-1243): a NaN first operand is dropped and the
     // running value is never NaN, which is exactly maxNum/minNum (v_max_f32 / v_min_f32); the only
     // difference, the sign of a zero result, cannot change `tmin <= tmax`.
@@ -150,15 +160,18 @@ __device__ __forceinline__ bool slab_test(const Lane<T> &L, const T bmin[3], con
 // Written as one running predicate with select-style updates (the reference's early returns
 // in the same order): all loads of the record are issued together, and the lane state stays
 // in the same registers on every path.
-template <typename T, bool PLAIN = false>
+// CHECK (work splitting, see k_traverse_wide): `bad` collects "accepted a distance below the entry distance of the
+// leaf box it was found in (or a NaN)" — the one situation in which folding separately traversed subtrees could differ
+// from the sequential loop; such a ray is traced again sequentially.
+template <typename T, bool PLAIN = false, bool CHECK = false>
 __device__ __forceinline__ void tri_test(Lane<T> &L, const LeafTri<T> &tri, bool active, uint32_t range0,
-                                         uint32_t range1, uint32_t skip, bool cull) {
+                                         uint32_t range1, uint32_t skip, bool cull, T leaf_tmin = T(0), bool *bad = nullptr) {
   const uint32_t prim = tri.prim_id;
   bool ok = PLAIN ? active : (active & (prim >= range0) & (prim < range1) & (prim != skip)); // nanort.h:2387-2395
   if (PLAIN) cull = false;
-  const T A0 = tri.p0[0] - L.org[0], A1 = tri.p0[1] - L.org[1], A2 = tri.p0[2] - L.org[2];
-  const T B0 = tri.p1[0] - L.org[0], B1 = tri.p1[1] - L.org[1], B2 = tri.p1[2] - L.org[2];
-  const T C0 = tri.p2[0] - L.org[0], C1 = tri.p2[1] - L.org[1], C2 = tri.p2[2] - L.org[2];
+  const T A0 = tri.p0[0] - L.org0, A1 = tri.p0[1] - L.org1, A2 = tri.p0[2] - L.org2;
+  const T B0 = tri.p1[0] - L.org0, B1 = tri.p1[1] - L.org1, B2 = tri.p1[2] - L.org2;
+  const T C0 = tri.p2[0] - L.org0, C1 = tri.p2[1] - L.org1, C2 = tri.p2[2] - L.org2;
   const T Akz = sel3(A0, A1, A2, L.kz), Bkz = sel3(B0, B1, B2, L.kz), Ckz = sel3(C0, C1, C2, L.kz);
   const T Ax = sel3(A0, A1, A2, L.kx) - L.Sx * Akz;
   const T Ay = sel3(A0, A1, A2, L.ky) - L.Sy * Akz;
@@ -190,6 +203,7 @@ __device__ __forceinline__ void tri_test(Lane<T> &L, const LeafTri<T> &tri, bool
     // `if (tt > t) return; if (tt < min_t) return;` — equality (and NaN) accepted (nanort.h:1133-1139)
     const bool acc = !(tt > L.hit_t) & !(tt < L.min_t);
     const T uu = V * rcp, vv = W * rcp;
+    if (CHECK) *bad = *bad | (acc & !(tt >= leaf_tmin));
     L.hit_t = acc ? tt : L.hit_t;
     L.u = acc ? uu : L.u;
     L.v = acc ? vv : L.v;
@@ -206,7 +220,7 @@ __device__ __forceinline__ void sphere_test(Lane<T> &L, const LeafSphere<T> &sp,
                                             uint32_t range1) {
   const uint32_t prim = sp.prim_id;
   bool ok = active & (prim >= range0) & (prim < range1);
-  const T oc0 = L.org[0] - sp.c[0], oc1 = L.org[1] - sp.c[1], oc2 = L.org[2] - sp.c[2];
+  const T oc0 = L.org0 - sp.c[0], oc1 = L.org1 - sp.c[1], oc2 = L.org2 - sp.c[2];
   const T a = (L.d0 * L.d0 + L.d1 * L.d1) + L.d2 * L.d2;
   const T b = T(2.0) * ((L.d0 * oc0 + L.d1 * oc1) + L.d2 * oc2);
   const T c = ((oc0 * oc0 + oc1 * oc1) + oc2 * oc2) - sp.r * sp.r;
@@ -262,7 +276,7 @@ __device__ __forceinline__ void cylinder_test(Lane<T> &L, const LeafCylinder<T> 
   const uint32_t prim = cy.prim_id;
   const bool ok = active & (prim >= range0) & (prim < range1);
   const T kEPS = T(1.0e-6f);
-  const T org[3] = {L.org[0], L.org[1], L.org[2]}, dir[3] = {L.d0, L.d1, L.d2};
+  const T org[3] = {L.org0, L.org1, L.org2}, dir[3] = {L.d0, L.d1, L.d2};
   const T tmax = L.hit_t;
   const T rr = (cy.r0 < cy.r1) ? cy.r1 : cy.r0; // std::max(r0, r1)
   T d[3], m[3];
@@ -609,8 +623,8 @@ __device__ __forceinline__ bool slab_test_tmin(const Lane<T> &L, const T box[6],
     const int sg = k == 0 ? L.sign0 : (k == 1 ? L.sign1 : L.sign2);
     const T lo = sg ? box[3 + k] : box[k];
     const T hi = sg ? box[k] : box[3 + k];
-    const T t0 = (lo - L.org[k]) * L.inv[k];
-    const T t1 = (hi - L.org[k]) * L.inv[k] * mm;
+    const T t0 = (lo - L.org(k)) * L.inv(k);
+    const T t1 = (hi - L.org(k)) * L.inv(k) * mm;
     tmin = Const<T>::fmax(t0, tmin); // see slab_test
     tmax = Const<T>::fmin(t1, tmax);
   }
@@ -728,8 +742,8 @@ __device__ __forceinline__ SlabPair<float> slab_pair(const Lane<float> &L, const
     const int sg = k == 0 ? L.sign0 : (k == 1 ? L.sign1 : L.sign2);
     const f2 lo = {sg ? w.box0[3 + k] : w.box0[k], sg ? w.box1[3 + k] : w.box1[k]};
     const f2 hi = {sg ? w.box0[k] : w.box0[3 + k], sg ? w.box1[k] : w.box1[3 + k]};
-    const f2 o = {L.org[k], L.org[k]};
-    const f2 iv = {L.inv[k], L.inv[k]};
+    const f2 o = {L.org(k), L.org(k)};
+    const f2 iv = {L.inv(k), L.inv(k)};
     const f2 t0 = (lo - o) * iv;
     const f2 t1 = ((hi - o) * iv) * mm;
     tmin0 = Const<float>::fmax(t0.x, tmin0); // see slab_test
@@ -778,10 +792,50 @@ struct StackEntry<double> {
 
 // PLAIN: the launch uses trace options that cannot reject a primitive (full prim_ids_range, no skip_prim_id, no
 // back-face culling — the reference's defaults): the three id comparisons per triangle test are compiled out.
-template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false>
-__global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const TraverseArgs<T> a) {
+//
+// SPLIT — work splitting in the drain of a launch.  Per-ray step counts are heavy-tailed (C3 bounce wave: mean 24
+// WideNode steps, maximum 174) and a ray advances one step per trip through the loop, so once the work cursors have
+// run dry the last long rays would keep a whole wave — and the launch — alive with a handful of busy lanes.  From that
+// moment a wave hands its rays' PENDING SUBTREES to its idle lanes: each round every busy lane may give away the
+// OLDEST entry of its stack (the subtree the reference loop, nanort.h:2526-2548, would reach LAST) to a free lane of
+// the same wave, which becomes a helper: a copy of the ray that starts in that subtree from the hit distance the donor
+// holds at that moment.  Helpers split on in the same way.  Results are folded in LDS, per original ray, with the
+// reference's acceptance rule (nanort.h:1133: a larger t is rejected, an equal t replaces): smallest t wins, among
+// equal t the segment that comes LATEST in the sequential order wins — every segment carries a 32-bit key for that
+// (a donor keeps the lower half of its key interval, the helper takes the upper half).
+// Exactness: a helper's start distance is never tighter than the distance the sequential loop would hold on reaching
+// that subtree, so it tests a superset of the sequential loop's triangles; by induction over the traversal order the
+// folded result equals the sequential one provided every triangle a helper accepts has t >= the entry distance of the
+// leaf box it was found in (child boxes lie inside their parents' — `a.split` is only set for such trees — and the
+// slab arithmetic is monotone, so that is also >= every ancestor's entry distance: the sequential loop could not have
+// culled it by a box and still hold a nearer hit).  Helpers test exactly that at every acceptance (one compare; it
+// also catches NaN distances); a ray with a violation is traced again by its owner lane, sequentially.  The rule is
+// soaked on the CPU against the restated reference loop by a sequential model of this scheme (tests/test_split_model.py:
+// hostile meshes where the violation does occur) and on the GPU by the bit-for-bit parity suites, which run with
+// splitting on (batches of every size end in a drain).
+enum : uint32_t {
+  kMetaOwnerMask = 0x3Fu,   // helper: lane (within the wave) of the ray's owner
+  kMetaHelper = 1u << 6,    // this lane traverses a subtree of another lane's ray
+  kMetaNoSplit = 1u << 7,   // owner re-running its ray sequentially: never donates
+  kMetaOwnerOpen = 1u << 8, // owner: a fold record is open (helpers were spawned)
+  kMetaMainDone = 1u << 9,  // owner: its own segment is folded into the record
+  kMetaBad = 1u << 10,      // helper: accepted a distance below its leaf box's entry distance (or NaN)
+  kMetaLevelShift = 11,     // 5 bits: how often this segment's key interval was halved
+  kMetaLevelMask = 31u << 11,
+  kMetaDonatedShift = 16,   // 16 bits: stack entries [0, donated) were given away (marked dead in place)
+};
+template <typename T>
+struct FoldRec { // one per thread slot, used by the slot's lane when it owns a split ray
+  T t, u, v;
+  uint32_t key, prim;
+  uint32_t pend; // helpers outstanding (low 16 bits) | 0x80000000: some helper reported a violation
+};
+
+template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool SPLIT = false>
+__global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) void k_traverse_wide(const TraverseArgs<T> a) {
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
+  __shared__ FoldRec<T> s_fold[SPLIT ? kTraverseBlock : 1];
 
   typedef typename Wire<T>::Node Node;
   typedef typename Wire<T>::Ray Ray;
@@ -797,6 +851,14 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
   uint32_t cur = 0;        // W_TRAV: WideNode index; W_LEAF: leaf reference without the leaf bit
   int state = W_IDLE;
   int sp = 0;
+  uint32_t meta = 0, key = 0; // SPLIT: role of this lane (kMeta*), position of its segment in the sequential order
+  T leaf_tmin = T(0);         // SPLIT: entry distance of the box of the leaf this lane is at
+  const bool split_on = SPLIT && a.split != 0u;
+  unsigned drain_round = 0u;
+  // (profiling, NRT_DEBUG bit 8192: when did this wave start, run out of rays, finish — 100 MHz realtime ticks)
+  const bool clocked = (a.debug_flags & 8192u) != 0u && a.wave_clock != nullptr;
+  unsigned long long clk_begin = 0ull, clk_dry = 0ull;
+  if (clocked) clk_begin = __builtin_amdgcn_s_memrealtime();
   Claim ck;
   claim_init<T>(a, ck);
   if (blockIdx.x == 0 && threadIdx.x < kMaxParts) a.next_cursor[kCursorStrideWords * threadIdx.x] = 0u;
@@ -841,13 +903,21 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           const Ray r = (a.debug_flags & 4u) ? a.rays[rid] : load_ray_nt<T>(a.rays + rid);
           lane_init<T>(L, r);
           sp = 0;
+          if (SPLIT) {
+            meta = 0u;
+            key = 0u;
+          }
           if (STATS) st_steps = st_tris = 0;
           // The reference pops and tests the root first (nanort.h:2526-2533).  For a branch root that test is implied by
           // the first step: a ray that misses the root's box misses both children's boxes (each lies inside it and the
           // slab arithmetic is monotone), so the step on record 0 ends in W_POP with an empty stack — the same miss.
-          if (a.root_is_branch) {
+          if (a.root_is_branch && !a.root_test) {
             cur = 0u;
             state = W_TRAV;
+          } else if (a.root_is_branch) { // adopted tree whose child boxes may stick out of node 0's box: test it, as the reference does
+            const Node root = a.nodes[0];
+            cur = 0u;
+            state = slab_test<T>(L, root.bmin, root.bmax) ? W_TRAV : W_POP;
           } else { // single-leaf tree: test the root box, then its primitives
             const Node root = a.nodes[0];
             const bool root_hit = slab_test<T>(L, root.bmin, root.bmax);
@@ -862,6 +932,198 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
         }
         ck.next += take;
         fresh = __ballot(state == W_IDLE);
+      }
+      idle = __ballot(state == W_IDLE);
+    }
+    if (clocked && ck.exhausted && clk_dry == 0ull) clk_dry = __builtin_amdgcn_s_memrealtime();
+    if (SPLIT && split_on && ck.exhausted) {
+      const unsigned wbase = tid & ~63u; // this wave's slots of s_fold
+      // -- (a) finished helpers hand their result to the owner's record, one after the other
+      unsigned long long fh = __ballot(state == W_IDLE && rid != kInvalid && (meta & kMetaHelper) != 0u);
+      while (fh != 0ull) {
+        const unsigned h = (unsigned)__builtin_ctzll(fh);
+        fh &= fh - 1ull;
+        if (lane == h) {
+          FoldRec<T> &r = s_fold[wbase + (meta & kMetaOwnerMask)];
+          if (L.prim != kInvalid && (r.prim == kInvalid || L.hit_t < r.t || (L.hit_t == r.t && key > r.key))) {
+            r.t = L.hit_t;
+            r.u = L.u;
+            r.v = L.v;
+            r.key = key;
+            r.prim = L.prim;
+          }
+          r.pend = (r.pend - 1u) | ((meta & kMetaBad) ? 0x80000000u : 0u);
+          if (a.debug_flags & 4096u) atomicAdd(&a.counters[3], 1ull);
+          rid = kInvalid;
+          meta = 0u;
+        }
+      }
+      // -- (b) owners: fold the own segment once, then wait for the helpers; the last delivery settles the ray
+      if (state == W_IDLE && rid != kInvalid && (meta & kMetaOwnerOpen) != 0u) {
+        FoldRec<T> &r = s_fold[tid];
+        if (!(meta & kMetaMainDone)) {
+          if (L.prim != kInvalid && (r.prim == kInvalid || L.hit_t < r.t || (L.hit_t == r.t && key > r.key))) {
+            r.t = L.hit_t;
+            r.u = L.u;
+            r.v = L.v;
+            r.key = key;
+            r.prim = L.prim;
+          }
+          meta |= kMetaMainDone;
+        }
+        const uint32_t pend = r.pend;
+        if ((pend & 0xFFFFu) == 0u) {
+          if (a.debug_flags & 4096u) atomicAdd(&a.counters[(pend & 0x80000000u) ? 5 : 4], 1ull);
+          if (((pend & 0x80000000u) && !(a.debug_flags & 512u)) || (a.debug_flags & 1024u)) { // a helper saw t below its leaf box's entry distance: trace the ray again, sequentially
+            const Ray rr = load_ray_nt<T>(a.rays + rid);
+            lane_init<T>(L, rr);
+            sp = 0;
+            cur = 0u;
+            state = W_TRAV;
+            meta = kMetaNoSplit;
+            key = 0u;
+          } else {
+            const bool any_ = r.prim != kInvalid;
+            L.hit_t = any_ ? r.t : L.max_t;
+            L.u = r.u;
+            L.v = r.v;
+            L.prim = r.prim;
+            meta = 0u;
+          }
+        }
+      }
+      // -- (c) every lane that holds a settled result writes it now and becomes free
+      if (state == W_IDLE && rid != kInvalid && (meta & (kMetaHelper | kMetaOwnerOpen)) == 0u) {
+        NRT_WRITE_RESULT();
+        rid = kInvalid;
+      }
+      // -- (d) busy lanes give their oldest pending subtree to free lanes
+      const unsigned long long freel = __ballot(state == W_IDLE && rid == kInvalid);
+      const uint32_t donated = meta >> kMetaDonatedShift;
+      const uint32_t level = (meta & kMetaLevelMask) >> kMetaLevelShift;
+      const bool busy = state == W_TRAV || state == W_POP || state == W_LEAF;
+      // (a lane about to pop keeps the entry it is about to pop)
+      const bool can_give = busy && !(meta & kMetaNoSplit) && level < 31u && donated < 0xFFFFu &&
+                            (uint32_t)sp > donated + (state == W_POP ? 1u : 0u);
+      const unsigned long long donors = __ballot(can_give);
+      unsigned n_pair = (unsigned)__builtin_popcountll(donors);
+      const unsigned n_free = (unsigned)__builtin_popcountll(freel);
+      n_pair = n_pair < n_free ? n_pair : n_free;
+      if (a.debug_flags & 256u) n_pair = 0u; // (debugging: no donations)
+      // a round costs a few hundred issue slots for the whole wave: only when few lanes are still busy, and not every trip
+      drain_round++;
+      if ((unsigned)__builtin_popcountll(__ballot(busy)) > a.split_busy || drain_round % a.drain_steps != 0u) n_pair = 0u;
+      if (n_pair != 0u) {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const bool is_donor = can_give && (unsigned)__builtin_popcountll(donors & lt) < n_pair;
+        const bool is_recv = ((freel >> lane) & 1ull) != 0ull && (unsigned)__builtin_popcountll(freel & lt) < n_pair;
+        // receiver k takes from donor k: lane index of its source (scalar walk over the two masks; rare)
+        int src = (int)lane;
+        {
+          unsigned long long d = donors, f = freel;
+          for (unsigned k = 0; k < n_pair; k++) {
+            const int dl = __builtin_ctzll(d), fl = __builtin_ctzll(f);
+            d &= d - 1ull;
+            f &= f - 1ull;
+            src = ((int)lane == fl) ? dl : src;
+          }
+        }
+        // donor: take the oldest live entry off the bottom of its stack (it stays in place, marked dead)
+        typename SE::type e = SE::make(0u, T(0));
+        bool give = false;
+        uint32_t hkey = 0u, hmeta = 0u;
+        if (is_donor) {
+          if (donated < (uint32_t)STACK) {
+            e = s_stack[donated][tid];
+            s_stack[donated][tid] = SE::make(SE::ref(e), __builtin_nan(""));
+          } else {
+            const size_t o = (size_t)(donated - STACK) * a.spill_stride + gslot;
+            e = SE::make(a.spill[o], a.spill_tmin[o]);
+            a.spill_tmin[o] = __builtin_nan("");
+          }
+          give = SE::tmin(e) <= L.hit_t; // still alive?  (a dead or culled entry is just skipped)
+          const uint32_t nlevel = give ? level + 1u : level;
+          meta = (meta & ~(kMetaLevelMask | (0xFFFFu << kMetaDonatedShift))) | (nlevel << kMetaLevelShift) |
+                 ((donated + 1u) << kMetaDonatedShift);
+          hkey = give ? key + (1u << (32u - nlevel)) : 0u; // upper half of the donor's interval: after everything the donor still does
+          const uint32_t owner_lane = (meta & kMetaHelper) ? (meta & kMetaOwnerMask) : lane;
+          hmeta = kMetaHelper | owner_lane | (nlevel << kMetaLevelShift);
+          if (give) {
+            if (!(meta & (kMetaHelper | kMetaOwnerOpen))) { // first donation of an owner: open its record
+              FoldRec<T> &r = s_fold[tid];
+              r.prim = kInvalid;
+              r.pend = 0u;
+              meta |= kMetaOwnerOpen;
+            }
+          }
+        }
+        // (record initialisation above is ordered before the counting below: LDS operations of a wave execute in order)
+        if (is_donor && give) atomicAdd(&s_fold[wbase + (hmeta & kMetaOwnerMask)].pend, 1u);
+        if (a.debug_flags & 4096u) { // (debugging: event counts)
+          if (is_donor) atomicAdd(&a.counters[0], 1ull);
+          if (is_donor && give) atomicAdd(&a.counters[1], 1ull);
+        }
+        // receivers copy the ray and the entry from their source lane (value by value, each shuffle consumed at once:
+        // sources are busy lanes, receivers free ones, so overwriting in place never feeds a changed value to anyone)
+        // (every shuffle is a statement of its own, executed by the whole wave: inside `is_recv && __shfl(...)` the
+        // short-circuit would switch the source lanes off and the receivers would read nothing)
+        const int g_give = __shfl((int)(give ? 1 : 0), src);
+        const bool take = is_recv && g_give != 0;
+        if ((a.debug_flags & 4096u) && take) atomicAdd(&a.counters[2], 1ull);
+  // (the empty asm keeps the vectoriser from merging neighbouring values into one vector access, which would pin
+  // the lane's ray in scratch memory)
+#define NRT_TAKE(dst, val)                  \
+  do {                                      \
+    auto v_ = (val);                        \
+    asm volatile("" : "+v"(v_));            \
+    const auto g_ = __shfl(v_, src);        \
+    dst = take ? g_ : dst;                  \
+  } while (0)
+        {
+          const uint32_t pk = (uint32_t)L.kx | ((uint32_t)L.ky << 2) | ((uint32_t)L.kz << 4) | ((uint32_t)L.sign0 << 6) |
+                              ((uint32_t)L.sign1 << 7) | ((uint32_t)L.sign2 << 8);
+          const uint32_t g_pk = (uint32_t)__shfl((int)pk, src);
+          if (take) {
+            L.kx = (int)(g_pk & 3u);
+            L.ky = (int)((g_pk >> 2) & 3u);
+            L.kz = (int)((g_pk >> 4) & 3u);
+            L.sign0 = (int)((g_pk >> 6) & 1u);
+            L.sign1 = (int)((g_pk >> 7) & 1u);
+            L.sign2 = (int)((g_pk >> 8) & 1u);
+          }
+        }
+        {
+          const uint32_t g_ref = (uint32_t)__shfl((int)SE::ref(e), src);
+          cur = take ? (g_ref & ~kLeafBit) : cur;
+          state = take ? ((g_ref & kLeafBit) ? W_LEAF : W_TRAV) : state;
+        }
+        {
+          int r_ = (int)rid, k_ = (int)hkey, m_ = (int)hmeta;
+          const int g_r = __shfl(r_, src), g_k = __shfl(k_, src), g_m = __shfl(m_, src);
+          rid = take ? (uint32_t)g_r : rid;
+          key = take ? (uint32_t)g_k : key;
+          meta = take ? (uint32_t)g_m : meta;
+        }
+        NRT_TAKE(leaf_tmin, SE::tmin(e));
+        NRT_TAKE(L.org0, L.org0);
+        NRT_TAKE(L.org1, L.org1);
+        NRT_TAKE(L.org2, L.org2);
+        NRT_TAKE(L.inv0, L.inv0);
+        NRT_TAKE(L.inv1, L.inv1);
+        NRT_TAKE(L.inv2, L.inv2);
+        NRT_TAKE(L.min_t, L.min_t);
+        NRT_TAKE(L.max_t, L.max_t);
+        NRT_TAKE(L.hit_t, L.hit_t); // the donor's distance at this moment: never tighter than the sequential loop's on arrival here
+        NRT_TAKE(L.Sx, L.Sx);
+        NRT_TAKE(L.Sy, L.Sy);
+        NRT_TAKE(L.Sz, L.Sz);
+#undef NRT_TAKE
+        L.prim = take ? kInvalid : L.prim;
+        L.u = take ? T(0) : L.u;
+        L.v = take ? T(0) : L.v;
+        L.cap = take ? 0u : L.cap;
+        sp = take ? 0 : sp;
+        if (STATS && take) st_steps = st_tris = 0;
       }
       idle = __ballot(state == W_IDLE);
     }
@@ -891,6 +1153,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
         const uint32_t ref = SE::ref(e);
         sp = s1;
         cur = enter ? (ref & ~kLeafBit) : cur;
+        if (SPLIT) leaf_tmin = SE::tmin(e);
         state = fin ? W_IDLE : (enter ? ((ref & kLeafBit) ? W_LEAF : W_TRAV) : W_POP);
       }
       if (state == W_TRAV) {
@@ -912,7 +1175,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           sp++;
         }
         // both hit: the near one; one hit: that one
-        const uint32_t next = (both ? near1 : sl.h1) ? w.c1 : w.c0;
+        const bool go1 = both ? near1 : sl.h1;
+        const uint32_t next = go1 ? w.c1 : w.c0;
+        if (SPLIT) leaf_tmin = go1 ? sl.tm1 : sl.tm0;
         cur = any ? (next & ~kLeafBit) : cur;
         state = any ? ((next & kLeafBit) ? W_LEAF : W_TRAV) : W_POP;
       }
@@ -964,7 +1229,14 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
           cylinder_test<T>(L, cy, i < cnt, a.range0, a.range1, a.cyl_test_cap != 0u);
         } else {
           const LeafTri<T> tri = a.tris[first + (i < cnt ? i : 0u)];
-          if (PLAIN)
+          if (SPLIT) {
+            bool bad = false;
+            if (PLAIN)
+              tri_test<T, true, true>(L, tri, i < cnt, 0u, 0u, 0u, false, leaf_tmin, &bad);
+            else
+              tri_test<T, false, true>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull, leaf_tmin, &bad);
+            meta |= bad ? kMetaBad : 0u; // (only read in helper lanes)
+          } else if (PLAIN)
             tri_test<T, true>(L, tri, i < cnt, 0u, 0u, 0u, false);
           else
             tri_test<T>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull);
@@ -977,6 +1249,13 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_wide(const Traverse
   }
   if (rid != kInvalid) NRT_WRITE_RESULT(); // results still held in registers
 #undef NRT_WRITE_RESULT
+  if (clocked && lane == 0u) { // one record per wave, reduced on the host (atomics on one line would serialise the exits)
+    unsigned long long *rec = a.wave_clock + 3ull * (size_t)(gslot / kWave);
+    const unsigned long long clk_end = __builtin_amdgcn_s_memrealtime();
+    rec[0] = clk_begin;
+    rec[1] = clk_dry == 0ull ? clk_end : clk_dry;
+    rec[2] = clk_end;
+  }
   if (STATS && lane == 0) { // counters[0..7]: it1, act1, idle lanes at phase-2 entry, it2, act2, refills, refilled, phase-2 entries
     atomicAdd(&a.counters[0], st_it1);
     atomicAdd(&a.counters[1], st_act1);
@@ -1187,7 +1466,7 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
                                 const char **name_out) {
   constexpr bool f32 = sizeof(T) == 4;
   if (prim_kind == kPrimSpheres) { // one instantiation: 10 LDS entries (the caller sizes the overflow stack for it)
-    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 1, false>" : "nrt::k_traverse_wide<double, 10, false, 1, false>",
+    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 1, false, false>" : "nrt::k_traverse_wide<double, 10, false, 1, false, false>",
                     T, 10, false, kPrimSpheres);
     if (args.hits)
       hipLaunchKernelGGL((k_sphere_uv<T>), dim3((args.num_rays + 255u) / 256u), dim3(256), 0, s, args.rays, args.hits,
@@ -1195,33 +1474,40 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
     return hipGetLastError();
   }
   if (prim_kind == kPrimCylinders) {
-    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 2, false>" : "nrt::k_traverse_wide<double, 10, false, 2, false>",
+    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 2, false, false>" : "nrt::k_traverse_wide<double, 10, false, 2, false, false>",
                     T, 10, false, kPrimCylinders);
     return hipGetLastError();
   }
   switch (lds_stack) {
     case 8:
-      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 8, false, 0, false>" : "nrt::k_traverse_wide<double, 8, false, 0, false>",
+      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 8, false, 0, false, false>" : "nrt::k_traverse_wide<double, 8, false, 0, false, false>",
                       T, 8, false, kPrimTriangles);
       break;
     case 10:
       if (args.debug_flags & 32u) {
-        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, true, 0, false>" : "nrt::k_traverse_wide<double, 10, true, 0, false>",
+        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, true, 0, false, false>" : "nrt::k_traverse_wide<double, 10, true, 0, false, false>",
                         T, 10, true, kPrimTriangles);
+      } else if (args.split) { // the production variants: work splitting in the drain (a.split: see api.hip)
+        if (args.plain_options)
+          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, true>" : "nrt::k_traverse_wide<double, 10, false, 0, true, true>",
+                          T, 10, false, kPrimTriangles, true, true);
+        else
+          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, false, true>" : "nrt::k_traverse_wide<double, 10, false, 0, false, true>",
+                          T, 10, false, kPrimTriangles, false, true);
       } else if (args.plain_options) {
-        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true>" : "nrt::k_traverse_wide<double, 10, false, 0, true>",
+        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, false>" : "nrt::k_traverse_wide<double, 10, false, 0, true, false>",
                         T, 10, false, kPrimTriangles, true);
       } else {
-        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, false>" : "nrt::k_traverse_wide<double, 10, false, 0, false>",
+        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, false, false>" : "nrt::k_traverse_wide<double, 10, false, 0, false, false>",
                         T, 10, false, kPrimTriangles);
       }
       break;
     case 12:
-      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 12, false, 0, false>" : "nrt::k_traverse_wide<double, 12, false, 0, false>",
+      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 12, false, 0, false, false>" : "nrt::k_traverse_wide<double, 12, false, 0, false, false>",
                       T, 12, false, kPrimTriangles);
       break;
     default:
-      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 16, false, 0, false>" : "nrt::k_traverse_wide<double, 16, false, 0, false>",
+      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 16, false, 0, false, false>" : "nrt::k_traverse_wide<double, 16, false, 0, false, false>",
                       T, 16, false, kPrimTriangles);
       break;
   }
@@ -1240,7 +1526,7 @@ int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind) {
   } else {
     switch (lds_stack) {
       case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 8, false, kPrimTriangles>, kTraverseBlock, 0); break;
-      case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimTriangles>, kTraverseBlock, 0); break;
+      case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimTriangles, true, true>, kTraverseBlock, 0); break;
       case 12: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 12, false, kPrimTriangles>, kTraverseBlock, 0); break;
       default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 16, false, kPrimTriangles>, kTraverseBlock, 0); break;
     }

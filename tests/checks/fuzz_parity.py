@@ -3,7 +3,7 @@ meshes built to provoke the edge rules (grid-aligned vertices -> rays through ed
 edge functions and exact t ties; degenerate and duplicated triangles; axis-parallel, zero, NaN and infinite ray
 components; random trace options), fp32 and fp64, GPU-built trees and adopted oracle-built trees, and the occlusion
 query's flags.  Usage: python tests/checks/fuzz_parity.py [seconds] [seed]"""
-import sys, time
+import os, sys, time
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from nanort_amd import BVHAccel, TriangleMesh
@@ -50,6 +50,7 @@ while time.time() < t_end:
         opts["skip_prim_id"] = int(rng.integers(0, n))
     opts["cull_back_face"] = int(rng.random() < 0.3)
     mesh = TriangleMesh(v, f)
+    os.environ["NRT_SPLIT"] = "1" if rng.random() < 0.5 else "0"   # (read at context creation) drain-time work splitting on / off
     a = BVHAccel(real)
     gpu_built = rng.random() < 0.5
     if gpu_built:

@@ -5,6 +5,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,3 +30,31 @@ def test_header_host_path_equals_the_restatement_on_random_hostile_inputs():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "fuzz_header_host_path.py"), "8", "5"], cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "header host path == restatement" in r.stdout, r.stdout[-2000:]
+
+
+def test_saved_cross_tree_cases_stay_documented():
+    """The two residual cases of round 1's cross-tree fuzz (tests/golden/fuzz_case_r01_crosstree_*.npz):
+    on these grid-aligned meshes the REFERENCE's own answer depends on the tree beyond exact ties (a triangle's t one ulp
+    below its leaf box's entry distance; rays lying in a triangle's plane).  Same-tree parity is exact (GPU:
+    tests/test_gpu_split.py replays them); across trees the restatement agrees with itself on >= 99.8 % of the rays and
+    NOT on all of them — if that ever becomes 100 % the documented caveat can go."""
+    import glob
+    import os
+
+    from oracle.bindings import Oracle
+
+    orc = Oracle()
+    here = os.path.dirname(os.path.abspath(__file__))
+    differing = 0
+    for case in sorted(glob.glob(os.path.join(here, "golden", "fuzz_case_r01_crosstree_*.npz"))):
+        d = np.load(case)
+        v, f, rays, opts, nodes, idx = d["v"], d["f"], d["rays"], d["opts"], d["nodes"], d["idx"]
+        h, m = orc.traverse(nodes, idx, v, f, rays, opts)          # the tree the GPU builder produced in that round
+        n2, i2, _ = orc.build(v, f)                                  # the reference builder's tree
+        h2, m2 = orc.traverse(n2, i2, v, f, rays, opts)
+        assert (m == m2).mean() > 0.998
+        both = (m == 1) & (m2 == 1) & np.isfinite(h["t"]) & np.isfinite(h2["t"])
+        close = np.abs(h["t"][both] - h2["t"][both]) <= 1e-5 * np.maximum(1.0, np.abs(h2["t"][both]))
+        assert close.mean() > 0.998
+        differing += int((m != m2).sum()) + int((~close).sum())
+    assert differing > 0, "the cross-tree difference these fixtures document is gone"
