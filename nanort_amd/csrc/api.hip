@@ -119,6 +119,7 @@ struct nrt_ctx {
   // LOSE on C3 (profiles/r02c_split_*.txt: bounce wave 0.50 -> 0.51-0.59 ms depending on the hand-out policy), because
   // under the while-while loop every helper adds leaf rounds that stall the very ray it helps.  Off unless NRT_SPLIT=1.
   int split = 0;
+  unsigned drain_loop = 1; // per-lane loop for the last rays of a wave (env NRT_DRAIN=0: stay in the while-while loop)
   unsigned drain_steps = 8, split_busy = 8; // hand-out policy (env NRT_DRAIN_STEPS, NRT_SPLIT_BUSY)
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
 
@@ -254,6 +255,7 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   if (const char *e = getenv("NRT_BLOCKS_PER_CU")) c->max_blocks_per_cu = (unsigned)std::max(0, atoi(e));
   if (const char *e = getenv("NRT_WIDE")) c->wide = atoi(e) != 0;
   if (const char *e = getenv("NRT_SPLIT")) c->split = atoi(e) != 0;
+  if (const char *e = getenv("NRT_DRAIN")) c->drain_loop = atoi(e) != 0 ? 1u : 0u;
   if (const char *e = getenv("NRT_DRAIN_STEPS")) c->drain_steps = (unsigned)std::max(1, atoi(e));
   if (const char *e = getenv("NRT_SPLIT_BUSY")) c->split_busy = (unsigned)std::min(64, std::max(0, atoi(e)));
   if (const char *e = getenv("NRT_WIDE_STACK")) {
@@ -671,6 +673,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
                      !opt->cull_back_face) ? 1u : 0u;
   a.split = (c->split && use_wide && c->prim_kind == kPrimTriangles && !any_hit && c->root_is_branch && c->tree_nested) ? 1u : 0u;
   a.root_test = c->tree_nested ? 0u : 1u;
+  a.drain_loop = c->drain_loop;
   a.drain_steps = c->drain_steps;
   a.split_busy = c->split_busy;
   a.spill = (uint32_t *)slot->spill.p;

@@ -72,15 +72,17 @@ struct Lane {
   // (floats and integers alternate on purpose: as neighbours, Sx Sy Sz u v get merged into overlapping two- and
   // four-float vector accesses by the vectoriser, which then pins all five in scratch memory instead of registers)
   T Sx;
-  int kx;
+  uint32_t pk; // kx | ky << 2 | kz << 4 | (dir < 0 per axis) << 6..8: six small integers in one register (the kernel sits at
+               // the 80-register edge of six waves per SIMD; the loops turn the fields into lane masks once, on entry)
   T Sy;
-  int ky;
-  T Sz;
-  int kz;
-  T u;
   uint32_t prim;
+  T Sz;
+  T u;
   T v;
-  int sign0, sign1, sign2; // dir < 0 per axis (scalars: no runtime-indexed array)
+  __device__ __forceinline__ int kx() const { return (int)(pk & 3u); }
+  __device__ __forceinline__ int ky() const { return (int)((pk >> 2) & 3u); }
+  __device__ __forceinline__ int kz() const { return (int)((pk >> 4) & 3u); }
+  __device__ __forceinline__ int sign(int k) const { return (int)((pk >> (6 + k)) & 1u); }
 };
 
 template <typename T>
@@ -120,16 +122,13 @@ __device__ __forceinline__ void lane_init(Lane<T> &L, const typename Wire<T>::Ra
     kx = ky;
     ky = t;
   }
-  L.kx = kx;
-  L.ky = ky;
-  L.kz = kz;
+  uint32_t pk = (uint32_t)kx | ((uint32_t)ky << 2) | ((uint32_t)kz << 4);
   L.Sx = sel3(d0, d1, d2, kx) / dz;
   L.Sy = sel3(d0, d1, d2, ky) / dz;
   L.Sz = T(1.0) / dz;
   // Traverse prologue (nanort.h:2505-2516)
-  L.sign0 = d0 < T(0) ? 1 : 0;
-  L.sign1 = d1 < T(0) ? 1 : 0;
-  L.sign2 = d2 < T(0) ? 1 : 0;
+  pk |= (d0 < T(0) ? 64u : 0u) | (d1 < T(0) ? 128u : 0u) | (d2 < T(0) ? 256u : 0u);
+  L.pk = pk;
   L.inv0 = safe_inverse<T>(d0);
   L.inv1 = safe_inverse<T>(d1);
   L.inv2 = safe_inverse<T>(d2);
@@ -142,7 +141,7 @@ __device__ __forceinline__ bool slab_test(const Lane<T> &L, const T bmin[3], con
   T tmin = L.min_t, tmax = L.hit_t;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const int sg = k == 0 ? L.sign0 : (k == 1 ? L.sign1 : L.sign2);
+    const int sg = L.sign(k);
     const T lo = sg ? bmax[k] : bmin[k];
     const T hi = sg ? bmin[k] : bmax[k];
     const T t0 = (lo - L.org(k)) * L.inv(k);
@@ -172,13 +171,13 @@ __device__ __forceinline__ void tri_test(Lane<T> &L, const LeafTri<T> &tri, bool
   const T A0 = tri.p0[0] - L.org0, A1 = tri.p0[1] - L.org1, A2 = tri.p0[2] - L.org2;
   const T B0 = tri.p1[0] - L.org0, B1 = tri.p1[1] - L.org1, B2 = tri.p1[2] - L.org2;
   const T C0 = tri.p2[0] - L.org0, C1 = tri.p2[1] - L.org1, C2 = tri.p2[2] - L.org2;
-  const T Akz = sel3(A0, A1, A2, L.kz), Bkz = sel3(B0, B1, B2, L.kz), Ckz = sel3(C0, C1, C2, L.kz);
-  const T Ax = sel3(A0, A1, A2, L.kx) - L.Sx * Akz;
-  const T Ay = sel3(A0, A1, A2, L.ky) - L.Sy * Akz;
-  const T Bx = sel3(B0, B1, B2, L.kx) - L.Sx * Bkz;
-  const T By = sel3(B0, B1, B2, L.ky) - L.Sy * Bkz;
-  const T Cx = sel3(C0, C1, C2, L.kx) - L.Sx * Ckz;
-  const T Cy = sel3(C0, C1, C2, L.ky) - L.Sy * Ckz;
+  const T Akz = sel3(A0, A1, A2, L.kz()), Bkz = sel3(B0, B1, B2, L.kz()), Ckz = sel3(C0, C1, C2, L.kz());
+  const T Ax = sel3(A0, A1, A2, L.kx()) - L.Sx * Akz;
+  const T Ay = sel3(A0, A1, A2, L.ky()) - L.Sy * Akz;
+  const T Bx = sel3(B0, B1, B2, L.kx()) - L.Sx * Bkz;
+  const T By = sel3(B0, B1, B2, L.ky()) - L.Sy * Bkz;
+  const T Cx = sel3(C0, C1, C2, L.kx()) - L.Sx * Ckz;
+  const T Cy = sel3(C0, C1, C2, L.ky()) - L.Sy * Ckz;
   T U = Cx * By - Cy * Bx;
   T V = Ax * Cy - Ay * Cx;
   T W = Bx * Ay - By * Ax;
@@ -384,6 +383,8 @@ __device__ __forceinline__ unsigned lane_id() {
 //    (4 KiB apart); a wave drains its home range first and then steals from the others,
 //    `chunk` rays per atomicAdd.  Device-scope atomics on one word saturate near 100 per
 //    microsecond on this part, hence the static share and the modest chunk count.
+//    (Round 2 re-measured the whole family with per-wave time stamps — static share 0-75 %, chunks of 16-128 rays,
+//    claims issued one chunk ahead of need: nothing beats 75 % / 128; profiles/r02d_scheduling_sweep.txt.)
 struct Claim {
   uint32_t next, end; // claimed, not yet handed out: [next, end)
   uint32_t part, tried;
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(const TraverseArgs<
       if (COUNT) c_nodes++;
       if (slab_test<T>(L, nd.bmin, nd.bmax)) {
         if (nd.flag == 0) {
-          const int near = sel3(L.sign0, L.sign1, L.sign2, nd.axis);
+          const int near = L.sign(nd.axis);
           const uint32_t far_child = near ? nd.data[0] : nd.data[1];
           cur = near ? nd.data[1] : nd.data[0];
           // push far; near stays in `cur` (it would be popped next anyway: nanort.h:2542-2543)
@@ -620,7 +621,7 @@ __device__ __forceinline__ bool slab_test_tmin(const Lane<T> &L, const T box[6],
   T tmin = L.min_t, tmax = L.hit_t;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const int sg = k == 0 ? L.sign0 : (k == 1 ? L.sign1 : L.sign2);
+    const int sg = L.sign(k);
     const T lo = sg ? box[3 + k] : box[k];
     const T hi = sg ? box[k] : box[3 + k];
     const T t0 = (lo - L.org(k)) * L.inv(k);
@@ -739,7 +740,7 @@ __device__ __forceinline__ SlabPair<float> slab_pair(const Lane<float> &L, const
   float tmin0 = L.min_t, tmin1 = L.min_t, tmax0 = L.hit_t, tmax1 = L.hit_t;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const int sg = k == 0 ? L.sign0 : (k == 1 ? L.sign1 : L.sign2);
+    const int sg = L.sign(k);
     const f2 lo = {sg ? w.box0[3 + k] : w.box0[k], sg ? w.box1[3 + k] : w.box1[k]};
     const f2 hi = {sg ? w.box0[k] : w.box0[3 + k], sg ? w.box1[k] : w.box1[3 + k]};
     const f2 o = {L.org(k), L.org(k)};
@@ -855,6 +856,9 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) 
   T leaf_tmin = T(0);         // SPLIT: entry distance of the box of the leaf this lane is at
   const bool split_on = SPLIT && a.split != 0u;
   unsigned drain_round = 0u;
+  // (the sphere and cylinder kernels are left as they were: the extra loop body would cost them a wave per SIMD)
+  constexpr bool kDrain = !STATS && KIND == kPrimTriangles;
+  const bool drain_on = kDrain && (split_on || a.drain_loop != 0u); // see "the drain" below
   // (profiling, NRT_DEBUG bit 8192: when did this wave start, run out of rays, finish — 100 MHz realtime ticks)
   const bool clocked = (a.debug_flags & 8192u) != 0u && a.wave_clock != nullptr;
   unsigned long long clk_begin = 0ull, clk_dry = 0ull;
@@ -883,6 +887,77 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) 
     h_.prim_id = hit_ ? L.prim : kInvalid;              \
     if (a.hits) store_hit_nt<T>(a.hits + rid, h_);      \
     if (a.mask) a.mask[rid] = hit_ ? (KIND == kPrimCylinders ? (uint8_t)(1u | (L.cap << 1)) : (uint8_t)1) : (uint8_t)0; \
+  } while (0)
+
+  // One stack pop (a lane in W_POP): the entry is entered iff its t_min still beats the hit distance — the reference's
+  // slab test at pop time (see the comment above the kernel); an empty stack finishes the ray.
+#define NRT_POP_ENTRY()                                                                                \
+  do {                                                                                                 \
+    const int s1_ = sp > 0 ? sp - 1 : 0;                                                               \
+    typename SE::type e_ = s_stack[s1_ < STACK ? s1_ : STACK - 1][tid];                                \
+    if (s1_ >= STACK) { /* rare: the entry lives in the global overflow stack */                       \
+      const size_t o_ = (size_t)(s1_ - STACK) * a.spill_stride + gslot;                                \
+      e_ = SE::make(a.spill[o_], a.spill_tmin[o_]);                                                    \
+    }                                                                                                  \
+    const bool fin_ = (sp == 0);                        /* empty stack: the ray is done */             \
+    const bool enter_ = !fin_ & (SE::tmin(e_) <= L.hit_t);                                             \
+    const uint32_t ref_ = SE::ref(e_);                                                                 \
+    sp = s1_;                                                                                          \
+    cur = enter_ ? (ref_ & ~kLeafBit) : cur;                                                           \
+    if (SPLIT) leaf_tmin = SE::tmin(e_);                                                               \
+    state = fin_ ? W_IDLE : (enter_ ? ((ref_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP);                  \
+  } while (0)
+
+  // One step of a lane in W_TRAV over the WideNode record `w_`: both child boxes tested, the far child of two hits
+  // pushed with its t_min, the near one (or the only one) entered.
+#define NRT_STEP_NODE(w_)                                                                              \
+  do {                                                                                                 \
+    const SlabPair<T> sl_ = slab_pair(L, (w_));                                                        \
+    const bool near1_ = L.sign((w_).axis) != 0; /* near child = data[dir_sign[axis]] (nanort.h:2538) */ \
+    const bool both_ = sl_.h0 & sl_.h1, any_ = sl_.h0 | sl_.h1;                                        \
+    if (both_) { /* the far child waits with its t_min */                                              \
+      const uint32_t rf_ = near1_ ? (w_).c0 : (w_).c1;                                                 \
+      const T tf_ = near1_ ? sl_.tm0 : sl_.tm1;                                                        \
+      if (sp < STACK) {                                                                                \
+        s_stack[sp][tid] = SE::make(rf_, tf_);                                                         \
+      } else {                                                                                         \
+        const size_t o_ = (size_t)(sp - STACK) * a.spill_stride + gslot;                               \
+        a.spill[o_] = rf_;                                                                             \
+        a.spill_tmin[o_] = tf_;                                                                        \
+      }                                                                                                \
+      sp++;                                                                                            \
+    }                                                                                                  \
+    /* both hit: the near one; one hit: that one */                                                    \
+    const bool go1_ = both_ ? near1_ : sl_.h1;                                                         \
+    const uint32_t next_ = go1_ ? (w_).c1 : (w_).c0;                                                   \
+    if (SPLIT) leaf_tmin = go1_ ? sl_.tm1 : sl_.tm0;                                                   \
+    cur = any_ ? (next_ & ~kLeafBit) : cur;                                                            \
+    state = any_ ? ((next_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP;                                     \
+  } while (0)
+
+  // One primitive record (slot `slot_` of the leaf-ordered arrays) against a lane's ray; `act_` false -> no effect.
+#define NRT_TEST_PRIM(slot_, act_)                                                                     \
+  do {                                                                                                 \
+    if (KIND == kPrimSpheres) {                                                                        \
+      const LeafSphere<T> sp_ = a.spheres[(slot_)];                                                    \
+      sphere_test<T>(L, sp_, (act_), a.range0, a.range1);                                              \
+    } else if (KIND == kPrimCylinders) {                                                               \
+      const LeafCylinder<T> cy_ = a.cylinders[(slot_)];                                                \
+      cylinder_test<T>(L, cy_, (act_), a.range0, a.range1, a.cyl_test_cap != 0u);                      \
+    } else {                                                                                           \
+      const LeafTri<T> tri_ = a.tris[(slot_)];                                                         \
+      if (SPLIT) {                                                                                     \
+        bool bad_ = false;                                                                             \
+        if (PLAIN)                                                                                     \
+          tri_test<T, true, true>(L, tri_, (act_), 0u, 0u, 0u, false, leaf_tmin, &bad_);               \
+        else                                                                                           \
+          tri_test<T, false, true>(L, tri_, (act_), a.range0, a.range1, a.skip_prim, cull, leaf_tmin, &bad_); \
+        meta |= bad_ ? kMetaBad : 0u; /* (only read in helper lanes) */                                \
+      } else if (PLAIN)                                                                                \
+        tri_test<T, true>(L, tri_, (act_), 0u, 0u, 0u, false);                                         \
+      else                                                                                             \
+        tri_test<T>(L, tri_, (act_), a.range0, a.range1, a.skip_prim, cull);                           \
+    }                                                                                                  \
   } while (0)
 
   for (;;) {
@@ -936,197 +1011,7 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) 
       idle = __ballot(state == W_IDLE);
     }
     if (clocked && ck.exhausted && clk_dry == 0ull) clk_dry = __builtin_amdgcn_s_memrealtime();
-    if (SPLIT && split_on && ck.exhausted) {
-      const unsigned wbase = tid & ~63u; // this wave's slots of s_fold
-      // -- (a) finished helpers hand their result to the owner's record, one after the other
-      unsigned long long fh = __ballot(state == W_IDLE && rid != kInvalid && (meta & kMetaHelper) != 0u);
-      while (fh != 0ull) {
-        const unsigned h = (unsigned)__builtin_ctzll(fh);
-        fh &= fh - 1ull;
-        if (lane == h) {
-          FoldRec<T> &r = s_fold[wbase + (meta & kMetaOwnerMask)];
-          if (L.prim != kInvalid && (r.prim == kInvalid || L.hit_t < r.t || (L.hit_t == r.t && key > r.key))) {
-            r.t = L.hit_t;
-            r.u = L.u;
-            r.v = L.v;
-            r.key = key;
-            r.prim = L.prim;
-          }
-          r.pend = (r.pend - 1u) | ((meta & kMetaBad) ? 0x80000000u : 0u);
-          if (a.debug_flags & 4096u) atomicAdd(&a.counters[3], 1ull);
-          rid = kInvalid;
-          meta = 0u;
-        }
-      }
-      // -- (b) owners: fold the own segment once, then wait for the helpers; the last delivery settles the ray
-      if (state == W_IDLE && rid != kInvalid && (meta & kMetaOwnerOpen) != 0u) {
-        FoldRec<T> &r = s_fold[tid];
-        if (!(meta & kMetaMainDone)) {
-          if (L.prim != kInvalid && (r.prim == kInvalid || L.hit_t < r.t || (L.hit_t == r.t && key > r.key))) {
-            r.t = L.hit_t;
-            r.u = L.u;
-            r.v = L.v;
-            r.key = key;
-            r.prim = L.prim;
-          }
-          meta |= kMetaMainDone;
-        }
-        const uint32_t pend = r.pend;
-        if ((pend & 0xFFFFu) == 0u) {
-          if (a.debug_flags & 4096u) atomicAdd(&a.counters[(pend & 0x80000000u) ? 5 : 4], 1ull);
-          if (((pend & 0x80000000u) && !(a.debug_flags & 512u)) || (a.debug_flags & 1024u)) { // a helper saw t below its leaf box's entry distance: trace the ray again, sequentially
-            const Ray rr = load_ray_nt<T>(a.rays + rid);
-            lane_init<T>(L, rr);
-            sp = 0;
-            cur = 0u;
-            state = W_TRAV;
-            meta = kMetaNoSplit;
-            key = 0u;
-          } else {
-            const bool any_ = r.prim != kInvalid;
-            L.hit_t = any_ ? r.t : L.max_t;
-            L.u = r.u;
-            L.v = r.v;
-            L.prim = r.prim;
-            meta = 0u;
-          }
-        }
-      }
-      // -- (c) every lane that holds a settled result writes it now and becomes free
-      if (state == W_IDLE && rid != kInvalid && (meta & (kMetaHelper | kMetaOwnerOpen)) == 0u) {
-        NRT_WRITE_RESULT();
-        rid = kInvalid;
-      }
-      // -- (d) busy lanes give their oldest pending subtree to free lanes
-      const unsigned long long freel = __ballot(state == W_IDLE && rid == kInvalid);
-      const uint32_t donated = meta >> kMetaDonatedShift;
-      const uint32_t level = (meta & kMetaLevelMask) >> kMetaLevelShift;
-      const bool busy = state == W_TRAV || state == W_POP || state == W_LEAF;
-      // (a lane about to pop keeps the entry it is about to pop)
-      const bool can_give = busy && !(meta & kMetaNoSplit) && level < 31u && donated < 0xFFFFu &&
-                            (uint32_t)sp > donated + (state == W_POP ? 1u : 0u);
-      const unsigned long long donors = __ballot(can_give);
-      unsigned n_pair = (unsigned)__builtin_popcountll(donors);
-      const unsigned n_free = (unsigned)__builtin_popcountll(freel);
-      n_pair = n_pair < n_free ? n_pair : n_free;
-      if (a.debug_flags & 256u) n_pair = 0u; // (debugging: no donations)
-      // a round costs a few hundred issue slots for the whole wave: only when few lanes are still busy, and not every trip
-      drain_round++;
-      if ((unsigned)__builtin_popcountll(__ballot(busy)) > a.split_busy || drain_round % a.drain_steps != 0u) n_pair = 0u;
-      if (n_pair != 0u) {
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const bool is_donor = can_give && (unsigned)__builtin_popcountll(donors & lt) < n_pair;
-        const bool is_recv = ((freel >> lane) & 1ull) != 0ull && (unsigned)__builtin_popcountll(freel & lt) < n_pair;
-        // receiver k takes from donor k: lane index of its source (scalar walk over the two masks; rare)
-        int src = (int)lane;
-        {
-          unsigned long long d = donors, f = freel;
-          for (unsigned k = 0; k < n_pair; k++) {
-            const int dl = __builtin_ctzll(d), fl = __builtin_ctzll(f);
-            d &= d - 1ull;
-            f &= f - 1ull;
-            src = ((int)lane == fl) ? dl : src;
-          }
-        }
-        // donor: take the oldest live entry off the bottom of its stack (it stays in place, marked dead)
-        typename SE::type e = SE::make(0u, T(0));
-        bool give = false;
-        uint32_t hkey = 0u, hmeta = 0u;
-        if (is_donor) {
-          if (donated < (uint32_t)STACK) {
-            e = s_stack[donated][tid];
-            s_stack[donated][tid] = SE::make(SE::ref(e), __builtin_nan(""));
-          } else {
-            const size_t o = (size_t)(donated - STACK) * a.spill_stride + gslot;
-            e = SE::make(a.spill[o], a.spill_tmin[o]);
-            a.spill_tmin[o] = __builtin_nan("");
-          }
-          give = SE::tmin(e) <= L.hit_t; // still alive?  (a dead or culled entry is just skipped)
-          const uint32_t nlevel = give ? level + 1u : level;
-          meta = (meta & ~(kMetaLevelMask | (0xFFFFu << kMetaDonatedShift))) | (nlevel << kMetaLevelShift) |
-                 ((donated + 1u) << kMetaDonatedShift);
-          hkey = give ? key + (1u << (32u - nlevel)) : 0u; // upper half of the donor's interval: after everything the donor still does
-          const uint32_t owner_lane = (meta & kMetaHelper) ? (meta & kMetaOwnerMask) : lane;
-          hmeta = kMetaHelper | owner_lane | (nlevel << kMetaLevelShift);
-          if (give) {
-            if (!(meta & (kMetaHelper | kMetaOwnerOpen))) { // first donation of an owner: open its record
-              FoldRec<T> &r = s_fold[tid];
-              r.prim = kInvalid;
-              r.pend = 0u;
-              meta |= kMetaOwnerOpen;
-            }
-          }
-        }
-        // (record initialisation above is ordered before the counting below: LDS operations of a wave execute in order)
-        if (is_donor && give) atomicAdd(&s_fold[wbase + (hmeta & kMetaOwnerMask)].pend, 1u);
-        if (a.debug_flags & 4096u) { // (debugging: event counts)
-          if (is_donor) atomicAdd(&a.counters[0], 1ull);
-          if (is_donor && give) atomicAdd(&a.counters[1], 1ull);
-        }
-        // receivers copy the ray and the entry from their source lane (value by value, each shuffle consumed at once:
-        // sources are busy lanes, receivers free ones, so overwriting in place never feeds a changed value to anyone)
-        // (every shuffle is a statement of its own, executed by the whole wave: inside `is_recv && __shfl(...)` the
-        // short-circuit would switch the source lanes off and the receivers would read nothing)
-        const int g_give = __shfl((int)(give ? 1 : 0), src);
-        const bool take = is_recv && g_give != 0;
-        if ((a.debug_flags & 4096u) && take) atomicAdd(&a.counters[2], 1ull);
-  // (the empty asm keeps the vectoriser from merging neighbouring values into one vector access, which would pin
-  // the lane's ray in scratch memory)
-#define NRT_TAKE(dst, val)                  \
-  do {                                      \
-    auto v_ = (val);                        \
-    asm volatile("" : "+v"(v_));            \
-    const auto g_ = __shfl(v_, src);        \
-    dst = take ? g_ : dst;                  \
-  } while (0)
-        {
-          const uint32_t pk = (uint32_t)L.kx | ((uint32_t)L.ky << 2) | ((uint32_t)L.kz << 4) | ((uint32_t)L.sign0 << 6) |
-                              ((uint32_t)L.sign1 << 7) | ((uint32_t)L.sign2 << 8);
-          const uint32_t g_pk = (uint32_t)__shfl((int)pk, src);
-          if (take) {
-            L.kx = (int)(g_pk & 3u);
-            L.ky = (int)((g_pk >> 2) & 3u);
-            L.kz = (int)((g_pk >> 4) & 3u);
-            L.sign0 = (int)((g_pk >> 6) & 1u);
-            L.sign1 = (int)((g_pk >> 7) & 1u);
-            L.sign2 = (int)((g_pk >> 8) & 1u);
-          }
-        }
-        {
-          const uint32_t g_ref = (uint32_t)__shfl((int)SE::ref(e), src);
-          cur = take ? (g_ref & ~kLeafBit) : cur;
-          state = take ? ((g_ref & kLeafBit) ? W_LEAF : W_TRAV) : state;
-        }
-        {
-          int r_ = (int)rid, k_ = (int)hkey, m_ = (int)hmeta;
-          const int g_r = __shfl(r_, src), g_k = __shfl(k_, src), g_m = __shfl(m_, src);
-          rid = take ? (uint32_t)g_r : rid;
-          key = take ? (uint32_t)g_k : key;
-          meta = take ? (uint32_t)g_m : meta;
-        }
-        NRT_TAKE(leaf_tmin, SE::tmin(e));
-        NRT_TAKE(L.org0, L.org0);
-        NRT_TAKE(L.org1, L.org1);
-        NRT_TAKE(L.org2, L.org2);
-        NRT_TAKE(L.inv0, L.inv0);
-        NRT_TAKE(L.inv1, L.inv1);
-        NRT_TAKE(L.inv2, L.inv2);
-        NRT_TAKE(L.min_t, L.min_t);
-        NRT_TAKE(L.max_t, L.max_t);
-        NRT_TAKE(L.hit_t, L.hit_t); // the donor's distance at this moment: never tighter than the sequential loop's on arrival here
-        NRT_TAKE(L.Sx, L.Sx);
-        NRT_TAKE(L.Sy, L.Sy);
-        NRT_TAKE(L.Sz, L.Sz);
-#undef NRT_TAKE
-        L.prim = take ? kInvalid : L.prim;
-        L.u = take ? T(0) : L.u;
-        L.v = take ? T(0) : L.v;
-        L.cap = take ? 0u : L.cap;
-        sp = take ? 0 : sp;
-        if (STATS && take) st_steps = st_tris = 0;
-      }
-      idle = __ballot(state == W_IDLE);
-    }
+    if (drain_on && ck.exhausted) break; // the last rays of this wave: the loop below
     if (idle == ~0ull) {
       if (ck.exhausted) break;
       continue;
@@ -1141,45 +1026,11 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) 
         st_act1 += (unsigned)__builtin_popcountll(__ballot(true));
       }
       // a lane that must pop does so first and, if the popped entry survives, steps into it in the same iteration
-      if (state == W_POP) {
-        const int s1 = sp > 0 ? sp - 1 : 0;
-        typename SE::type e = s_stack[s1 < STACK ? s1 : STACK - 1][tid];
-        if (s1 >= STACK) { // rare: the entry lives in the global overflow stack
-          const size_t o = (size_t)(s1 - STACK) * a.spill_stride + gslot;
-          e = SE::make(a.spill[o], a.spill_tmin[o]);
-        }
-        const bool fin = (sp == 0);                                // empty stack: the ray is done
-        const bool enter = !fin & (SE::tmin(e) <= L.hit_t);        // the reference's slab test at pop time
-        const uint32_t ref = SE::ref(e);
-        sp = s1;
-        cur = enter ? (ref & ~kLeafBit) : cur;
-        if (SPLIT) leaf_tmin = SE::tmin(e);
-        state = fin ? W_IDLE : (enter ? ((ref & kLeafBit) ? W_LEAF : W_TRAV) : W_POP);
-      }
+      if (state == W_POP) NRT_POP_ENTRY();
       if (state == W_TRAV) {
         if (STATS) st_steps++;
         const WideNode<T> w = a.wide[cur];
-        const SlabPair<T> sl = slab_pair(L, w);
-        const bool near1 = sel3(L.sign0, L.sign1, L.sign2, w.axis) != 0; // near child = data[dir_sign[axis]] (nanort.h:2538)
-        const bool both = sl.h0 & sl.h1, any = sl.h0 | sl.h1;
-        if (both) { // the far child waits with its t_min
-          const uint32_t rf = near1 ? w.c0 : w.c1;
-          const T tf = near1 ? sl.tm0 : sl.tm1;
-          if (sp < STACK) {
-            s_stack[sp][tid] = SE::make(rf, tf);
-          } else {
-            const size_t o = (size_t)(sp - STACK) * a.spill_stride + gslot;
-            a.spill[o] = rf;
-            a.spill_tmin[o] = tf;
-          }
-          sp++;
-        }
-        // both hit: the near one; one hit: that one
-        const bool go1 = both ? near1 : sl.h1;
-        const uint32_t next = go1 ? w.c1 : w.c0;
-        if (SPLIT) leaf_tmin = go1 ? sl.tm1 : sl.tm0;
-        cur = any ? (next & ~kLeafBit) : cur;
-        state = any ? ((next & kLeafBit) ? W_LEAF : W_TRAV) : W_POP;
+        NRT_STEP_NODE(w);
       }
       // Leave when only a few lanes still walk — unless nothing else could be done anyway: no lane waits at a leaf
       // and there are no rays left to hand out (the drain of a launch: the last long rays then stay in this
@@ -1221,34 +1072,260 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) 
           if (i < cnt) st_tris++;
         }
         // no divergent region here: lanes past their count re-test their first record with ok = false
-        if (KIND == kPrimSpheres) {
-          const LeafSphere<T> sp = a.spheres[first + (i < cnt ? i : 0u)];
-          sphere_test<T>(L, sp, i < cnt, a.range0, a.range1);
-        } else if (KIND == kPrimCylinders) {
-          const LeafCylinder<T> cy = a.cylinders[first + (i < cnt ? i : 0u)];
-          cylinder_test<T>(L, cy, i < cnt, a.range0, a.range1, a.cyl_test_cap != 0u);
-        } else {
-          const LeafTri<T> tri = a.tris[first + (i < cnt ? i : 0u)];
-          if (SPLIT) {
-            bool bad = false;
-            if (PLAIN)
-              tri_test<T, true, true>(L, tri, i < cnt, 0u, 0u, 0u, false, leaf_tmin, &bad);
-            else
-              tri_test<T, false, true>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull, leaf_tmin, &bad);
-            meta |= bad ? kMetaBad : 0u; // (only read in helper lanes)
-          } else if (PLAIN)
-            tri_test<T, true>(L, tri, i < cnt, 0u, 0u, 0u, false);
-          else
-            tri_test<T>(L, tri, i < cnt, a.range0, a.range1, a.skip_prim, cull);
-        }
+        NRT_TEST_PRIM(first + (i < cnt ? i : 0u), i < cnt);
       }
       // occlusion query: any accepted primitive settles the ray — drop what is left of its stack
       if (a.any_hit) sp = (state == W_LEAF && L.hit_t < L.max_t) ? 0 : sp;
       state = (state == W_LEAF) ? W_POP : state;
     }
   }
+  // ---- the drain: this wave found every work cursor empty ------------------------------------------------------
+  // It holds at most 64 - refill_min rays, the survivors of its last refill — by construction the long ones — and
+  // nothing will ever fill its idle lanes again, so batching lanes per phase (the point of the loop above) has nothing
+  // left to win and only makes each ray wait for the others' leaf rounds: measured, a wave needed 84 us on average and
+  // up to 237 us to finish these rays on the C3 bounce wave, 30-45 % of the launch (profiles/r02c_split_drain_probe.txt).
+  // Here every lane does what it needs on every trip: pop, then one inner-node step OR one primitive test, the node and
+  // the primitive records of all lanes fetched up front so that the two latencies overlap.  Same operations per ray in the
+  // same order as above, hence the same records.
+  if constexpr (kDrain) if (drain_on && __ballot(state != W_IDLE) != 0ull) {
+    if (state == W_IDLE && rid != kInvalid) { // finished lanes: write now, the registers are needed no longer
+      NRT_WRITE_RESULT();
+      rid = kInvalid;
+    }
+    uint32_t li = 0u; // next record of the leaf this lane is at
+    for (;;) {
+      unsigned long long busy_lanes = __ballot(state != W_IDLE);
+      if (SPLIT && split_on) {
+        // Work splitting (see the comment above the kernel): every `drain_steps` trips — and whenever no lane is busy, to
+        // settle what the helpers left — finished helpers deliver, owners fold and settle, settled lanes write their
+        // records and become free, and (while at most `split_busy` lanes are busy) busy lanes hand their oldest pending
+        // subtree to free lanes.
+        const unsigned n_busy = (unsigned)__builtin_popcountll(busy_lanes);
+        if (busy_lanes == 0ull || drain_round % a.drain_steps == 0u) {
+          const bool hand_out = n_busy != 0u && n_busy <= a.split_busy;
+          const unsigned wbase = tid & ~63u; // this wave's slots of s_fold
+          // -- (a) finished helpers hand their result to the owner's record, one after the other
+          unsigned long long fh = __ballot(state == W_IDLE && rid != kInvalid && (meta & kMetaHelper) != 0u);
+          while (fh != 0ull) {
+            const unsigned h = (unsigned)__builtin_ctzll(fh);
+            fh &= fh - 1ull;
+            if (lane == h) {
+              FoldRec<T> &r = s_fold[wbase + (meta & kMetaOwnerMask)];
+              if (L.prim != kInvalid && (r.prim == kInvalid || L.hit_t < r.t || (L.hit_t == r.t && key > r.key))) {
+                r.t = L.hit_t;
+                r.u = L.u;
+                r.v = L.v;
+                r.key = key;
+                r.prim = L.prim;
+              }
+              r.pend = (r.pend - 1u) | ((meta & kMetaBad) ? 0x80000000u : 0u);
+              if (a.debug_flags & 4096u) atomicAdd(&a.counters[3], 1ull);
+              rid = kInvalid;
+              meta = 0u;
+            }
+          }
+          // -- (b) owners: fold the own segment once, then wait for the helpers; the last delivery settles the ray
+          if (state == W_IDLE && rid != kInvalid && (meta & kMetaOwnerOpen) != 0u) {
+            FoldRec<T> &r = s_fold[tid];
+            if (!(meta & kMetaMainDone)) {
+              if (L.prim != kInvalid && (r.prim == kInvalid || L.hit_t < r.t || (L.hit_t == r.t && key > r.key))) {
+                r.t = L.hit_t;
+                r.u = L.u;
+                r.v = L.v;
+                r.key = key;
+                r.prim = L.prim;
+              }
+              meta |= kMetaMainDone;
+            }
+            const uint32_t pend = r.pend;
+            if ((pend & 0xFFFFu) == 0u) {
+              if (a.debug_flags & 4096u) atomicAdd(&a.counters[(pend & 0x80000000u) ? 5 : 4], 1ull);
+              if (((pend & 0x80000000u) && !(a.debug_flags & 512u)) || (a.debug_flags & 1024u)) { // a helper saw t below its leaf box's entry distance: trace the ray again, sequentially
+                const Ray rr = load_ray_nt<T>(a.rays + rid);
+                lane_init<T>(L, rr);
+                sp = 0;
+                cur = 0u;
+                state = W_TRAV;
+                meta = kMetaNoSplit;
+                key = 0u;
+              } else {
+                const bool any_ = r.prim != kInvalid;
+                L.hit_t = any_ ? r.t : L.max_t;
+                L.u = r.u;
+                L.v = r.v;
+                L.prim = r.prim;
+                meta = 0u;
+              }
+            }
+          }
+          // -- (c) every lane that holds a settled result writes it now and becomes free
+          if (state == W_IDLE && rid != kInvalid && (meta & (kMetaHelper | kMetaOwnerOpen)) == 0u) {
+            NRT_WRITE_RESULT();
+            rid = kInvalid;
+          }
+          // -- (d) busy lanes give their oldest pending subtree to free lanes
+          const unsigned long long freel = __ballot(state == W_IDLE && rid == kInvalid);
+          const uint32_t donated = meta >> kMetaDonatedShift;
+          const uint32_t level = (meta & kMetaLevelMask) >> kMetaLevelShift;
+          const bool busy = state == W_TRAV || state == W_POP || state == W_LEAF;
+          // (a lane about to pop keeps the entry it is about to pop)
+          const bool can_give = busy && !(meta & kMetaNoSplit) && level < 31u && donated < 0xFFFFu &&
+                                (uint32_t)sp > donated + (state == W_POP ? 1u : 0u);
+          const unsigned long long donors = __ballot(can_give);
+          unsigned n_pair = (unsigned)__builtin_popcountll(donors);
+          const unsigned n_free = (unsigned)__builtin_popcountll(freel);
+          n_pair = n_pair < n_free ? n_pair : n_free;
+          if (a.debug_flags & 256u) n_pair = 0u; // (debugging: no donations)
+          if (!hand_out) n_pair = 0u; // (settling only)
+          if (n_pair != 0u) {
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const bool is_donor = can_give && (unsigned)__builtin_popcountll(donors & lt) < n_pair;
+            const bool is_recv = ((freel >> lane) & 1ull) != 0ull && (unsigned)__builtin_popcountll(freel & lt) < n_pair;
+            // receiver k takes from donor k: lane index of its source (scalar walk over the two masks; rare)
+            int src = (int)lane;
+            {
+              unsigned long long d = donors, f = freel;
+              for (unsigned k = 0; k < n_pair; k++) {
+                const int dl = __builtin_ctzll(d), fl = __builtin_ctzll(f);
+                d &= d - 1ull;
+                f &= f - 1ull;
+                src = ((int)lane == fl) ? dl : src;
+              }
+            }
+            // donor: take the oldest live entry off the bottom of its stack (it stays in place, marked dead)
+            typename SE::type e = SE::make(0u, T(0));
+            bool give = false;
+            uint32_t hkey = 0u, hmeta = 0u;
+            if (is_donor) {
+              if (donated < (uint32_t)STACK) {
+                e = s_stack[donated][tid];
+                s_stack[donated][tid] = SE::make(SE::ref(e), __builtin_nan(""));
+              } else {
+                const size_t o = (size_t)(donated - STACK) * a.spill_stride + gslot;
+                e = SE::make(a.spill[o], a.spill_tmin[o]);
+                a.spill_tmin[o] = __builtin_nan("");
+              }
+              give = SE::tmin(e) <= L.hit_t; // still alive?  (a dead or culled entry is just skipped)
+              const uint32_t nlevel = give ? level + 1u : level;
+              meta = (meta & ~(kMetaLevelMask | (0xFFFFu << kMetaDonatedShift))) | (nlevel << kMetaLevelShift) |
+                     ((donated + 1u) << kMetaDonatedShift);
+              hkey = give ? key + (1u << (32u - nlevel)) : 0u; // upper half of the donor's interval: after everything the donor still does
+              const uint32_t owner_lane = (meta & kMetaHelper) ? (meta & kMetaOwnerMask) : lane;
+              hmeta = kMetaHelper | owner_lane | (nlevel << kMetaLevelShift);
+              if (give) {
+                if (!(meta & (kMetaHelper | kMetaOwnerOpen))) { // first donation of an owner: open its record
+                  FoldRec<T> &r = s_fold[tid];
+                  r.prim = kInvalid;
+                  r.pend = 0u;
+                  meta |= kMetaOwnerOpen;
+                }
+              }
+            }
+            // (record initialisation above is ordered before the counting below: LDS operations of a wave execute in order)
+            if (is_donor && give) atomicAdd(&s_fold[wbase + (hmeta & kMetaOwnerMask)].pend, 1u);
+            if (a.debug_flags & 4096u) { // (debugging: event counts)
+              if (is_donor) atomicAdd(&a.counters[0], 1ull);
+              if (is_donor && give) atomicAdd(&a.counters[1], 1ull);
+            }
+            // receivers copy the ray and the entry from their source lane (value by value, each shuffle consumed at once:
+            // sources are busy lanes, receivers free ones, so overwriting in place never feeds a changed value to anyone)
+            // (every shuffle is a statement of its own, executed by the whole wave: inside `is_recv && __shfl(...)` the
+            // short-circuit would switch the source lanes off and the receivers would read nothing)
+            const int g_give = __shfl((int)(give ? 1 : 0), src);
+            const bool take = is_recv && g_give != 0;
+            if ((a.debug_flags & 4096u) && take) atomicAdd(&a.counters[2], 1ull);
+  // (the empty asm keeps the vectoriser from merging neighbouring values into one vector access, which would pin
+  // the lane's ray in scratch memory)
+#define NRT_TAKE(dst, val)                  \
+  do {                                      \
+    auto v_ = (val);                        \
+    asm volatile("" : "+v"(v_));            \
+    const auto g_ = __shfl(v_, src);        \
+    dst = take ? g_ : dst;                  \
+  } while (0)
+            {
+              const uint32_t g_pk = (uint32_t)__shfl((int)L.pk, src);
+              L.pk = take ? g_pk : L.pk;
+            }
+            {
+              const uint32_t g_ref = (uint32_t)__shfl((int)SE::ref(e), src);
+              cur = take ? (g_ref & ~kLeafBit) : cur;
+              state = take ? ((g_ref & kLeafBit) ? W_LEAF : W_TRAV) : state;
+            }
+            {
+              int r_ = (int)rid, k_ = (int)hkey, m_ = (int)hmeta;
+              const int g_r = __shfl(r_, src), g_k = __shfl(k_, src), g_m = __shfl(m_, src);
+              rid = take ? (uint32_t)g_r : rid;
+              key = take ? (uint32_t)g_k : key;
+              meta = take ? (uint32_t)g_m : meta;
+            }
+            NRT_TAKE(leaf_tmin, SE::tmin(e));
+            NRT_TAKE(L.org0, L.org0);
+            NRT_TAKE(L.org1, L.org1);
+            NRT_TAKE(L.org2, L.org2);
+            NRT_TAKE(L.inv0, L.inv0);
+            NRT_TAKE(L.inv1, L.inv1);
+            NRT_TAKE(L.inv2, L.inv2);
+            NRT_TAKE(L.min_t, L.min_t);
+            NRT_TAKE(L.max_t, L.max_t);
+            NRT_TAKE(L.hit_t, L.hit_t); // the donor's distance at this moment: never tighter than the sequential loop's on arrival here
+            NRT_TAKE(L.Sx, L.Sx);
+            NRT_TAKE(L.Sy, L.Sy);
+            NRT_TAKE(L.Sz, L.Sz);
+#undef NRT_TAKE
+            L.prim = take ? kInvalid : L.prim;
+            L.u = take ? T(0) : L.u;
+            L.v = take ? T(0) : L.v;
+            L.cap = take ? 0u : L.cap;
+            sp = take ? 0 : sp;
+            li = take ? 0u : li;
+            if (STATS && take) st_steps = st_tris = 0;
+          }
+
+          busy_lanes = __ballot(state != W_IDLE);
+        }
+        drain_round++;
+      }
+      if (busy_lanes == 0ull) break;
+      if (state == W_POP) {
+        NRT_POP_ENTRY();
+        li = 0u;
+      }
+      const bool tw = state == W_TRAV, tl = state == W_LEAF;
+      uint32_t cnt = 1u, first = 0u;
+      if (tl) {
+        if (a.packed_leaves) {
+          cnt = (cur >> kPackedFirstBits) + 1u;
+          first = cur & kPackedFirstMask;
+        } else {
+          const Node *nd = a.nodes + cur;
+          cnt = nd->data[0];
+          first = nd->data[1];
+        }
+      }
+      if (a.debug_flags & 1u) cnt = 0u;
+      WideNode<T> w;
+      if (tw) w = a.wide[cur];
+      const bool tp = tl && li < cnt; // (an empty leaf of an adopted tree: nothing to test)
+      if (tp) NRT_TEST_PRIM(first + li, true);
+      if (tw) {
+        NRT_STEP_NODE(w);
+        li = 0u;
+      }
+      if (tl) {
+        li++;
+        if (li >= cnt) {
+          if (a.any_hit) sp = (L.hit_t < L.max_t) ? 0 : sp; // occlusion query: any accepted primitive settles the ray
+          state = W_POP;
+        }
+      }
+    }
+  }
   if (rid != kInvalid) NRT_WRITE_RESULT(); // results still held in registers
 #undef NRT_WRITE_RESULT
+#undef NRT_POP_ENTRY
+#undef NRT_STEP_NODE
+#undef NRT_TEST_PRIM
   if (clocked && lane == 0u) { // one record per wave, reduced on the host (atomics on one line would serialise the exits)
     unsigned long long *rec = a.wave_clock + 3ull * (size_t)(gslot / kWave);
     const unsigned long long clk_end = __builtin_amdgcn_s_memrealtime();
