@@ -25,8 +25,9 @@
 //     Link with -lnanort_hip.
 //
 // Macros accepted for source compatibility: NANORT_USE_CPP11_FEATURE,
-// NANORT_ENABLE_PARALLEL_BUILD (host build stays single-threaded here — the
-// parallel build is the GPU's job), NANORT_ENABLE_SERIALIZATION.
+// NANORT_ENABLE_PARALLEL_BUILD (with OpenMP or NANORT_USE_CPP11_FEATURE the generic
+// host build of user primitives runs in parallel and yields the same tree as the serial
+// one; the built-in primitive types build on the GPU), NANORT_ENABLE_SERIALIZATION.
 #ifndef NANORT_H_
 #define NANORT_H_
 
@@ -47,6 +48,9 @@
 #ifdef NANORT_USE_HIP_BACKEND
 #include "nanort_hip.h"
 #endif
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define kNANORT_MAX_STACK_DEPTH (512)
 #define kNANORT_MIN_PRIMITIVES_FOR_PARALLEL_BUILD (1024 * 8)
@@ -63,6 +67,69 @@
 #endif
 
 namespace nanort {
+
+namespace detail {
+
+// Worker threads for the host-side loops of this header (the parallel host build, the hit scatter of TraverseBatch):
+// what the process may actually use — the cgroup CPU quota when there is one (an OpenMP default of "every hardware
+// thread" inside a quota'd container collapses, and starves the HIP runtime's own threads), else the OpenMP / hardware
+// thread count — clamped to [1, 64].
+inline unsigned int HostThreads() {
+  static unsigned int cached = 0;
+  if (cached) return cached;
+  unsigned int n = 1;
+#if defined(_OPENMP)
+  n = static_cast<unsigned int>(std::max(1, omp_get_max_threads()));
+#elif defined(NANORT_USE_CPP11_FEATURE)
+  n = std::max(1u, std::thread::hardware_concurrency());
+#endif
+  long quota = -1, period = 0;
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+    char q[32];
+    if (std::fscanf(f, "%31s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0) quota = std::atol(q);
+    std::fclose(f);
+  } else if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+    if (std::fscanf(g, "%ld", &quota) != 1) quota = -1;
+    std::fclose(g);
+    if (FILE *h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (std::fscanf(h, "%ld", &period) != 1) period = 0;
+      std::fclose(h);
+    }
+  }
+  if (quota > 0 && period > 0 && static_cast<unsigned long>(quota / period) >= 1 && static_cast<unsigned long>(quota / period) < n)
+    n = static_cast<unsigned int>(quota / period);
+  cached = std::min(64u, std::max(1u, n));
+  return cached;
+}
+
+// f(i) for i in [0, n) on up to `threads` workers, dynamically scheduled; serial when the header was compiled without
+// OpenMP and without NANORT_USE_CPP11_FEATURE (the reference's two ways of building in parallel, nanort.h:2018-2117).
+template <class F>
+inline void ParallelFor(unsigned int n, unsigned int threads, const F &f) {
+  if (threads > n) threads = n;
+#if defined(_OPENMP)
+  if (threads > 1) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (long long i = 0; i < static_cast<long long>(n); i++) f(static_cast<unsigned int>(i));
+    return;
+  }
+#elif defined(NANORT_USE_CPP11_FEATURE)
+  if (threads > 1) {
+    std::atomic<unsigned int> next(0);
+    std::vector<std::thread> pool;
+    for (unsigned int t = 0; t < threads; t++)
+      pool.push_back(std::thread([&]() {
+        for (unsigned int i = next++; i < n; i = next++) f(i);
+      }));
+    for (size_t t = 0; t < pool.size(); t++) pool[t].join();
+    return;
+  }
+#endif
+  for (unsigned int i = 0; i < n; i++) f(i);
+}
+
+}  // namespace detail
+
 
 typedef enum {
   RAY_TYPE_NONE = 0x0,
@@ -1112,8 +1179,8 @@ class BVHAccel {
   // Launches on different streams may overlap on the GPU.
   bool TraverseBatchDevice(const Ray<T> *d_rays, size_t num_rays, TriangleIntersection<T> *d_isects, unsigned char *d_hit,
                            void *hip_stream, const BVHTraceOptions &options = BVHTraceOptions()) const {
-    if (!ctx_ || device_tree_stale_) {
-      backend_error_ = "TraverseBatchDevice: no tree on the GPU (Build() with the built-in triangle types, or TraverseBatch() once after Load())";
+    if (!ctx_ || device_tree_stale_ || device_prim_kind_ != 0) {
+      backend_error_ = "TraverseBatchDevice: no triangle tree on the GPU (Build() with the built-in triangle types, or TraverseBatch() once after Load())";
       return false;
     }
     nrt_trace_options o;
@@ -1128,8 +1195,8 @@ class BVHAccel {
   // TraverseBatch() would report in hit_out[i], but a ray stops at the first primitive it accepts (shadow rays).
   bool OccludedBatch(const Ray<T> *rays, size_t num_rays, unsigned char *occluded_out, const BVHTraceOptions &options = BVHTraceOptions()) const {
     typedef detail::HipApi<T> Api;
-    if (!ctx_ || device_tree_stale_) {
-      backend_error_ = "OccludedBatch: no tree on the GPU (Build() with the built-in triangle types, or TraverseBatch() once after Load())";
+    if (!ctx_ || device_tree_stale_ || device_prim_kind_ != 0) {
+      backend_error_ = "OccludedBatch: no triangle tree on the GPU (Build() with the built-in triangle types, or TraverseBatch() once after Load())";
       return false;
     }
     nrt_trace_options o;
@@ -1144,8 +1211,8 @@ class BVHAccel {
   bool OccludedBatchDevice(const Ray<T> *d_rays, size_t num_rays, unsigned char *d_occluded, void *hip_stream,
                            const BVHTraceOptions &options = BVHTraceOptions()) const {
     typedef detail::HipApi<T> Api;
-    if (!ctx_ || device_tree_stale_) {
-      backend_error_ = "OccludedBatchDevice: no tree on the GPU";
+    if (!ctx_ || device_tree_stale_ || device_prim_kind_ != 0) {
+      backend_error_ = "OccludedBatchDevice: no triangle tree on the GPU";
       return false;
     }
     nrt_trace_options o;
@@ -1168,8 +1235,8 @@ class BVHAccel {
                      const BVHTraceOptions &options = BVHTraceOptions(), bool test_cap = true) const {
     static_assert(detail::same_type<T, float>::value, "the cylinder primitive is fp32");
     static_assert(sizeof(CylinderIntersection) == sizeof(nrt_cyl_hit_f32), "CylinderIntersection layout");
-    if (!ctx_ || !cyl_endpoints_) {
-      backend_error_ = "TraverseBatch: Build() with CylinderGeometry/CylinderPred first";
+    if (!ctx_ || !cyl_endpoints_ || device_prim_kind_ != 2) {
+      backend_error_ = "TraverseBatch(CylinderIntersection*): Build() with CylinderGeometry/CylinderPred first";
       return false;
     }
     if (test_cap != cyl_test_cap_ || device_tree_stale_) {  // the flag lives with the primitives on the device
@@ -1217,6 +1284,12 @@ class BVHAccel {
       backend_error_ = "TraverseBatch: no GPU context (Build() with TriangleMesh/TriangleSAHPred first)";
       return false;
     }
+    const int want_kind = detail::same_type<Hit, TriangleIntersection<T> >::value ? 0 : 1;
+    if (device_prim_kind_ != want_kind) {  // records of one primitive kind must not be read as another's
+      backend_error_ = want_kind == 0 ? "TraverseBatch(TriangleIntersection*): this accel was not built over a TriangleMesh"
+                                      : "TraverseBatch(SphereIntersection*): this accel was not built over a SphereGeometry";
+      return false;
+    }
     if (device_tree_stale_) {
       if (nodes_.empty() || Api::SetTree(ctx_.get(), reinterpret_cast<const typename Api::NodePod *>(&nodes_[0]), nodes_.size(),
                                          indices_.empty() ? NULL : &indices_[0], indices_.size()) != NRT_OK) {
@@ -1242,10 +1315,12 @@ class BVHAccel {
       backend_error_ = nrtLastError(ctx_.get());
       return false;
     }
-    // isects[i] is written only on a hit, like Traverse().  (A few threads at most: an OpenMP default of "all hardware
-    // threads" inside a CPU-quota'd container starves the HIP runtime's own threads — measured 10x slower.)
+    // isects[i] is written only on a hit, like Traverse().  (At most half of what the process may use, detail::HostThreads():
+    // an OpenMP default of "all hardware threads" inside a CPU-quota'd container starves the HIP runtime's own threads —
+    // measured 10x slower.)
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) num_threads(4) if (num_rays > (1u << 18))
+    const int scatter_threads = static_cast<int>(std::min(8u, std::max(1u, detail::HostThreads() / 2)));
+#pragma omp parallel for schedule(static) num_threads(scatter_threads) if (num_rays > (1u << 18))
 #endif
     for (long long i = 0; i < static_cast<long long>(num_rays); i++)
       if (mask[i]) std::memcpy(static_cast<void *>(&isects[i]), &tmp[i], sizeof(HitPod));
@@ -1284,6 +1359,221 @@ class BVHAccel {
     return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
   }
 
+  // Bounding box of the primitives in indices_[lo, hi) (`threads` > 1: in chunks; min / max do not depend on the order).
+  template <class Prim>
+  void RangeBounds(const Prim &prim, unsigned int lo, unsigned int hi, unsigned int threads, real3<T> *out_min, real3<T> *out_max) const {
+    const unsigned int count = hi - lo;
+    const unsigned int chunks = (threads > 1 && count >= 16384u) ? threads * 4u : 1u;
+    std::vector<BBox<T> > part(chunks);
+    const unsigned int *idx = &indices_[0];
+    detail::ParallelFor(chunks, threads, [&](unsigned int c) {
+      const unsigned int b = lo + static_cast<unsigned int>((static_cast<unsigned long long>(count) * c) / chunks);
+      const unsigned int e = lo + static_cast<unsigned int>((static_cast<unsigned long long>(count) * (c + 1)) / chunks);
+      BBox<T> acc;
+      for (unsigned int i = b; i < e; i++) {
+        real3<T> a, bb;
+        prim.BoundingBox(&a, &bb, idx[i]);
+        for (int k = 0; k < 3; k++) {
+          acc.bmin[k] = std::min(acc.bmin[k], a[k]);
+          acc.bmax[k] = std::max(acc.bmax[k], bb[k]);
+        }
+      }
+      part[c] = acc;
+    });
+    BBox<T> all = part[0];
+    for (unsigned int c = 1; c < chunks; c++)
+      for (int k = 0; k < 3; k++) {
+        all.bmin[k] = std::min(all.bmin[k], part[c].bmin[k]);
+        all.bmax[k] = std::max(all.bmax[k], part[c].bmax[k]);
+      }
+    *out_min = all.bmin;
+    *out_max = all.bmax;
+  }
+
+  // One node of the generic host builder over indices_[lo, hi): its box, the leaf decision, or the binned-SAH split over
+  // x, y and z followed by the partition of the range (pred is this thread's own copy: Set() mutates it).
+  // Returns true for a leaf; else *mid and *axis describe the split.
+  template <class Prim, class Pred>
+  bool SplitRange(const Prim &prim, Pred &pred, unsigned int lo, unsigned int hi, unsigned int depth, unsigned int threads,
+                  std::vector<HostBin> &bins, std::vector<BBox<T> > &sweep, BVHNode<T> *node, unsigned int *mid_out, int *axis_out) {
+    const unsigned int K = options_.bin_size;
+    real3<T> nmin, nmax;
+    RangeBounds(prim, lo, hi, threads, &nmin, &nmax);
+    for (int k = 0; k < 3; k++) {
+      node->bmin[k] = nmin[k];
+      node->bmax[k] = nmax[k];
+    }
+    const unsigned int count = hi - lo;
+    if (count <= options_.min_leaf_primitives || depth >= options_.max_tree_depth || count < 2) {
+      node->flag = 1;
+      node->axis = 0;
+      node->data[0] = count;
+      node->data[1] = lo;
+      return true;
+    }
+    // bin the centres over the node's box on x, y and z (`threads` > 1: per-chunk bins merged in chunk order — counts
+    // add and boxes min / max, so the merged bins are the serial ones)
+    real3<T> scale;
+    for (int k = 0; k < 3; k++) {
+      const T ext = nmax[k] - nmin[k];
+      scale[k] = ext > static_cast<T>(0.0) ? static_cast<T>(K) / ext : static_cast<T>(0.0);
+    }
+    const unsigned int chunks = (threads > 1 && count >= 16384u) ? threads * 4u : 1u;
+    std::vector<HostBin> chunk_bins;
+    if (chunks > 1) chunk_bins.assign(static_cast<size_t>(chunks) * 3 * K, HostBin());
+    std::fill(bins.begin(), bins.end(), HostBin());
+    const unsigned int *idx = &indices_[0];
+    detail::ParallelFor(chunks, threads, [&](unsigned int c) {
+      HostBin *dst = chunks > 1 ? &chunk_bins[static_cast<size_t>(c) * 3 * K] : &bins[0];
+      const unsigned int b = lo + static_cast<unsigned int>((static_cast<unsigned long long>(count) * c) / chunks);
+      const unsigned int e = lo + static_cast<unsigned int>((static_cast<unsigned long long>(count) * (c + 1)) / chunks);
+      for (unsigned int i = b; i < e; i++) {
+        real3<T> a, bb, cc;
+        prim.BoundingBoxAndCenter(&a, &bb, &cc, idx[i]);
+        for (int k = 0; k < 3; k++) {
+          const long q = static_cast<long>((cc[k] - nmin[k]) * scale[k]);
+          const unsigned int slot = static_cast<unsigned int>(std::min<long>(static_cast<long>(K) - 1, std::max<long>(0, q)));
+          HostBin &hb = dst[static_cast<size_t>(k) * K + slot];
+          hb.count++;
+          for (int d = 0; d < 3; d++) {
+            hb.box.bmin[d] = std::min(hb.box.bmin[d], a[d]);
+            hb.box.bmax[d] = std::max(hb.box.bmax[d], bb[d]);
+          }
+        }
+      }
+    });
+    for (unsigned int c = 0; chunks > 1 && c < chunks; c++)
+      for (size_t j = 0; j < static_cast<size_t>(3) * K; j++) {
+        const HostBin &src = chunk_bins[static_cast<size_t>(c) * 3 * K + j];
+        HostBin &hb = bins[j];
+        hb.count += src.count;
+        for (int d = 0; d < 3; d++) {
+          hb.box.bmin[d] = std::min(hb.box.bmin[d], src.box.bmin[d]);
+          hb.box.bmax[d] = std::max(hb.box.bmax[d], src.box.bmax[d]);
+        }
+      }
+    // two sweeps per axis; candidate s splits bins [0,s) | [s,K)
+    T axis_cost[3], axis_cut[3];
+    for (int k = 0; k < 3; k++) {
+      axis_cost[k] = std::numeric_limits<T>::infinity();
+      axis_cut[k] = nmin[k] + (nmax[k] - nmin[k]) * static_cast<T>(0.5);
+      BBox<T> acc;
+      for (unsigned int s2 = K; s2-- > 1;) {  // suffix boxes
+        const HostBin &hb = bins[static_cast<size_t>(k) * K + s2];
+        for (int d = 0; d < 3; d++) {
+          acc.bmin[d] = std::min(acc.bmin[d], hb.box.bmin[d]);
+          acc.bmax[d] = std::max(acc.bmax[d], hb.box.bmax[d]);
+        }
+        sweep[s2] = acc;
+      }
+      size_t left_n = 0;
+      BBox<T> left;
+      for (unsigned int s2 = 1; s2 < K; s2++) {
+        const HostBin &hb = bins[static_cast<size_t>(k) * K + s2 - 1];
+        left_n += hb.count;
+        for (int d = 0; d < 3; d++) {
+          left.bmin[d] = std::min(left.bmin[d], hb.box.bmin[d]);
+          left.bmax[d] = std::max(left.bmax[d], hb.box.bmax[d]);
+        }
+        const size_t right_n = count - left_n;
+        if (left_n == 0 || right_n == 0) continue;
+        const T c = static_cast<T>(left_n) * HalfArea(left.bmin, left.bmax) + static_cast<T>(right_n) * HalfArea(sweep[s2].bmin, sweep[s2].bmax);
+        if (c < axis_cost[k]) {
+          axis_cost[k] = c;
+          axis_cut[k] = nmin[k] + (nmax[k] - nmin[k]) * (static_cast<T>(s2) / static_cast<T>(K));
+        }
+      }
+    }
+    int order[3] = {0, 1, 2};
+    if (axis_cost[order[1]] < axis_cost[order[0]]) std::swap(order[0], order[1]);
+    if (axis_cost[order[2]] < axis_cost[order[1]]) std::swap(order[1], order[2]);
+    if (axis_cost[order[1]] < axis_cost[order[0]]) std::swap(order[0], order[1]);
+
+    unsigned int mid = lo;
+    int axis = order[0];
+    for (int attempt = 0; attempt < 3; attempt++) {
+      axis = order[attempt];
+      pred.Set(axis, axis_cut[axis]);
+      unsigned int *first = &indices_[lo];
+      unsigned int *split = std::partition(first, first + count, pred);
+      mid = lo + static_cast<unsigned int>(split - first);
+      if (mid != lo && mid != hi) break;
+      mid = lo + (count >> 1);  // object median when the predicate cannot separate them
+    }
+    node->flag = 0;
+    node->axis = axis;
+    node->data[0] = 0;
+    node->data[1] = 0;
+    *mid_out = mid;
+    *axis_out = axis;
+    return false;
+  }
+
+  // A subtree to be built by a worker: its range, depth, and the stub that stands for it among the top nodes.
+  struct SubtreeTask {
+    unsigned int lo, hi, depth, stub;
+    std::vector<BVHNode<T> > nodes;  // local pre-order, child indices relative to nodes[0]
+    unsigned int max_depth, leaves, branches;
+  };
+
+  // Pre-order build of indices_[lo, hi) into `out` (child indices local to `out`).  With `tasks`: ranges that reach
+  // `stop_depth` with at least `stop_count` primitives are not descended into — a stub (flag 2) is emitted and the range
+  // recorded instead.
+  template <class Prim, class Pred>
+  void BuildRange(const Prim &prim, Pred &pred, unsigned int lo0, unsigned int hi0, unsigned int depth0, unsigned int threads,
+                  std::vector<BVHNode<T> > &out, unsigned int *max_depth, unsigned int *leaves, unsigned int *branches,
+                  std::vector<SubtreeTask> *tasks, unsigned int stop_depth, unsigned int stop_count) {
+    const unsigned int K = options_.bin_size;
+    std::vector<HostBin> bins(3 * static_cast<size_t>(K));
+    std::vector<BBox<T> > sweep(K);
+    std::vector<Pending> todo;
+    Pending root = {lo0, hi0, depth0, 0, false};
+    todo.push_back(root);
+    while (!todo.empty()) {
+      const Pending cur = todo.back();
+      todo.pop_back();
+      const unsigned int me = static_cast<unsigned int>(out.size());
+      if (me != 0 && cur.is_high_child) out[cur.parent].data[1] = me;
+      if (tasks && cur.depth >= stop_depth && cur.hi - cur.lo >= stop_count && me != 0) {
+        BVHNode<T> stub;
+        stub.flag = 2;
+        stub.axis = 0;
+        stub.data[0] = static_cast<unsigned int>(tasks->size());
+        stub.data[1] = 0;
+        out.push_back(stub);
+        SubtreeTask t;
+        t.lo = cur.lo;
+        t.hi = cur.hi;
+        t.depth = cur.depth;
+        t.stub = me;
+        t.max_depth = t.leaves = t.branches = 0;
+        tasks->push_back(t);
+        continue;
+      }
+      *max_depth = std::max(*max_depth, cur.depth);
+      BVHNode<T> node;
+      unsigned int mid = 0;
+      int axis = 0;
+      if (SplitRange(prim, pred, cur.lo, cur.hi, cur.depth, threads, bins, sweep, &node, &mid, &axis)) {
+        out.push_back(node);
+        (*leaves)++;
+        continue;
+      }
+      node.data[0] = me + 1;
+      out.push_back(node);
+      (*branches)++;
+      Pending high = {mid, cur.hi, cur.depth + 1, me, true};
+      Pending low = {cur.lo, mid, cur.depth + 1, me, false};
+      todo.push_back(high);
+      todo.push_back(low);
+    }
+  }
+
+  // BVHAccel::Build for user primitives (nanort.h:1892-2149): binned SAH over x, y and z, pre-order node array.
+  // Parallel (NANORT_ENABLE_PARALLEL_BUILD with OpenMP, or NANORT_USE_CPP11_FEATURE; n >=
+  // min_primitives_for_parallel_build) in the reference's shape — a shallow top tree, then one worker per subtree,
+  // then the splice (nanort.h:2018-2117) — with the top levels' box and bin passes chunked over the workers as well.
+  // The tree does not depend on the number of threads: it is the serial one, node for node.
   template <class Prim, class Pred>
   bool BuildImpl(unsigned int n, const Prim &prim, const Pred &pred, const BVHBuildOptions<T> &options, detail::generic_tag) {
     options_ = options;
@@ -1295,127 +1585,67 @@ class BVHAccel {
     indices_.resize(n);
     for (unsigned int i = 0; i < n; i++) indices_[i] = i;
 
-    const unsigned int K = options_.bin_size;
-    std::vector<HostBin> bins(3 * static_cast<size_t>(K));
-    std::vector<BBox<T> > sweep(K);
-    std::vector<Pending> todo;
-    Pending root = {0, n, 0, 0, false};
-    todo.push_back(root);
-    while (!todo.empty()) {
-      const Pending cur = todo.back();
-      todo.pop_back();
-      const unsigned int me = static_cast<unsigned int>(nodes_.size());
-      if (me != 0 && cur.is_high_child) nodes_[cur.parent].data[1] = me;
-      stats_.max_tree_depth = std::max(stats_.max_tree_depth, cur.depth);
-
-      BVHNode<T> node;
-      real3<T> nmin, nmax;
-      prim.BoundingBox(&nmin, &nmax, indices_[cur.lo]);
-      for (unsigned int i = cur.lo + 1; i < cur.hi; i++) {
-        real3<T> a, b;
-        prim.BoundingBox(&a, &b, indices_[i]);
-        for (int k = 0; k < 3; k++) {
-          nmin[k] = std::min(nmin[k], a[k]);
-          nmax[k] = std::max(nmax[k], b[k]);
+    unsigned int threads = 1;
+#if defined(NANORT_ENABLE_PARALLEL_BUILD) && (defined(_OPENMP) || defined(NANORT_USE_CPP11_FEATURE))
+    if (n >= options_.min_primitives_for_parallel_build) threads = detail::HostThreads();
+#endif
+    Pred top_pred = pred;
+    if (threads <= 1) {
+      BuildRange(prim, top_pred, 0, n, 0, 1, nodes_, &stats_.max_tree_depth, &stats_.num_leaf_nodes, &stats_.num_branch_nodes,
+                 static_cast<std::vector<SubtreeTask> *>(0), 0, 0);
+    } else {
+      // deep enough for a few subtrees per worker (at least the reference's shallow_depth)
+      unsigned int stop_depth = std::max(1u, options_.shallow_depth);
+      while ((1u << stop_depth) < 4u * threads && stop_depth < 12u) stop_depth++;
+      std::vector<BVHNode<T> > top;
+      std::vector<SubtreeTask> tasks;
+      BuildRange(prim, top_pred, 0, n, 0, threads, top, &stats_.max_tree_depth, &stats_.num_leaf_nodes, &stats_.num_branch_nodes, &tasks,
+                 stop_depth, 1024u);
+      detail::ParallelFor(static_cast<unsigned int>(tasks.size()), threads, [&](unsigned int k) {
+        SubtreeTask &t = tasks[k];
+        Pred local_pred = pred;
+        BuildRange(prim, local_pred, t.lo, t.hi, t.depth, 1, t.nodes, &t.max_depth, &t.leaves, &t.branches,
+                   static_cast<std::vector<SubtreeTask> *>(0), 0, 0);
+      });
+      // splice: where each top node and each subtree lands in the final pre-order array
+      std::vector<unsigned int> final_of(top.size());
+      unsigned int at = 0;
+      for (size_t i = 0; i < top.size(); i++) {
+        final_of[i] = at;
+        at += top[i].flag == 2 ? static_cast<unsigned int>(tasks[top[i].data[0]].nodes.size()) : 1u;
+      }
+      nodes_.resize(at);
+      for (size_t i = 0; i < top.size(); i++) {
+        if (top[i].flag == 2) {
+          const SubtreeTask &t = tasks[top[i].data[0]];
+          const unsigned int base = final_of[i];
+          for (size_t j = 0; j < t.nodes.size(); j++) {
+            BVHNode<T> nd = t.nodes[j];
+            if (nd.flag == 0) {
+              nd.data[0] += base;
+              nd.data[1] += base;
+            }
+            nodes_[base + j] = nd;
+          }
+          stats_.max_tree_depth = std::max(stats_.max_tree_depth, t.max_depth);
+          stats_.num_leaf_nodes += t.leaves;
+          stats_.num_branch_nodes += t.branches;
+        } else {
+          BVHNode<T> nd = top[i];
+          if (nd.flag == 0) {
+            nd.data[0] = final_of[nd.data[0]];
+            nd.data[1] = final_of[nd.data[1]];
+          }
+          nodes_[final_of[i]] = nd;
         }
       }
-      for (int k = 0; k < 3; k++) {
-        node.bmin[k] = nmin[k];
-        node.bmax[k] = nmax[k];
-      }
-      const unsigned int count = cur.hi - cur.lo;
-      if (count <= options_.min_leaf_primitives || cur.depth >= options_.max_tree_depth || count < 2) {
-        node.flag = 1;
-        node.axis = 0;
-        node.data[0] = count;
-        node.data[1] = cur.lo;
-        nodes_.push_back(node);
-        stats_.num_leaf_nodes++;
-        continue;
-      }
-
-      // bin the centres over the node's box on x, y and z
-      std::fill(bins.begin(), bins.end(), HostBin());
-      real3<T> scale;
-      for (int k = 0; k < 3; k++) {
-        const T ext = nmax[k] - nmin[k];
-        scale[k] = ext > static_cast<T>(0.0) ? static_cast<T>(K) / ext : static_cast<T>(0.0);
-      }
-      for (unsigned int i = cur.lo; i < cur.hi; i++) {
-        real3<T> a, b, c;
-        prim.BoundingBoxAndCenter(&a, &b, &c, indices_[i]);
-        for (int k = 0; k < 3; k++) {
-          const long q = static_cast<long>((c[k] - nmin[k]) * scale[k]);
-          const unsigned int slot = static_cast<unsigned int>(std::min<long>(static_cast<long>(K) - 1, std::max<long>(0, q)));
-          HostBin &hb = bins[static_cast<size_t>(k) * K + slot];
-          hb.count++;
-          for (int d = 0; d < 3; d++) {
-            hb.box.bmin[d] = std::min(hb.box.bmin[d], a[d]);
-            hb.box.bmax[d] = std::max(hb.box.bmax[d], b[d]);
-          }
-        }
-      }
-      // two sweeps per axis; candidate s splits bins [0,s) | [s,K)
-      T axis_cost[3], axis_cut[3];
-      for (int k = 0; k < 3; k++) {
-        axis_cost[k] = std::numeric_limits<T>::infinity();
-        axis_cut[k] = nmin[k] + (nmax[k] - nmin[k]) * static_cast<T>(0.5);
-        BBox<T> acc;
-        for (unsigned int s = K; s-- > 1;) {  // suffix boxes
-          const HostBin &hb = bins[static_cast<size_t>(k) * K + s];
-          for (int d = 0; d < 3; d++) {
-            acc.bmin[d] = std::min(acc.bmin[d], hb.box.bmin[d]);
-            acc.bmax[d] = std::max(acc.bmax[d], hb.box.bmax[d]);
-          }
-          sweep[s] = acc;
-        }
-        size_t left_n = 0;
-        BBox<T> left;
-        for (unsigned int s = 1; s < K; s++) {
-          const HostBin &hb = bins[static_cast<size_t>(k) * K + s - 1];
-          left_n += hb.count;
-          for (int d = 0; d < 3; d++) {
-            left.bmin[d] = std::min(left.bmin[d], hb.box.bmin[d]);
-            left.bmax[d] = std::max(left.bmax[d], hb.box.bmax[d]);
-          }
-          const size_t right_n = count - left_n;
-          if (left_n == 0 || right_n == 0) continue;
-          const T c = static_cast<T>(left_n) * HalfArea(left.bmin, left.bmax) + static_cast<T>(right_n) * HalfArea(sweep[s].bmin, sweep[s].bmax);
-          if (c < axis_cost[k]) {
-            axis_cost[k] = c;
-            axis_cut[k] = nmin[k] + (nmax[k] - nmin[k]) * (static_cast<T>(s) / static_cast<T>(K));
-          }
-        }
-      }
-      int order[3] = {0, 1, 2};
-      if (axis_cost[order[1]] < axis_cost[order[0]]) std::swap(order[0], order[1]);
-      if (axis_cost[order[2]] < axis_cost[order[1]]) std::swap(order[1], order[2]);
-      if (axis_cost[order[1]] < axis_cost[order[0]]) std::swap(order[0], order[1]);
-
-      unsigned int mid = cur.lo;
-      int axis = order[0];
-      for (int attempt = 0; attempt < 3; attempt++) {
-        axis = order[attempt];
-        pred.Set(axis, axis_cut[axis]);
-        unsigned int *first = &indices_[cur.lo];
-        unsigned int *split = std::partition(first, first + count, pred);
-        mid = cur.lo + static_cast<unsigned int>(split - first);
-        if (mid != cur.lo && mid != cur.hi) break;
-        mid = cur.lo + (count >> 1);  // object median when the predicate cannot separate them
-      }
-      node.flag = 0;
-      node.axis = axis;
-      node.data[0] = me + 1;
-      node.data[1] = 0;
-      nodes_.push_back(node);
-      stats_.num_branch_nodes++;
-      Pending high = {mid, cur.hi, cur.depth + 1, me, true};
-      Pending low = {cur.lo, mid, cur.depth + 1, me, false};
-      todo.push_back(high);
-      todo.push_back(low);
     }
 #ifdef NANORT_USE_HIP_BACKEND
-    device_tree_stale_ = true;
+    // user primitives live on the host only: a device context left over from an earlier built-in Build() holds other
+    // primitives and must not be traced against this tree
+    ctx_.reset();
+    device_tree_stale_ = false;
+    device_prim_kind_ = -1;
 #endif
     return true;
   }
@@ -1426,12 +1656,12 @@ class BVHAccel {
                  detail::triangle_tag) {
     (void)pred;
     typedef detail::HipApi<T> Api;
-    return HipBuild(n, options, [&](nrt_ctx *c) { return Api::SetMesh(c, mesh.GetVertices(), mesh.GetVertexStrideBytes(), mesh.GetFaces(), n); });
+    return HipBuild(n, options, 0, [&](nrt_ctx *c) { return Api::SetMesh(c, mesh.GetVertices(), mesh.GetVertexStrideBytes(), mesh.GetFaces(), n); });
   }
   bool BuildImpl(unsigned int n, const SphereGeometry &geom, const SpherePred &pred, const BVHBuildOptions<T> &options,
                  detail::sphere_tag) {
     (void)pred;
-    return HipBuild(n, options, [&](nrt_ctx *c) { return nrtSetSpheres_f32(c, geom.GetCenters(), geom.GetRadii(), n); });
+    return HipBuild(n, options, 1, [&](nrt_ctx *c) { return nrtSetSpheres_f32(c, geom.GetCenters(), geom.GetRadii(), n); });
   }
 
   // (the intersector's test_cap flag is a traversal-time property: TraverseBatch() re-sends the primitives if it differs)
@@ -1441,11 +1671,12 @@ class BVHAccel {
     cyl_endpoints_ = geom.GetEndpoints();
     cyl_radii_ = geom.GetRadii();
     cyl_test_cap_ = true;
-    return HipBuild(n, options, [&](nrt_ctx *c) { return nrtSetCylinders_f32(c, geom.GetEndpoints(), geom.GetRadii(), n, 1); });
+    return HipBuild(n, options, 2, [&](nrt_ctx *c) { return nrtSetCylinders_f32(c, geom.GetEndpoints(), geom.GetRadii(), n, 1); });
   }
 
   template <class SetPrims>
-  bool HipBuild(unsigned int n, const BVHBuildOptions<T> &options, SetPrims set_prims) {
+  bool HipBuild(unsigned int n, const BVHBuildOptions<T> &options, int prim_kind, SetPrims set_prims) {
+    device_prim_kind_ = -1;
     typedef detail::HipApi<T> Api;
     static_assert(sizeof(BVHNode<T>) == sizeof(typename Api::NodePod), "BVHNode layout");
     static_assert(sizeof(BVHBuildOptions<T>) == sizeof(typename Api::BuildPod), "BVHBuildOptions layout");
@@ -1490,6 +1721,7 @@ class BVHAccel {
     stats_.num_branch_nodes = st.num_branch_nodes;
     stats_.build_secs = st.build_secs;
     device_tree_stale_ = false;
+    device_prim_kind_ = prim_kind;
     return true;
   }
 #endif
@@ -1502,6 +1734,7 @@ class BVHAccel {
 #ifdef NANORT_USE_HIP_BACKEND
   std::shared_ptr<nrt_ctx> ctx_;
   mutable bool device_tree_stale_ = false;
+  int device_prim_kind_ = -1;  // what the device context was built over: 0 triangles, 1 spheres, 2 cylinders, -1 nothing usable
   const float *cyl_endpoints_ = NULL;  // cylinder primitive: what Build() was given
   const float *cyl_radii_ = NULL;
   mutable bool cyl_test_cap_ = true;

@@ -542,10 +542,14 @@ __global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info, uint32_t top_
   }
 }
 
+// The reference's leaf rule (nanort.h:1781-1783): a range of at most min_leaf_primitives, or one at the depth cap, is a leaf.
+struct LeafRule {
+  uint32_t max_depth, leaf_max; // leaf_max = max(min_leaf_primitives, 1)
+};
 template <typename T>
-__device__ __forceinline__ uint32_t classify(uint32_t n, uint32_t depth, uint32_t max_depth) {
+__device__ __forceinline__ uint32_t classify(uint32_t n, uint32_t depth, LeafRule rule) {
   if (n <= (uint32_t)kSmall) return KIND_SMALL;
-  if (depth >= max_depth) return KIND_LEAF; // reference leaf rule (nanort.h:1781-1783) on an oversize node
+  if (depth >= rule.max_depth || n <= rule.leaf_max) return KIND_LEAF; // the rule applied to a node too large for one wave
   return KIND_SPLIT;
 }
 
@@ -565,7 +569,7 @@ __global__ void k_combine_scene(BoundsAcc<T> *scene) {
 }
 
 template <typename T>
-__global__ void k_make_root(BoundsAcc<T> *scene, uint32_t n, uint32_t max_depth, uint32_t buf, TopNode<T> *top,
+__global__ void k_make_root(BoundsAcc<T> *scene, uint32_t n, LeafRule rule, uint32_t buf, TopNode<T> *top,
                             uint32_t *small_list, LevelInfo *info) {
   if (threadIdx.x < 12) combine_scene<T>(scene, threadIdx.x);
   __syncthreads();
@@ -581,7 +585,7 @@ __global__ void k_make_root(BoundsAcc<T> *scene, uint32_t n, uint32_t max_depth,
   t.l = 0;
   t.r = n;
   t.depth = 0;
-  t.kind = classify<T>(n, 0, max_depth);
+  t.kind = classify<T>(n, 0, rule);
   t.axis = 0;
   t.split_bin = kMedian;
   t.nleft = 0;
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(256) void k_gather_records(const PrimRec<T> *__rest
 // k_partition reduced into (then reset, see clean_bins).
 template <typename T>
 __device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *active, BoundsAcc<T> *child_acc, uint32_t a,
-                                              uint32_t num_active, uint32_t max_active, uint32_t max_depth, uint32_t dst_buf,
+                                              uint32_t num_active, uint32_t max_active, LeafRule rule, uint32_t dst_buf,
                                               uint32_t *small_list, LevelInfo *info) {
   const TopNode<T> p = top[active[a]];
   for (uint32_t c = 0; c < 2; c++) {
@@ -759,7 +763,7 @@ __device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *a
     t.l = c == 0 ? p.l : p.l + p.nleft;
     t.r = c == 0 ? p.l + p.nleft : p.r;
     t.depth = p.depth + 1;
-    t.kind = classify<T>(t.r - t.l, t.depth, max_depth);
+    t.kind = classify<T>(t.r - t.l, t.depth, rule);
     t.axis = 0;
     t.split_bin = kMedian;
     t.nleft = 0;
@@ -779,24 +783,24 @@ __device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *a
 // do it at the head of k_level_setup and save the launch.
 template <typename T>
 __global__ __launch_bounds__(256) void k_children(TopNode<T> *top, const uint32_t *__restrict__ active, BoundsAcc<T> *child_acc,
-                                                  uint32_t max_active, uint32_t max_depth, uint32_t dst_buf,
+                                                  uint32_t max_active, LeafRule rule, uint32_t dst_buf,
                                                   uint32_t *small_list, LevelInfo *info) {
   const uint32_t a = blockIdx.x * 256u + threadIdx.x;
   const uint32_t num_active = info->num_active;
   if (a >= num_active) return;
-  make_children<T>(top, active, child_acc, a, num_active, max_active, max_depth, dst_buf, small_list, info);
+  make_children<T>(top, active, child_acc, a, num_active, max_active, rule, dst_buf, small_list, info);
 }
 
 template <typename T>
 __global__ __launch_bounds__(1024) void k_level_setup(TopNode<T> *top, uint32_t *active, uint32_t *chunk_base,
                                                        LevelInfo *info, BoundsAcc<T> *child_acc, uint32_t max_active,
-                                                       uint32_t max_depth, uint32_t dst_buf, uint32_t *small_list,
+                                                       LeafRule rule, uint32_t dst_buf, uint32_t *small_list,
                                                        int with_children) {
   // phase A: finish the previous level — its active list is still in `active` — by creating its children
   if (with_children) {
     const uint32_t prev_active = info->num_active;
     for (uint32_t a = threadIdx.x; a < prev_active; a += 1024u)
-      make_children<T>(top, active, child_acc, a, prev_active, max_active, max_depth, dst_buf, small_list, info);
+      make_children<T>(top, active, child_acc, a, prev_active, max_active, rule, dst_buf, small_list, info);
     __syncthreads(); // (block-wide: the children are visible to the scan below, and `active` may be rewritten)
   }
   // phase B: the new level's active list and chunk ranges
@@ -1866,7 +1870,8 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
       hipLaunchKernelGGL((k_gather_records<T>), dim3((n + 255) / 256), dim3(256), 0, s, recs[0], vals[pp], n, recs[1]);
       cur = 1;
     }
-    hipLaunchKernelGGL((k_make_root<T>), dim3(1), dim3(64), 0, s, scene, n, max_depth, (uint32_t)cur, top, small_list,
+    const LeafRule rule = {max_depth, min_leaf > 1u ? min_leaf : 1u};
+    hipLaunchKernelGGL((k_make_root<T>), dim3(1), dim3(64), 0, s, scene, n, rule, (uint32_t)cur, top, small_list,
                        info);
     BCHK(hipGetLastError());
 
@@ -1883,9 +1888,9 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
       const bool wide = prev_max > 1024;
       if (wide)
         hipLaunchKernelGGL((k_children<T>), dim3((unsigned)((prev_max + 255) / 256)), dim3(256), 0, s, top, active, child_acc,
-                           (uint32_t)plan.max_active, max_depth, (uint32_t)cur, small_list, info);
+                           (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, info);
       hipLaunchKernelGGL((k_level_setup<T>), dim3(1), dim3(1024), 0, s, top, active, chunk_base, info, child_acc,
-                         (uint32_t)plan.max_active, max_depth, (uint32_t)cur, small_list, wide ? 0 : 1);
+                         (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, wide ? 0 : 1);
       if (level >= next_check) {
         BCHK(hipMemcpyAsync(&h, info, offsetof(LevelInfo, level_begin), hipMemcpyDeviceToHost, s));
         BCHK(hipStreamSynchronize(s));

@@ -11,7 +11,7 @@ def prim_bounds(verts, faces):
     return p.min(axis=1), p.max(axis=1)
 
 
-def validate_bvh(nodes, indices, verts, faces, min_leaf=4, max_depth=256, stats=None, exact_bounds=True):
+def validate_bvh(nodes, indices, verts, faces, min_leaf=4, max_depth=256, stats=None, exact_bounds=True, low_side_first=False):
     """Raises AssertionError on the first violated invariant; returns a dict of tree metrics."""
     n = faces.shape[0]
     nn = nodes.shape[0]
@@ -83,6 +83,45 @@ def validate_bvh(nodes, indices, verts, faces, min_leaf=4, max_depth=256, stats=
     else:
         assert (nodes["bmin"][bi] <= cmin).all() and (nodes["bmax"][bi] >= cmax).all()
     del umin, umax
+    # N1: data[0] is the LOW side of the split along `axis`, data[1] the high side (nanort.h:1841-1868: the partition
+    # puts the primitives below the cut first; the traversal's near/far choice, :2538, relies on it).  Checked on the
+    # centroids: no primitive of the left child lies beyond every primitive of the right child's low end (equality when the
+    # centroids coincide and the split fell back to the middle of the range).  `low_side_first`: asserted for the GPU
+    # builder's trees; the reference's own trees break it wherever its X-only binning (nanort.h:1357) left it with the
+    # middle-of-the-range fallback (:1851-1856), whose halves are in index order, not in spatial order.
+    sub_first = np.zeros(nn, dtype=np.int64)
+    sub_cnt = np.zeros(nn, dtype=np.int64)
+    sub_first[li] = first
+    sub_cnt[li] = cnt
+    for i in bi[::-1]:  # children follow their parent in pre-order: fill bottom-up
+        l, r = int(nodes["data"][i, 0]), int(nodes["data"][i, 1])
+        sub_first[i] = sub_first[l]
+        sub_cnt[i] = sub_cnt[l] + sub_cnt[r]
+        assert sub_first[r] == sub_first[l] + sub_cnt[l], "right child's primitives must follow the left child's"
+    if low_side_first:  # the converse of the leaf rule (N3): nothing that should have been a leaf was split
+        assert (sub_cnt[bi] > max(min_leaf, 1)).all(), "a range of at most min_leaf_primitives was split"
+    cen = verts[faces].astype(np.float64).sum(axis=1)[indices]  # 3 x centroid, in index-array order
+    scale = np.maximum(1.0, np.abs(cen[np.isfinite(cen)]).max()) if np.isfinite(cen).any() else 1.0
+    bdepth = depth[bi]
+    for d_ in (np.unique(bdepth) if low_side_first else ()):
+        sel = bi[bdepth == d_]
+        sel = sel[np.argsort(sub_first[sel], kind="stable")]
+        l = nodes["data"][sel, 0].astype(np.int64)
+        r = nodes["data"][sel, 1].astype(np.int64)
+        ax = nodes["axis"][sel].astype(np.int64)
+        starts = np.stack([sub_first[l], sub_first[r], sub_first[r] + sub_cnt[r]], axis=1).reshape(-1)
+        pad = starts[-1] >= n
+        st = starts[:-1] if pad else starts
+        for a_ in range(3):
+            m = ax == a_
+            if not m.any():
+                continue
+            hi = np.maximum.reduceat(cen[:, a_], st)
+            lo = np.minimum.reduceat(cen[:, a_], st)
+            left_max = hi[0::3][: m.shape[0]][m]
+            right_min = lo[1::3][: m.shape[0]][m]
+            ok = (left_max <= right_min + 1e-5 * scale) | ~np.isfinite(left_max) | ~np.isfinite(right_min)
+            assert ok.all(), "data[0] must hold the low side of the split along `axis`"
     # stack need of the reference traversal (512 entries, nanort.h:2497)
     assert max_d + 2 <= 512
     if stats is not None:

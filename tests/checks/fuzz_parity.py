@@ -61,7 +61,7 @@ while time.time() < t_end:
         assert a.Build(n, mesh, bo)
         nodes, idx = a.GetTree()
         if rounds % 8 == 0:  # the builder's output: a valid reference-format tree obeying these options
-            validate_bvh(nodes, idx, v, f, stats=a.GetStatistics(), min_leaf=int(bo["min_leaf_primitives"]), max_depth=int(bo["max_tree_depth"]))
+            validate_bvh(nodes, idx, v, f, stats=a.GetStatistics(), min_leaf=int(bo["min_leaf_primitives"]), max_depth=int(bo["max_tree_depth"]), low_side_first=True)
     else:
         nodes, idx, _ = orc.build(v, f)
         a.SetMesh(mesh); a.SetTree(nodes, idx)

@@ -225,6 +225,14 @@ static int spheres(const char *scene_path, int W, int H, const char *out_path) {
   }
   printf("batch_vs_per_ray_mismatches %llu worst_uv %.3g\n", (unsigned long long)bad, worst_uv);
   if (bad || worst_uv > 1e-6) return 5;
+  {  // records of one primitive kind must not be handed out as another's: the triangle and cylinder overloads refuse
+    std::vector<nanort::TriangleIntersection<float> > th(16);
+    std::vector<nanort::CylinderIntersection> ch(16);
+    const bool tri_ok = accel.TraverseBatch(rays.data(), 16, th.data());
+    const bool cyl_ok = accel.TraverseBatch(rays.data(), 16, ch.data());
+    printf("wrong_kind_refused %d\n", (!tri_ok && !cyl_ok && !accel.LastBackendError().empty()) ? 1 : 0);
+    if (tri_ok || cyl_ok) return 6;
+  }
 #endif
   fp = fopen(out_path, "wb");
   if (!fp) return 2;

@@ -188,6 +188,7 @@ def test_builtin_sphere_primitive_hip_backend(tmp_path):
                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert rr.returncode == 0, rr.stdout
     assert "batch_vs_per_ray_mismatches 0" in rr.stdout
+    assert "wrong_kind_refused 1" in rr.stdout  # the triangle / cylinder overloads refuse a sphere-built accel
     hits, mask, nodes, idx = read_output(out, W * H, 20000, False)
     oh, om = SphereOracle().traverse(nodes, idx, c, r, scenes.particle_camera_rays(W, H))
     assert np.array_equal(mask, om) and hits.tobytes() == oh.tobytes()
@@ -607,3 +608,28 @@ def test_more_reference_examples_write_the_same_images(tmp_path, example, inputs
         res[tag] = {f: open(str(d / f), "rb").read() for f in outputs}
     for f in outputs:
         assert res["ref"][f] == res["mine"][f] and len(res["ref"][f]) > 1000, f
+
+
+def test_parallel_host_build_gives_the_serial_tree(tmp_path):
+    """NANORT_ENABLE_PARALLEL_BUILD (OpenMP) and NANORT_USE_CPP11_FEATURE (std::thread) build user primitives in parallel,
+    as the reference does under the same macros (nanort.h:2018-2117: shallow tree, one worker per subtree, splice) — and
+    the tree is the serial one, node for node, whatever the number of threads."""
+    import re
+
+    src = os.path.join(ROOT, "tests", "cpp", "par_build_check.cc")
+    variants = {"serial": [], "openmp": ["-fopenmp", "-DNANORT_ENABLE_PARALLEL_BUILD"], "threads": ["-DNANORT_USE_CPP11_FEATURE", "-pthread"]}
+    out = {}
+    for name, flags in variants.items():
+        exe = tmp_path / ("pb_" + name)
+        cxx(["-std=c++11", "-O2", "-Wall", "-Wextra"] + flags + ["-I", INC, src, "-o", str(exe)])
+        for n in (5000, 300000):
+            r = subprocess.run([str(exe), str(n)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert r.returncode == 0 and r.stdout.startswith("ok 1"), r.stdout
+            m = re.search(r"nodes (\d+) depth (\d+) leaves (\d+) branches (\d+) hash ([0-9a-f]+)\s+([0-9.]+) ms threads (\d+)", r.stdout)
+            out[(name, n)] = m.groups()
+    for n in (5000, 300000):
+        assert out[("serial", n)][:5] == out[("openmp", n)][:5] == out[("threads", n)][:5], out
+    assert out[("serial", 300000)][6] == "1"
+    threads = int(out[("threads", 300000)][6])
+    if threads >= 4:  # (lenient: a busy CI box)
+        assert float(out[("threads", 300000)][5]) < float(out[("serial", 300000)][5]) / 1.5, out
