@@ -568,6 +568,27 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   return NRT_OK;
 }
 
+// Library-internal (scene.hip): where a built fp32 context keeps its tree on the device.  Waits for the context's own
+// stream, so the arrays are complete; they stay valid until the context is rebuilt or destroyed.
+nrt_status nrt_internal_tree_view(nrt_ctx *c, nrt::TreeViewF32 *out) {
+  if (!c || !out) return NRT_ERR_INVALID;
+  if (c->prec != 4 || !c->d_nodes || !c->d_wide) return fail(c, NRT_ERR_INVALID, "no fp32 tree on the device");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  out->nodes = (const nrt_node_f32 *)c->d_nodes;
+  out->indices = c->d_indices;
+  out->wide = c->d_wide;
+  out->prims = c->d_tris;
+  out->num_nodes = (uint32_t)c->num_nodes;
+  out->num_indices = (uint32_t)c->num_indices;
+  out->packed_leaves = c->packed_leaves;
+  out->root_is_branch = c->root_is_branch;
+  out->tree_nested = c->tree_nested;
+  out->prim_kind = (uint32_t)c->prim_kind;
+  out->tree_depth = c->tree_depth;
+  return NRT_OK;
+}
+
 // ---------------------------------------------------------------------------
 // traverse
 // ---------------------------------------------------------------------------

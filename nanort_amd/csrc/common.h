@@ -119,6 +119,43 @@ constexpr uint32_t kPackedFirstBits = 27;
 constexpr uint32_t kPackedFirstMask = (1u << kPackedFirstBits) - 1u;
 constexpr uint32_t kPackedMaxCount = 16;
 
+// Device-side view of a context's fp32 tree for the code inside this library that walks it in its own kernels (the
+// two-level scene kernel, scene.hip).  Not part of the C ABI.
+struct TreeViewF32 {
+  const nrt_node_f32 *nodes;     // reference-format node array
+  const uint32_t *indices;       // index permutation
+  const void *wide;              // WideNode<float>[branches]
+  const void *prims;             // leaf-ordered primitive records (LeafTri<float> for triangle contexts)
+  uint32_t num_nodes, num_indices;
+  uint32_t packed_leaves, root_is_branch, tree_nested, prim_kind, tree_depth;
+};
+
+// ---- two-level (instanced) traversal: one kernel for a whole ray batch (traverse.hip k_scene_trace) -------------
+// Per instance, in HBM: where its tree lives and the three matrices nanosg's Node::Update derives (nanosg.h:397-437).
+struct SceneInst {
+  const void *wide;           // WideNode<float>[]
+  const void *tris;           // LeafTri<float>[] in index-array order
+  const nrt_node_f32 *nodes;  // reference-format nodes (leaf {count, first} when the leaf references are not packed; node 0's box)
+  uint32_t packed_leaves, root_is_branch, tree_nested, pad;
+  float inv_xform[4][4];      // world -> local, points
+  float inv_xform33[4][4];    // world -> local, directions
+  float xform[4][4];          // local -> world
+};
+constexpr int kSceneLdsStack = 12; // per-lane stack entries of k_scene_trace kept in LDS; deeper ones go to the overflow arrays
+struct SceneTraceArgs {
+  const nrt_ray_f32 *rays;
+  uint32_t n;
+  const SceneInst *insts;
+  const float *list_t;        // [cap][n]: entry distances of the instances a ray enters, nearest first (k_scene_list*)
+  const uint32_t *list_node;  // [cap][n]: their ids
+  const uint32_t *count;      // [n]: list lengths
+  nrt_scene_hit_f32 *hits;    // [n] out
+  uint8_t *mask;              // [n] out, may be null
+  uint32_t *spill;            // overflow stack [spill_levels][spill_stride], may be null
+  float *spill_tmin;
+  uint32_t spill_stride;
+};
+
 template <typename T>
 struct TraverseArgs {
   const typename Wire<T>::Node *nodes;

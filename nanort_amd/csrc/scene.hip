@@ -3,17 +3,14 @@
 // Replaces nanosg::Scene<float, M>::Commit / Traverse (reference examples/nanosg/nanosg.h:700-870) and the
 // BVHAccel::ListNodeIntersections it rests on (reference nanort.h:2608-2692).  Structure:
 //
-//   k_scene_list     per ray: which node boxes does the ray enter, sorted by entry distance, at most 64
-//                    (the listing does not depend on the shape of the reference's top-level BVH: every
-//                    ancestor box contains the leaf box and the slab arithmetic is monotone, so it is a scan
-//                    over the node table);
-//   for list position j (front to back) — one host synchronisation per round, independent of the number of nodes:
-//     k_scene_count    per node: how many rays have it as their j-th entry and survive the early cull
-//                      (t_nearest < t_min, nanosg.h:795);
-//     k_scene_gather   those rays, compacted into one segment per node and transformed into the node's space;
-//     for every node with a non-empty segment:
-//       k_traverse_wide  the single-level kernel, unchanged, over the node's own tree (nrtTraverseBatchDevice);
-//       k_scene_apply    world-space distance of each local hit, strict-nearer update of the ray's result.
+//   k_scene_list_bvh  per ray: which node boxes does the ray enter, sorted by entry distance, at most 64 — a walk
+//                     over the TOP-LEVEL BVH of the instances' world boxes (built on the GPU by the ordinary builder
+//                     with min_leaf_primitives = 1, as nanosg.h:730-735 does on the host).  The set of listed nodes
+//                     does not depend on the shape of that tree (every ancestor box contains the leaf box and the slab
+//                     arithmetic is monotone); scenes of a handful of nodes skip the tree (k_scene_list: a scan);
+//   k_scene_trace     (traverse.hip) per ray: the reference's loop over that list — early cull, ray into the node's
+//                     space, the node's own tree walked in the same lane, world distance, strict-nearer update —
+//                     for the whole batch in one launch: no per-node launches, no host round trips.
 //
 // The per-node arithmetic (Matrix::Mult / Inverse / MultV, XformBoundingBox, the two slab tests) follows the
 // reference operation for operation; this file is compiled with the same no-contraction / IEEE flags.
@@ -29,6 +26,12 @@
 
 #include "common.h"
 
+struct nrt_ctx;
+nrt_status nrt_internal_tree_view(nrt_ctx *c, nrt::TreeViewF32 *out); // api.hip
+namespace nrt {
+hipError_t launch_scene_trace(const SceneTraceArgs &args, hipStream_t s); // traverse.hip
+}
+
 namespace {
 
 struct NodeDev { // per-instance table in HBM
@@ -39,6 +42,8 @@ struct NodeDev { // per-instance table in HBM
 };
 
 constexpr int kMaxList = 64; // kMaxIntersections, nanosg.h:782
+constexpr int kTopStack = 64; // per-ray stack of the top-level walk (a deeper top-level tree falls back to the scan)
+constexpr uint32_t kScanMaxNodes = 8; // scenes of at most this many nodes are listed by the scan
 
 // Matrix::MultV — nanosg.h:232-240
 __host__ __device__ inline void mult_v(float dst[3], const float m[4][4], const float v[3]) {
@@ -88,8 +93,7 @@ __device__ inline bool node_interval(const nrt_ray_f32 &r, const NodeDev &nd, fl
 __global__ __launch_bounds__(256) void k_scene_list(const nrt_ray_f32 *__restrict__ rays, uint32_t n,
                                                     const NodeDev *__restrict__ nodes, uint32_t num_nodes, uint32_t cap,
                                                     float *__restrict__ list_t, uint32_t *__restrict__ list_node,
-                                                    uint32_t *__restrict__ count, float *__restrict__ best_t,
-                                                    nrt_scene_hit_f32 *__restrict__ best, uint32_t *max_count) {
+                                                    uint32_t *__restrict__ count) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const nrt_ray_f32 r = rays[i];
@@ -115,125 +119,79 @@ __global__ __launch_bounds__(256) void k_scene_list(const nrt_ray_f32 *__restric
     if (cnt < cap) cnt++;
   }
   count[i] = cnt;
-  best_t[i] = 3.402823466e+38f; // t_nearest = numeric_limits<T>::max(), nanosg.h:787
-  nrt_scene_hit_f32 h;
-  h.t = r.max_t;
-  h.u = 0.0f;
-  h.v = 0.0f;
-  h.prim_id = 0xFFFFFFFFu;
-  h.node_id = 0xFFFFFFFFu;
-  best[i] = h;
-  if (cnt) atomicMax(max_count, cnt);
 }
 
-// Does ray i visit its j-th listed node in round j?  (early cull, nanosg.h:795).  A ray has ONE node at list position j,
-// so within a round no ray is handled twice and best_t[i] only changes through the ray's own node: the decisions of a
-// whole round can be taken up front, for all nodes at once.
-__device__ inline bool round_take(uint32_t i, uint32_t n, uint32_t j, const float *__restrict__ list_t,
-                                  const uint32_t *__restrict__ list_node, const uint32_t *__restrict__ count,
-                                  const float *__restrict__ best_t, uint32_t &node) {
-  node = 0xFFFFFFFFu;
-  if (i >= n || j >= count[i]) return false;
-  if (best_t[i] < list_t[(size_t)j * n + i]) return false;
-  node = list_node[(size_t)j * n + i];
-  return true;
-}
-
-// One atomic per (wave, distinct node): lanes of a wave mostly share a node.  Returns the lane's rank among the lanes
-// of its wave that hold the same node, and through `base` what the group's leader got back from the atomic.
-__device__ inline uint32_t wave_group_add(bool take, uint32_t node, uint32_t *__restrict__ counters, uint32_t &base) {
-  const unsigned lane = threadIdx.x & 63u;
-  uint32_t rank = 0;
-  base = 0;
-  unsigned long long todo = __ballot(take);
-  while (todo) {
-    const int leader = __builtin_ctzll(todo);
-    const uint32_t lnode = __shfl(node, leader);
-    const unsigned long long grp = __ballot(take && node == lnode);
-    uint32_t b = 0;
-    if ((int)lane == leader) b = atomicAdd(&counters[lnode], (uint32_t)__builtin_popcountll(grp));
-    b = __shfl(b, leader);
-    if (take && node == lnode) {
-      base = b;
-      rank = (uint32_t)__builtin_popcountll(grp & ((1ull << lane) - 1ull));
-    }
-    todo &= ~grp;
-  }
-  return rank;
-}
-
-// round j, step 1: how many rays go to each node
-__global__ __launch_bounds__(256) void k_scene_count(uint32_t n, uint32_t j, const float *__restrict__ list_t,
-                                                     const uint32_t *__restrict__ list_node,
-                                                     const uint32_t *__restrict__ count, const float *__restrict__ best_t,
-                                                     uint32_t *__restrict__ node_count) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  uint32_t node, base;
-  const bool take = round_take(i, n, j, list_t, list_node, count, best_t, node);
-  wave_group_add(take, node, node_count, base);
-}
-
-// round j, step 2: compact the rays of every node into its segment [node_offset[k], node_offset[k] + node_count[k]) and
-// transform them into the node's space.  node_cursor starts at zero.
-__global__ __launch_bounds__(256) void k_scene_gather(const nrt_ray_f32 *__restrict__ rays, uint32_t n, uint32_t j,
-                                                      const NodeDev *__restrict__ nodes, const float *__restrict__ list_t,
-                                                      const uint32_t *__restrict__ list_node,
-                                                      const uint32_t *__restrict__ count,
-                                                      const float *__restrict__ best_t,
-                                                      const uint32_t *__restrict__ node_offset,
-                                                      uint32_t *__restrict__ node_cursor, uint32_t *__restrict__ sel_index,
-                                                      nrt_ray_f32 *__restrict__ local_rays) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  uint32_t node, base;
-  const bool take = round_take(i, n, j, list_t, list_node, count, best_t, node);
-  const uint32_t rank = wave_group_add(take, node, node_cursor, base);
-  if (!take) return;
-  const uint32_t slot = node_offset[node] + base + rank;
-  const nrt_ray_f32 r = rays[i];
-  const NodeDev &nd = nodes[node];
-  nrt_ray_f32 lr;
-  mult_v(lr.org, nd.inv_xform, r.org);   // nanosg.h:807
-  mult_v(lr.dir, nd.inv_xform33, r.dir); // nanosg.h:808
-  lr.min_t = 0.0f;                       // Ray() defaults (nanort.h:477-487): the world interval is not propagated
-  lr.max_t = 3.402823466e+38f;
-  lr.type = 0;
-  local_rays[slot] = lr;
-  sel_index[slot] = i;
-}
-
-__global__ __launch_bounds__(256) void k_scene_apply(const nrt_ray_f32 *__restrict__ rays, uint32_t node,
-                                                     const NodeDev *__restrict__ nodes, uint32_t sel_count,
-                                                     const uint32_t *__restrict__ sel_index,
-                                                     const nrt_ray_f32 *__restrict__ local_rays,
-                                                     const nrt_hit_f32 *__restrict__ local_hits,
-                                                     const uint8_t *__restrict__ local_mask, float *__restrict__ best_t,
-                                                     nrt_scene_hit_f32 *__restrict__ best) {
-  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-  if (s >= sel_count || !local_mask[s]) return;
-  const uint32_t i = sel_index[s];
-  const nrt_ray_f32 lr = local_rays[s];
-  const nrt_hit_f32 lh = local_hits[s];
-  float lp[3], wp[3];
+// The same listing through the top-level BVH: reference-format nodes over the instances' world boxes, leaves name the
+// instances through `top_indices`.  Inner boxes are tested as ListNodeIntersections tests them (IntersectRayAABB with
+// hit_t == ray.max_t throughout, nanort.h:2651), leaves with node_interval; entries are kept sorted by (entry distance,
+// node id) — the order the scan above produces — whatever order the walk finds them in.
+__device__ inline bool top_box_hit(const nrt_ray_f32 &r, const float inv[3], const int sign[3], const float bmin[3], const float bmax[3]) {
+  float tmin = r.min_t, tmax = r.max_t;
 #pragma unroll
-  for (int k = 0; k < 3; k++) lp[k] = lr.org[k] + lh.t * lr.dir[k]; // nanosg.h:823-825
-  mult_v(wp, nodes[node].xform, lp);
-  const float px = wp[0] - rays[i].org[0], py = wp[1] - rays[i].org[1], pz = wp[2] - rays[i].org[2];
-  const float t_world = __builtin_sqrtf(px * px + py * py + pz * pz); // vlength, nanort.h:383-385
-  if (t_world < best_t[i]) {                                           // strict, nanosg.h:838
-    best_t[i] = t_world;
-    nrt_scene_hit_f32 h;
-    h.t = t_world;
-    h.u = lh.u;
-    h.v = lh.v;
-    h.prim_id = lh.prim_id;
-    h.node_id = node;
-    best[i] = h;
+  for (int k = 0; k < 3; k++) {
+    const float lo = sign[k] ? bmax[k] : bmin[k], hi = sign[k] ? bmin[k] : bmax[k];
+    const float t0 = (lo - r.org[k]) * inv[k];
+    const float t1 = (hi - r.org[k]) * inv[k] * 1.00000024f;
+    tmin = (t0 > tmin) ? t0 : tmin;
+    tmax = (t1 < tmax) ? t1 : tmax;
   }
+  return tmin <= tmax;
 }
 
-__global__ __launch_bounds__(256) void k_scene_mask(const float *__restrict__ best_t, uint32_t n, uint8_t *__restrict__ mask) {
+__global__ __launch_bounds__(256) void k_scene_list_bvh(const nrt_ray_f32 *__restrict__ rays, uint32_t n,
+                                                        const nrt_node_f32 *__restrict__ top_nodes,
+                                                        const uint32_t *__restrict__ top_indices,
+                                                        const NodeDev *__restrict__ nodes, uint32_t cap,
+                                                        float *__restrict__ list_t, uint32_t *__restrict__ list_node,
+                                                        uint32_t *__restrict__ count) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i < n) mask[i] = best_t[i] < 3.402823466e+38f ? 1 : 0;
+  if (i >= n) return;
+  const nrt_ray_f32 r = rays[i];
+  float inv[3];
+  int sign[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float d = r.dir[k];
+    sign[k] = d < 0.0f ? 1 : 0;
+    inv[k] = (__builtin_fabsf(d) < 1.1920928955078125e-07f) ? __builtin_huge_valf() * (sign[k] ? -1.0f : 1.0f) : 1.0f / d;
+  }
+  uint32_t stack[kTopStack];
+  int sp = 0;
+  stack[0] = 0u;
+  uint32_t cnt = 0;
+  while (sp >= 0) {
+    const nrt_node_f32 nd = top_nodes[stack[sp]];
+    sp--;
+    if (!top_box_hit(r, inv, sign, nd.bmin, nd.bmax)) continue;
+    if (nd.flag == 0) {
+      const int near = sign[nd.axis];
+      stack[++sp] = nd.data[1 - near];
+      stack[++sp] = nd.data[near];
+      continue;
+    }
+    for (uint32_t q = 0; q < nd.data[0]; q++) {
+      const uint32_t k = top_indices[nd.data[1] + q];
+      float t;
+      if (!node_interval(r, nodes[k], t)) continue;
+      uint32_t pos = cnt < cap ? cnt : cap;
+      while (pos > 0) {
+        const float pt = list_t[(size_t)(pos - 1) * n + i];
+        const uint32_t pk = list_node[(size_t)(pos - 1) * n + i];
+        if (pt < t || (pt == t && pk < k)) break;
+        if (pos < cap) {
+          list_t[(size_t)pos * n + i] = pt;
+          list_node[(size_t)pos * n + i] = pk;
+        }
+        pos--;
+      }
+      if (pos < cap) {
+        list_t[(size_t)pos * n + i] = t;
+        list_node[(size_t)pos * n + i] = k;
+      }
+      if (cnt < cap) cnt++;
+    }
+  }
+  count[i] = cnt;
 }
 
 // ---- host-side restatement of the per-node update (nanosg.h:92-241, 246-302, 397-437) ----------------
@@ -335,9 +293,11 @@ struct nrt_scene {
   std::vector<Inst> insts;
   std::vector<NodeDev> host_nodes;
   bool committed = false;
-  nrt::DevBuf d_nodes, d_rays, d_list_t, d_list_node, d_count, d_best_t, d_best, d_sel_index, d_local_rays, d_local_hits,
-      d_local_mask, d_mask, d_scalars, d_node_counters; // d_scalars: [0] max_count
-  std::vector<uint32_t> h_node_counters;
+  nrt_ctx *top = nullptr;        // top-level BVH over the nodes' world boxes (scenes of more than kScanMaxNodes nodes)
+  nrt::TreeViewF32 top_view;
+  bool use_top = false;
+  uint32_t max_inst_depth = 0;   // deepest instance tree: sizes the overflow stack of k_scene_trace
+  nrt::DevBuf d_nodes, d_insts, d_rays, d_list_t, d_list_node, d_count, d_best, d_mask, d_spill, d_spill_tmin;
 };
 
 static nrt_status sfail(nrt_scene *s, nrt_status st, const char *fmt, ...) {
@@ -383,11 +343,11 @@ void nrtSceneDestroy(nrt_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
-  nrt::DevBuf *bufs[] = {&s->d_nodes,     &s->d_rays,       &s->d_list_t,     &s->d_list_node,  &s->d_count,
-                         &s->d_best_t,    &s->d_best,       &s->d_sel_index,  &s->d_local_rays, &s->d_local_hits,
-                         &s->d_local_mask, &s->d_mask,       &s->d_scalars,    &s->d_node_counters};
+  nrt::DevBuf *bufs[] = {&s->d_nodes, &s->d_insts, &s->d_rays, &s->d_list_t, &s->d_list_node, &s->d_count,
+                         &s->d_best,  &s->d_mask,  &s->d_spill, &s->d_spill_tmin};
   for (nrt::DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
+  if (s->top) nrtDestroy(s->top);
   (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -425,6 +385,54 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
   }
   SCHK(s, nrt::devbuf_ensure(&s->d_nodes, s->host_nodes.size() * sizeof(NodeDev)));
   SCHK(s, hipMemcpy(s->d_nodes.p, s->host_nodes.data(), s->host_nodes.size() * sizeof(NodeDev), hipMemcpyHostToDevice));
+  // per-instance table of k_scene_trace: where each node's tree lives + its three matrices
+  std::vector<nrt::SceneInst> table(s->insts.size());
+  s->max_inst_depth = 0;
+  for (size_t i = 0; i < s->insts.size(); i++) {
+    nrt::TreeViewF32 tv;
+    if (nrt_internal_tree_view(s->insts[i].mesh, &tv) != NRT_OK || tv.prim_kind != (uint32_t)nrt::kPrimTriangles)
+      return sfail(s, NRT_ERR_INVALID, "nrtSceneCommit: node %zu is not a built f32 triangle mesh", i);
+    nrt::SceneInst &e = table[i];
+    e.wide = tv.wide;
+    e.tris = tv.prims;
+    e.nodes = tv.nodes;
+    e.packed_leaves = tv.packed_leaves;
+    e.root_is_branch = tv.root_is_branch;
+    e.tree_nested = tv.tree_nested;
+    e.pad = 0;
+    memcpy(e.inv_xform, s->host_nodes[i].inv_xform, sizeof(e.inv_xform));
+    memcpy(e.inv_xform33, s->host_nodes[i].inv_xform33, sizeof(e.inv_xform33));
+    memcpy(e.xform, s->host_nodes[i].xform, sizeof(e.xform));
+    s->max_inst_depth = std::max(s->max_inst_depth, tv.tree_depth);
+  }
+  SCHK(s, nrt::devbuf_ensure(&s->d_insts, table.size() * sizeof(nrt::SceneInst)));
+  SCHK(s, hipMemcpy(s->d_insts.p, table.data(), table.size() * sizeof(nrt::SceneInst), hipMemcpyHostToDevice));
+  // top-level BVH over the world boxes (nanosg.h:726-735: BVHAccel over the nodes with min_leaf_primitives = 1), built
+  // by the ordinary GPU builder: a box is handed over as a zero-radius "cylinder" from its low to its high corner, whose
+  // bounding box is exactly the box.  Which nodes a ray lists does not depend on this tree's shape.
+  s->use_top = false;
+  if (s->insts.size() > kScanMaxNodes) {
+    if (!s->top && nrtCreate(s->device, &s->top) != NRT_OK)
+      return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level context: %s", nrtLastError(nullptr));
+    std::vector<float> ends(6 * s->insts.size()), radii(2 * s->insts.size(), 0.0f);
+    for (size_t i = 0; i < s->insts.size(); i++)
+      for (int k = 0; k < 3; k++) {
+        ends[6 * i + k] = s->host_nodes[i].xbmin[k];
+        ends[6 * i + 3 + k] = s->host_nodes[i].xbmax[k];
+      }
+    nrt_build_options_f32 o;
+    memset(&o, 0, sizeof(o));
+    o.cost_t_aabb = 0.2f;
+    o.min_leaf_primitives = 1;
+    o.max_tree_depth = 256;
+    o.bin_size = 64;
+    o.shallow_depth = 4;
+    o.min_primitives_for_parallel_build = 1024 * 8;
+    if (nrtSetCylinders_f32(s->top, ends.data(), radii.data(), (uint32_t)s->insts.size(), 0) != NRT_OK ||
+        nrtBuild_f32(s->top, &o, nullptr, nullptr) != NRT_OK || nrt_internal_tree_view(s->top, &s->top_view) != NRT_OK)
+      return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level build: %s", nrtLastError(s->top));
+    s->use_top = s->top_view.tree_depth + 2 < (uint32_t)kTopStack; // (else: the scan)
+  }
   s->committed = true;
   return NRT_OK;
 }
@@ -464,8 +472,9 @@ nrt_status nrtSceneNodeState_f32(nrt_scene *s, uint32_t node_id, float out[64]) 
 
 } // extern "C"
 
-// `device` = rays / hits_out / mask_out are device pointers (no PCIe traffic); the call itself stays synchronous: it
-// reads one counter array back per list position to size the per-node launches.
+// `device` = rays / hits_out / mask_out are device pointers (no PCIe traffic).  Two launches on the scene's stream — the
+// listing and k_scene_trace — and one synchronisation at the end (the scene owns the per-ray lists, so the call returns
+// with them free for the next one).
 static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t n64, nrt_scene_hit_f32 *hits_out,
                                  uint8_t *mask_out, bool device) {
   if (!s) return NRT_ERR_INVALID;
@@ -480,76 +489,38 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   SCHK(s, nrt::devbuf_ensure(&s->d_list_t, (size_t)cap * n * sizeof(float)));
   SCHK(s, nrt::devbuf_ensure(&s->d_list_node, (size_t)cap * n * sizeof(uint32_t)));
   SCHK(s, nrt::devbuf_ensure(&s->d_count, (size_t)n * sizeof(uint32_t)));
-  SCHK(s, nrt::devbuf_ensure(&s->d_best_t, (size_t)n * sizeof(float)));
   if (!device) SCHK(s, nrt::devbuf_ensure(&s->d_best, (size_t)n * sizeof(nrt_scene_hit_f32)));
-  SCHK(s, nrt::devbuf_ensure(&s->d_sel_index, (size_t)n * sizeof(uint32_t)));
-  SCHK(s, nrt::devbuf_ensure(&s->d_local_rays, (size_t)n * sizeof(nrt_ray_f32)));
-  SCHK(s, nrt::devbuf_ensure(&s->d_local_hits, (size_t)n * sizeof(nrt_hit_f32)));
-  SCHK(s, nrt::devbuf_ensure(&s->d_local_mask, (size_t)n));
-  if (!device || !mask_out) SCHK(s, nrt::devbuf_ensure(&s->d_mask, (size_t)n));
-  SCHK(s, nrt::devbuf_ensure(&s->d_scalars, 64));
-  uint32_t *d_max_count = (uint32_t *)s->d_scalars.p;
+  if (!device && mask_out) SCHK(s, nrt::devbuf_ensure(&s->d_mask, (size_t)n));
+  const unsigned grid = (n + 255u) / 256u;
+  const uint32_t levels = s->max_inst_depth + 2 > (uint32_t)nrt::kSceneLdsStack ? s->max_inst_depth + 2 - nrt::kSceneLdsStack : 0;
+  if (levels) {
+    SCHK(s, nrt::devbuf_ensure(&s->d_spill, (size_t)levels * grid * 256u * sizeof(uint32_t)));
+    SCHK(s, nrt::devbuf_ensure(&s->d_spill_tmin, (size_t)levels * grid * 256u * sizeof(float)));
+  }
   const NodeDev *d_nodes = (const NodeDev *)s->d_nodes.p;
   const nrt_ray_f32 *d_rays = device ? rays : (const nrt_ray_f32 *)s->d_rays.p;
-  nrt_scene_hit_f32 *d_best = device ? hits_out : (nrt_scene_hit_f32 *)s->d_best.p;
-  uint8_t *d_mask = (device && mask_out) ? mask_out : (uint8_t *)s->d_mask.p;
-  const unsigned grid = (n + 255u) / 256u;
 
   if (!device) SCHK(s, hipMemcpyAsync(s->d_rays.p, rays, (size_t)n * sizeof(nrt_ray_f32), hipMemcpyHostToDevice, s->stream));
-  SCHK(s, hipMemsetAsync(s->d_scalars.p, 0, 64, s->stream));
-  hipLaunchKernelGGL(k_scene_list, dim3(grid), dim3(256), 0, s->stream, d_rays, n, d_nodes, num_nodes, cap,
-                     (float *)s->d_list_t.p, (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p, (float *)s->d_best_t.p,
-                     d_best, d_max_count);
+  if (s->use_top)
+    hipLaunchKernelGGL(k_scene_list_bvh, dim3(grid), dim3(256), 0, s->stream, d_rays, n, s->top_view.nodes, s->top_view.indices,
+                       d_nodes, cap, (float *)s->d_list_t.p, (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p);
+  else
+    hipLaunchKernelGGL(k_scene_list, dim3(grid), dim3(256), 0, s->stream, d_rays, n, d_nodes, num_nodes, cap,
+                       (float *)s->d_list_t.p, (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p);
   SCHK(s, hipGetLastError());
-  uint32_t max_count = 0;
-  SCHK(s, hipMemcpyAsync(&max_count, d_max_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-  SCHK(s, hipStreamSynchronize(s->stream));
-
-  // per-node counters of a round: [0, N) counts, [N, 2N) segment offsets, [2N, 3N) gather cursors
-  SCHK(s, nrt::devbuf_ensure(&s->d_node_counters, (size_t)3 * num_nodes * sizeof(uint32_t)));
-  uint32_t *d_node_count = (uint32_t *)s->d_node_counters.p, *d_node_offset = d_node_count + num_nodes,
-           *d_node_cursor = d_node_offset + num_nodes;
-  s->h_node_counters.resize((size_t)3 * num_nodes);
-  uint32_t *h_count = s->h_node_counters.data(), *h_offset = h_count + num_nodes;
-  for (uint32_t j = 0; j < max_count; j++) {
-    SCHK(s, hipMemsetAsync(d_node_count, 0, (size_t)3 * num_nodes * sizeof(uint32_t), s->stream));
-    hipLaunchKernelGGL(k_scene_count, dim3(grid), dim3(256), 0, s->stream, n, j, (const float *)s->d_list_t.p,
-                       (const uint32_t *)s->d_list_node.p, (const uint32_t *)s->d_count.p, (const float *)s->d_best_t.p,
-                       d_node_count);
-    SCHK(s, hipGetLastError());
-    SCHK(s, hipMemcpyAsync(h_count, d_node_count, (size_t)num_nodes * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    SCHK(s, hipStreamSynchronize(s->stream)); // the only host round trip of the round
-    uint32_t total = 0;
-    for (uint32_t k = 0; k < num_nodes; k++) {
-      h_offset[k] = total;
-      total += h_count[k];
-    }
-    if (total == 0) continue;
-    SCHK(s, hipMemcpyAsync(d_node_offset, h_offset, (size_t)num_nodes * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
-    hipLaunchKernelGGL(k_scene_gather, dim3(grid), dim3(256), 0, s->stream, d_rays, n, j, d_nodes, (const float *)s->d_list_t.p,
-                       (const uint32_t *)s->d_list_node.p, (const uint32_t *)s->d_count.p, (const float *)s->d_best_t.p,
-                       (const uint32_t *)d_node_offset, d_node_cursor, (uint32_t *)s->d_sel_index.p,
-                       (nrt_ray_f32 *)s->d_local_rays.p);
-    SCHK(s, hipGetLastError());
-    for (uint32_t k = 0; k < num_nodes; k++) {
-      const uint32_t m = h_count[k], off = h_offset[k];
-      if (m == 0) continue;
-      const nrt_ray_f32 *lr = (const nrt_ray_f32 *)s->d_local_rays.p + off;
-      nrt_hit_f32 *lh = (nrt_hit_f32 *)s->d_local_hits.p + off;
-      uint8_t *lm = (uint8_t *)s->d_local_mask.p + off;
-      // the single-level kernel over node k's own tree, default trace options (nanosg.h:817)
-      if (nrtTraverseBatchDevice_f32(s->insts[k].mesh, lr, m, nullptr, lh, lm, s->stream) != NRT_OK)
-        return sfail(s, NRT_ERR_DEVICE, "nrtSceneTraverseBatch: node %u: %s", k, nrtLastError(s->insts[k].mesh));
-      hipLaunchKernelGGL(k_scene_apply, dim3((m + 255u) / 256u), dim3(256), 0, s->stream, d_rays, k, d_nodes, m,
-                         (const uint32_t *)s->d_sel_index.p + off, lr, (const nrt_hit_f32 *)lh, (const uint8_t *)lm,
-                         (float *)s->d_best_t.p, d_best);
-      SCHK(s, hipGetLastError());
-    }
-  }
-  if (!device || mask_out) {
-    hipLaunchKernelGGL(k_scene_mask, dim3(grid), dim3(256), 0, s->stream, (const float *)s->d_best_t.p, n, d_mask);
-    SCHK(s, hipGetLastError());
-  }
+  nrt::SceneTraceArgs a;
+  a.rays = d_rays;
+  a.n = n;
+  a.insts = (const nrt::SceneInst *)s->d_insts.p;
+  a.list_t = (const float *)s->d_list_t.p;
+  a.list_node = (const uint32_t *)s->d_list_node.p;
+  a.count = (const uint32_t *)s->d_count.p;
+  a.hits = device ? hits_out : (nrt_scene_hit_f32 *)s->d_best.p;
+  a.mask = device ? mask_out : (mask_out ? (uint8_t *)s->d_mask.p : nullptr);
+  a.spill = (uint32_t *)s->d_spill.p;
+  a.spill_tmin = (float *)s->d_spill_tmin.p;
+  a.spill_stride = grid * 256u;
+  SCHK(s, nrt::launch_scene_trace(a, s->stream));
   if (!device) {
     SCHK(s, hipMemcpyAsync(hits_out, s->d_best.p, (size_t)n * sizeof(nrt_scene_hit_f32), hipMemcpyDeviceToHost, s->stream));
     if (mask_out) SCHK(s, hipMemcpyAsync(mask_out, s->d_mask.p, (size_t)n, hipMemcpyDeviceToHost, s->stream));

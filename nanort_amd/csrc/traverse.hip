@@ -791,6 +791,57 @@ struct StackEntry<double> {
   }
 };
 
+// The two per-lane moves of the WideNode walk, shared by k_traverse_wide and the two-level kernel k_scene_trace.  They
+// expand inside a kernel that has these names in scope: L (Lane<T>), cur, state, sp, tid, gslot, s_stack[STACK][block],
+// SE = StackEntry<T>, `a` with .spill / .spill_tmin / .spill_stride, the constant SPLIT and (when it is true) leaf_tmin.
+
+// One stack pop (a lane in W_POP): the entry is entered iff its t_min still beats the hit distance — the reference's
+// slab test at pop time (see the comment above the kernel); an empty stack finishes the ray.
+#define NRT_POP_ENTRY()                                                                                \
+do {                                                                                                 \
+  const int s1_ = sp > 0 ? sp - 1 : 0;                                                               \
+  typename SE::type e_ = s_stack[s1_ < STACK ? s1_ : STACK - 1][tid];                                \
+  if (s1_ >= STACK) { /* rare: the entry lives in the global overflow stack */                       \
+    const size_t o_ = (size_t)(s1_ - STACK) * a.spill_stride + gslot;                                \
+    e_ = SE::make(a.spill[o_], a.spill_tmin[o_]);                                                    \
+  }                                                                                                  \
+  const bool fin_ = (sp == 0);                        /* empty stack: the ray is done */             \
+  const bool enter_ = !fin_ & (SE::tmin(e_) <= L.hit_t);                                             \
+  const uint32_t ref_ = SE::ref(e_);                                                                 \
+  sp = s1_;                                                                                          \
+  cur = enter_ ? (ref_ & ~kLeafBit) : cur;                                                           \
+  if (SPLIT) leaf_tmin = SE::tmin(e_);                                                               \
+  state = fin_ ? W_IDLE : (enter_ ? ((ref_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP);                  \
+} while (0)
+
+// One step of a lane in W_TRAV over the WideNode record `w_`: both child boxes tested, the far child of two hits
+// pushed with its t_min, the near one (or the only one) entered.
+#define NRT_STEP_NODE(w_)                                                                              \
+do {                                                                                                 \
+  const SlabPair<T> sl_ = slab_pair(L, (w_));                                                        \
+  const bool near1_ = L.sign((w_).axis) != 0; /* near child = data[dir_sign[axis]] (nanort.h:2538) */ \
+  const bool both_ = sl_.h0 & sl_.h1, any_ = sl_.h0 | sl_.h1;                                        \
+  if (both_) { /* the far child waits with its t_min */                                              \
+    const uint32_t rf_ = near1_ ? (w_).c0 : (w_).c1;                                                 \
+    const T tf_ = near1_ ? sl_.tm0 : sl_.tm1;                                                        \
+    if (sp < STACK) {                                                                                \
+      s_stack[sp][tid] = SE::make(rf_, tf_);                                                         \
+    } else {                                                                                         \
+      const size_t o_ = (size_t)(sp - STACK) * a.spill_stride + gslot;                               \
+      a.spill[o_] = rf_;                                                                             \
+      a.spill_tmin[o_] = tf_;                                                                        \
+    }                                                                                                \
+    sp++;                                                                                            \
+  }                                                                                                  \
+  /* both hit: the near one; one hit: that one */                                                    \
+  const bool go1_ = both_ ? near1_ : sl_.h1;                                                         \
+  const uint32_t next_ = go1_ ? (w_).c1 : (w_).c0;                                                   \
+  if (SPLIT) leaf_tmin = go1_ ? sl_.tm1 : sl_.tm0;                                                   \
+  cur = any_ ? (next_ & ~kLeafBit) : cur;                                                            \
+  state = any_ ? ((next_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP;                                     \
+} while (0)
+
+
 // PLAIN: the launch uses trace options that cannot reject a primitive (full prim_ids_range, no skip_prim_id, no
 // back-face culling — the reference's defaults): the three id comparisons per triangle test are compiled out.
 //
@@ -887,52 +938,6 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) 
     h_.prim_id = hit_ ? L.prim : kInvalid;              \
     if (a.hits) store_hit_nt<T>(a.hits + rid, h_);      \
     if (a.mask) a.mask[rid] = hit_ ? (KIND == kPrimCylinders ? (uint8_t)(1u | (L.cap << 1)) : (uint8_t)1) : (uint8_t)0; \
-  } while (0)
-
-  // One stack pop (a lane in W_POP): the entry is entered iff its t_min still beats the hit distance — the reference's
-  // slab test at pop time (see the comment above the kernel); an empty stack finishes the ray.
-#define NRT_POP_ENTRY()                                                                                \
-  do {                                                                                                 \
-    const int s1_ = sp > 0 ? sp - 1 : 0;                                                               \
-    typename SE::type e_ = s_stack[s1_ < STACK ? s1_ : STACK - 1][tid];                                \
-    if (s1_ >= STACK) { /* rare: the entry lives in the global overflow stack */                       \
-      const size_t o_ = (size_t)(s1_ - STACK) * a.spill_stride + gslot;                                \
-      e_ = SE::make(a.spill[o_], a.spill_tmin[o_]);                                                    \
-    }                                                                                                  \
-    const bool fin_ = (sp == 0);                        /* empty stack: the ray is done */             \
-    const bool enter_ = !fin_ & (SE::tmin(e_) <= L.hit_t);                                             \
-    const uint32_t ref_ = SE::ref(e_);                                                                 \
-    sp = s1_;                                                                                          \
-    cur = enter_ ? (ref_ & ~kLeafBit) : cur;                                                           \
-    if (SPLIT) leaf_tmin = SE::tmin(e_);                                                               \
-    state = fin_ ? W_IDLE : (enter_ ? ((ref_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP);                  \
-  } while (0)
-
-  // One step of a lane in W_TRAV over the WideNode record `w_`: both child boxes tested, the far child of two hits
-  // pushed with its t_min, the near one (or the only one) entered.
-#define NRT_STEP_NODE(w_)                                                                              \
-  do {                                                                                                 \
-    const SlabPair<T> sl_ = slab_pair(L, (w_));                                                        \
-    const bool near1_ = L.sign((w_).axis) != 0; /* near child = data[dir_sign[axis]] (nanort.h:2538) */ \
-    const bool both_ = sl_.h0 & sl_.h1, any_ = sl_.h0 | sl_.h1;                                        \
-    if (both_) { /* the far child waits with its t_min */                                              \
-      const uint32_t rf_ = near1_ ? (w_).c0 : (w_).c1;                                                 \
-      const T tf_ = near1_ ? sl_.tm0 : sl_.tm1;                                                        \
-      if (sp < STACK) {                                                                                \
-        s_stack[sp][tid] = SE::make(rf_, tf_);                                                         \
-      } else {                                                                                         \
-        const size_t o_ = (size_t)(sp - STACK) * a.spill_stride + gslot;                               \
-        a.spill[o_] = rf_;                                                                             \
-        a.spill_tmin[o_] = tf_;                                                                        \
-      }                                                                                                \
-      sp++;                                                                                            \
-    }                                                                                                  \
-    /* both hit: the near one; one hit: that one */                                                    \
-    const bool go1_ = both_ ? near1_ : sl_.h1;                                                         \
-    const uint32_t next_ = go1_ ? (w_).c1 : (w_).c0;                                                   \
-    if (SPLIT) leaf_tmin = go1_ ? sl_.tm1 : sl_.tm0;                                                   \
-    cur = any_ ? (next_ & ~kLeafBit) : cur;                                                            \
-    state = any_ ? ((next_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP;                                     \
   } while (0)
 
   // One primitive record (slot `slot_` of the leaf-ordered arrays) against a lane's ray; `act_` false -> no effect.
@@ -1323,8 +1328,6 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) 
   }
   if (rid != kInvalid) NRT_WRITE_RESULT(); // results still held in registers
 #undef NRT_WRITE_RESULT
-#undef NRT_POP_ENTRY
-#undef NRT_STEP_NODE
 #undef NRT_TEST_PRIM
   if (clocked && lane == 0u) { // one record per wave, reduced on the host (atomics on one line would serialise the exits)
     unsigned long long *rec = a.wave_clock + 3ull * (size_t)(gslot / kWave);
@@ -1343,6 +1346,187 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) 
     atomicAdd(&a.counters[6], st_refilled);
     atomicAdd(&a.counters[7], st_entries2);
   }
+}
+
+// ---------------------------------------------------------------------------
+// Two-level (instanced) traversal, nanosg::Scene::Traverse (examples/nanosg/nanosg.h:778-870) for a whole batch in ONE
+// launch.  A ray arrives with the list of instances whose world boxes it enters, nearest entry first (at most 64:
+// BVHAccel::ListNodeIntersections, nanort.h:2608-2692 — built by scene.hip's listing kernel over the top-level BVH).
+// The lane then does what the reference's loop does, candidate after candidate: skip the instance if the nearest world
+// distance so far is below its entry distance (nanosg.h:795), else carry the ray into the instance's space (MultV with
+// inv_xform / inv_xform33, :806-808, the local interval left at Ray()'s defaults), walk the instance's OWN tree with the
+// single-level machinery above (same WideNode step, same watertight test, same order: the local record is what
+// nrtTraverseBatchDevice would return for that local ray, bit for bit), measure the world distance of the local hit
+// (:823-836) and keep it if strictly nearer (:838).  Lanes of a wave are at different candidates of different instances
+// at the same time — every lane carries its instance's array bases — so there is no per-instance launch, no compaction
+// and no host round trip; the wave alternates between the inner-node phase and the leaf phase like k_traverse_wide.
+// (No refill: a wave keeps its 64 rays to the end.  Instanced scenes are traced through this kernel at 1-2 Grays/s,
+// DESIGN.md §8; the refill machinery of k_traverse_wide is what the single-level path buys its last factor of two with.)
+// ---------------------------------------------------------------------------
+enum : int { S_NEXT = 4, S_FIN = 5, S_DONE = 6 }; // besides W_TRAV / W_LEAF / W_POP: pick the next candidate / a local walk ended / ray finished
+
+__device__ __forceinline__ void scene_mult_v(float dst[3], const float m[4][4], const float v[3]) { // Matrix::MultV, nanosg.h:232-240
+  const float t0 = m[0][0] * v[0] + m[1][0] * v[1] + m[2][0] * v[2] + m[3][0];
+  const float t1 = m[0][1] * v[0] + m[1][1] * v[1] + m[2][1] * v[2] + m[3][1];
+  const float t2 = m[0][2] * v[0] + m[1][2] * v[1] + m[2][2] * v[2] + m[3][2];
+  dst[0] = t0;
+  dst[1] = t1;
+  dst[2] = t2;
+}
+
+template <int STACK>
+__global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTraceArgs a) {
+  typedef float T;
+  typedef StackEntry<float> SE;
+  __shared__ SE::type s_stack[STACK][kTraverseBlock];
+  constexpr bool SPLIT = false;
+  float leaf_tmin = 0.f; // (names the shared step / pop macros mention under SPLIT only)
+  (void)leaf_tmin;
+
+  const unsigned tid = threadIdx.x;
+  const unsigned gslot = blockIdx.x * kTraverseBlock + tid;
+  const uint32_t i = gslot;
+  const bool live = i < a.n;
+
+  Lane<float> L;
+  uint32_t cur = 0;
+  int state = S_DONE, sp = 0;
+  uint32_t cnt = 0, j = 0, inst = 0;
+  float best_t = 3.402823466e+38f; // t_nearest = numeric_limits<T>::max(), nanosg.h:787
+  bool has_hit = false;
+  float worg[3] = {0.f, 0.f, 0.f}, wdir[3] = {0.f, 0.f, 0.f};
+  const WideNode<float> *wide = nullptr;
+  const LeafTri<float> *tris = nullptr;
+  const nrt_node_f32 *nodes = nullptr;
+  uint32_t packed = 1u;
+  if (live) {
+    const nrt_ray_f32 r = a.rays[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      worg[k] = r.org[k];
+      wdir[k] = r.dir[k];
+    }
+    cnt = a.count[i];
+    nrt_scene_hit_f32 h; // the miss record; overwritten by every strictly nearer hit
+    h.t = r.max_t;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    h.prim_id = 0xFFFFFFFFu;
+    h.node_id = 0xFFFFFFFFu;
+    a.hits[i] = h;
+    state = S_NEXT;
+  }
+
+  for (;;) {
+    // ---- candidates: finish a local walk, pick the next instance ---------------------------------------------------
+    if (state == S_FIN) {
+      if (L.hit_t < L.max_t) { // the local Traverse() hit (strict final predicate, nanort.h:2552)
+        const SceneInst &nd = a.insts[inst];
+        float lp[3], wp[3];
+        lp[0] = L.org0 + L.hit_t * L.d0; // nanosg.h:823-825
+        lp[1] = L.org1 + L.hit_t * L.d1;
+        lp[2] = L.org2 + L.hit_t * L.d2;
+        scene_mult_v(wp, nd.xform, lp);
+        const float px = wp[0] - worg[0], py = wp[1] - worg[1], pz = wp[2] - worg[2];
+        const float t_world = __builtin_sqrtf(px * px + py * py + pz * pz); // vlength, nanort.h:383-385
+        if (t_world < best_t) {                                             // strict, nanosg.h:838
+          best_t = t_world;
+          has_hit = true;
+          nrt_scene_hit_f32 h;
+          h.t = t_world;
+          h.u = L.u;
+          h.v = L.v;
+          h.prim_id = L.prim;
+          h.node_id = inst;
+          a.hits[i] = h;
+        }
+      }
+      j++;
+      state = S_NEXT;
+    }
+    if (state == S_NEXT) {
+      state = S_DONE;
+      while (j < cnt) {
+        const float t_min = a.list_t[(size_t)j * a.n + i];
+        if (best_t < t_min) { // early cull, nanosg.h:795
+          j++;
+          continue;
+        }
+        inst = a.list_node[(size_t)j * a.n + i];
+        const SceneInst &nd = a.insts[inst];
+        nrt_ray_f32 lr;
+        scene_mult_v(lr.org, nd.inv_xform, worg);   // nanosg.h:807
+        scene_mult_v(lr.dir, nd.inv_xform33, wdir); // nanosg.h:808
+        lr.min_t = 0.0f;                            // Ray() defaults (nanort.h:477-487): the world interval is not propagated
+        lr.max_t = 3.402823466e+38f;
+        lr.type = 0;
+        lane_init<float>(L, lr);
+        wide = (const WideNode<float> *)nd.wide;
+        tris = (const LeafTri<float> *)nd.tris;
+        nodes = nd.nodes;
+        packed = nd.packed_leaves;
+        sp = 0;
+        cur = 0u;
+        if (nd.root_is_branch && nd.tree_nested) {
+          state = W_TRAV; // (a ray that misses node 0's box misses both children's: see k_traverse_wide)
+        } else {
+          const nrt_node_f32 root = nodes[0];
+          const bool root_hit = slab_test<float>(L, root.bmin, root.bmax);
+          if (nd.root_is_branch) {
+            state = root_hit ? W_TRAV : W_POP;
+          } else { // single-leaf tree
+            cur = packed ? (((root.data[0] - 1u) << kPackedFirstBits) | root.data[1]) : 0u;
+            state = root_hit ? W_LEAF : W_POP;
+          }
+        }
+        break;
+      }
+    }
+    if (__ballot(state != S_DONE) == 0ull) break;
+
+    // ---- phase 1: inner nodes / stack pops ---------------------------------------------------------------------
+    unsigned n_wait = (unsigned)__builtin_popcountll(__ballot(state == W_LEAF || state == S_FIN));
+    while (state == W_TRAV || state == W_POP) {
+      if (state == W_POP) {
+        NRT_POP_ENTRY();
+        state = (state == W_IDLE) ? S_FIN : state; // an empty stack ends this instance's walk
+      }
+      if (state == W_TRAV) {
+        const WideNode<float> w = wide[cur];
+        NRT_STEP_NODE(w);
+      }
+      n_wait += (unsigned)__builtin_popcountll(__ballot(state == W_LEAF || state == S_FIN));
+      if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < 8u && n_wait != 0u) break;
+    }
+
+    // ---- phase 2: leaves -----------------------------------------------------------------------------------------
+    if (__ballot(state == W_LEAF) != 0ull) {
+      uint32_t lcnt = 0, first = 0;
+      if (state == W_LEAF) {
+        if (packed) {
+          lcnt = (cur >> kPackedFirstBits) + 1u;
+          first = cur & kPackedFirstMask;
+        } else {
+          lcnt = nodes[cur].data[0];
+          first = nodes[cur].data[1];
+        }
+      }
+      for (uint32_t k = 0; __ballot(k < lcnt) != 0ull; k++) {
+        if (k < lcnt) { // (divergent on purpose: the lanes' record arrays differ)
+          const LeafTri<float> tri = tris[first + k];
+          tri_test<float, true>(L, tri, true, 0u, 0u, 0u, false); // default trace options (nanosg.h:817)
+        }
+      }
+      state = (state == W_LEAF) ? W_POP : state;
+    }
+  }
+  if (live && a.mask) a.mask[i] = has_hit ? 1 : 0;
+}
+
+hipError_t launch_scene_trace(const SceneTraceArgs &args, hipStream_t s) {
+  if (args.n == 0) return hipSuccess;
+  hipLaunchKernelGGL((k_scene_trace<kSceneLdsStack>), dim3((args.n + kTraverseBlock - 1) / kTraverseBlock), dim3(kTraverseBlock), 0, s, args);
+  return hipGetLastError();
 }
 
 // BVHNode[] -> dense WideNode[]: (1) branches per 1024-node tile, (2) exclusive scan of the

@@ -185,3 +185,39 @@ def test_device_resident_entry_point_matches_the_host_one():
     assert d_hits.cpu().numpy().tobytes() == h.tobytes()
     bmin, bmax = sc.GetBoundingBox()
     assert np.all(bmin < bmax)
+
+
+def test_ten_thousand_instances_through_the_top_level_bvh(oracle):
+    """10 000 transformed copies of two small meshes: the listing walks the top-level BVH (built on the GPU over the
+    nodes' world boxes), the trace is ONE launch.  Equal to the restatement (a scan over all 10 000 node boxes per ray, as
+    nanosg's own top-level traversal is equivalent to) in every field."""
+    from scene_fixture import xform
+
+    rng = np.random.default_rng(5)
+    sv, sf = scenes.sphere(16, 8)
+    sv = sv - np.array([0, 5, 0], dtype=np.float32)
+    pv, pf = scenes.plane(6, 4)
+    pv = (pv - pv.mean(axis=0)).astype(np.float32)
+    meshes = []
+    for v, f in ((sv, sf), (pv, pf)):
+        a = BVHAccel(np.float32)
+        assert a.Build(f.shape[0], TriangleMesh(v, f))
+        nodes, idx = a.GetTree()
+        meshes.append((v, f, a, (nodes, idx)))
+    sc = Scene()
+    O = ob.SceneOracle(oracle)
+    N = 10000
+    for k in range(N):
+        v, f, a, tree = meshes[k % 2]
+        s = rng.uniform(0.004, 0.02, 3) if k % 2 == 0 else rng.uniform(0.008, 0.03, 3)
+        x = xform(tuple(s), rng.uniform(0, 6.28), rng.uniform(0, 6.28), tuple(rng.uniform(-8, 8, 3) + np.array([0, 5, 0])))
+        sc.AddNode(a, x)
+        O.add_node(v, f, x, tree=tree)  # the same local node arrays: every field must agree
+    assert sc.Commit() and O.commit()
+    rays = scenes.camera_rays(256, 192)
+    rays["org"] += rng.uniform(-0.5, 0.5, size=(rays.shape[0], 3)).astype(np.float32)
+    h, m = sc.TraverseBatch(rays)
+    oh, om = O.traverse(rays)
+    assert 0.05 < om.mean() < 0.95
+    assert np.array_equal(m, om)
+    assert fields_equal(h, oh, ("t", "u", "v", "prim_id", "node_id"))
