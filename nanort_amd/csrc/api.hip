@@ -103,6 +103,10 @@ struct nrt_ctx {
   std::mutex host_mutex;   // the host-buffer traversal calls share one set of staging buffers: one at a time
   unsigned long long *d_counters = nullptr;  // 8 x u64 (counting pass / profiling instantiation only)
   DevBuf st_rays, st_hits, st_mask;
+  // host entry point with page-locked caller buffers: upload / trace / download pipelined over three streams
+  hipStream_t copy_in = nullptr, copy_out = nullptr;
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_tr[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+  int host_pipeline = 1; // (env NRT_HOST_PIPELINE=0: one upload, one launch, one download)
   DevBuf b_wave_clock; // profiling (NRT_DEBUG bit 8192)
   uint32_t wave_clock_waves = 0;
 
@@ -255,6 +259,7 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   if (const char *e = getenv("NRT_BLOCKS_PER_CU")) c->max_blocks_per_cu = (unsigned)std::max(0, atoi(e));
   if (const char *e = getenv("NRT_WIDE")) c->wide = atoi(e) != 0;
   if (const char *e = getenv("NRT_SPLIT")) c->split = atoi(e) != 0;
+  if (const char *e = getenv("NRT_HOST_PIPELINE")) c->host_pipeline = atoi(e) != 0;
   if (const char *e = getenv("NRT_DRAIN")) c->drain_loop = atoi(e) != 0 ? 1u : 0u;
   if (const char *e = getenv("NRT_DRAIN_STEPS")) c->drain_steps = (unsigned)std::max(1, atoi(e));
   if (const char *e = getenv("NRT_SPLIT_BUSY")) c->split_busy = (unsigned)std::min(64, std::max(0, atoi(e)));
@@ -290,6 +295,11 @@ void nrtDestroy(nrt_ctx *c) {
   hipEvent_t evs[] = {c->ev_b0, c->ev_b1};
   for (hipEvent_t ev : evs)
     if (ev) (void)hipEventDestroy(ev);
+  for (int k = 0; k < 2; k++)
+    for (hipEvent_t e : {c->ev_in[k], c->ev_tr[k], c->ev_out[k]})
+      if (e) (void)hipEventDestroy(e);
+  if (c->copy_in) (void)hipStreamDestroy(c->copy_in);
+  if (c->copy_out) (void)hipStreamDestroy(c->copy_out);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -741,6 +751,20 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   return NRT_OK;
 }
 
+// Is `p` page-locked host memory the device can copy from / to asynchronously (hipHostMalloc / nrtHostAlloc / registered)?
+static bool is_pinned_host(const void *p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError(); // (plain malloc'd memory: "invalid value", not an error of ours)
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+// Host entry point.  With pageable caller buffers the copies are staged by the runtime and block the host: upload ->
+// trace -> download, one after the other.  With PAGE-LOCKED buffers (nrtHostAlloc) the batch is cut into pieces and
+// pipelined over three streams — piece k+1 uploads while piece k is traced and piece k-1 downloads (PCIe is full duplex) —
+// so the call approaches the slower of the two copy directions instead of their sum plus the kernel.
 template <typename T>
 static nrt_status traverse_host(nrt_ctx *c, const typename Wire<T>::Ray *rays, uint64_t n,
                                 const nrt_trace_options *opt, typename Wire<T>::Hit *hits, uint8_t *mask) {
@@ -751,6 +775,42 @@ static nrt_status traverse_host(nrt_ctx *c, const typename Wire<T>::Ray *rays, u
   typedef typename Wire<T>::Hit Hit;
   std::lock_guard<std::mutex> host_lock(c->host_mutex);
   HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t kPiece = 1ull << 19; // rays per pipeline stage (19 MB up, 8 MB down in fp32)
+  if (n >= 2 * kPiece && c->host_pipeline && is_pinned_host(rays) && is_pinned_host(hits) && (!mask || is_pinned_host(mask))) {
+    if (!c->copy_in) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking));
+    if (!c->copy_out) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++)
+      for (hipEvent_t *e : {&c->ev_in[k], &c->ev_tr[k], &c->ev_out[k]})
+        if (!*e) HIPCHK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    nrt_status st;
+    if ((st = ensure(c, c->st_rays, 2 * kPiece * sizeof(Ray))) || (st = ensure(c, c->st_hits, 2 * kPiece * sizeof(Hit))) ||
+        (st = ensure(c, c->st_mask, 2 * kPiece)))
+      return st;
+    uint64_t piece = 0;
+    for (uint64_t off = 0; off < n; off += kPiece, piece++) {
+      const uint64_t m = std::min(kPiece, n - off);
+      const int b = (int)(piece & 1);
+      Ray *d_r = (Ray *)c->st_rays.p + (size_t)b * kPiece;
+      Hit *d_h = (Hit *)c->st_hits.p + (size_t)b * kPiece;
+      uint8_t *d_m = (uint8_t *)c->st_mask.p + (size_t)b * kPiece;
+      // the ray slot is free once the trace that read it (two pieces ago) is done; the record slot once its download is
+      if (piece >= 2) HIPCHK(c, hipStreamWaitEvent(c->copy_in, c->ev_tr[b], 0));
+      HIPCHK(c, hipMemcpyAsync(d_r, rays + off, m * sizeof(Ray), hipMemcpyHostToDevice, c->copy_in));
+      HIPCHK(c, hipEventRecord(c->ev_in[b], c->copy_in));
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[b], 0));
+      if (piece >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_out[b], 0));
+      st = traverse_device<T>(c, d_r, m, opt, d_h, d_m, c->stream, false, true);
+      if (st) return st;
+      HIPCHK(c, hipEventRecord(c->ev_tr[b], c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->copy_out, c->ev_tr[b], 0));
+      HIPCHK(c, hipMemcpyAsync(hits + off, d_h, m * sizeof(Hit), hipMemcpyDeviceToHost, c->copy_out));
+      if (mask) HIPCHK(c, hipMemcpyAsync(mask + off, d_m, m, hipMemcpyDeviceToHost, c->copy_out));
+      HIPCHK(c, hipEventRecord(c->ev_out[b], c->copy_out));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->copy_out));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NRT_OK;
+  }
   const uint64_t kMaxChunk = 1ull << 26; // rays per launch (keeps staging bounded)
   for (uint64_t off = 0; off < n; off += kMaxChunk) {
     const uint64_t m = std::min(kMaxChunk, n - off);

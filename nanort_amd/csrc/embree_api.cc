@@ -16,10 +16,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../../include/embree2/rtcore.h"
 #include "../../include/embree2/rtcore_ray.h"
@@ -188,14 +193,35 @@ bool commit_locked(Scene *s) {
   return true;
 }
 
-constexpr int kHostThreads = 8;
+// Host threads for the record conversion: what the process may use (cgroup CPU quota), at most 16 — never the OpenMP
+// default, which on a many-core host inside a quota'd container starves the HIP runtime's own threads.
+static int host_threads() {
+  static int cached = 0;
+  if (cached) return cached;
+  long n = 8;
+#ifdef _OPENMP
+  n = omp_get_num_procs();
+#endif
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32];
+    long period = 0;
+    if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0 && atol(q) / period >= 1) n = std::min(n, atol(q) / period);
+    fclose(f);
+  }
+  cached = (int)std::max(1l, std::min(16l, n));
+  return cached;
+}
 constexpr size_t kParallelMin = 1u << 16;
+constexpr size_t kPiece = 1u << 19; // rays per pipeline stage of a stream query
 
 inline RTCRay *ray_at(RTCRay *base, size_t i, size_t stride) {
   return reinterpret_cast<RTCRay *>(reinterpret_cast<char *>(base) + i * stride);
 }
 
-// The one query path.  `get(i)` yields the i-th ray of the caller's stream.
+// The one query path.  `get(i)` yields the i-th ray of the caller's stream.  A stream is 96 bytes of RTCRay per ray, of
+// which the traversal needs 32 and returns 20: the records are converted on the host into the (page-locked) staging the
+// scene call copies from.  Long streams go piece by piece with the three stages overlapped — while the GPU traces piece k
+// (a helper thread sits in nrtSceneTraverseBatch_f32) this thread's team converts piece k+1 and writes piece k-1 back.
 template <class Get>
 void trace(Scene *s, size_t n, bool occluded, Get get) {
   if (!s || n == 0) return;
@@ -214,11 +240,11 @@ void trace(Scene *s, size_t n, bool occluded, Get get) {
       ok = false;
     }
   }
-  if (ok) {
-    // A 1920x1080 stream is 200 MB of RTCRay records: converting it on one core costs more than the traversal.  A small
-    // fixed team (not the OpenMP default, which on a many-core host starves the HIP runtime's own threads).
-#pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n > kParallelMin)
-    for (size_t i = 0; i < n; i++) {
+  const int threads = host_threads();
+  (void)threads;
+  auto convert = [&](size_t lo, size_t hi) {
+#pragma omp parallel for schedule(static) num_threads(threads) if (hi - lo > kParallelMin)
+    for (size_t i = lo; i < hi; i++) {
       const RTCRay *r = get(i);
       nrt_ray_f32 &o = rays[i];
       for (int k = 0; k < 3; k++) {
@@ -229,31 +255,61 @@ void trace(Scene *s, size_t n, bool occluded, Get get) {
       o.max_t = r->tfar;
       o.type = 0u;  // RAY_TYPE_NONE: the reference's Ray default, not read by traversal
     }
-    if (nrtSceneTraverseBatch_f32(s->scene, rays, n, hits, mask) != NRT_OK) {
-      report(s->device, RTC_UNKNOWN_ERROR, "rtcIntersect/rtcOccluded: %s", nrtSceneLastError(s->scene));
-      ok = false;
+  };
+  auto write_back = [&](size_t lo, size_t hi, bool good) {
+#pragma omp parallel for schedule(static) num_threads(threads) if (hi - lo > kParallelMin)
+    for (size_t i = lo; i < hi; i++) {
+      RTCRay *r = get(i);
+      const bool hit = good && mask[i] != 0;
+      if (occluded) {
+        if (hit) r->geomID = 0;
+        continue;
+      }
+      if (hit) {  // nanort-embree.cc:541-548
+        const nrt_scene_hit_f32 &h = hits[i];
+        r->tfar = h.t;
+        r->u = h.u;
+        r->v = h.v;
+        r->geomID = h.node_id;
+        r->primID = h.prim_id;
+        r->instID = RTC_INVALID_GEOMETRY_ID;
+      } else {  // :549-553
+        r->geomID = RTC_INVALID_GEOMETRY_ID;
+        r->primID = RTC_INVALID_GEOMETRY_ID;
+        r->instID = RTC_INVALID_GEOMETRY_ID;
+      }
     }
+  };
+  auto gpu = [&](size_t lo, size_t hi) {
+    return nrtSceneTraverseBatch_f32(s->scene, rays + lo, hi - lo, hits + lo, mask + lo) == NRT_OK;
+  };
+  if (!ok) {
+    write_back(0, n, false);
+    return;
   }
-#pragma omp parallel for schedule(static) num_threads(kHostThreads) if (n > kParallelMin)
-  for (size_t i = 0; i < n; i++) {
-    RTCRay *r = get(i);
-    const bool hit = ok && mask[i] != 0;
-    if (occluded) {
-      if (hit) r->geomID = 0;
-      continue;
+  if (n < 2 * kPiece) {
+    convert(0, n);
+    ok = gpu(0, n);
+    if (!ok) report(s->device, RTC_UNKNOWN_ERROR, "rtcIntersect/rtcOccluded: %s", nrtSceneLastError(s->scene));
+    write_back(0, n, ok);
+    return;
+  }
+  const size_t pieces = (n + kPiece - 1) / kPiece;
+  std::vector<char> good(pieces, 0);
+  std::thread worker;
+  for (size_t k = 0; k <= pieces; k++) {
+    if (k < pieces) convert(k * kPiece, std::min(n, (k + 1) * kPiece));
+    if (worker.joinable()) worker.join();  // piece k-1 is traced
+    if (k < pieces) {
+      const size_t lo = k * kPiece, hi = std::min(n, (k + 1) * kPiece);
+      worker = std::thread([&good, &gpu, k, lo, hi]() { good[k] = gpu(lo, hi) ? 1 : 0; });
     }
-    if (hit) {  // nanort-embree.cc:541-548
-      const nrt_scene_hit_f32 &h = hits[i];
-      r->tfar = h.t;
-      r->u = h.u;
-      r->v = h.v;
-      r->geomID = h.node_id;
-      r->primID = h.prim_id;
-      r->instID = RTC_INVALID_GEOMETRY_ID;
-    } else {  // :549-553
-      r->geomID = RTC_INVALID_GEOMETRY_ID;
-      r->primID = RTC_INVALID_GEOMETRY_ID;
-      r->instID = RTC_INVALID_GEOMETRY_ID;
+    if (k >= 1) {  // overlaps the trace of piece k
+      if (!good[k - 1] && ok) {
+        ok = false;
+        report(s->device, RTC_UNKNOWN_ERROR, "rtcIntersect/rtcOccluded: %s", nrtSceneLastError(s->scene));
+      }
+      write_back((k - 1) * kPiece, std::min(n, k * kPiece), good[k - 1] != 0);
     }
   }
 }

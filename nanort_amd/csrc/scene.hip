@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -374,14 +375,28 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
   if (s->insts.empty()) return sfail(s, NRT_ERR_EMPTY, "nrtSceneCommit: empty scene (the reference's Commit() returns false)");
   SCHK(s, hipSetDevice(s->device));
   s->host_nodes.resize(s->insts.size());
+  // per distinct mesh context (instances share them): where its tree lives, and its root box
+  struct MeshInfo {
+    nrt::TreeViewF32 tv;
+    nrt_node_f32 root;
+  };
+  std::vector<std::pair<nrt_ctx *, MeshInfo> > meshes;
+  std::unordered_map<nrt_ctx *, uint32_t> mesh_index;
+  std::vector<uint32_t> mesh_of(s->insts.size());
   for (size_t i = 0; i < s->insts.size(); i++) {
+    std::unordered_map<nrt_ctx *, uint32_t>::iterator it = mesh_index.find(s->insts[i].mesh);
+    uint32_t m = it == mesh_index.end() ? (uint32_t)meshes.size() : it->second;
+    if (it == mesh_index.end()) {
+      mesh_index[s->insts[i].mesh] = m;
+      MeshInfo mi;
+      if (nrt_internal_tree_view(s->insts[i].mesh, &mi.tv) != NRT_OK || mi.tv.prim_kind != (uint32_t)nrt::kPrimTriangles)
+        return sfail(s, NRT_ERR_PRECISION, "nrtSceneCommit: node %zu is not a built f32 triangle mesh: %s", i, nrtLastError(s->insts[i].mesh));
+      SCHK(s, hipMemcpy(&mi.root, mi.tv.nodes, sizeof(mi.root), hipMemcpyDeviceToHost));
+      meshes.push_back(std::make_pair(s->insts[i].mesh, mi));
+    }
+    mesh_of[i] = m;
     // local AABB = the root box of the node's tree (accel_.BoundingBox, nanosg.h:411)
-    uint64_t nn = 0, ni = 0;
-    nrtTreeSize(s->insts[i].mesh, &nn, &ni);
-    std::vector<nrt_node_f32> nodes((size_t)nn);
-    if (nrtGetTree_f32(s->insts[i].mesh, nodes.data(), nullptr) != NRT_OK)
-      return sfail(s, NRT_ERR_PRECISION, "nrtSceneCommit: node %zu is not a built f32 mesh: %s", i, nrtLastError(s->insts[i].mesh));
-    node_update(s->insts[i].local, nodes[0].bmin, nodes[0].bmax, &s->host_nodes[i]);
+    node_update(s->insts[i].local, meshes[m].second.root.bmin, meshes[m].second.root.bmax, &s->host_nodes[i]);
   }
   SCHK(s, nrt::devbuf_ensure(&s->d_nodes, s->host_nodes.size() * sizeof(NodeDev)));
   SCHK(s, hipMemcpy(s->d_nodes.p, s->host_nodes.data(), s->host_nodes.size() * sizeof(NodeDev), hipMemcpyHostToDevice));
@@ -389,9 +404,7 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
   std::vector<nrt::SceneInst> table(s->insts.size());
   s->max_inst_depth = 0;
   for (size_t i = 0; i < s->insts.size(); i++) {
-    nrt::TreeViewF32 tv;
-    if (nrt_internal_tree_view(s->insts[i].mesh, &tv) != NRT_OK || tv.prim_kind != (uint32_t)nrt::kPrimTriangles)
-      return sfail(s, NRT_ERR_INVALID, "nrtSceneCommit: node %zu is not a built f32 triangle mesh", i);
+    const nrt::TreeViewF32 &tv = meshes[mesh_of[i]].second.tv;
     nrt::SceneInst &e = table[i];
     e.wide = tv.wide;
     e.tris = tv.prims;
