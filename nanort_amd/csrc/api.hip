@@ -25,7 +25,7 @@ int traverse_blocks_per_cu(int lds_stack);
 template <typename T>
 hipError_t launch_traverse_wide(const TraverseArgs<T> &, unsigned grid, int lds_stack, int prim_kind, hipStream_t, const char **name_out);
 template <typename T>
-int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind);
+int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool split);
 template <typename T>
 hipError_t launch_gather_leaf_spheres(const uint32_t *, const T *, const T *, LeafSphere<T> *, uint32_t, hipStream_t);
 template <typename T>
@@ -123,7 +123,6 @@ struct nrt_ctx {
   // LOSE on C3 (profiles/r02c_split_*.txt: bounce wave 0.50 -> 0.51-0.59 ms depending on the hand-out policy), because
   // under the while-while loop every helper adds leaf rounds that stall the very ray it helps.  Off unless NRT_SPLIT=1.
   int split = 0;
-  unsigned drain_loop = 1; // per-lane loop for the last rays of a wave (env NRT_DRAIN=0: stay in the while-while loop)
   unsigned drain_steps = 8, split_busy = 8; // hand-out policy (env NRT_DRAIN_STEPS, NRT_SPLIT_BUSY)
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
 
@@ -260,7 +259,6 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   if (const char *e = getenv("NRT_WIDE")) c->wide = atoi(e) != 0;
   if (const char *e = getenv("NRT_SPLIT")) c->split = atoi(e) != 0;
   if (const char *e = getenv("NRT_HOST_PIPELINE")) c->host_pipeline = atoi(e) != 0;
-  if (const char *e = getenv("NRT_DRAIN")) c->drain_loop = atoi(e) != 0 ? 1u : 0u;
   if (const char *e = getenv("NRT_DRAIN_STEPS")) c->drain_steps = (unsigned)std::max(1, atoi(e));
   if (const char *e = getenv("NRT_SPLIT_BUSY")) c->split_busy = (unsigned)std::min(64, std::max(0, atoi(e)));
   if (const char *e = getenv("NRT_WIDE_STACK")) {
@@ -648,8 +646,8 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
     return fail(c, NRT_ERR_INVALID, "nrtOccludedBatch: occlusion queries run on the triangle WideNode kernel only");
   const bool use_wide = (c->wide || spheres || any_hit) && !count && c->d_wide;
   if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
-  if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles);
-  if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind);
+  if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, c->split != 0);
+  if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, false);
   unsigned blocks_per_cu = spheres ? c->sphere_blocks_per_cu : (use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu);
   if (c->max_blocks_per_cu && blocks_per_cu > c->max_blocks_per_cu) blocks_per_cu = c->max_blocks_per_cu;
   const int stack_entries = spheres ? 10 : (use_wide ? c->wide_stack : c->lds_stack);
@@ -704,7 +702,6 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
                      !opt->cull_back_face) ? 1u : 0u;
   a.split = (c->split && use_wide && c->prim_kind == kPrimTriangles && !any_hit && c->root_is_branch && c->tree_nested) ? 1u : 0u;
   a.root_test = c->tree_nested ? 0u : 1u;
-  a.drain_loop = c->drain_loop;
   a.drain_steps = c->drain_steps;
   a.split_busy = c->split_busy;
   a.spill = (uint32_t *)slot->spill.p;

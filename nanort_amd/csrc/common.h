@@ -179,7 +179,6 @@ struct TraverseArgs {
   uint32_t split;         // work splitting in the drain (triangle closest-hit launches over a tree whose child boxes lie inside their parents')
   uint32_t drain_steps;   // splitting launches: a round of hand-outs every this many trips through the outer loop once the wave is out of rays
   uint32_t split_busy;    // ... and only while at most this many lanes of the wave are busy
-  uint32_t drain_loop;    // once a wave is out of rays it finishes the ones it holds in the per-lane loop (k_traverse_wide, "the drain")
   uint32_t root_test;     // node 0's box must be tested before its children (an adopted tree whose child boxes may stick out)
   uint32_t *spill;        // [spill_levels][spill_stride] overflow stack, may be null
   T *spill_tmin;          // same shape, entry t_min (wide kernel)

@@ -883,7 +883,8 @@ struct FoldRec { // one per thread slot, used by the slot's lane when it owns a 
   uint32_t pend; // helpers outstanding (low 16 bits) | 0x80000000: some helper reported a violation
 };
 
-template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool SPLIT = false>
+// CLOCK: profiling instantiation that stamps when each wave starts, runs dry and finishes (tools/drain_probe.py).
+template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool SPLIT = false, bool CLOCK = false>
 __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) void k_traverse_wide(const TraverseArgs<T> a) {
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
@@ -908,10 +909,12 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) 
   const bool split_on = SPLIT && a.split != 0u;
   unsigned drain_round = 0u;
   // (the sphere and cylinder kernels are left as they were: the extra loop body would cost them a wave per SIMD)
-  constexpr bool kDrain = !STATS && KIND == kPrimTriangles;
-  const bool drain_on = kDrain && (split_on || a.drain_loop != 0u); // see "the drain" below
+  // (compiled into the splitting variants only — splitting lives in it.  In the production variants it measured neutral
+  // at run time, and its mere presence cost them 3 % through register allocation: profiles/r02f_variant_bisect.txt.)
+  constexpr bool kDrain = SPLIT && !STATS && KIND == kPrimTriangles;
+  const bool drain_on = kDrain && split_on; // see "the drain" below
   // (profiling, NRT_DEBUG bit 8192: when did this wave start, run out of rays, finish — 100 MHz realtime ticks)
-  const bool clocked = (a.debug_flags & 8192u) != 0u && a.wave_clock != nullptr;
+  const bool clocked = CLOCK && a.wave_clock != nullptr;
   unsigned long long clk_begin = 0ull, clk_dry = 0ull;
   if (clocked) clk_begin = __builtin_amdgcn_s_memrealtime();
   Claim ck;
@@ -1727,7 +1730,7 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
                                 const char **name_out) {
   constexpr bool f32 = sizeof(T) == 4;
   if (prim_kind == kPrimSpheres) { // one instantiation: 10 LDS entries (the caller sizes the overflow stack for it)
-    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 1, false, false>" : "nrt::k_traverse_wide<double, 10, false, 1, false, false>",
+    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 1, false, false, false>" : "nrt::k_traverse_wide<double, 10, false, 1, false, false, false>",
                     T, 10, false, kPrimSpheres);
     if (args.hits)
       hipLaunchKernelGGL((k_sphere_uv<T>), dim3((args.num_rays + 255u) / 256u), dim3(256), 0, s, args.rays, args.hits,
@@ -1735,40 +1738,47 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
     return hipGetLastError();
   }
   if (prim_kind == kPrimCylinders) {
-    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 2, false, false>" : "nrt::k_traverse_wide<double, 10, false, 2, false, false>",
+    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 2, false, false, false>" : "nrt::k_traverse_wide<double, 10, false, 2, false, false, false>",
                     T, 10, false, kPrimCylinders);
     return hipGetLastError();
   }
   switch (lds_stack) {
     case 8:
-      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 8, false, 0, false, false>" : "nrt::k_traverse_wide<double, 8, false, 0, false, false>",
+      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 8, false, 0, false, false, false>" : "nrt::k_traverse_wide<double, 8, false, 0, false, false, false>",
                       T, 8, false, kPrimTriangles);
       break;
     case 10:
       if (args.debug_flags & 32u) {
-        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, true, 0, false, false>" : "nrt::k_traverse_wide<double, 10, true, 0, false, false>",
+        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, true, 0, false, false, false>" : "nrt::k_traverse_wide<double, 10, true, 0, false, false, false>",
                         T, 10, true, kPrimTriangles);
-      } else if (args.split) { // the production variants: work splitting in the drain (a.split: see api.hip)
+      } else if (args.wave_clock) { // profiling: per-wave time stamps (default trace options only)
+        if (args.split)
+          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, true, true>" : "nrt::k_traverse_wide<double, 10, false, 0, true, true, true>",
+                          T, 10, false, kPrimTriangles, true, true, true);
+        else
+          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, false, true>" : "nrt::k_traverse_wide<double, 10, false, 0, true, false, true>",
+                          T, 10, false, kPrimTriangles, true, false, true);
+      } else if (args.split) { // work splitting in the drain (a.split: see api.hip)
         if (args.plain_options)
-          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, true>" : "nrt::k_traverse_wide<double, 10, false, 0, true, true>",
+          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, true, false>" : "nrt::k_traverse_wide<double, 10, false, 0, true, true, false>",
                           T, 10, false, kPrimTriangles, true, true);
         else
-          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, false, true>" : "nrt::k_traverse_wide<double, 10, false, 0, false, true>",
+          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, false, true, false>" : "nrt::k_traverse_wide<double, 10, false, 0, false, true, false>",
                           T, 10, false, kPrimTriangles, false, true);
       } else if (args.plain_options) {
-        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, false>" : "nrt::k_traverse_wide<double, 10, false, 0, true, false>",
+        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, false, false>" : "nrt::k_traverse_wide<double, 10, false, 0, true, false, false>",
                         T, 10, false, kPrimTriangles, true);
       } else {
-        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, false, false>" : "nrt::k_traverse_wide<double, 10, false, 0, false, false>",
+        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, false, false, false>" : "nrt::k_traverse_wide<double, 10, false, 0, false, false, false>",
                         T, 10, false, kPrimTriangles);
       }
       break;
     case 12:
-      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 12, false, 0, false, false>" : "nrt::k_traverse_wide<double, 12, false, 0, false, false>",
+      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 12, false, 0, false, false, false>" : "nrt::k_traverse_wide<double, 12, false, 0, false, false, false>",
                       T, 12, false, kPrimTriangles);
       break;
     default:
-      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 16, false, 0, false, false>" : "nrt::k_traverse_wide<double, 16, false, 0, false, false>",
+      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 16, false, 0, false, false, false>" : "nrt::k_traverse_wide<double, 16, false, 0, false, false, false>",
                       T, 16, false, kPrimTriangles);
       break;
   }
@@ -1777,7 +1787,7 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
 #undef NRT_LAUNCH_WIDE
 
 template <typename T>
-int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind) {
+int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool split) {
   int n = 0;
   hipError_t e;
   if (prim_kind == kPrimSpheres) {
@@ -1787,7 +1797,12 @@ int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind) {
   } else {
     switch (lds_stack) {
       case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 8, false, kPrimTriangles>, kTraverseBlock, 0); break;
-      case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimTriangles, true, true>, kTraverseBlock, 0); break;
+      case 10:
+        if (split)
+          e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimTriangles, true, true>, kTraverseBlock, 0);
+        else
+          e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimTriangles, true, false>, kTraverseBlock, 0);
+        break;
       case 12: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 12, false, kPrimTriangles>, kTraverseBlock, 0); break;
       default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 16, false, kPrimTriangles>, kTraverseBlock, 0); break;
     }
@@ -1851,8 +1866,8 @@ template hipError_t launch_traverse<float>(const TraverseArgs<float> &, unsigned
 template hipError_t launch_traverse<double>(const TraverseArgs<double> &, unsigned, bool, int, hipStream_t);
 template hipError_t launch_traverse_wide<float>(const TraverseArgs<float> &, unsigned, int, int, hipStream_t, const char **);
 template hipError_t launch_traverse_wide<double>(const TraverseArgs<double> &, unsigned, int, int, hipStream_t, const char **);
-template int traverse_wide_blocks_per_cu<float>(int, int);
-template int traverse_wide_blocks_per_cu<double>(int, int);
+template int traverse_wide_blocks_per_cu<float>(int, int, bool);
+template int traverse_wide_blocks_per_cu<double>(int, int, bool);
 template hipError_t launch_gather_leaf_spheres<float>(const uint32_t *, const float *, const float *, LeafSphere<float> *,
                                                       uint32_t, hipStream_t);
 template hipError_t launch_gather_leaf_spheres<double>(const uint32_t *, const double *, const double *,

@@ -26,5 +26,5 @@ for name, rays in (("primary", rays1), ("bounce", rays2)):
         dry, end = c[:, 1] - t0, c[:, 2] - t0
         q = lambda x, p: float(np.percentile(x, p))
         print("%s (%s): span %.1f us (event %.1f) | start spread %.1f | dry: first %.1f p10 %.1f median %.1f p90 %.1f last %.1f | done: p10 %.1f median %.1f p90 %.1f last %.1f | drain mean %.1f longest %.1f | idle wave-time before the end %.1f%%" % (
-            name, a.LastKernelName()[-12:], end.max(), a.LastTraverseMs() * 1e3, (c[:, 0] - t0).max(), dry.min(), q(dry, 10), q(dry, 50), q(dry, 90), dry.max(),
+            name, a.LastKernelName()[-19:], end.max(), a.LastTraverseMs() * 1e3, (c[:, 0] - t0).max(), dry.min(), q(dry, 10), q(dry, 50), q(dry, 90), dry.max(),
             q(end, 10), q(end, 50), q(end, 90), end.max(), (end - dry).mean(), (end - dry).max(), 100.0 * (end.max() - end).sum() / (end.max() * n)), flush=True)
