@@ -25,7 +25,7 @@ int traverse_blocks_per_cu(int lds_stack);
 template <typename T>
 hipError_t launch_traverse_wide(const TraverseArgs<T> &, unsigned grid, int lds_stack, int prim_kind, hipStream_t, const char **name_out);
 template <typename T>
-int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool split);
+int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool split, bool wide4);
 template <typename T>
 hipError_t launch_gather_leaf_spheres(const uint32_t *, const T *, const T *, LeafSphere<T> *, uint32_t, hipStream_t);
 template <typename T>
@@ -33,7 +33,7 @@ hipError_t launch_gather_leaf_cylinders(const uint32_t *, const T *, const T *, 
 hipError_t launch_cylinder_post(const nrt_ray_f32 *, const nrt_hit_f32 *, const uint8_t *, const float *, uint32_t, void *,
                                 uint8_t *, hipStream_t);
 template <typename T>
-hipError_t launch_make_wide(const typename Wire<T>::Node *, uint32_t, uint32_t packed, uint32_t *scratch, WideNode<T> *,
+hipError_t launch_make_wide(const typename Wire<T>::Node *, uint32_t, uint32_t packed, uint32_t *scratch, WideNode<T> *, Wide4Node<T> *,
                             hipStream_t);
 template <typename T>
 hipError_t launch_gather_leaf_tris(const uint32_t *, const uint32_t *, const T *, LeafTri<T> *,
@@ -69,11 +69,12 @@ struct nrt_ctx {
   uint32_t num_faces = 0, num_verts = 0;
 
   // tree (grow-only buffers: a per-frame rebuild allocates nothing in the steady state)
-  DevBuf b_nodes, b_indices, b_tris, b_wide, b_wide_scratch, b_build_ws;
+  DevBuf b_nodes, b_indices, b_tris, b_wide, b_wide4, b_wide_scratch, b_build_ws;
   void *d_nodes = nullptr;       // == b_nodes.p while a tree is present
   uint32_t *d_indices = nullptr; // == b_indices.p
   void *d_tris = nullptr;        // LeafTri<T>[num_indices] == b_tris.p
   void *d_wide = nullptr;        // WideNode<T>[branches]   == b_wide.p
+  void *d_wide4 = nullptr;       // Wide4Node<T>[branches]  == b_wide4.p (triangle trees only, and only when wide4 is on)
   uint32_t num_branch_records = 0; // nodes with flag == 0 in the node array (reachable or not)
   uint64_t num_nodes = 0, num_indices = 0;
   uint32_t tree_depth = 0;
@@ -123,6 +124,10 @@ struct nrt_ctx {
   // LOSE on C3 (profiles/r02c_split_*.txt: bounce wave 0.50 -> 0.51-0.59 ms depending on the hand-out policy), because
   // under the while-while loop every helper adds leaf rounds that stall the very ray it helps.  Off unless NRT_SPLIT=1.
   int split = 0;
+  // Two tree levels per step (Wide4Node records, traverse.hip NRT_STEP_NODE4): the production walk of fp32 triangle trees
+  // whose child boxes lie inside their parents'.  env NRT_WIDE4=0 goes back to one level per step.
+  int wide4 = 1;
+  unsigned wide4_blocks_per_cu = 0;
   unsigned drain_steps = 8, split_busy = 8; // hand-out policy (env NRT_DRAIN_STEPS, NRT_SPLIT_BUSY)
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
 
@@ -175,6 +180,7 @@ static hipError_t wait_for_launches(nrt_ctx *c) {
 // Forget the current tree (the buffers stay allocated for the next one).
 static void free_tree(nrt_ctx *c) {
   c->d_wide = nullptr;
+  c->d_wide4 = nullptr;
   c->d_nodes = nullptr;
   c->d_indices = nullptr;
   c->d_tris = nullptr;
@@ -258,6 +264,7 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   if (const char *e = getenv("NRT_BLOCKS_PER_CU")) c->max_blocks_per_cu = (unsigned)std::max(0, atoi(e));
   if (const char *e = getenv("NRT_WIDE")) c->wide = atoi(e) != 0;
   if (const char *e = getenv("NRT_SPLIT")) c->split = atoi(e) != 0;
+  if (const char *e = getenv("NRT_WIDE4")) c->wide4 = atoi(e) != 0;
   if (const char *e = getenv("NRT_HOST_PIPELINE")) c->host_pipeline = atoi(e) != 0;
   if (const char *e = getenv("NRT_DRAIN_STEPS")) c->drain_steps = (unsigned)std::max(1, atoi(e));
   if (const char *e = getenv("NRT_SPLIT_BUSY")) c->split_busy = (unsigned)std::min(64, std::max(0, atoi(e)));
@@ -286,7 +293,7 @@ void nrtDestroy(nrt_ctx *c) {
   }
   free_tree(c);
   free_mesh(c);
-  DevBuf *bufs[] = {&c->b_verts, &c->b_radii, &c->b_faces, &c->st_rays, &c->st_hits, &c->st_mask, &c->b_nodes, &c->b_indices, &c->b_tris, &c->b_wide, &c->b_wide_scratch, &c->b_build_ws, &c->b_wave_clock};
+  DevBuf *bufs[] = {&c->b_verts, &c->b_radii, &c->b_faces, &c->st_rays, &c->st_hits, &c->st_mask, &c->b_nodes, &c->b_indices, &c->b_tris, &c->b_wide, &c->b_wide4, &c->b_wide_scratch, &c->b_build_ws, &c->b_wave_clock};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->d_counters) (void)hipFree(c->d_counters);
@@ -437,8 +444,13 @@ static nrt_status finish_tree(nrt_ctx *c) {
                       c->num_indices <= (uint64_t)kPackedFirstMask) ? 1u : 0u;
   const size_t tiles = (c->num_nodes + 1023) / 1024;
   if ((st = ensure(c, c->b_wide_scratch, (tiles + c->num_nodes + 1) * sizeof(uint32_t)))) return st;
+  c->d_wide4 = nullptr;
+  if (c->wide4 && c->prim_kind == kPrimTriangles && sizeof(T) == 4) {
+    if ((st = ensure(c, c->b_wide4, std::max<size_t>(1, c->num_branch_records) * sizeof(Wide4Node<T>)))) return st;
+    c->d_wide4 = c->b_wide4.p;
+  }
   HIPCHK(c, launch_make_wide<T>((const typename Wire<T>::Node *)c->d_nodes, (uint32_t)c->num_nodes, c->packed_leaves,
-                                (uint32_t *)c->b_wide_scratch.p, (WideNode<T> *)c->d_wide, c->stream));
+                                (uint32_t *)c->b_wide_scratch.p, (WideNode<T> *)c->d_wide, (Wide4Node<T> *)c->d_wide4, c->stream));
   return NRT_OK;
 }
 
@@ -646,11 +658,15 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
     return fail(c, NRT_ERR_INVALID, "nrtOccludedBatch: occlusion queries run on the triangle WideNode kernel only");
   const bool use_wide = (c->wide || spheres || any_hit) && !count && c->d_wide;
   if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
-  if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, c->split != 0);
-  if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, false);
-  unsigned blocks_per_cu = spheres ? c->sphere_blocks_per_cu : (use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu);
+  // two levels per step: closest-hit walks of nested fp32 triangle trees, outside the profiling / splitting variants
+  const bool use_wide4 = use_wide && !spheres && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch &&
+                         !c->split && !(c->debug_flags & (32u | 8192u));
+  if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, c->split != 0, false);
+  if (use_wide4 && c->wide4_blocks_per_cu == 0) c->wide4_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(kWide4LdsStack, kPrimTriangles, false, true);
+  if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, false, false);
+  unsigned blocks_per_cu = spheres ? c->sphere_blocks_per_cu : (use_wide4 ? c->wide4_blocks_per_cu : (use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu));
   if (c->max_blocks_per_cu && blocks_per_cu > c->max_blocks_per_cu) blocks_per_cu = c->max_blocks_per_cu;
-  const int stack_entries = spheres ? 10 : (use_wide ? c->wide_stack : c->lds_stack);
+  const int stack_entries = spheres ? 10 : (use_wide4 ? kWide4LdsStack : (use_wide ? c->wide_stack : c->lds_stack));
   uint64_t need_blocks = (n + kTraverseBlock - 1) / kTraverseBlock;
   unsigned grid = (unsigned)std::min<uint64_t>(need_blocks, (uint64_t)c->num_cus * blocks_per_cu);
   const unsigned parts = std::max(1u, std::min(c->num_parts, grid));
@@ -659,7 +675,9 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   const uint32_t total_waves = grid * (kTraverseBlock / kWave);
   // static share: a multiple of 64 rays per wave, c->static_pct percent of the batch in total
   const uint32_t static_per_wave = (uint32_t)(((uint64_t)n * c->static_pct / 100) / total_waves / 64) * 64;
-  const uint32_t levels = c->tree_depth + 2 > (uint32_t)stack_entries ? c->tree_depth + 2 - stack_entries : 0;
+  // deepest possible stack: one pending sibling per level of the path — three per TWO levels when a step covers two
+  const uint32_t max_entries = use_wide4 ? 3u * (c->tree_depth / 2u + 1u) + 2u : c->tree_depth + 2u;
+  const uint32_t levels = max_entries > (uint32_t)stack_entries ? max_entries - stack_entries : 0;
   if (levels) { // (growing a buffer frees the old one, which waits for every launch in flight)
     nrt_status st = ensure(c, slot->spill, (size_t)levels * total_threads * sizeof(uint32_t));
     if (st) return st;
@@ -677,6 +695,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.cylinders = (const LeafCylinder<T> *)c->d_tris;
   a.cyl_test_cap = c->cyl_test_cap;
   a.wide = (const WideNode<T> *)c->d_wide;
+  a.wide4 = use_wide4 ? (const Wide4Node<T> *)c->d_wide4 : nullptr;
   a.packed_leaves = c->packed_leaves;
   a.root_is_branch = c->root_is_branch;
   a.debug_flags = c->debug_flags;

@@ -114,6 +114,26 @@ struct alignas(16) WideNode {
 };
 static_assert(sizeof(WideNode<float>) == 64, "WideNode<float>");
 static_assert(sizeof(WideNode<double>) == 112, "WideNode<double>");
+// Two levels of the tree in one record: the boxes of the (up to) four GRANDCHILDREN of a branch node, component-major
+// so that one 16-byte load brings the same plane of all four boxes.  Slots 0,1 = the children of child data[0], slots
+// 2,3 = the children of child data[1]; a child that is itself a leaf sits in the first slot of its half (its own box
+// and leaf reference) and the second slot of that half is empty (c == kWide4Empty).  There is one record per branch
+// node, at the same dense index as its WideNode, so any branch can be entered through either array; a walk that
+// starts at record 0 and follows c[] only ever touches the records of the even-depth branches.
+// axis0 = split axis of the node, axis1 / axis2 = split axes of child data[0] / data[1] (0 when that child is a leaf).
+// Walking this array visits the same leaves in the same order as the binary loop (see NRT_STEP_NODE4, traverse.hip).
+template <typename T>
+struct alignas(16) Wide4Node {
+  T bmin[3][4]; // [component][slot]
+  T bmax[3][4];
+  uint32_t c[4]; // child references, encoded like WideNode::c0 / c1
+  int32_t axis0, axis1, axis2;
+  uint32_t pad;
+};
+static_assert(sizeof(Wide4Node<float>) == 128, "Wide4Node<float>");
+static_assert(sizeof(Wide4Node<double>) == 224, "Wide4Node<double>");
+constexpr uint32_t kWide4Empty = 0xFFFFFFFFu;
+constexpr int kWide4LdsStack = 12; // per-lane LDS stack entries of the WIDTH = 4 variants (24 KiB per block: six blocks per CU)
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kPackedFirstBits = 27;
 constexpr uint32_t kPackedFirstMask = (1u << kPackedFirstBits) - 1u;
@@ -165,6 +185,7 @@ struct TraverseArgs {
   const LeafCylinder<T> *cylinders; // primitive kind 2 (leaf order)
   uint32_t cyl_test_cap;         // primitive kind 2: the intersector's test_cap flag
   const WideNode<T> *wide; // may be null (binary kernel only)
+  const Wide4Node<T> *wide4; // may be null: two tree levels per record (the WIDTH = 4 variants)
   uint32_t packed_leaves;  // leaf references of `wide` are PACKED (see WideNode)
   uint32_t root_is_branch; // node 0 is a branch (every tree of more than one node)
   uint32_t debug_flags;    // profiling only (env NRT_DEBUG): 1 = skip triangle tests, 2 = skip traversal

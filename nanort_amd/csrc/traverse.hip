@@ -16,6 +16,11 @@
 //                            hit iff t_best < ray.max_t)
 #include "common.h"
 
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+
 namespace nrt {
 
 template <typename T>
@@ -767,6 +772,53 @@ __device__ __forceinline__ SlabPair<double> slab_pair(const Lane<double> &L, con
   return r;
 }
 
+// The four boxes of one Wide4Node.  fp32: slots (0,1) and (2,3) ride in register pairs as in slab_pair.
+template <typename T>
+struct Slab4 {
+  bool h[4];
+  T tm[4];
+};
+
+__device__ __forceinline__ Slab4<float> slab4(const Lane<float> &L, const Wide4Node<float> &w) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 mm = {Const<float>::maxmult(), Const<float>::maxmult()};
+  float tmin[4] = {L.min_t, L.min_t, L.min_t, L.min_t}, tmax[4] = {L.hit_t, L.hit_t, L.hit_t, L.hit_t};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int sg = L.sign(k);
+    const f2 o = {L.org(k), L.org(k)};
+    const f2 iv = {L.inv(k), L.inv(k)};
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const f2 lo = {sg ? w.bmax[k][2 * p] : w.bmin[k][2 * p], sg ? w.bmax[k][2 * p + 1] : w.bmin[k][2 * p + 1]};
+      const f2 hi = {sg ? w.bmin[k][2 * p] : w.bmax[k][2 * p], sg ? w.bmin[k][2 * p + 1] : w.bmax[k][2 * p + 1]};
+      const f2 t0 = (lo - o) * iv;
+      const f2 t1 = ((hi - o) * iv) * mm;
+      tmin[2 * p] = Const<float>::fmax(t0.x, tmin[2 * p]); // see slab_test
+      tmin[2 * p + 1] = Const<float>::fmax(t0.y, tmin[2 * p + 1]);
+      tmax[2 * p] = Const<float>::fmin(t1.x, tmax[2 * p]);
+      tmax[2 * p + 1] = Const<float>::fmin(t1.y, tmax[2 * p + 1]);
+    }
+  }
+  Slab4<float> r;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    r.h[j] = tmin[j] <= tmax[j];
+    r.tm[j] = tmin[j];
+  }
+  return r;
+}
+
+__device__ __forceinline__ Slab4<double> slab4(const Lane<double> &L, const Wide4Node<double> &w) {
+  Slab4<double> r;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const double box[6] = {w.bmin[0][j], w.bmin[1][j], w.bmin[2][j], w.bmax[0][j], w.bmax[1][j], w.bmax[2][j]};
+    r.h[j] = slab_test_tmin<double>(L, box, r.tm[j]);
+  }
+  return r;
+}
+
 // One stack entry: child reference + its t_min (the t_min is kept as raw bits next to the reference so
 // that one LDS access moves both).
 template <typename T>
@@ -842,6 +894,57 @@ do {                                                                            
 } while (0)
 
 
+// The same step over a Wide4Node record: the four grandchild boxes tested at once.  Why this visits the same leaves in
+// the same order as the binary loop (nanort.h:2526-2548) on a tree whose child boxes lie inside their parents':
+//  * order — the binary loop enters near child (by the node's axis) before far child, and inside each child its near
+//    grandchild (by the child's axis) before its far one; the four slots are ranked by exactly that rule, the first hit
+//    in rank order is entered and the others are pushed in reverse rank order, so they pop in rank order;
+//  * culling — the binary loop would also test the child's own box; a ray that hits a grandchild's box within
+//    [min_t, hit_t] hits the child's box within it too (the grandchild's box lies inside, the slab arithmetic is
+//    monotone), and a ray that misses the child's box misses both grandchildren, so skipping that test changes nothing;
+//  * hit distance — a grandchild of the FAR child is tested here with the hit distance of this moment instead of the
+//    later one the binary loop would use; every pushed entry is re-tested against the current hit distance when it is
+//    popped (NRT_POP_ENTRY), which is the binary loop's decision.
+// The half of a leaf child has one slot (the other is marked empty and never hit).
+#define NRT_STEP_NODE4(w_)                                                                             \
+do {                                                                                                 \
+  const Slab4<T> sl_ = slab4(L, (w_));                                                               \
+  const bool sA_ = L.sign((w_).axis1) != 0, sB_ = L.sign((w_).axis2) != 0, s0_ = L.sign((w_).axis0) != 0; \
+  const bool v1_ = (w_).c[1] != kWide4Empty, v3_ = (w_).c[3] != kWide4Empty;                         \
+  const bool h0_ = sl_.h[0], h1_ = sl_.h[1] & v1_, h2_ = sl_.h[2], h3_ = sl_.h[3] & v3_;             \
+  /* inside each half: near slot first */                                                            \
+  const bool an_ = sA_ ? h1_ : h0_, af_ = sA_ ? h0_ : h1_, bn_ = sB_ ? h3_ : h2_, bf_ = sB_ ? h2_ : h3_; \
+  const uint32_t ran_ = sA_ ? (w_).c[1] : (w_).c[0], raf_ = sA_ ? (w_).c[0] : (w_).c[1];             \
+  const uint32_t rbn_ = sB_ ? (w_).c[3] : (w_).c[2], rbf_ = sB_ ? (w_).c[2] : (w_).c[3];             \
+  const T tan_ = sA_ ? sl_.tm[1] : sl_.tm[0], taf_ = sA_ ? sl_.tm[0] : sl_.tm[1];                    \
+  const T tbn_ = sB_ ? sl_.tm[3] : sl_.tm[2], tbf_ = sB_ ? sl_.tm[2] : sl_.tm[3];                    \
+  /* the near half (by the node's own axis) first: ranks 0..3 */                                     \
+  const bool q0_ = s0_ ? bn_ : an_, q1_ = s0_ ? bf_ : af_, q2_ = s0_ ? an_ : bn_, q3_ = s0_ ? af_ : bf_; \
+  const uint32_t r0_ = s0_ ? rbn_ : ran_, r1_ = s0_ ? rbf_ : raf_, r2_ = s0_ ? ran_ : rbn_, r3_ = s0_ ? raf_ : rbf_; \
+  const T t1_ = s0_ ? tbf_ : taf_, t2_ = s0_ ? tan_ : tbn_, t3_ = s0_ ? taf_ : tbf_;                 \
+  NRT_PUSH_IF(q3_ & (q0_ | q1_ | q2_), r3_, t3_);                                                    \
+  NRT_PUSH_IF(q2_ & (q0_ | q1_), r2_, t2_);                                                          \
+  NRT_PUSH_IF(q1_ & q0_, r1_, t1_);                                                                  \
+  const bool any_ = q0_ | q1_ | q2_ | q3_;                                                           \
+  const uint32_t next_ = q0_ ? r0_ : (q1_ ? r1_ : (q2_ ? r2_ : r3_));                                \
+  cur = any_ ? (next_ & ~kLeafBit) : cur;                                                            \
+  state = any_ ? ((next_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP;                                     \
+} while (0)
+
+#define NRT_PUSH_IF(cond_, ref_, tm_)                                                                  \
+do {                                                                                                 \
+  if (cond_) {                                                                                       \
+    if (sp < STACK) {                                                                                \
+      s_stack[sp][tid] = SE::make((ref_), (tm_));                                                    \
+    } else {                                                                                         \
+      const size_t o_ = (size_t)(sp - STACK) * a.spill_stride + gslot;                               \
+      a.spill[o_] = (ref_);                                                                          \
+      a.spill_tmin[o_] = (tm_);                                                                      \
+    }                                                                                                \
+    sp++;                                                                                            \
+  }                                                                                                  \
+} while (0)
+
 // PLAIN: the launch uses trace options that cannot reject a primitive (full prim_ids_range, no skip_prim_id, no
 // back-face culling — the reference's defaults): the three id comparisons per triangle test are compiled out.
 //
@@ -883,9 +986,14 @@ struct FoldRec { // one per thread slot, used by the slot's lane when it owns a 
   uint32_t pend; // helpers outstanding (low 16 bits) | 0x80000000: some helper reported a violation
 };
 
+#ifndef NRT_W4_WAVES
+#define NRT_W4_WAVES 1 // minimum waves per SIMD asked of the WIDTH = 4 variants (1: whatever the register allocation gives)
+#endif
 // CLOCK: profiling instantiation that stamps when each wave starts, runs dry and finishes (tools/drain_probe.py).
-template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool SPLIT = false, bool CLOCK = false>
-__global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) void k_traverse_wide(const TraverseArgs<T> a) {
+// WIDTH: 2 = one WideNode (two boxes) per step, 4 = one Wide4Node (two levels, four boxes) per step.
+template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool SPLIT = false, bool CLOCK = false, int WIDTH = 2>
+__global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((WIDTH == 4 && sizeof(T) == 4) ? NRT_W4_WAVES : 1)) void k_traverse_wide(const TraverseArgs<T> a) {
+  static_assert(WIDTH == 2 || (WIDTH == 4 && !SPLIT && !STATS && KIND == kPrimTriangles), "the two-level step is a triangle closest-hit variant");
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
   __shared__ FoldRec<T> s_fold[SPLIT ? kTraverseBlock : 1];
@@ -1037,8 +1145,30 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : 1) 
       if (state == W_POP) NRT_POP_ENTRY();
       if (state == W_TRAV) {
         if (STATS) st_steps++;
-        const WideNode<T> w = a.wide[cur];
-        NRT_STEP_NODE(w);
+        if constexpr (WIDTH == 4) {
+          const Wide4Node<T> w = a.wide4[cur];
+          NRT_STEP_NODE4(w);
+        } else {
+#ifdef NRT_PROBE_EXTRA_LOADS // sensitivity probe (tools/variant_ab.sh): N more 16-byte reads of the record about to be fetched
+          typedef uint32_t u4v_ __attribute__((ext_vector_type(4)));
+          u4v_ d0_; // (issued before the record's own loads, which return after them; kept live past the step)
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d0_) : "v"(a.wide + cur) : "memory");
+          for (int x_ = 1; x_ < NRT_PROBE_EXTRA_LOADS; x_++) // (same destination: the returns are in order)
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "+v"(d0_) : "v"(a.wide + cur) : "memory");
+#endif
+          const WideNode<T> w = a.wide[cur];
+#ifdef NRT_PROBE_EXTRA_VALU // ... N more dependent v_fma_f32 per step
+          {
+            float f_ = __uint_as_float(cur);
+            for (int x_ = 0; x_ < NRT_PROBE_EXTRA_VALU; x_++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f_));
+            asm volatile("" :: "v"(f_));
+          }
+#endif
+          NRT_STEP_NODE(w);
+#ifdef NRT_PROBE_EXTRA_LOADS
+          asm volatile("" :: "v"(d0_));
+#endif
+        }
       }
       // Leave when only a few lanes still walk — unless nothing else could be done anyway: no lane waits at a leaf
       // and there are no rays left to hand out (the drain of a launch: the last long rays then stay in this
@@ -1601,13 +1731,14 @@ __global__ __launch_bounds__(256) void k_wide_index(const typename Wire<T>::Node
 template <typename T>
 __global__ __launch_bounds__(256) void k_make_wide(const typename Wire<T>::Node *__restrict__ nodes, uint32_t n,
                                                    const uint32_t *__restrict__ dense_of, uint32_t packed,
-                                                   WideNode<T> *__restrict__ wide) {
+                                                   WideNode<T> *__restrict__ wide, Wide4Node<T> *__restrict__ wide4) {
+  typedef typename Wire<T>::Node Node;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  const typename Wire<T>::Node nd = nodes[i];
+  const Node nd = nodes[i];
   if (nd.flag != 0) return;
   if (nd.data[0] >= n || nd.data[1] >= n) return; // an unreachable record of a loaded tree: never visited
-  const typename Wire<T>::Node a = nodes[nd.data[0]], b = nodes[nd.data[1]];
+  const Node a = nodes[nd.data[0]], b = nodes[nd.data[1]];
   WideNode<T> w;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -1623,6 +1754,45 @@ __global__ __launch_bounds__(256) void k_make_wide(const typename Wire<T>::Node 
   w.axis = nd.axis;
   w.pad = 0;
   wide[dense_of[i]] = w;
+  if (wide4 == nullptr) return;
+  // the record over two levels: each child's children (or the child itself, when it is a leaf)
+  Wide4Node<T> q;
+  q.axis0 = nd.axis;
+  q.pad = 0;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const Node &ch = h == 0 ? a : b;
+    const uint32_t ch_ref = h == 0 ? w.c0 : w.c1;
+    const bool two = ch.flag == 0 && ch.data[0] < n && ch.data[1] < n;
+    int32_t axis = 0;
+    if (two) {
+      axis = ch.axis;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const uint32_t gi = ch.data[j];
+        const Node g = nodes[gi];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          q.bmin[k][2 * h + j] = g.bmin[k];
+          q.bmax[k][2 * h + j] = g.bmax[k];
+        }
+        const uint32_t lg = packed ? (((g.data[0] - 1u) << kPackedFirstBits) | g.data[1]) : gi;
+        q.c[2 * h + j] = g.flag != 0 ? (kLeafBit | lg) : dense_of[gi];
+      }
+    } else { // a leaf child (or a branch whose children cannot be read: then it is entered through its own record)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        q.bmin[k][2 * h] = ch.bmin[k];
+        q.bmax[k][2 * h] = ch.bmax[k];
+        q.bmin[k][2 * h + 1] = ch.bmin[k];
+        q.bmax[k][2 * h + 1] = ch.bmax[k];
+      }
+      q.c[2 * h] = ch_ref;
+      q.c[2 * h + 1] = kWide4Empty;
+    }
+    if (h == 0) q.axis1 = axis; else q.axis2 = axis;
+  }
+  wide4[dense_of[i]] = q;
 }
 
 // Leaf-ordered triangle records from (indices, faces, tight vertices).
@@ -1719,81 +1889,86 @@ int traverse_blocks_per_cu(int lds_stack) {
 }
 
 // `name_out` (optional) receives the name of the variant launched, as rocprofv3 prints it without the argument list.
-#define NRT_LAUNCH_WIDE(NAME, ...)                                                                  \
-  do {                                                                                                \
-    hipLaunchKernelGGL((k_traverse_wide<__VA_ARGS__>), dim3(grid), dim3(kTraverseBlock), 0, s, args); \
-    if (name_out) *name_out = NAME;                                                                   \
+static const char *variant_name(bool f32, int stack, bool stats, int kind, bool plain, bool split, bool clock, int width) {
+  static std::mutex m;
+  static std::map<std::string, std::string> *names = new std::map<std::string, std::string>(); // (never destroyed: the pointers are handed out)
+  char buf[160];
+  snprintf(buf, sizeof(buf), "nrt::k_traverse_wide<%s, %d, %s, %d, %s, %s, %s, %d>", f32 ? "float" : "double", stack,
+           stats ? "true" : "false", kind, plain ? "true" : "false", split ? "true" : "false", clock ? "true" : "false", width);
+  std::lock_guard<std::mutex> lock(m);
+  return names->emplace(buf, buf).first->second.c_str();
+}
+#define NRT_LAUNCH_WIDE(STACK_, STATS_, KIND_, PLAIN_, SPLIT_, CLOCK_, WIDTH_)                                          \
+  do {                                                                                                                  \
+    hipLaunchKernelGGL((k_traverse_wide<T, STACK_, STATS_, KIND_, PLAIN_, SPLIT_, CLOCK_, WIDTH_>), dim3(grid),         \
+                       dim3(kTraverseBlock), 0, s, args);                                                               \
+    if (name_out) *name_out = variant_name(sizeof(T) == 4, STACK_, STATS_, KIND_, PLAIN_, SPLIT_, CLOCK_, WIDTH_);      \
   } while (0)
 
 template <typename T>
 hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int lds_stack, int prim_kind, hipStream_t s,
                                 const char **name_out) {
-  constexpr bool f32 = sizeof(T) == 4;
   if (prim_kind == kPrimSpheres) { // one instantiation: 10 LDS entries (the caller sizes the overflow stack for it)
-    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 1, false, false, false>" : "nrt::k_traverse_wide<double, 10, false, 1, false, false, false>",
-                    T, 10, false, kPrimSpheres);
+    NRT_LAUNCH_WIDE(10, false, kPrimSpheres, false, false, false, 2);
     if (args.hits)
       hipLaunchKernelGGL((k_sphere_uv<T>), dim3((args.num_rays + 255u) / 256u), dim3(256), 0, s, args.rays, args.hits,
                          args.centers, args.num_rays);
     return hipGetLastError();
   }
   if (prim_kind == kPrimCylinders) {
-    NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 2, false, false, false>" : "nrt::k_traverse_wide<double, 10, false, 2, false, false, false>",
-                    T, 10, false, kPrimCylinders);
+    NRT_LAUNCH_WIDE(10, false, kPrimCylinders, false, false, false, 2);
     return hipGetLastError();
   }
+  if (args.wide4) { // two tree levels per step (the caller checked what that needs)
+    if constexpr (sizeof(T) == 4) {
+      if (args.plain_options)
+        NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, false, false, 4);
+      else
+        NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, false, false, false, 4);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   switch (lds_stack) {
-    case 8:
-      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 8, false, 0, false, false, false>" : "nrt::k_traverse_wide<double, 8, false, 0, false, false, false>",
-                      T, 8, false, kPrimTriangles);
-      break;
+    case 8: NRT_LAUNCH_WIDE(8, false, kPrimTriangles, false, false, false, 2); break;
     case 10:
       if (args.debug_flags & 32u) {
-        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, true, 0, false, false, false>" : "nrt::k_traverse_wide<double, 10, true, 0, false, false, false>",
-                        T, 10, true, kPrimTriangles);
+        NRT_LAUNCH_WIDE(10, true, kPrimTriangles, false, false, false, 2);
       } else if (args.wave_clock) { // profiling: per-wave time stamps (default trace options only)
         if (args.split)
-          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, true, true>" : "nrt::k_traverse_wide<double, 10, false, 0, true, true, true>",
-                          T, 10, false, kPrimTriangles, true, true, true);
+          NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, true, true, 2);
         else
-          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, false, true>" : "nrt::k_traverse_wide<double, 10, false, 0, true, false, true>",
-                          T, 10, false, kPrimTriangles, true, false, true);
+          NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, false, true, 2);
       } else if (args.split) { // work splitting in the drain (a.split: see api.hip)
         if (args.plain_options)
-          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, true, false>" : "nrt::k_traverse_wide<double, 10, false, 0, true, true, false>",
-                          T, 10, false, kPrimTriangles, true, true);
+          NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, true, false, 2);
         else
-          NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, false, true, false>" : "nrt::k_traverse_wide<double, 10, false, 0, false, true, false>",
-                          T, 10, false, kPrimTriangles, false, true);
+          NRT_LAUNCH_WIDE(10, false, kPrimTriangles, false, true, false, 2);
       } else if (args.plain_options) {
-        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, true, false, false>" : "nrt::k_traverse_wide<double, 10, false, 0, true, false, false>",
-                        T, 10, false, kPrimTriangles, true);
+        NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, false, false, 2);
       } else {
-        NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 10, false, 0, false, false, false>" : "nrt::k_traverse_wide<double, 10, false, 0, false, false, false>",
-                        T, 10, false, kPrimTriangles);
+        NRT_LAUNCH_WIDE(10, false, kPrimTriangles, false, false, false, 2);
       }
       break;
-    case 12:
-      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 12, false, 0, false, false, false>" : "nrt::k_traverse_wide<double, 12, false, 0, false, false, false>",
-                      T, 12, false, kPrimTriangles);
-      break;
-    default:
-      NRT_LAUNCH_WIDE(f32 ? "nrt::k_traverse_wide<float, 16, false, 0, false, false, false>" : "nrt::k_traverse_wide<double, 16, false, 0, false, false, false>",
-                      T, 16, false, kPrimTriangles);
-      break;
+    case 12: NRT_LAUNCH_WIDE(12, false, kPrimTriangles, false, false, false, 2); break;
+    default: NRT_LAUNCH_WIDE(16, false, kPrimTriangles, false, false, false, 2); break;
   }
   return hipGetLastError();
 }
 #undef NRT_LAUNCH_WIDE
 
 template <typename T>
-int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool split) {
+int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool split, bool wide4) {
   int n = 0;
-  hipError_t e;
+  hipError_t e = hipErrorInvalidValue;
   if (prim_kind == kPrimSpheres) {
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimSpheres>, kTraverseBlock, 0);
   } else if (prim_kind == kPrimCylinders) {
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimCylinders>, kTraverseBlock, 0);
+  } else if (wide4) {
+    if constexpr (sizeof(T) == 4)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, kWide4LdsStack, false, kPrimTriangles, true, false, false, 4>, kTraverseBlock, 0);
   } else {
     switch (lds_stack) {
       case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 8, false, kPrimTriangles>, kTraverseBlock, 0); break;
@@ -1814,14 +1989,14 @@ int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool split) {
 // scratch: tile counts (ceil(n/1024) u32) followed by dense_of (n u32)
 template <typename T>
 hipError_t launch_make_wide(const typename Wire<T>::Node *nodes, uint32_t n, uint32_t packed, uint32_t *scratch,
-                            WideNode<T> *wide, hipStream_t s) {
+                            WideNode<T> *wide, Wide4Node<T> *wide4, hipStream_t s) {
   if (n == 0) return hipSuccess;
   const uint32_t tiles = (n + 1023u) / 1024u;
   uint32_t *tile_count = scratch, *dense_of = scratch + tiles;
   hipLaunchKernelGGL((k_wide_count<T>), dim3(tiles), dim3(256), 0, s, nodes, n, tile_count);
   hipLaunchKernelGGL(k_wide_scan_tiles, dim3(1), dim3(256), 0, s, tile_count, tiles);
   hipLaunchKernelGGL((k_wide_index<T>), dim3(tiles), dim3(256), 0, s, nodes, n, tile_count, dense_of);
-  hipLaunchKernelGGL((k_make_wide<T>), dim3((n + 255u) / 256u), dim3(256), 0, s, nodes, n, dense_of, packed, wide);
+  hipLaunchKernelGGL((k_make_wide<T>), dim3((n + 255u) / 256u), dim3(256), 0, s, nodes, n, dense_of, packed, wide, wide4);
   return hipGetLastError();
 }
 
@@ -1866,16 +2041,16 @@ template hipError_t launch_traverse<float>(const TraverseArgs<float> &, unsigned
 template hipError_t launch_traverse<double>(const TraverseArgs<double> &, unsigned, bool, int, hipStream_t);
 template hipError_t launch_traverse_wide<float>(const TraverseArgs<float> &, unsigned, int, int, hipStream_t, const char **);
 template hipError_t launch_traverse_wide<double>(const TraverseArgs<double> &, unsigned, int, int, hipStream_t, const char **);
-template int traverse_wide_blocks_per_cu<float>(int, int, bool);
-template int traverse_wide_blocks_per_cu<double>(int, int, bool);
+template int traverse_wide_blocks_per_cu<float>(int, int, bool, bool);
+template int traverse_wide_blocks_per_cu<double>(int, int, bool, bool);
 template hipError_t launch_gather_leaf_spheres<float>(const uint32_t *, const float *, const float *, LeafSphere<float> *,
                                                       uint32_t, hipStream_t);
 template hipError_t launch_gather_leaf_spheres<double>(const uint32_t *, const double *, const double *,
                                                        LeafSphere<double> *, uint32_t, hipStream_t);
 template hipError_t launch_make_wide<float>(const nrt_node_f32 *, uint32_t, uint32_t, uint32_t *, WideNode<float> *,
-                                            hipStream_t);
+                                            Wide4Node<float> *, hipStream_t);
 template hipError_t launch_make_wide<double>(const nrt_node_f64 *, uint32_t, uint32_t, uint32_t *, WideNode<double> *,
-                                             hipStream_t);
+                                             Wide4Node<double> *, hipStream_t);
 template int traverse_blocks_per_cu<float>(int);
 template int traverse_blocks_per_cu<double>(int);
 template hipError_t launch_gather_leaf_tris<float>(const uint32_t *, const uint32_t *, const float *,
