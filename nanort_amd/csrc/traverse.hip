@@ -986,6 +986,12 @@ struct FoldRec { // one per thread slot, used by the slot's lane when it owns a 
   uint32_t pend; // helpers outstanding (low 16 bits) | 0x80000000: some helper reported a violation
 };
 
+#ifndef NRT_W4_TRI_UNROLL
+#define NRT_W4_TRI_UNROLL 2 // triangle records fetched per trip of the leaf loop in the WIDTH = 4 variants (1 or 2)
+#endif
+#ifndef NRT_W2_TRI_UNROLL
+#define NRT_W2_TRI_UNROLL 2 // ... and in the one-level variants (fp32 and fp64)
+#endif
 #ifndef NRT_W4_WAVES
 #define NRT_W4_WAVES 1 // minimum waves per SIMD asked of the WIDTH = 4 variants (1: whatever the register allocation gives)
 #endif
@@ -1203,6 +1209,23 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
         st_entries2++;
         st_idle2 += (unsigned)__builtin_popcountll(__ballot(state == W_IDLE));
       }
+      if constexpr (!SPLIT && !STATS && KIND == kPrimTriangles && (WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL) > 1) {
+        // several records per trip, all fetched before any is tested (same tests in the same order; fewer dependent
+        // round trips per leaf — this variant has the registers for it)
+        constexpr uint32_t U_ = WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL;
+        for (uint32_t i = 0; __ballot(i < cnt) != 0ull; i += U_) {
+          LeafTri<T> t_[U_];
+#pragma unroll
+          for (uint32_t j = 0; j < U_; j++) t_[j] = a.tris[first + (i + j < cnt ? i + j : 0u)];
+#pragma unroll
+          for (uint32_t j = 0; j < U_; j++) {
+            if (PLAIN)
+              tri_test<T, true>(L, t_[j], i + j < cnt, 0u, 0u, 0u, false);
+            else
+              tri_test<T>(L, t_[j], i + j < cnt, a.range0, a.range1, a.skip_prim, cull);
+          }
+        }
+      } else
       for (uint32_t i = 0; __ballot(i < cnt) != 0ull; i++) {
         if (STATS) {
           st_it2++;
