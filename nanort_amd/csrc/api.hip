@@ -42,10 +42,12 @@ struct BuildResult {
   uint64_t num_nodes;
   uint32_t max_depth, num_leaves, num_branches, max_leaf_count;
 };
+// (build.hip) enqueues a whole build; its size and statistics arrive in `pinned` behind `ev`: gpu_build_result waits for them
 template <typename T>
 hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, bool cylinders, uint32_t num_faces,
                      uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, bool morton_order,
-                     DevBuf *workspace, DevBuf *nodes_buf, DevBuf *indices_buf, BuildResult *res, std::string *err);
+                     DevBuf *workspace, DevBuf *nodes_buf, DevBuf *indices_buf, void *pinned, hipEvent_t ev, std::string *err);
+hipError_t gpu_build_result(const void *pinned, hipEvent_t ev, BuildResult *res);
 } // namespace nrt
 
 using namespace nrt;
@@ -132,6 +134,8 @@ struct nrt_ctx {
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
 
   hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;
+  hipEvent_t ev_build_state = nullptr; // the builder's state block has reached build_state
+  void *build_state = nullptr;         // page-locked, kBuildPinnedBytes
   int last_timed_slot = -1; // slot of the most recent timed traversal launch (nrtLastTraverseMs)
   bool have_build_time = false;
   const char *last_kernel = ""; // variant of the most recent traversal launch (nrtLastKernelName)
@@ -231,6 +235,8 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   if ((e = hipSetDevice(device)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
       (e = hipEventCreate(&c->ev_b0)) != hipSuccess || (e = hipEventCreate(&c->ev_b1)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&c->ev_build_state, hipEventDisableTiming)) != hipSuccess ||
+      (e = hipHostMalloc(&c->build_state, kBuildPinnedBytes, hipHostMallocDefault)) != hipSuccess ||
       (e = hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) {
     fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
     nrtDestroy(c);
@@ -297,7 +303,8 @@ void nrtDestroy(nrt_ctx *c) {
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->d_counters) (void)hipFree(c->d_counters);
-  hipEvent_t evs[] = {c->ev_b0, c->ev_b1};
+  if (c->build_state) (void)hipHostFree(c->build_state);
+  hipEvent_t evs[] = {c->ev_b0, c->ev_b1, c->ev_build_state};
   for (hipEvent_t ev : evs)
     if (ev) (void)hipEventDestroy(ev);
   for (int k = 0; k < 2; k++)
@@ -416,8 +423,10 @@ static nrt_status set_cylinders(nrt_ctx *c, const float *endpoints, const float 
 // ---------------------------------------------------------------------------
 // tree adoption / retrieval
 // ---------------------------------------------------------------------------
+// Private traversal layout of a tree, in two steps so that a build can enqueue the first while the tree's size is still
+// on its way to the host: (1) leaf-ordered primitive records (needs the index array only), (2) WideNode / Wide4Node arrays.
 template <typename T>
-static nrt_status finish_tree(nrt_ctx *c) {
+static nrt_status finish_leaf_records(nrt_ctx *c) {
   nrt_status st;
   // leaf-ordered primitive records for the traversal kernel
   if (c->prim_kind == kPrimSpheres) {
@@ -436,7 +445,12 @@ static nrt_status finish_tree(nrt_ctx *c) {
     HIPCHK(c, launch_gather_leaf_tris<T>(c->d_indices, c->d_faces, (const T *)c->d_verts,
                                          (LeafTri<T> *)c->d_tris, (uint32_t)c->num_indices, c->stream));
   }
-  // one WideNode per branch; a binary tree has (num_nodes - 1) / 2 of them
+  return NRT_OK;
+}
+
+template <typename T>
+static nrt_status finish_wide(nrt_ctx *c) {
+  nrt_status st;
   // one WideNode per record with flag == 0 (a loaded tree may carry unreachable ones)
   if ((st = ensure(c, c->b_wide, std::max<size_t>(1, c->num_branch_records) * sizeof(WideNode<T>)))) return st;
   c->d_wide = c->b_wide.p;
@@ -452,6 +466,12 @@ static nrt_status finish_tree(nrt_ctx *c) {
   HIPCHK(c, launch_make_wide<T>((const typename Wire<T>::Node *)c->d_nodes, (uint32_t)c->num_nodes, c->packed_leaves,
                                 (uint32_t *)c->b_wide_scratch.p, (WideNode<T> *)c->d_wide, (Wide4Node<T> *)c->d_wide4, c->stream));
   return NRT_OK;
+}
+
+template <typename T>
+static nrt_status finish_tree(nrt_ctx *c) {
+  nrt_status st = finish_leaf_records<T>(c);
+  return st ? st : finish_wide<T>(c);
 }
 
 template <typename T>
@@ -560,19 +580,25 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   std::string err;
   HIPCHK(c, hipEventRecord(c->ev_b0, c->stream));
   hipError_t e = gpu_build<T>(c->stream, (const T *)c->d_verts, c->d_faces, (const T *)c->d_radii, c->prim_kind == kPrimCylinders, c->num_faces, min_leaf, max_depth,
-                              bin_size, c->morton != 0, &c->b_build_ws, &c->b_nodes, &c->b_indices, &res, &err);
+                              bin_size, c->morton != 0, &c->b_build_ws, &c->b_nodes, &c->b_indices, c->build_state, c->ev_build_state, &err);
   if (e != hipSuccess) return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s (%s)", err.c_str(), hipGetErrorString(e));
+  // everything is enqueued; the leaf-ordered primitive records need the index array only, so they are enqueued too before
+  // the host waits for the tree's size (the GPU stays busy meanwhile)
   c->d_nodes = c->b_nodes.p;
   c->d_indices = (uint32_t *)c->b_indices.p;
-  c->num_nodes = res.num_nodes;
   c->num_indices = c->num_faces;
+  nrt_status fst = finish_leaf_records<T>(c);
+  if (fst) return fst;
+  if ((e = gpu_build_result(c->build_state, c->ev_build_state, &res)) != hipSuccess)
+    return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s", hipGetErrorString(e));
+  c->num_nodes = res.num_nodes;
   c->tree_depth = res.max_depth;
   c->max_leaf_count = res.max_leaf_count;
   c->num_branch_records = res.num_branches;
   c->root_is_branch = res.num_nodes > 1 ? 1u : 0u;
   c->min_leaf_count = 1; // the GPU builder never emits an empty leaf
   c->tree_nested = 1;    // a branch's box is the exact union of its children's
-  nrt_status fst = finish_tree<T>(c); // leaf-ordered triangles + WideNode array: part of the build
+  fst = finish_wide<T>(c); // WideNode arrays: part of the build
   if (fst) return fst;
   HIPCHK(c, hipEventRecord(c->ev_b1, c->stream));
   HIPCHK(c, hipEventSynchronize(c->ev_b1));

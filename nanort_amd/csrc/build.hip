@@ -52,7 +52,10 @@ struct BuildResult {
 };
 
 constexpr int kSmall = 256;     // nodes at or below this many primitives go to the subtree phase
-constexpr int kTile = 2048;     // primitives per top-phase chunk (256 threads x 8 rounds)
+#ifndef NRT_BUILD_TILE
+#define NRT_BUILD_TILE 2048
+#endif
+constexpr int kTile = NRT_BUILD_TILE; // primitives per top-phase chunk (256 threads x kTile / 256 rounds); any value gives the same tree
 constexpr int kMaxBins = 64;    // top phase: lane == bin
 constexpr int kSmallBins = 16;  // subtree phase: 3 x 15 candidates == 45 lanes
 constexpr uint32_t kMedian = 0xFFFFFFFFu;
@@ -173,6 +176,7 @@ struct LevelInfo {
   uint32_t child_base;  // first top index of the children created by the level being processed
   uint32_t top_cap;
   uint32_t num_levels;  // levels recorded in level_begin
+  uint32_t num_nodes;   // nodes of the finished tree (k_layout)
   uint32_t level_begin[kMaxTopLevels + 2];
 };
 
@@ -922,13 +926,14 @@ __global__ __launch_bounds__(256) void k_bin(const TopNode<T> *__restrict__ top,
   // nodes, wide bins — whole tiles land in one or two bins of an axis and every LDS atomic of a wave would hit the same
   // address (serialised 64 ways).  Run merging cuts those atomics 8x there and costs a compare per axis where the input
   // is incoherent (deep levels).
-  static_assert(kTile == 256 * 8, "k_bin: 8 primitives per lane");
+  static_assert(kTile % 256 == 0, "k_bin: a whole number of primitives per lane");
+  constexpr uint32_t kPerLane = kTile / 256;
   {
     int pb[3] = {-1, -1, -1};
     uint32_t pc[3] = {0, 0, 0};
     U pmin[3][3], pmax[3][3];
-    const uint32_t p0 = begin + threadIdx.x * 8u;
-    for (uint32_t it = 0; it < 8u; it++) {
+    const uint32_t p0 = begin + threadIdx.x * kPerLane;
+    for (uint32_t it = 0; it < kPerLane; it++) {
       const uint32_t p = p0 + it;
       if (p >= end) break;
       const PrimRec<T> r = recs[p];
@@ -1014,24 +1019,33 @@ __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *_
   int best_axis = 0;
   uint32_t best_bin = kMedian, best_nl = 0;
   typedef typename Ord<T>::U U;
+  // everything this wave reads from memory is requested up front — the three axes' bins and the node's range — so that the
+  // kernel pays one round trip instead of one per axis (the bins are reset right after, and stores pin later loads in place)
+  const uint32_t n = nd.r - nd.l, cb = nd.chunk_base, nch = nd.nchunks;
+  uint32_t cnt3[3] = {0, 0, 0};
+  U mn3[3][3], mx3[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if ((int)lane < K) cnt3[k] = g.count[k][lane];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      mn3[k][d] = Ord<T>::highest();
+      mx3[k][d] = Ord<T>::lowest();
+      if ((int)lane < K) {
+        mn3[k][d] = g.bmin[k][lane][d];
+        mx3[k][d] = g.bmax[k][lane][d];
+      }
+    }
+  }
+#pragma unroll
   for (int k = 0; k < 3; k++) {
     // scans on the integer images (see row_scan_step_e): DPP + scalar registers, no LDS crossbar
-    uint32_t cnt = 0;
+    const uint32_t cnt = cnt3[k];
     U pmn[3], pmx[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-      pmn[d] = Ord<T>::highest();
-      pmx[d] = Ord<T>::lowest();
-    }
-    if ((int)lane < K) {
-      cnt = g.count[k][lane];
-      if (cnt) {
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          pmn[d] = g.bmin[k][lane][d];
-          pmx[d] = g.bmax[k][lane][d];
-        }
-      }
+      pmn[d] = cnt ? mn3[k][d] : Ord<T>::highest();
+      pmx[d] = cnt ? mx3[k][d] : Ord<T>::lowest();
     }
     clean_bins<T>(&g, k, lane); // consumed: leave the slot clean for the next level (see clean_bins)
     if (a + num_active < max_active) clean_bins<T>(&gbins[a + num_active], k, lane);
@@ -1066,12 +1080,10 @@ __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *_
       best_nl = lane_bcast(nl, who);
     }
   }
-  const uint32_t n = nd.r - nd.l;
   if (best_bin == kMedian) best_nl = n >> 1; // no separable centroids: object median (nanort.h:1849)
 
   // per-chunk low-side counts -> exclusive prefix inside this node
   uint32_t carry = 0;
-  const uint32_t cb = nd.chunk_base, nch = nd.nchunks;
   for (uint32_t j0 = 0; j0 < nch; j0 += 64u) {
     const uint32_t j = j0 + lane;
     uint32_t left = 0;
@@ -1674,11 +1686,73 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
 // relayout: sizes bottom-up, DFS pre-order top-down (single block over the
 // small top array), then emission / splice
 // ---------------------------------------------------------------------------
+constexpr uint32_t kLayoutLds = 16384; // top arrays up to this many nodes are laid out from LDS (2 x 4 bytes per node, dynamic)
+constexpr uint32_t kLayoutOwn = kLayoutLds / 1024;
 template <typename T>
 __global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, LevelInfo *info) {
   const uint32_t *level_begin = info->level_begin;
   const int num_levels = (int)info->num_levels;
   // level_begin[0..num_levels]: top nodes of level L are [level_begin[L], level_begin[L+1])
+  // Two sweeps over the levels, each a chain of dependent reads (a parent's size needs its children's, a child's index
+  // its parent's).  For the usual small top array everything the sweeps touch is on chip: sizes and indices in LDS, each
+  // thread's own nodes' {kind, child} in registers, the level bounds in LDS — a level costs an LDS round trip and a barrier
+  // instead of two trips to L2 (14 levels each way at C3).
+  extern __shared__ uint32_t s_dyn[];
+  __shared__ uint32_t s_level[kMaxTopLevels + 2];
+  const uint32_t total = level_begin[num_levels];
+  if (total <= kLayoutLds) {
+    uint32_t *s_size = s_dyn, *s_dfs = s_dyn + kLayoutLds;
+    for (int L = (int)threadIdx.x; L <= num_levels; L += 1024) s_level[L] = level_begin[L];
+    uint32_t kc[kLayoutOwn]; // kind | child0 << 2 of node threadIdx.x + 1024 j
+#pragma unroll
+    for (uint32_t j = 0; j < kLayoutOwn; j++) {
+      const uint32_t i = threadIdx.x + 1024u * j;
+      kc[j] = 0xFFFFFFFFu;
+      if (i < total) {
+        const uint32_t kind = top[i].kind;
+        kc[j] = kind | (top[i].child0 << 2);
+        s_size[i] = kind == KIND_LEAF ? 1u : (kind == KIND_SMALL ? top[i].size : 0u);
+      }
+    }
+    __syncthreads();
+    for (int L = num_levels - 1; L >= 0; L--) {
+      const uint32_t lo = s_level[L], hi = s_level[L + 1];
+#pragma unroll
+      for (uint32_t j = 0; j < kLayoutOwn; j++) {
+        const uint32_t i = threadIdx.x + 1024u * j;
+        if (i >= lo && i < hi && (kc[j] & 3u) == KIND_SPLIT) s_size[i] = 1u + s_size[kc[j] >> 2] + s_size[(kc[j] >> 2) + 1u];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      s_dfs[0] = 0;
+      info->num_nodes = s_size[0];
+    }
+    __syncthreads();
+    for (int L = 0; L < num_levels; L++) {
+      const uint32_t lo = s_level[L], hi = s_level[L + 1];
+#pragma unroll
+      for (uint32_t j = 0; j < kLayoutOwn; j++) {
+        const uint32_t i = threadIdx.x + 1024u * j;
+        if (i >= lo && i < hi && (kc[j] & 3u) == KIND_SPLIT) {
+          const uint32_t c0 = kc[j] >> 2, d0 = s_dfs[i] + 1u;
+          s_dfs[c0] = d0;
+          s_dfs[c0 + 1u] = d0 + s_size[c0];
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kLayoutOwn; j++) {
+      const uint32_t i = threadIdx.x + 1024u * j;
+      if (i < total) {
+        const uint32_t kind = kc[j] & 3u;
+        if (kind == KIND_SPLIT || kind == KIND_LEAF) top[i].size = s_size[i];
+        top[i].dfs = s_dfs[i];
+      }
+    }
+    __syncthreads();
+  } else {
   for (int L = num_levels - 1; L >= 0; L--) {
     for (uint32_t i = level_begin[L] + threadIdx.x; i < level_begin[L + 1]; i += 1024u) {
       TopNode<T> &t = top[i];
@@ -1687,7 +1761,10 @@ __global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, LevelInfo *inf
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) top[0].dfs = 0;
+  if (threadIdx.x == 0) {
+    top[0].dfs = 0;
+    info->num_nodes = top[0].size;
+  }
   __syncthreads();
   for (int L = 0; L < num_levels; L++) {
     for (uint32_t i = level_begin[L] + threadIdx.x; i < level_begin[L + 1]; i += 1024u) {
@@ -1698,6 +1775,7 @@ __global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, LevelInfo *inf
       }
     }
     __syncthreads();
+  }
   }
   // stats of the top part
   uint32_t leaves = 0, branches = 0, deepest = 0;
@@ -1816,21 +1894,29 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
     }                                                                   \
   } while (0)
 
-// Builds into caller-owned grow-only buffers (no allocation in the steady state of a
-// per-frame rebuild).  Host synchronisations: one or two to learn that the top phase has
-// run out of large nodes, one to size the node array.
+// Builds into caller-owned grow-only buffers (no allocation in the steady state of a per-frame rebuild).
+// The host has to learn two things from the device: that the top phase has run out of large nodes, and the tree's size
+// and statistics.  Neither read-back leaves the GPU idle: the state block is copied into page-locked memory (`pinned`,
+// >= kBuildPinnedBytes) behind `ev`, and the stream is kept fed while the host waits for that event — with the level's own
+// kernels in the first case (they do nothing if the level turns out to be empty), with the emission kernels in the second
+// (their grids are upper bounds; the node array is sized for the 2n - 1 nodes a tree over n primitives can have).
+// gpu_build returns once everything is enqueued; gpu_build_result() waits for the final state block.
 template <typename T>
 hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, bool cylinders, uint32_t n,
                      uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, bool morton_order, DevBuf *workspace, DevBuf *nodes_buf,
-                     DevBuf *indices_buf, BuildResult *res, std::string *err) {
+                     DevBuf *indices_buf, void *pinned, hipEvent_t ev, std::string *err) {
   typedef typename Wire<T>::Node Node;
+  static_assert(offsetof(LevelInfo, level_begin) <= kBuildPinnedBytes, "state block");
   const int K = (int)(bin_size < 2 ? 2 : (bin_size > (uint32_t)kMaxBins ? (uint32_t)kMaxBins : bin_size));
   const int Ks = K < kSmallBins ? K : kSmallBins;
+  const size_t state_bytes = offsetof(LevelInfo, level_begin);
+  volatile const LevelInfo *hp = (volatile const LevelInfo *)pinned;
 
   for (size_t top_scale = 1;; top_scale *= 8) {
     const BuildPlan<T> plan(n, top_scale);
     BCHK(devbuf_ensure(workspace, plan.total));
     BCHK(devbuf_ensure(indices_buf, (size_t)n * sizeof(uint32_t)));
+    BCHK(devbuf_ensure(nodes_buf, (2 * (size_t)n) * sizeof(Node)));
     char *base = (char *)workspace->p;
     PrimRec<T> *recs[2] = {(PrimRec<T> *)(base + plan.off_recs0), (PrimRec<T> *)(base + plan.off_recs1)};
     Node *scratch = (Node *)(base + plan.off_scratch);
@@ -1876,11 +1962,13 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     BCHK(hipGetLastError());
 
     // ---- top phase: level after level, grids sized by upper bounds ----------------------------
-    LevelInfo h;
+    // From the level at which the nodes could first all be small, the state block written by k_level_setup is read
+    // back every level; the level's kernels are enqueued before the host waits for it.
     int expect = 0;
     for (size_t m = (size_t)n / kSmall; m > 0; m >>= 1) expect++;
-    int next_check = (n <= (uint32_t)kSmall) ? 0 : expect + 2;
+    const int first_check = (n <= (uint32_t)kSmall) ? 0 : expect + 2;
     bool overflow = false;
+    uint32_t num_small = 0;
     for (int level = 0;; level++) {
       // children of the level partitioned last (their records are in recs[cur]): inside k_level_setup while a level
       // cannot have more than 1024 active nodes, by a grid of their own below that
@@ -1891,15 +1979,10 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
                            (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, info);
       hipLaunchKernelGGL((k_level_setup<T>), dim3(1), dim3(1024), 0, s, top, active, chunk_base, info, child_acc,
                          (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, wide ? 0 : 1);
-      if (level >= next_check) {
-        BCHK(hipMemcpyAsync(&h, info, offsetof(LevelInfo, level_begin), hipMemcpyDeviceToHost, s));
-        BCHK(hipStreamSynchronize(s));
-        if (h.error) {
-          overflow = true;
-          break;
-        }
-        if (h.num_active == 0) break;
-        next_check = level + 3;
+      const bool check = level >= first_check;
+      if (check) {
+        BCHK(hipMemcpyAsync(pinned, info, state_bytes, hipMemcpyDeviceToHost, s));
+        BCHK(hipEventRecord(ev, s));
       }
       const size_t a_max = level < 31 ? std::min<size_t>((size_t)1 << level, plan.max_active) : plan.max_active;
       const size_t c_max = std::min<size_t>((size_t)n / kTile + a_max + 1, plan.max_chunks);
@@ -1911,41 +1994,56 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
                          chunk_left, recs[cur], recs[1 - cur], K, child_acc);
       BCHK(hipGetLastError());
       cur = 1 - cur;
+      if (check) {
+        BCHK(hipEventSynchronize(ev));
+        if (hp->error) {
+          overflow = true;
+          break;
+        }
+        if (hp->num_active == 0) { // (the three launches above found nothing to do)
+          num_small = hp->num_small;
+          break;
+        }
+      }
     }
     if (overflow) continue; // lopsided splits outgrew the top array: retry with a larger one
 
-    // ---- subtree phase + relayout ----------------------------------------------------------------
-    const uint32_t num_small = h.num_small;
+    // ---- subtree phase + relayout + emission ---------------------------------------------------------
     if (num_small) {
       hipLaunchKernelGGL((k_subtree<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
                          min_leaf, max_depth, scratch, indices, info);
     }
-    hipLaunchKernelGGL((k_layout<T>), dim3(1), dim3(1024), 0, s, top, info);
-    BCHK(hipGetLastError());
-    TopNode<T> root;
-    BCHK(hipMemcpyAsync(&root, top, sizeof(root), hipMemcpyDeviceToHost, s));
-    BCHK(hipMemcpyAsync(&h, info, offsetof(LevelInfo, level_begin), hipMemcpyDeviceToHost, s));
-    BCHK(hipStreamSynchronize(s));
-    const uint64_t num_nodes = root.size;
-    BCHK(devbuf_ensure(nodes_buf, num_nodes * sizeof(Node)));
+    BCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_layout<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)(2 * kLayoutLds * sizeof(uint32_t)))); // (per device: set on every build, it costs nothing)
+    hipLaunchKernelGGL((k_layout<T>), dim3(1), dim3(1024), 2 * kLayoutLds * sizeof(uint32_t), s, top, info);
+    BCHK(hipMemcpyAsync(pinned, info, state_bytes, hipMemcpyDeviceToHost, s));
+    BCHK(hipEventRecord(ev, s));
     Node *nodes = (Node *)nodes_buf->p;
-    hipLaunchKernelGGL((k_emit_top<T>), dim3((h.top_count + 255) / 256), dim3(256), 0, s, top, info, recs[0], recs[1],
+    hipLaunchKernelGGL((k_emit_top<T>), dim3((unsigned)((plan.max_top + 255) / 256)), dim3(256), 0, s, top, info, recs[0], recs[1],
                        nodes, indices);
     if (num_small)
       hipLaunchKernelGGL((k_emit_small<T>), dim3(num_small), dim3(64), 0, s, top, small_list, scratch, nodes, info);
     BCHK(hipGetLastError());
-    res->num_nodes = num_nodes;
-    res->max_depth = h.max_depth;
-    res->num_leaves = h.num_leaves;
-    res->num_branches = h.num_branches;
-    res->max_leaf_count = h.max_leaf_count;
     return hipSuccess;
   }
 }
 
+// Waits for the state block of the build enqueued last with this (pinned, ev) pair.
+hipError_t gpu_build_result(const void *pinned, hipEvent_t ev, BuildResult *res) {
+  hipError_t e = hipEventSynchronize(ev);
+  if (e != hipSuccess) return e;
+  volatile const LevelInfo *hp = (volatile const LevelInfo *)pinned;
+  res->num_nodes = hp->num_nodes;
+  res->max_depth = hp->max_depth;
+  res->num_leaves = hp->num_leaves;
+  res->num_branches = hp->num_branches;
+  res->max_leaf_count = hp->max_leaf_count;
+  return hipSuccess;
+}
+
 template hipError_t gpu_build<float>(hipStream_t, const float *, const uint32_t *, const float *, bool, uint32_t, uint32_t,
-                                     uint32_t, uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
+                                     uint32_t, uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, void *, hipEvent_t, std::string *);
 template hipError_t gpu_build<double>(hipStream_t, const double *, const uint32_t *, const double *, bool, uint32_t, uint32_t,
-                                      uint32_t, uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, BuildResult *, std::string *);
+                                      uint32_t, uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, void *, hipEvent_t, std::string *);
 
 } // namespace nrt

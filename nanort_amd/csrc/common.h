@@ -20,6 +20,7 @@ constexpr int kLdsStackDefault = 32; // per-lane stack entries kept in LDS (32 -
 constexpr unsigned kInvalid = 0xFFFFFFFFu;
 constexpr unsigned kCursorStrideWords = 1024; // per-partition work cursors 4 KiB apart (separate memory channels)
 constexpr unsigned kMaxParts = 16;
+constexpr size_t kBuildPinnedBytes = 1024; // page-locked block the builder's state is read back into (build.hip)
 
 // Grow-only device buffer owned by a context.
 struct DevBuf {
