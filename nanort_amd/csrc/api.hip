@@ -624,6 +624,7 @@ nrt_status nrt_internal_tree_view(nrt_ctx *c, nrt::TreeViewF32 *out) {
   out->nodes = (const nrt_node_f32 *)c->d_nodes;
   out->indices = c->d_indices;
   out->wide = c->d_wide;
+  out->wide4 = c->d_wide4;
   out->prims = c->d_tris;
   out->num_nodes = (uint32_t)c->num_nodes;
   out->num_indices = (uint32_t)c->num_indices;

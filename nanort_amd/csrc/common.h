@@ -146,6 +146,7 @@ struct TreeViewF32 {
   const nrt_node_f32 *nodes;     // reference-format node array
   const uint32_t *indices;       // index permutation
   const void *wide;              // WideNode<float>[branches]
+  const void *wide4;             // Wide4Node<float>[branches], or null when the tree is not walked two levels per step
   const void *prims;             // leaf-ordered primitive records (LeafTri<float> for triangle contexts)
   uint32_t num_nodes, num_indices;
   uint32_t packed_leaves, root_is_branch, tree_nested, prim_kind, tree_depth;
@@ -155,6 +156,7 @@ struct TreeViewF32 {
 // Per instance, in HBM: where its tree lives and the three matrices nanosg's Node::Update derives (nanosg.h:397-437).
 struct SceneInst {
   const void *wide;           // WideNode<float>[]
+  const void *wide4;          // Wide4Node<float>[] (two levels per step) or null: the tree is walked one level per step
   const void *tris;           // LeafTri<float>[] in index-array order
   const nrt_node_f32 *nodes;  // reference-format nodes (leaf {count, first} when the leaf references are not packed; node 0's box)
   uint32_t packed_leaves, root_is_branch, tree_nested, pad;
@@ -175,6 +177,8 @@ struct SceneTraceArgs {
   uint32_t *spill;            // overflow stack [spill_levels][spill_stride], may be null
   float *spill_tmin;
   uint32_t spill_stride;
+  uint32_t *cursor;           // work cursor (next unclaimed ray), zero at launch
+  uint32_t refill_min;        // free lanes of a wave before it claims more rays
 };
 
 template <typename T>

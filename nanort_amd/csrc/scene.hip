@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -30,7 +31,8 @@
 struct nrt_ctx;
 nrt_status nrt_internal_tree_view(nrt_ctx *c, nrt::TreeViewF32 *out); // api.hip
 namespace nrt {
-hipError_t launch_scene_trace(const SceneTraceArgs &args, hipStream_t s); // traverse.hip
+hipError_t launch_scene_trace(const SceneTraceArgs &args, unsigned grid, hipStream_t s); // traverse.hip
+int scene_trace_blocks_per_cu();
 }
 
 namespace {
@@ -298,7 +300,8 @@ struct nrt_scene {
   nrt::TreeViewF32 top_view;
   bool use_top = false;
   uint32_t max_inst_depth = 0;   // deepest instance tree: sizes the overflow stack of k_scene_trace
-  nrt::DevBuf d_nodes, d_insts, d_rays, d_list_t, d_list_node, d_count, d_best, d_mask, d_spill, d_spill_tmin;
+  nrt::DevBuf d_nodes, d_insts, d_rays, d_list_t, d_list_node, d_count, d_best, d_mask, d_spill, d_spill_tmin, d_cursor;
+  unsigned trace_blocks_per_cu = 0, num_cus = 0, refill_min = 56; // persistent grid of k_scene_trace (env NRT_SCENE_REFILL; 16-48 measured slower on small scenes, 64 slower on 10 000 instances)
 };
 
 static nrt_status sfail(nrt_scene *s, nrt_status st, const char *fmt, ...) {
@@ -345,7 +348,7 @@ void nrtSceneDestroy(nrt_scene *s) {
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
   nrt::DevBuf *bufs[] = {&s->d_nodes, &s->d_insts, &s->d_rays, &s->d_list_t, &s->d_list_node, &s->d_count,
-                         &s->d_best,  &s->d_mask,  &s->d_spill, &s->d_spill_tmin};
+                         &s->d_best,  &s->d_mask,  &s->d_spill, &s->d_spill_tmin, &s->d_cursor};
   for (nrt::DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (s->top) nrtDestroy(s->top);
@@ -407,6 +410,7 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
     const nrt::TreeViewF32 &tv = meshes[mesh_of[i]].second.tv;
     nrt::SceneInst &e = table[i];
     e.wide = tv.wide;
+    e.wide4 = (tv.tree_nested && tv.root_is_branch) ? tv.wide4 : nullptr; // two levels per step need nested boxes (traverse.hip)
     e.tris = tv.prims;
     e.nodes = tv.nodes;
     e.packed_leaves = tv.packed_leaves;
@@ -416,7 +420,8 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
     memcpy(e.inv_xform, s->host_nodes[i].inv_xform, sizeof(e.inv_xform));
     memcpy(e.inv_xform33, s->host_nodes[i].inv_xform33, sizeof(e.inv_xform33));
     memcpy(e.xform, s->host_nodes[i].xform, sizeof(e.xform));
-    s->max_inst_depth = std::max(s->max_inst_depth, tv.tree_depth);
+    // deepest stack a walk of this tree can need: one pending sibling per level, three per two levels when stepping two
+    s->max_inst_depth = std::max(s->max_inst_depth, e.wide4 ? 3u * (tv.tree_depth / 2u + 1u) : tv.tree_depth);
   }
   SCHK(s, nrt::devbuf_ensure(&s->d_insts, table.size() * sizeof(nrt::SceneInst)));
   SCHK(s, hipMemcpy(s->d_insts.p, table.data(), table.size() * sizeof(nrt::SceneInst), hipMemcpyHostToDevice));
@@ -504,12 +509,22 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   SCHK(s, nrt::devbuf_ensure(&s->d_count, (size_t)n * sizeof(uint32_t)));
   if (!device) SCHK(s, nrt::devbuf_ensure(&s->d_best, (size_t)n * sizeof(nrt_scene_hit_f32)));
   if (!device && mask_out) SCHK(s, nrt::devbuf_ensure(&s->d_mask, (size_t)n));
-  const unsigned grid = (n + 255u) / 256u;
+  const unsigned grid = (n + 255u) / 256u; // the listing kernels: one ray per thread
+  if (s->trace_blocks_per_cu == 0) {
+    s->trace_blocks_per_cu = (unsigned)nrt::scene_trace_blocks_per_cu();
+    hipDeviceProp_t prop;
+    SCHK(s, hipGetDeviceProperties(&prop, s->device));
+    s->num_cus = (unsigned)prop.multiProcessorCount;
+    if (const char *e = getenv("NRT_SCENE_REFILL")) s->refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
+  }
+  const unsigned trace_grid = std::min(grid, s->num_cus * s->trace_blocks_per_cu); // the trace kernel: every block resident
   const uint32_t levels = s->max_inst_depth + 2 > (uint32_t)nrt::kSceneLdsStack ? s->max_inst_depth + 2 - nrt::kSceneLdsStack : 0;
   if (levels) {
-    SCHK(s, nrt::devbuf_ensure(&s->d_spill, (size_t)levels * grid * 256u * sizeof(uint32_t)));
-    SCHK(s, nrt::devbuf_ensure(&s->d_spill_tmin, (size_t)levels * grid * 256u * sizeof(float)));
+    SCHK(s, nrt::devbuf_ensure(&s->d_spill, (size_t)levels * trace_grid * 256u * sizeof(uint32_t)));
+    SCHK(s, nrt::devbuf_ensure(&s->d_spill_tmin, (size_t)levels * trace_grid * 256u * sizeof(float)));
   }
+  SCHK(s, nrt::devbuf_ensure(&s->d_cursor, 256));
+  SCHK(s, hipMemsetAsync(s->d_cursor.p, 0, sizeof(uint32_t), s->stream));
   const NodeDev *d_nodes = (const NodeDev *)s->d_nodes.p;
   const nrt_ray_f32 *d_rays = device ? rays : (const nrt_ray_f32 *)s->d_rays.p;
 
@@ -532,8 +547,10 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   a.mask = device ? mask_out : (mask_out ? (uint8_t *)s->d_mask.p : nullptr);
   a.spill = (uint32_t *)s->d_spill.p;
   a.spill_tmin = (float *)s->d_spill_tmin.p;
-  a.spill_stride = grid * 256u;
-  SCHK(s, nrt::launch_scene_trace(a, s->stream));
+  a.spill_stride = trace_grid * 256u;
+  a.cursor = (uint32_t *)s->d_cursor.p;
+  a.refill_min = s->refill_min;
+  SCHK(s, nrt::launch_scene_trace(a, trace_grid, s->stream));
   if (!device) {
     SCHK(s, hipMemcpyAsync(hits_out, s->d_best.p, (size_t)n * sizeof(nrt_scene_hit_f32), hipMemcpyDeviceToHost, s->stream));
     if (mask_out) SCHK(s, hipMemcpyAsync(mask_out, s->d_mask.p, (size_t)n, hipMemcpyDeviceToHost, s->stream));

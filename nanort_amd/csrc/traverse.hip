@@ -1540,11 +1540,14 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
   (void)leaf_tmin;
 
   const unsigned tid = threadIdx.x;
+  const unsigned lane = lane_id();
   const unsigned gslot = blockIdx.x * kTraverseBlock + tid;
-  const uint32_t i = gslot;
-  const bool live = i < a.n;
 
+  // Persistent threads: a lane whose ray is finished takes the next one from a work cursor (claimed for the whole wave by
+  // one atomic once `refill_min` lanes are free), so a wave keeps its lanes busy to the end of the batch instead of
+  // waiting for the slowest of 64 fixed rays.
   Lane<float> L;
+  uint32_t i = 0; // this lane's ray
   uint32_t cur = 0;
   int state = S_DONE, sp = 0;
   uint32_t cnt = 0, j = 0, inst = 0;
@@ -1552,28 +1555,46 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
   bool has_hit = false;
   float worg[3] = {0.f, 0.f, 0.f}, wdir[3] = {0.f, 0.f, 0.f};
   const WideNode<float> *wide = nullptr;
+  const Wide4Node<float> *wide4 = nullptr; // non-null: this instance's tree is walked two levels per step
   const LeafTri<float> *tris = nullptr;
   const nrt_node_f32 *nodes = nullptr;
   uint32_t packed = 1u;
-  if (live) {
-    const nrt_ray_f32 r = a.rays[i];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      worg[k] = r.org[k];
-      wdir[k] = r.dir[k];
-    }
-    cnt = a.count[i];
-    nrt_scene_hit_f32 h; // the miss record; overwritten by every strictly nearer hit
-    h.t = r.max_t;
-    h.u = 0.0f;
-    h.v = 0.0f;
-    h.prim_id = 0xFFFFFFFFu;
-    h.node_id = 0xFFFFFFFFu;
-    a.hits[i] = h;
-    state = S_NEXT;
-  }
+  bool exhausted = false;
 
   for (;;) {
+    // ---- refill free lanes -------------------------------------------------------------------------------------------
+    {
+      const unsigned long long free_lanes = __ballot(state == S_DONE);
+      const unsigned want = (unsigned)__builtin_popcountll(free_lanes);
+      if (!exhausted && want >= a.refill_min) {
+        uint32_t base = 0;
+        if (lane == (unsigned)__builtin_ctzll(free_lanes)) base = atomicAdd(a.cursor, want);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(free_lanes));
+        exhausted = base + want >= a.n;
+        const uint32_t mine = base + (uint32_t)__builtin_popcountll(free_lanes & ((1ull << lane) - 1ull));
+        if (state == S_DONE && mine < a.n) {
+          i = mine;
+          const nrt_ray_f32 r = a.rays[i];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            worg[k] = r.org[k];
+            wdir[k] = r.dir[k];
+          }
+          cnt = a.count[i];
+          j = 0;
+          best_t = 3.402823466e+38f;
+          has_hit = false;
+          nrt_scene_hit_f32 h; // the miss record; overwritten by every strictly nearer hit
+          h.t = r.max_t;
+          h.u = 0.0f;
+          h.v = 0.0f;
+          h.prim_id = 0xFFFFFFFFu;
+          h.node_id = 0xFFFFFFFFu;
+          a.hits[i] = h;
+          state = S_NEXT;
+        }
+      }
+    }
     // ---- candidates: finish a local walk, pick the next instance ---------------------------------------------------
     if (state == S_FIN) {
       if (L.hit_t < L.max_t) { // the local Traverse() hit (strict final predicate, nanort.h:2552)
@@ -1618,6 +1639,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
         lr.type = 0;
         lane_init<float>(L, lr);
         wide = (const WideNode<float> *)nd.wide;
+        wide4 = (const Wide4Node<float> *)nd.wide4;
         tris = (const LeafTri<float> *)nd.tris;
         nodes = nd.nodes;
         packed = nd.packed_leaves;
@@ -1637,8 +1659,12 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
         }
         break;
       }
+      if (state == S_DONE && a.mask) a.mask[i] = has_hit ? 1 : 0; // this ray is finished
     }
-    if (__ballot(state != S_DONE) == 0ull) break;
+    if (__ballot(state != S_DONE) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
 
     // ---- phase 1: inner nodes / stack pops ---------------------------------------------------------------------
     unsigned n_wait = (unsigned)__builtin_popcountll(__ballot(state == W_LEAF || state == S_FIN));
@@ -1648,8 +1674,13 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
         state = (state == W_IDLE) ? S_FIN : state; // an empty stack ends this instance's walk
       }
       if (state == W_TRAV) {
-        const WideNode<float> w = wide[cur];
-        NRT_STEP_NODE(w);
+        if (wide4 != nullptr) { // (trees whose child boxes lie inside their parents': two levels per step, NRT_STEP_NODE4)
+          const Wide4Node<float> w = wide4[cur];
+          NRT_STEP_NODE4(w);
+        } else {
+          const WideNode<float> w = wide[cur];
+          NRT_STEP_NODE(w);
+        }
       }
       n_wait += (unsigned)__builtin_popcountll(__ballot(state == W_LEAF || state == S_FIN));
       if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < 8u && n_wait != 0u) break;
@@ -1667,22 +1698,29 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
           first = nodes[cur].data[1];
         }
       }
-      for (uint32_t k = 0; __ballot(k < lcnt) != 0ull; k++) {
+      for (uint32_t k = 0; __ballot(k < lcnt) != 0ull; k += 2u) { // two records per trip, as in k_traverse_wide
         if (k < lcnt) { // (divergent on purpose: the lanes' record arrays differ)
-          const LeafTri<float> tri = tris[first + k];
-          tri_test<float, true>(L, tri, true, 0u, 0u, 0u, false); // default trace options (nanosg.h:817)
+          const bool two = k + 1u < lcnt;
+          const LeafTri<float> t0 = tris[first + k];
+          const LeafTri<float> t1 = tris[first + (two ? k + 1u : k)];
+          tri_test<float, true>(L, t0, true, 0u, 0u, 0u, false); // default trace options (nanosg.h:817)
+          tri_test<float, true>(L, t1, two, 0u, 0u, 0u, false);
         }
       }
       state = (state == W_LEAF) ? W_POP : state;
     }
   }
-  if (live && a.mask) a.mask[i] = has_hit ? 1 : 0;
 }
 
-hipError_t launch_scene_trace(const SceneTraceArgs &args, hipStream_t s) {
+hipError_t launch_scene_trace(const SceneTraceArgs &args, unsigned grid, hipStream_t s) {
   if (args.n == 0) return hipSuccess;
-  hipLaunchKernelGGL((k_scene_trace<kSceneLdsStack>), dim3((args.n + kTraverseBlock - 1) / kTraverseBlock), dim3(kTraverseBlock), 0, s, args);
+  hipLaunchKernelGGL((k_scene_trace<kSceneLdsStack>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
   return hipGetLastError();
+}
+int scene_trace_blocks_per_cu() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scene_trace<kSceneLdsStack>, kTraverseBlock, 0) != hipSuccess || n < 1) n = 4;
+  return n > 8 ? 8 : n;
 }
 
 // BVHNode[] -> dense WideNode[]: (1) branches per 1024-node tile, (2) exclusive scan of the
