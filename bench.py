@@ -719,8 +719,10 @@ def main():
         bbytes = build_bytes(wl.faces.shape[0], wl.num_nodes, wl.rb)
         roof = {
             "kernel": kernel_name,
-            "limiting": "latency (per-ray dependent chain node fetch -> slab test -> next fetch; waves wait on L1/L2 about half of their "
-                        "cycles) with the vector ALUs a third busy and HBM far from saturated: see valu / hbm; no MFMA in this path",
+            "limiting": "no single resource: per step, the latency of the dependent chain (node fetch -> slab tests -> next fetch; waves "
+                        "wait on L1/L2 ~40 % of their cycles), the vector L1's address work (~0.7 clk per scattered 16-byte lane access) "
+                        "and VALU issue (~38 % busy) cost about the same (perturbation probes: profiles/r02g_sensitivity_probe.txt, "
+                        "r02g_node_fetch_ubench.txt); HBM is far from saturated: see valu / hbm; no MFMA in this path",
             "launch_ms": round((k_ms1 + k_ms2) / 2, 4),
             "algorithmic": {"bytes_per_launch": int((bytes1 + bytes2) // 2), "GBs": round(alg_gbs, 1),
                             "x_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4), "served_from_cache": True,
