@@ -51,7 +51,18 @@ struct BuildResult {
   uint32_t max_depth, num_leaves, num_branches, max_leaf_count;
 };
 
-constexpr int kSmall = 256;     // nodes at or below this many primitives go to the subtree phase
+constexpr int kSmall = 256;     // nodes at or below this many primitives are binned with kSmallBins bins (part of the tree's definition)
+#ifndef NRT_BUILD_HANDOFF
+#define NRT_BUILD_HANDOFF 256
+#endif
+// Nodes at or below this many primitives leave the level-synchronous top phase for the one-wave-per-node subtree phase.
+// Both phases take the same decisions for a node (same bins — see node_bins —, same cost, same tie rules, same leaf rule),
+// so this is a scheduling knob: any value <= kSmall gives the same tree (tools/tree_hash.py).
+constexpr int kHandoff = NRT_BUILD_HANDOFF;
+static_assert(kHandoff <= kSmall && kHandoff >= 64, "hand-off size");
+#ifndef NRT_SUBTREE_REC_LDS
+#define NRT_SUBTREE_REC_LDS 0 // 1: k_subtree copies its node's primitive records into LDS (10 KB per wave: 10 waves per CU instead of 22; measured slower, profiles/r02j_build_subtree_ab.txt)
+#endif
 #ifndef NRT_BUILD_TILE
 #define NRT_BUILD_TILE 2048
 #endif
@@ -185,6 +196,9 @@ __device__ __forceinline__ T bin_scale(T lo, T hi, int K) {
   const T ext = hi - lo;
   return (ext > T(0)) ? T(K) / ext : T(0);
 }
+// Bins of a node of n primitives: `kpack` carries the build's bin count for large nodes (low byte) and the one for nodes
+// of at most kSmall primitives (second byte) — the subtree phase's lane == (axis, bin) layout holds 16.
+__device__ __forceinline__ int node_bins(int kpack, uint32_t n) { return n <= (uint32_t)kSmall ? ((kpack >> 8) & 0xFF) : (kpack & 0xFF); }
 template <typename T>
 __device__ __forceinline__ int bin_of(T c, T lo, T scale, int K) {
   int i = (int)((c - lo) * scale);
@@ -552,7 +566,7 @@ struct LeafRule {
 };
 template <typename T>
 __device__ __forceinline__ uint32_t classify(uint32_t n, uint32_t depth, LeafRule rule) {
-  if (n <= (uint32_t)kSmall) return KIND_SMALL;
+  if (n <= (uint32_t)kHandoff) return KIND_SMALL;
   if (depth >= rule.max_depth || n <= rule.leaf_max) return KIND_LEAF; // the rule applied to a node too large for one wave
   return KIND_SPLIT;
 }
@@ -891,7 +905,7 @@ __device__ __forceinline__ uint32_t find_task(const uint32_t *chunk_base, uint32
 template <typename T>
 __global__ __launch_bounds__(256) void k_bin(const TopNode<T> *__restrict__ top, const uint32_t *__restrict__ active,
                                              const uint32_t *__restrict__ chunk_base, const LevelInfo *info,
-                                             const PrimRec<T> *__restrict__ recs, int K, GBins<T> *gbins,
+                                             const PrimRec<T> *__restrict__ recs, int kpack, GBins<T> *gbins,
                                              uint32_t *__restrict__ chunk_hist) {
   if (blockIdx.x >= info->num_chunks) return; // grids are upper bounds
   const uint32_t num_active = info->num_active;
@@ -915,6 +929,7 @@ __global__ __launch_bounds__(256) void k_bin(const TopNode<T> *__restrict__ top,
   const TopNode<T> &nd = top[active[a]];
   const uint32_t begin = nd.l + (chunk - chunk_base[a]) * kTile;
   const uint32_t end = (nd.r - begin < (uint32_t)kTile) ? nd.r : begin + kTile;
+  const int K = node_bins(kpack, nd.r - nd.l);
   T lo[3], sc[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -1005,7 +1020,7 @@ __global__ __launch_bounds__(256) void k_bin(const TopNode<T> *__restrict__ top,
 // FindCutFromBinBuffer (nanort.h:1393-1422), argmin over 3 x (K-1) candidates.
 template <typename T>
 __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *__restrict__ active,
-                                              GBins<T> *gbins, int K,
+                                              GBins<T> *gbins, int kpack,
                                               const uint32_t *__restrict__ chunk_hist, uint32_t *chunk_left_base,
                                               const LevelInfo *info, uint32_t max_active) {
   const uint32_t a = blockIdx.x;
@@ -1022,6 +1037,7 @@ __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *_
   // everything this wave reads from memory is requested up front — the three axes' bins and the node's range — so that the
   // kernel pays one round trip instead of one per axis (the bins are reset right after, and stores pin later loads in place)
   const uint32_t n = nd.r - nd.l, cb = nd.chunk_base, nch = nd.nchunks;
+  const int K = node_bins(kpack, n);
   uint32_t cnt3[3] = {0, 0, 0};
   U mn3[3][3], mx3[3][3];
 #pragma unroll
@@ -1130,7 +1146,7 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
                                                    const uint32_t *__restrict__ chunk_base, const LevelInfo *info,
                                                    const uint32_t *__restrict__ chunk_left_base,
                                                    const PrimRec<T> *__restrict__ src, PrimRec<T> *__restrict__ dst,
-                                                   int K, BoundsAcc<T> *child_acc) {
+                                                   int kpack, BoundsAcc<T> *child_acc) {
   typedef typename Ord<T>::U U;
   __shared__ uint32_t s_task;
   __shared__ uint32_t s_w[2][4];
@@ -1153,7 +1169,8 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
   const uint32_t split_bin = nd.split_bin, nleft = nd.nleft;
   const T lo = axis == 0 ? nd.cmin[0] : (axis == 1 ? nd.cmin[1] : nd.cmin[2]);
   const T hi = axis == 0 ? nd.cmax[0] : (axis == 1 ? nd.cmax[1] : nd.cmax[2]);
-  const T sc = bin_scale<T>(lo, hi, K);
+  const T sc = bin_scale<T>(lo, hi, node_bins(kpack, nd.r - nd.l));
+  const int K = node_bins(kpack, nd.r - nd.l);
 
   T acc_lo[2][3], acc_hi[2][3], acc_clo[2][3], acc_chi[2][3];
 #pragma unroll
@@ -1282,8 +1299,13 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
                                                 uint32_t *indices, LevelInfo *info) {
   typedef typename Wire<T>::Node Node;
   typedef typename Ord<T>::U U;
-  __shared__ PrimRec<T> s_rec[kSmall];
-  __shared__ uint16_t s_perm[2][kSmall];
+#if NRT_SUBTREE_REC_LDS
+  __shared__ PrimRec<T> s_rec[kHandoff];
+#define NRT_SUB_REC(id_) s_rec[(id_)]
+#else // records stay where they are (10 KB per subtree, contiguous: L1 / L2 hits); 10 KB less LDS per wave = more waves per CU
+#define NRT_SUB_REC(id_) src[(id_)]
+#endif
+  __shared__ uint16_t s_perm[2][kHandoff];
   __shared__ SubPending<T> s_stack[kSubStack];
   __shared__ uint32_t s_cnt[3][kSmallBins];
   __shared__ U s_bmin[3][kSmallBins][3];
@@ -1295,7 +1317,9 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
   const uint32_t L = task.l, n_all = task.r - task.l;
   const PrimRec<T> *src = (task.buf ? recs1 : recs0) + L;
   for (uint32_t i = lane; i < n_all; i += 64u) {
+#if NRT_SUBTREE_REC_LDS
     s_rec[i] = src[i];
+#endif
     s_perm[0][i] = (uint16_t)i;
   }
   if (lane < 3 * kSmallBins) { // bins start clean and are handed on clean by their readers
@@ -1339,7 +1363,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
     PrimRec<T> r0;
     if (have) {
       id0 = s_perm[pb][i_first];
-      r0 = s_rec[id0];
+      r0 = NRT_SUB_REC(id0);
     }
 
     Node nd;
@@ -1357,7 +1381,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
       nd.data[1] = L + lo;
       if (lane == 0) out[me] = nd;
       if (have) indices[L + i_first] = r0.prim;
-      for (uint32_t i = i_first + 64u; i < hi; i += 64u) indices[L + i] = s_rec[s_perm[pb][i]].prim;
+      for (uint32_t i = i_first + 64u; i < hi; i += 64u) indices[L + i] = NRT_SUB_REC(s_perm[pb][i]).prim;
       leaves++;
       biggest_leaf = n > biggest_leaf ? n : biggest_leaf;
     } else {
@@ -1384,7 +1408,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
         }
       };
       if (have) bin_one(r0);
-      for (uint32_t i = i_first + 64u; i < hi; i += 64u) bin_one(s_rec[s_perm[pb][i]]);
+      for (uint32_t i = i_first + 64u; i < hi; i += 64u) bin_one(NRT_SUB_REC(s_perm[pb][i]));
       __syncthreads();
 
       // ---- lane == (axis, bin): sweeps inside 16-lane groups, on the integer images ----------------------
@@ -1488,7 +1512,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
           PrimRec<T> r = r0;
           if (valid && i0 != lo) {
             id = s_perm[pb][i];
-            r = s_rec[id];
+            r = NRT_SUB_REC(id);
           }
           bool left = false;
           if (valid) {
@@ -1681,6 +1705,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
     atomicMax(&info->max_leaf_count, biggest_leaf);
   }
 }
+#undef NRT_SUB_REC
 
 // ---------------------------------------------------------------------------
 // relayout: sizes bottom-up, DFS pre-order top-down (single block over the
@@ -1856,9 +1881,9 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
       off_chunk_hist, off_chunk_left, off_small, off_scene, off_info, off_sort, sort_blocks, total;
   BuildPlan(uint32_t n, size_t top_scale) {
     typedef typename Wire<T>::Node Node;
-    max_active = (size_t)n / kSmall + 2;
+    max_active = (size_t)n / kHandoff + 2;
     max_chunks = (size_t)n / kTile + max_active + 1;
-    max_top = top_scale * (4 * ((size_t)n / kSmall + 1) + 64);
+    max_top = top_scale * (4 * ((size_t)n / kHandoff + 1) + 64);
     size_t o = 0;
     auto take = [&](size_t bytes) {
       const size_t at = o;
@@ -1965,8 +1990,8 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     // From the level at which the nodes could first all be small, the state block written by k_level_setup is read
     // back every level; the level's kernels are enqueued before the host waits for it.
     int expect = 0;
-    for (size_t m = (size_t)n / kSmall; m > 0; m >>= 1) expect++;
-    const int first_check = (n <= (uint32_t)kSmall) ? 0 : expect + 2;
+    for (size_t m = (size_t)n / kHandoff; m > 0; m >>= 1) expect++;
+    const int first_check = (n <= (uint32_t)kHandoff) ? 0 : expect + 2;
     bool overflow = false;
     uint32_t num_small = 0;
     for (int level = 0;; level++) {
@@ -1987,11 +2012,11 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
       const size_t a_max = level < 31 ? std::min<size_t>((size_t)1 << level, plan.max_active) : plan.max_active;
       const size_t c_max = std::min<size_t>((size_t)n / kTile + a_max + 1, plan.max_chunks);
       hipLaunchKernelGGL((k_bin<T>), dim3((unsigned)c_max), dim3(256), 0, s, top, active, chunk_base, info, recs[cur],
-                         K, gbins, chunk_hist);
-      hipLaunchKernelGGL((k_split<T>), dim3((unsigned)a_max), dim3(64), 0, s, top, active, gbins, K, chunk_hist,
+                         K | (Ks << 8), gbins, chunk_hist);
+      hipLaunchKernelGGL((k_split<T>), dim3((unsigned)a_max), dim3(64), 0, s, top, active, gbins, K | (Ks << 8), chunk_hist,
                          chunk_left, info, (uint32_t)plan.max_active);
       hipLaunchKernelGGL((k_partition<T>), dim3((unsigned)c_max), dim3(256), 0, s, top, active, chunk_base, info,
-                         chunk_left, recs[cur], recs[1 - cur], K, child_acc);
+                         chunk_left, recs[cur], recs[1 - cur], K | (Ks << 8), child_acc);
       BCHK(hipGetLastError());
       cur = 1 - cur;
       if (check) {
