@@ -37,6 +37,7 @@
 // Hit records do not depend on tree topology, which is what
 // parity is judged on.
 #include <stddef.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <string>
@@ -1879,11 +1880,12 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
   size_t max_top, max_active, max_chunks;
   size_t off_recs0, off_recs1, off_scratch, off_top, off_child_acc, off_active, off_chunk_base, off_gbins,
       off_chunk_hist, off_chunk_left, off_small, off_scene, off_info, off_sort, sort_blocks, total;
-  BuildPlan(uint32_t n, size_t top_scale) {
+  BuildPlan(uint32_t n, size_t top_scale, bool tiny_top = false) {
     typedef typename Wire<T>::Node Node;
     max_active = (size_t)n / kHandoff + 2;
     max_chunks = (size_t)n / kTile + max_active + 1;
     max_top = top_scale * (4 * ((size_t)n / kHandoff + 1) + 64);
+    if (tiny_top) max_top = 16; // test hook: the first attempt overflows, the retry path runs
     size_t o = 0;
     auto take = [&](size_t bytes) {
       const size_t at = o;
@@ -1937,8 +1939,12 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
   const size_t state_bytes = offsetof(LevelInfo, level_begin);
   volatile const LevelInfo *hp = (volatile const LevelInfo *)pinned;
 
+  // (test hook, NRT_BUILD_TINY_TOP=1: the first attempt gets a 16-node top array, so every build of more than a few
+  // thousand primitives overflows once and is retried — the path lopsided splits take)
+  const char *tiny_env = getenv("NRT_BUILD_TINY_TOP");
+  const bool tiny_top = tiny_env && atoi(tiny_env) != 0;
   for (size_t top_scale = 1;; top_scale *= 8) {
-    const BuildPlan<T> plan(n, top_scale);
+    const BuildPlan<T> plan(n, top_scale, tiny_top && top_scale == 1);
     BCHK(devbuf_ensure(workspace, plan.total));
     BCHK(devbuf_ensure(indices_buf, (size_t)n * sizeof(uint32_t)));
     BCHK(devbuf_ensure(nodes_buf, (2 * (size_t)n) * sizeof(Node)));

@@ -111,6 +111,20 @@ def test_build_is_deterministic(c1_mesh):
     assert n1.tobytes() == n2.tobytes() and np.array_equal(i1, i2)
 
 
+def test_top_array_overflow_is_retried_with_the_same_result(monkeypatch):
+    """Lopsided splits can outgrow the top-phase node array; the builder then starts over with a larger one.  The test hook
+    gives the first attempt a 16-node array, so the retry path runs: same tree as an ordinary build, for both precisions."""
+    v, f = scenes.sphere(96, 48)
+    for real in (np.float32, np.float64):
+        vv = v.astype(real)
+        _, n1, i1 = build(real, vv, f)
+        monkeypatch.setenv("NRT_BUILD_TINY_TOP", "1")
+        a, n2, i2 = build(real, vv, f)
+        monkeypatch.delenv("NRT_BUILD_TINY_TOP")
+        assert n1.tobytes() == n2.tobytes() and np.array_equal(i1, i2)
+        validate_bvh(n2, i2, vv, f, stats=a.GetStatistics())
+
+
 def test_fp64_build(oracle, c1_mesh):
     v, f = c1_mesh
     v64 = v.astype(np.float64)
