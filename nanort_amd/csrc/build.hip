@@ -949,7 +949,7 @@ __global__ __launch_bounds__(256) void k_bin(const TopNode<T> *__restrict__ top,
     uint32_t pc[3] = {0, 0, 0};
     U pmin[3][3], pmax[3][3];
     const uint32_t p0 = begin + threadIdx.x * kPerLane;
-    for (uint32_t it = 0; it < kPerLane; it++) {
+    for (uint32_t it = 0; it < kPerLane; it++) { // (requesting record it + 1 before binning record it was measured: slower, the LDS atomics are the bound)
       const uint32_t p = p0 + it;
       if (p >= end) break;
       const PrimRec<T> r = recs[p];
@@ -1183,13 +1183,18 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
     }
 
   uint32_t run_l = 0, run_r = 0;
+  // (the records of the next round are requested before this round's barriers: a chunk is 8 rounds, and their loads would
+  // otherwise be 8 exposed round trips — there are only about two blocks per CU to hide them)
+  PrimRec<T> r_next;
+  if (begin + tid < end) r_next = src[begin + tid];
   for (uint32_t p0 = begin; p0 < end; p0 += 256u) {
     const uint32_t p = p0 + tid;
     const bool valid = p < end;
     PrimRec<T> r;
     bool left = false;
+    if (valid) r = r_next;
+    if (p + 256u < end) r_next = src[p + 256u];
     if (valid) {
-      r = src[p];
       if (split_bin == kMedian) {
         left = (p - nd.l) < nleft;
       } else {
