@@ -52,6 +52,9 @@ class Oracle:
             h = getattr(L, "orc_traverse_split_model_" + s)
             h.argtypes = [vp, vp, vp, sz, vp, vp, u64, vp, u32, u32, ctypes.c_int, vp, vp, vp, vp]
             h.restype = None
+            w4 = getattr(L, "orc_traverse_wide4_model_" + s)
+            w4.argtypes = [vp, vp, vp, sz, vp, vp, u64, vp, vp, vp, vp, vp, vp, u64, vp]
+            w4.restype = None
         L.orc_free.argtypes = [vp]
         L.orc_sizeof.argtypes = [ctypes.c_int]
         L.orc_sizeof.restype = ctypes.c_int
@@ -129,6 +132,34 @@ class Oracle:
             int(split_permille), int(seed), 1 if check_helpers else 0, _p(hits), _p(mask), _p(flagged), _p(splits),
         )
         return hits, mask, flagged, splits
+
+
+    def traverse_wide4_model(self, nodes, indices, verts, faces, rays, opts=None, trail_cap=0):
+        """The sequential MODEL of the kernel's two-levels-per-step walk (oracle/wide4_model_body.inc).
+        Returns (hits, mask, counters(steps, leaves, tris, max_stack), trail_reference, trail_model): the two trails are the
+        leaf sequences (node indices, all rays concatenated) of the reference loop and of the model, when trail_cap > 0."""
+        real = verts.dtype
+        s = suffix(real)
+        assert nodes.dtype == node_dtype(real) and rays.dtype == ray_dtype(real)
+        faces = np.ascontiguousarray(faces, dtype=np.uint32)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        nodes = np.ascontiguousarray(nodes)
+        rays = np.ascontiguousarray(rays)
+        n = rays.shape[0]
+        hits = np.zeros((n,), dtype=hit_dtype(real))
+        mask = np.zeros((n,), dtype=np.uint8)
+        counters = np.zeros((4,), dtype=np.uint64)
+        t_ref = np.zeros((max(1, trail_cap),), dtype=np.uint32)
+        t_w4 = np.zeros((max(1, trail_cap),), dtype=np.uint32)
+        lens = np.zeros((2,), dtype=np.uint64)
+        w = _trace_opt_words(opts)
+        getattr(self.L, "orc_traverse_wide4_model_" + s)(
+            _p(nodes), _p(indices), _p(verts), 3 * verts.dtype.itemsize, _p(faces), _p(rays), n, _p(w), _p(hits), _p(mask),
+            _p(counters), _p(t_ref) if trail_cap else None, _p(t_w4) if trail_cap else None, int(trail_cap), _p(lens))
+        if trail_cap:
+            assert lens[0] <= trail_cap and lens[1] <= trail_cap, "trail buffer too small: %s" % lens
+            return hits, mask, counters, t_ref[: int(lens[0])], t_w4[: int(lens[1])]
+        return hits, mask, counters, None, None
 
 
 class _ShimBuildOptions(ctypes.Structure):

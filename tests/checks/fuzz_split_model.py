@@ -11,7 +11,8 @@ from nanort_amd.wire import ray_dtype, default_trace_options
 from oracle.bindings import Oracle
 
 
-def one_round(rng, orc, stats):
+def hostile_case(rng, orc):
+    """One random hostile mesh + ray batch + trace options + a tree from the restated reference builder."""
     real = np.float32 if rng.random() < 0.7 else np.float64
     n = int(rng.choice([1, 2, 3, 5, 17, 64, 257, 1500, 6000]))
     kind = rng.integers(0, 3)
@@ -44,6 +45,12 @@ def one_round(rng, orc, stats):
     opts["cull_back_face"] = int(rng.random() < 0.3)
     nodes, idx, _ = orc.build(v, f, min_leaf=int(rng.choice([1, 2, 4, 8, 16])), bin_size=int(rng.choice([2, 4, 16, 64])),
                               max_depth=int(rng.choice([256, 256, 12, 3])))
+    return v, f, rays, opts, nodes, idx
+
+
+def one_round(rng, orc, stats):
+    v, f, rays, opts, nodes, idx = hostile_case(rng, orc)
+    m = rays.shape[0]
     oh, om = orc.traverse(nodes, idx, v, f, rays, opts)
     pm = int(rng.choice([50, 300, 1000]))
     sh, sm, fl, sp = orc.traverse_split_model(nodes, idx, v, f, rays, opts, split_permille=pm, seed=int(rng.integers(1, 1 << 30)))
