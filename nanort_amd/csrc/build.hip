@@ -901,13 +901,71 @@ __device__ __forceinline__ uint32_t find_task(const uint32_t *chunk_base, uint32
   return lo;
 }
 
-// LDS bin reduction of one chunk; flush to the node's global bins; per-chunk
-// per-bin counts kept for the stable partition's offsets.
+// The cut search of one node by one full wave, lane == bin: prefix (left) and suffix (right) sweeps of count and AABB,
+// cost = nL*SA(L) + nR*SA(R) as in FindCutFromBinBuffer (nanort.h:1393-1422), argmin over 3 x (K-1) candidates (ties:
+// lowest axis, then lowest bin).  cnt3 / mn3 / mx3: this lane's bin of each axis (integer images; an empty bin's bounds
+// are ignored).  Shared by k_split (bins from the node's global slot) and k_bin (a node that fits one chunk: bins
+// straight from LDS).
 template <typename T>
-__global__ __launch_bounds__(256) void k_bin(const TopNode<T> *__restrict__ top, const uint32_t *__restrict__ active,
+__device__ __forceinline__ void eval_split(int K, unsigned lane, const uint32_t cnt3[3], const typename Ord<T>::U mn3[3][3],
+                                           const typename Ord<T>::U mx3[3][3], int &best_axis, uint32_t &best_bin,
+                                           uint32_t &best_nl) {
+  typedef typename Ord<T>::U U;
+  T best_cost = Lim<T>::inf();
+  best_axis = 0;
+  best_bin = kMedian;
+  best_nl = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    // scans on the integer images (see row_scan_step_e): DPP + scalar registers, no LDS crossbar
+    const uint32_t cnt = cnt3[k];
+    U pmn[3], pmx[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      pmn[d] = cnt ? mn3[k][d] : Ord<T>::highest();
+      pmx[d] = cnt ? mx3[k][d] : Ord<T>::lowest();
+    }
+    uint32_t pc = cnt, sc = cnt;
+    U smn[3] = {pmn[0], pmn[1], pmn[2]}, smx[3] = {pmx[0], pmx[1], pmx[2]};
+    wave_prefix_e<T>(pc, pmn, pmx, lane); // inclusive over lanes 0..lane
+    wave_suffix_e<T>(sc, smn, smx, lane); // inclusive over lanes lane..63
+    // candidate s == lane (1..K-1): left = bins [0, s), right = bins [s, K)
+    const uint32_t nl = wave_shr1<uint32_t>(0u, pc);
+    T cost = Lim<T>::inf();
+    {
+      T lmn[3], lmx[3], rmn[3], rmx[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        lmn[d] = Ord<T>::dec(wave_shr1<U>(Ord<T>::highest(), pmn[d]));
+        lmx[d] = Ord<T>::dec(wave_shr1<U>(Ord<T>::lowest(), pmx[d]));
+        rmn[d] = Ord<T>::dec(smn[d]);
+        rmx[d] = Ord<T>::dec(smx[d]);
+      }
+      if (lane >= 1 && (int)lane < K && nl > 0 && sc > 0) cost = T(nl) * half_area<T>(lmn, lmx) + T(sc) * half_area<T>(rmn, rmx);
+    }
+    if (!(cost == cost)) cost = Lim<T>::inf(); // a NaN cost never wins
+    // wave argmin, ties -> lowest lane
+    const U ecost = Ord<T>::enc(cost);
+    const U ebest = wave_umin<U>(ecost);
+    const T c = Ord<T>::dec(ebest);
+    const int who = (int)__builtin_ctzll(__ballot(ecost == ebest));
+    if (c < best_cost) { // ties -> lowest axis
+      best_cost = c;
+      best_axis = k;
+      best_bin = (uint32_t)who;
+      best_nl = lane_bcast(nl, who);
+    }
+  }
+}
+
+// LDS bin reduction of one chunk; flush to the node's global bins; per-chunk
+// per-bin counts kept for the stable partition's offsets.  A node that fits ONE chunk has all its bins right here:
+// the block's first wave does the node's cut search on the spot (no global bins, no histogram, nothing left for k_split).
+template <typename T>
+__global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__restrict__ active,
                                              const uint32_t *__restrict__ chunk_base, const LevelInfo *info,
                                              const PrimRec<T> *__restrict__ recs, int kpack, GBins<T> *gbins,
-                                             uint32_t *__restrict__ chunk_hist) {
+                                             uint32_t *__restrict__ chunk_hist, uint32_t *chunk_left_base, uint32_t max_active) {
   if (blockIdx.x >= info->num_chunks) return; // grids are upper bounds
   const uint32_t num_active = info->num_active;
   typedef typename Ord<T>::U U;
@@ -927,10 +985,11 @@ __global__ __launch_bounds__(256) void k_bin(const TopNode<T> *__restrict__ top,
   }
   __syncthreads();
   const uint32_t a = s_task;
-  const TopNode<T> &nd = top[active[a]];
+  TopNode<T> &nd = top[active[a]];
   const uint32_t begin = nd.l + (chunk - chunk_base[a]) * kTile;
   const uint32_t end = (nd.r - begin < (uint32_t)kTile) ? nd.r : begin + kTile;
   const int K = node_bins(kpack, nd.r - nd.l);
+  const bool whole_node = nd.nchunks == 1u;
   T lo[3], sc[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -1001,6 +1060,37 @@ __global__ __launch_bounds__(256) void k_bin(const TopNode<T> *__restrict__ top,
     }
   }
   __syncthreads();
+  if (whole_node) { // the node's complete bins are in LDS: split it here (k_split skips it)
+    if (threadIdx.x < 64u) {
+      const unsigned lane = threadIdx.x;
+      uint32_t cnt3[3] = {0, 0, 0};
+      U mn3[3][3], mx3[3][3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if ((int)lane < K) cnt3[k] = s_cnt[k][lane];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          mn3[k][d] = s_min[k][lane][d];
+          mx3[k][d] = s_max[k][lane][d];
+        }
+      }
+      int best_axis;
+      uint32_t best_bin, best_nl;
+      eval_split<T>(K, lane, cnt3, mn3, mx3, best_axis, best_bin, best_nl);
+      if (best_bin == kMedian) best_nl = (nd.r - nd.l) >> 1; // no separable centroids: object median (nanort.h:1849)
+      if (lane == 0) {
+        nd.axis = best_axis;
+        nd.split_bin = best_bin;
+        nd.nleft = best_nl;
+        nd.child0 = info->child_base + 2 * a;
+        chunk_left_base[chunk] = 0; // the chunk's low side starts at the node's
+      }
+      // this node's global slot was never touched; the slot the next level may hand out is reset as k_split would
+      if (a + num_active < max_active)
+        for (int k = 0; k < 3; k++) clean_bins<T>(&gbins[a + num_active], k, lane);
+    }
+    return;
+  }
   GBins<T> *g = &gbins[a];
   for (int i = threadIdx.x; i < 3 * kMaxBins; i += 256) {
     const int k = i / kMaxBins, b = i % kMaxBins;
@@ -1031,13 +1121,11 @@ __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *_
   const unsigned lane = threadIdx.x;
   TopNode<T> &nd = top[active[a]];
   GBins<T> &g = gbins[a];
-  T best_cost = Lim<T>::inf();
-  int best_axis = 0;
-  uint32_t best_bin = kMedian, best_nl = 0;
   typedef typename Ord<T>::U U;
   // everything this wave reads from memory is requested up front — the three axes' bins and the node's range — so that the
   // kernel pays one round trip instead of one per axis (the bins are reset right after, and stores pin later loads in place)
   const uint32_t n = nd.r - nd.l, cb = nd.chunk_base, nch = nd.nchunks;
+  if (nch == 1u) return; // a node of one chunk was split by its k_bin block (which also reset slot a + num_active)
   const int K = node_bins(kpack, n);
   uint32_t cnt3[3] = {0, 0, 0};
   U mn3[3][3], mx3[3][3];
@@ -1056,47 +1144,12 @@ __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *_
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    // scans on the integer images (see row_scan_step_e): DPP + scalar registers, no LDS crossbar
-    const uint32_t cnt = cnt3[k];
-    U pmn[3], pmx[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-      pmn[d] = cnt ? mn3[k][d] : Ord<T>::highest();
-      pmx[d] = cnt ? mx3[k][d] : Ord<T>::lowest();
-    }
     clean_bins<T>(&g, k, lane); // consumed: leave the slot clean for the next level (see clean_bins)
     if (a + num_active < max_active) clean_bins<T>(&gbins[a + num_active], k, lane);
-    uint32_t pc = cnt, sc = cnt;
-    U smn[3] = {pmn[0], pmn[1], pmn[2]}, smx[3] = {pmx[0], pmx[1], pmx[2]};
-    wave_prefix_e<T>(pc, pmn, pmx, lane); // inclusive over lanes 0..lane
-    wave_suffix_e<T>(sc, smn, smx, lane); // inclusive over lanes lane..63
-    // candidate s == lane (1..K-1): left = bins [0, s), right = bins [s, K)
-    const uint32_t nl = wave_shr1<uint32_t>(0u, pc);
-    T cost = Lim<T>::inf();
-    {
-      T lmn[3], lmx[3], rmn[3], rmx[3];
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        lmn[d] = Ord<T>::dec(wave_shr1<U>(Ord<T>::highest(), pmn[d]));
-        lmx[d] = Ord<T>::dec(wave_shr1<U>(Ord<T>::lowest(), pmx[d]));
-        rmn[d] = Ord<T>::dec(smn[d]);
-        rmx[d] = Ord<T>::dec(smx[d]);
-      }
-      if (lane >= 1 && (int)lane < K && nl > 0 && sc > 0) cost = T(nl) * half_area<T>(lmn, lmx) + T(sc) * half_area<T>(rmn, rmx);
-    }
-    if (!(cost == cost)) cost = Lim<T>::inf(); // a NaN cost never wins
-    // wave argmin, ties -> lowest lane
-    const U ecost = Ord<T>::enc(cost);
-    const U ebest = wave_umin<U>(ecost);
-    const T c = Ord<T>::dec(ebest);
-    const int who = (int)__builtin_ctzll(__ballot(ecost == ebest));
-    if (c < best_cost) { // ties -> lowest axis
-      best_cost = c;
-      best_axis = k;
-      best_bin = (uint32_t)who;
-      best_nl = lane_bcast(nl, who);
-    }
   }
+  int best_axis;
+  uint32_t best_bin, best_nl;
+  eval_split<T>(K, lane, cnt3, mn3, mx3, best_axis, best_bin, best_nl);
   if (best_bin == kMedian) best_nl = n >> 1; // no separable centroids: object median (nanort.h:1849)
 
   // per-chunk low-side counts -> exclusive prefix inside this node
@@ -2023,7 +2076,7 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
       const size_t a_max = level < 31 ? std::min<size_t>((size_t)1 << level, plan.max_active) : plan.max_active;
       const size_t c_max = std::min<size_t>((size_t)n / kTile + a_max + 1, plan.max_chunks);
       hipLaunchKernelGGL((k_bin<T>), dim3((unsigned)c_max), dim3(256), 0, s, top, active, chunk_base, info, recs[cur],
-                         K | (Ks << 8), gbins, chunk_hist);
+                         K | (Ks << 8), gbins, chunk_hist, chunk_left, (uint32_t)plan.max_active);
       hipLaunchKernelGGL((k_split<T>), dim3((unsigned)a_max), dim3(64), 0, s, top, active, gbins, K | (Ks << 8), chunk_hist,
                          chunk_left, info, (uint32_t)plan.max_active);
       hipLaunchKernelGGL((k_partition<T>), dim3((unsigned)c_max), dim3(256), 0, s, top, active, chunk_base, info,
