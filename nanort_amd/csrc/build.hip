@@ -163,7 +163,9 @@ struct TopNode {
   uint32_t dfs;       // final node index
   uint32_t buf;       // record buffer holding [l, r) once the node stops splitting
   uint32_t chunk_base, nchunks;
+  uint32_t parent;    // top index of the parent | kHighChild when this is its high-side child; kNoParent for node 0
 };
+constexpr uint32_t kHighChild = 0x80000000u, kNoParent = 0x7FFFFFFFu;
 
 template <typename T>
 struct BoundsAcc { // integer-ordered images: bmin[3] bmax[3] cmin[3] cmax[3]
@@ -614,6 +616,7 @@ __global__ void k_make_root(BoundsAcc<T> *scene, uint32_t n, LeafRule rule, uint
   t.buf = buf;
   t.chunk_base = 0;
   t.nchunks = 0;
+  t.parent = kNoParent;
   top[0] = t;
   if (t.kind == KIND_SMALL) small_list[atomicAdd(&info->num_small, 1u)] = 0;
 }
@@ -792,6 +795,7 @@ __device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *a
     t.buf = dst_buf;
     t.chunk_base = 0;
     t.nchunks = 0;
+    t.parent = active[a] | (c ? kHighChild : 0u);
     const uint32_t ci = p.child0 + c;
     top[ci] = t;
     if (t.kind == KIND_SMALL) small_list[atomicAdd(&info->num_small, 1u)] = ci;
@@ -1770,100 +1774,96 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
 // relayout: sizes bottom-up, DFS pre-order top-down (single block over the
 // small top array), then emission / splice
 // ---------------------------------------------------------------------------
+// Sizes and final (DFS pre-order) indices of the top nodes, from PARENT links — no level structure needed, so top nodes may
+// have been created in any order (the level-synchronous phase and the block-resident mid phase both append to the array):
+//   size(x) = sum of the contributions of x and its descendants (a subtree task contributes its node count, any other
+//             top node 1): every node adds its contribution to each of its ancestors;
+//   dfs(x)  = sum over the path root -> x of (1, plus the size of the low-side sibling where the path takes a high
+//             side): every node walks up its parent chain once more.
+// O(nodes x depth) operations and two barriers instead of two barriers per level.  Small top arrays (the usual case) keep
+// sizes and parents in LDS: one block does everything (k_layout).  Larger ones run the same three steps as grid-wide
+// kernels on the global arrays (k_layout_init / _sizes / _dfs).
 constexpr uint32_t kLayoutLds = 16384; // top arrays up to this many nodes are laid out from LDS (2 x 4 bytes per node, dynamic)
 constexpr uint32_t kLayoutOwn = kLayoutLds / 1024;
 template <typename T>
+__device__ __forceinline__ uint32_t layout_contribution(const TopNode<T> &t) { return t.kind == KIND_SMALL ? t.size : 1u; }
+
+// (the walk-up stops below depth kLayoutCut: the few nodes above it — on which every node's additions would pile up —
+// get their sizes level by level from their children afterwards)
+constexpr uint32_t kLayoutCut = 8;
+template <typename T>
 __global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, LevelInfo *info) {
-  const uint32_t *level_begin = info->level_begin;
-  const int num_levels = (int)info->num_levels;
-  // level_begin[0..num_levels]: top nodes of level L are [level_begin[L], level_begin[L+1])
-  // Two sweeps over the levels, each a chain of dependent reads (a parent's size needs its children's, a child's index
-  // its parent's).  For the usual small top array everything the sweeps touch is on chip: sizes and indices in LDS, each
-  // thread's own nodes' {kind, child} in registers, the level bounds in LDS — a level costs an LDS round trip and a barrier
-  // instead of two trips to L2 (14 levels each way at C3).
   extern __shared__ uint32_t s_dyn[];
-  __shared__ uint32_t s_level[kMaxTopLevels + 2];
-  const uint32_t total = level_begin[num_levels];
+  __shared__ uint32_t s_upper[1u << kLayoutCut]; // global path: the nodes above the cut
+  __shared__ uint32_t s_nupper;
+  const uint32_t total = info->top_count;
+  uint32_t *s_size = s_dyn, *s_par = s_dyn + kLayoutLds;
   if (total <= kLayoutLds) {
-    uint32_t *s_size = s_dyn, *s_dfs = s_dyn + kLayoutLds;
-    for (int L = (int)threadIdx.x; L <= num_levels; L += 1024) s_level[L] = level_begin[L];
-    uint32_t kc[kLayoutOwn]; // kind | child0 << 2 of node threadIdx.x + 1024 j
+    uint32_t own[kLayoutOwn], dep[kLayoutOwn]; // contribution and depth of node threadIdx.x + 1024 j
 #pragma unroll
     for (uint32_t j = 0; j < kLayoutOwn; j++) {
       const uint32_t i = threadIdx.x + 1024u * j;
-      kc[j] = 0xFFFFFFFFu;
+      own[j] = 0;
+      dep[j] = 0xFFFFFFFFu;
       if (i < total) {
-        const uint32_t kind = top[i].kind;
-        kc[j] = kind | (top[i].child0 << 2);
-        s_size[i] = kind == KIND_LEAF ? 1u : (kind == KIND_SMALL ? top[i].size : 0u);
+        own[j] = layout_contribution<T>(top[i]);
+        dep[j] = top[i].depth;
+        s_size[i] = own[j];
+        s_par[i] = top[i].parent;
       }
     }
     __syncthreads();
-    for (int L = num_levels - 1; L >= 0; L--) {
-      const uint32_t lo = s_level[L], hi = s_level[L + 1];
 #pragma unroll
-      for (uint32_t j = 0; j < kLayoutOwn; j++) {
-        const uint32_t i = threadIdx.x + 1024u * j;
-        if (i >= lo && i < hi && (kc[j] & 3u) == KIND_SPLIT) s_size[i] = 1u + s_size[kc[j] >> 2] + s_size[(kc[j] >> 2) + 1u];
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      s_dfs[0] = 0;
-      info->num_nodes = s_size[0];
-    }
-    __syncthreads();
-    for (int L = 0; L < num_levels; L++) {
-      const uint32_t lo = s_level[L], hi = s_level[L + 1];
-#pragma unroll
-      for (uint32_t j = 0; j < kLayoutOwn; j++) {
-        const uint32_t i = threadIdx.x + 1024u * j;
-        if (i >= lo && i < hi && (kc[j] & 3u) == KIND_SPLIT) {
-          const uint32_t c0 = kc[j] >> 2, d0 = s_dfs[i] + 1u;
-          s_dfs[c0] = d0;
-          s_dfs[c0 + 1u] = d0 + s_size[c0];
+    for (uint32_t j = 0; j < kLayoutOwn; j++) {
+      const uint32_t i = threadIdx.x + 1024u * j;
+      if (i < total && dep[j] > kLayoutCut) { // ancestors at depth dep - 1 ... kLayoutCut
+        uint32_t p = s_par[i] & ~kHighChild;
+        for (uint32_t d = dep[j] - 1u; d >= kLayoutCut; d--) {
+          atomicAdd(&s_size[p], own[j]);
+          p = s_par[p] & ~kHighChild;
         }
       }
+    }
+    __syncthreads();
+    for (int d = (int)kLayoutCut - 1; d >= 0; d--) { // the top of the tree, level by level (at most 2^d nodes each)
+#pragma unroll
+      for (uint32_t j = 0; j < kLayoutOwn; j++) {
+        const uint32_t i = threadIdx.x + 1024u * j;
+        if (dep[j] == (uint32_t)d && top[i].kind == KIND_SPLIT) s_size[i] = 1u + s_size[top[i].child0] + s_size[top[i].child0 + 1u];
+      }
       __syncthreads();
     }
 #pragma unroll
     for (uint32_t j = 0; j < kLayoutOwn; j++) {
       const uint32_t i = threadIdx.x + 1024u * j;
       if (i < total) {
-        const uint32_t kind = kc[j] & 3u;
-        if (kind == KIND_SPLIT || kind == KIND_LEAF) top[i].size = s_size[i];
-        top[i].dfs = s_dfs[i];
+        uint32_t dfs = 0;
+        for (uint32_t x = i, pw = s_par[i]; (pw & ~kHighChild) != kNoParent; x = pw & ~kHighChild, pw = s_par[x])
+          dfs += 1u + ((pw & kHighChild) ? s_size[x - 1u] : 0u); // (children are allocated in pairs: the low side is x - 1)
+        top[i].dfs = dfs;
+        if (top[i].kind != KIND_SMALL) top[i].size = s_size[i];
       }
     }
-    __syncthreads();
+    if (threadIdx.x == 0) info->num_nodes = s_size[0];
   } else {
-  for (int L = num_levels - 1; L >= 0; L--) {
-    for (uint32_t i = level_begin[L] + threadIdx.x; i < level_begin[L + 1]; i += 1024u) {
-      TopNode<T> &t = top[i];
-      if (t.kind == KIND_SPLIT) t.size = 1 + top[t.child0].size + top[t.child0 + 1].size;
-      if (t.kind == KIND_LEAF) t.size = 1;
-    }
+    // global path, after k_layout_init / k_layout_sizes: the nodes above the cut, level by level; then k_layout_dfs
+    if (threadIdx.x == 0) s_nupper = 0;
     __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    top[0].dfs = 0;
-    info->num_nodes = top[0].size;
-  }
-  __syncthreads();
-  for (int L = 0; L < num_levels; L++) {
-    for (uint32_t i = level_begin[L] + threadIdx.x; i < level_begin[L + 1]; i += 1024u) {
-      const TopNode<T> &t = top[i];
-      if (t.kind == KIND_SPLIT) {
-        top[t.child0].dfs = t.dfs + 1;
-        top[t.child0 + 1].dfs = t.dfs + 1 + top[t.child0].size;
+    for (uint32_t i = threadIdx.x; i < total; i += 1024u)
+      if (top[i].depth < kLayoutCut && top[i].kind == KIND_SPLIT) s_upper[atomicAdd(&s_nupper, 1u)] = i;
+    __syncthreads();
+    for (int d = (int)kLayoutCut - 1; d >= 0; d--) {
+      for (uint32_t k = threadIdx.x; k < s_nupper; k += 1024u) {
+        TopNode<T> &t = top[s_upper[k]];
+        if (t.depth == (uint32_t)d) t.size = 1u + top[t.child0].size + top[t.child0 + 1u].size;
       }
+      __syncthreads();
     }
-    __syncthreads();
-  }
+    if (threadIdx.x == 0) info->num_nodes = top[0].size;
   }
   // stats of the top part
   uint32_t leaves = 0, branches = 0, deepest = 0;
-  for (uint32_t i = threadIdx.x; i < level_begin[num_levels]; i += 1024u) {
+  for (uint32_t i = threadIdx.x; i < total; i += 1024u) {
     const TopNode<T> &t = top[i];
     if (t.kind == KIND_SPLIT) branches++;
     if (t.kind == KIND_LEAF) {
@@ -1875,6 +1875,36 @@ __global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, LevelInfo *inf
   if (leaves) atomicAdd(&info->num_leaves, leaves);
   if (branches) atomicAdd(&info->num_branches, branches);
   if (deepest) atomicMax(&info->max_depth, deepest);
+}
+
+// The same three steps for top arrays too large for LDS: grid-wide, on the global arrays (TopNode::size is the accumulator).
+template <typename T>
+__global__ __launch_bounds__(256) void k_layout_init(TopNode<T> *top, const LevelInfo *info) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= info->top_count || info->top_count <= kLayoutLds) return;
+  if (top[i].kind != KIND_SMALL) top[i].size = 1u;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_layout_sizes(TopNode<T> *top, const LevelInfo *info) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= info->top_count || info->top_count <= kLayoutLds) return;
+  const uint32_t own = top[i].kind == KIND_SMALL ? top[i].size : 1u; // (a subtree task's size is final; nothing is added to it)
+  const uint32_t dep = top[i].depth;
+  if (dep <= kLayoutCut) return;
+  uint32_t p = top[i].parent & ~kHighChild;
+  for (uint32_t d = dep - 1u; d >= kLayoutCut; d--) { // ancestors at depth dep - 1 ... kLayoutCut (see k_layout)
+    atomicAdd(&top[p].size, own);
+    p = top[p].parent & ~kHighChild;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_layout_dfs(TopNode<T> *top, const LevelInfo *info) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= info->top_count || info->top_count <= kLayoutLds) return;
+  uint32_t dfs = 0;
+  for (uint32_t x = i, pw = top[i].parent; (pw & ~kHighChild) != kNoParent; x = pw & ~kHighChild, pw = top[x].parent)
+    dfs += 1u + ((pw & kHighChild) ? top[x - 1u].size : 0u);
+  top[i].dfs = dfs;
 }
 
 template <typename T>
@@ -2104,7 +2134,14 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     }
     BCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_layout<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)(2 * kLayoutLds * sizeof(uint32_t)))); // (per device: set on every build, it costs nothing)
+    if (plan.max_top > kLayoutLds) { // (a top array that may not fit LDS: the grid-wide form of the same steps; no-ops if it does fit)
+      const unsigned lg = (unsigned)((plan.max_top + 255) / 256);
+      hipLaunchKernelGGL((k_layout_init<T>), dim3(lg), dim3(256), 0, s, top, info);
+      hipLaunchKernelGGL((k_layout_sizes<T>), dim3(lg), dim3(256), 0, s, top, info);
+    }
     hipLaunchKernelGGL((k_layout<T>), dim3(1), dim3(1024), 2 * kLayoutLds * sizeof(uint32_t), s, top, info);
+    if (plan.max_top > kLayoutLds)
+      hipLaunchKernelGGL((k_layout_dfs<T>), dim3((unsigned)((plan.max_top + 255) / 256)), dim3(256), 0, s, top, info);
     BCHK(hipMemcpyAsync(pinned, info, state_bytes, hipMemcpyDeviceToHost, s));
     BCHK(hipEventRecord(ev, s));
     Node *nodes = (Node *)nodes_buf->p;
