@@ -350,7 +350,12 @@ PMC_PASSES = [
     ("write", "WRITE_SIZE"),
     ("sq", "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"),
     ("tcc", "TCC_HIT_sum TCC_MISS_sum"),
+    ("tcp", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"),
 ]
+# What the vector L1 (TCP) sustains in tag look-ups per second when every lane of every wave fetches scattered 16-byte
+# pieces, measured with tools/ubench/node_fetch.hip under the same counter (3145 M look-ups in 3.59 ms, table resident in
+# L2; 896 G/s when resident in L1): profiles/r02g_node_fetch_ubench.txt, r02l_tcp_counter_calibration.txt.
+L1_PEAK_GACC_S = 876.0
 
 
 def pmc_child(args):
@@ -432,7 +437,7 @@ def roofline_from_counters(pmc, k_ms, n_cus):
     """HBM and VALU rooflines of the primary / bounce launches from the in-run counter means (per launch)."""
     simds = n_cus * 4
     lane_peak = simds * VALU_LANES_PER_SIMD * CLOCK_GHZ * 1e9  # lane-operations per second
-    res = {"hbm": None, "valu": None}
+    res = {"hbm": None, "valu": None, "l1": None}
     waves = ("primary", "bounce")
     if all("FETCH_SIZE" in pmc[w] and "WRITE_SIZE" in pmc[w] for w in waves):
         # rocprofv3 reports both in KiB; gfx950: FETCH_SIZE counts 128-B read requests as 64 B -> x2 (MI355X_MICROARCH.md §HBM)
@@ -447,6 +452,20 @@ def roofline_from_counters(pmc, k_ms, n_cus):
             h = sum(pmc[w]["TCC_HIT_sum"] for w in waves)
             m = sum(pmc[w]["TCC_MISS_sum"] for w in waves)
             res["hbm"]["l2_hit_rate"] = round(h / max(1.0, h + m), 4)
+    if all("TCP_TOTAL_CACHE_ACCESSES_sum" in pmc[w] for w in waves):
+        # one look-up per active lane for scattered accesses, one per quad of lanes reading one 64-byte line (calibrated on the
+        # micro-benchmark): the address / tag path of the vector L1, which the node and triangle fetches of this kernel load
+        per = {}
+        for w in waves:
+            acc = pmc[w]["TCP_TOTAL_CACHE_ACCESSES_sum"]
+            per[w] = {"lookups": int(acc), "frac": round(acc / (k_ms[w] * 1e-3) / 1e9 / L1_PEAK_GACC_S, 4)}
+            if "TCP_TCC_READ_REQ_sum" in pmc[w]:
+                per[w]["requests_to_l2_per_lookup"] = round(pmc[w]["TCP_TCC_READ_REQ_sum"] / max(1.0, acc), 4)
+        tot = sum(per[w]["lookups"] for w in waves)
+        tot_s = sum(k_ms[w] for w in waves) * 1e-3
+        res["l1"] = {"lookups_per_launch": int(tot / 2), "achieved_Glookups_s": round(tot / tot_s / 1e9, 1), "peak_Glookups_s": L1_PEAK_GACC_S,
+                     "peak_definition": "measured: tools/ubench/node_fetch.hip, every lane fetching scattered 16-byte pieces (L2-resident table)",
+                     "frac": round(tot / tot_s / 1e9 / L1_PEAK_GACC_S, 4), "per_wave": per}
     if all("SQ_THREAD_CYCLES_VALU" in pmc[w] and "SQ_INSTS_VALU" in pmc[w] for w in waves):
         per = {}
         for w in waves:
@@ -720,9 +739,10 @@ def main():
         roof = {
             "kernel": kernel_name,
             "limiting": "no single resource: per step, the latency of the dependent chain (node fetch -> slab tests -> next fetch; waves "
-                        "wait on L1/L2 ~40 % of their cycles), the vector L1's address work (~0.7 clk per scattered 16-byte lane access) "
-                        "and VALU issue (~38 % busy) cost about the same (perturbation probes: profiles/r02g_sensitivity_probe.txt, "
-                        "r02g_node_fetch_ubench.txt); HBM is far from saturated: see valu / hbm; no MFMA in this path",
+                        "wait on L1/L2 ~40 % of their cycles), the vector L1's address work (~0.7 clk per scattered 16-byte lane access; "
+                        "see l1: look-ups against the measured peak) and VALU issue (~38 % busy) cost about the same (perturbation "
+                        "probes: profiles/r02g_sensitivity_probe.txt, r02g_node_fetch_ubench.txt); HBM is far from saturated: see "
+                        "valu / hbm; no MFMA in this path",
             "launch_ms": round((k_ms1 + k_ms2) / 2, 4),
             "algorithmic": {"bytes_per_launch": int((bytes1 + bytes2) // 2), "GBs": round(alg_gbs, 1),
                             "x_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4), "served_from_cache": True,
@@ -751,6 +771,8 @@ def main():
                 roof["hbm"], source = r["hbm"], "in-run rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; 3 steps of the same workload)"
             if r["valu"]:
                 roof["valu"] = r["valu"]
+            if r["l1"]:
+                roof["l1"] = r["l1"]
         if pmc_err:
             roof["pmc_error"] = pmc_err
         if "hbm" not in roof and args.config == "C3":
