@@ -1,0 +1,51 @@
+"""bench.py's roofline arithmetic on the CPU: counter means in, fractions of the stated peaks out (no GPU, no profiler)."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_roofline_from_counters_uses_the_documented_formulas():
+    b = load_bench()
+    # the counter means of profiles/r02m (primary / bounce launches of C3)
+    pmc = {
+        "primary": {"FETCH_SIZE": 89752.8, "WRITE_SIZE": 44100.0, "TCC_HIT_sum": 2.0e6, "TCC_MISS_sum": 1.0e6,
+                    "TCP_TOTAL_CACHE_ACCESSES_sum": 86277220.0, "TCP_TCC_READ_REQ_sum": 4158560.0,
+                    "SQ_THREAD_CYCLES_VALU": 4.88e9, "SQ_INSTS_VALU": 1.1655e8, "SQ_WAIT_ANY": 4.0e8, "SQ_WAVE_CYCLES": 1.0e9,
+                    "SQ_LDS_BANK_CONFLICT": 0.0, "GRBM_GUI_ACTIVE": 8 * 2.25e3 * 250.0},
+        "bounce": {"FETCH_SIZE": 170000.0, "WRITE_SIZE": 43000.0, "TCC_HIT_sum": 4.0e6, "TCC_MISS_sum": 2.0e6,
+                   "TCP_TOTAL_CACHE_ACCESSES_sum": 150973895.0, "TCP_TCC_READ_REQ_sum": 9737816.0,
+                   "SQ_THREAD_CYCLES_VALU": 7.0e9, "SQ_INSTS_VALU": 2.137e8, "SQ_WAIT_ANY": 7.0e8, "SQ_WAVE_CYCLES": 1.8e9,
+                   "SQ_LDS_BANK_CONFLICT": 0.0, "GRBM_GUI_ACTIVE": 8 * 2.25e3 * 465.0},
+        "profiled_us": {"primary": 250.0, "bounce": 465.0},
+    }
+    k_ms = {"primary": 0.2506, "bounce": 0.4653}
+    r = b.roofline_from_counters(pmc, k_ms, 256)
+    hbm, valu, l1 = r["hbm"], r["valu"], r["l1"]
+    # HBM: FETCH_SIZE (KiB) x 1024 x 2 + WRITE_SIZE (KiB) x 1024, both launches over both launch times
+    want = (89752.8 * 2048 + 44100.0 * 1024 + 170000.0 * 2048 + 43000.0 * 1024) / ((0.2506 + 0.4653) * 1e-3) / 1e9
+    assert abs(hbm["achieved_GBs"] - want) < 0.1 and abs(hbm["frac"] - want / b.HBM_PEAK_GBS) < 1e-3
+    assert abs(hbm["l2_hit_rate"] - 2.0 / 3.0) < 1e-3
+    # vector lanes: SQ_THREAD_CYCLES_VALU over 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz
+    peak = 256 * 4 * b.VALU_LANES_PER_SIMD * b.CLOCK_GHZ * 1e9
+    assert abs(valu["frac"] - (4.88e9 + 7.0e9) / ((0.2506 + 0.4653) * 1e-3) / peak) < 1e-3
+    assert abs(valu["lane_util"] - (4.88e9 + 7.0e9) / (64 * (1.1655e8 + 2.137e8))) < 1e-3
+    # vector L1: tag look-ups over the launch times against the micro-benchmark's measured rate
+    assert abs(l1["frac"] - (86277220.0 + 150973895.0) / ((0.2506 + 0.4653) * 1e-3) / 1e9 / b.L1_PEAK_GACC_S) < 1e-3
+    assert abs(l1["per_wave"]["bounce"]["requests_to_l2_per_lookup"] - 9737816.0 / 150973895.0) < 1e-3
+    for part in (hbm, valu, l1):
+        assert 0.0 < part["frac"] < 1.0
+
+
+def test_missing_counters_leave_their_part_out():
+    b = load_bench()
+    pmc = {"primary": {"FETCH_SIZE": 1.0, "WRITE_SIZE": 1.0}, "bounce": {"FETCH_SIZE": 1.0, "WRITE_SIZE": 1.0}}
+    r = b.roofline_from_counters(pmc, {"primary": 0.1, "bounce": 0.1}, 256)
+    assert r["hbm"] is not None and r["valu"] is None and r["l1"] is None
