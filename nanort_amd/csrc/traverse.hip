@@ -989,6 +989,9 @@ struct FoldRec { // one per thread slot, used by the slot's lane when it owns a 
 #ifndef NRT_W4_TRI_UNROLL
 #define NRT_W4_TRI_UNROLL 2 // triangle records fetched per trip of the leaf loop in the WIDTH = 4 variants (1 or 2)
 #endif
+#ifndef NRT_SPHERE_UNROLL
+#define NRT_SPHERE_UNROLL 2 // sphere records fetched per trip of the leaf loop (sphere kind)
+#endif
 #ifndef NRT_W2_TRI_UNROLL
 #define NRT_W2_TRI_UNROLL 2 // ... and in the one-level variants (fp32 and fp64)
 #endif
@@ -1224,6 +1227,14 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
             else
               tri_test<T>(L, t_[j], i + j < cnt, a.range0, a.range1, a.skip_prim, cull);
           }
+        }
+      } else if constexpr (!STATS && KIND == kPrimSpheres && NRT_SPHERE_UNROLL > 1) { // the same for the 20-byte sphere records
+        for (uint32_t i = 0; __ballot(i < cnt) != 0ull; i += NRT_SPHERE_UNROLL) {
+          LeafSphere<T> s_[NRT_SPHERE_UNROLL];
+#pragma unroll
+          for (uint32_t j = 0; j < NRT_SPHERE_UNROLL; j++) s_[j] = a.spheres[first + (i + j < cnt ? i + j : 0u)];
+#pragma unroll
+          for (uint32_t j = 0; j < NRT_SPHERE_UNROLL; j++) sphere_test<T>(L, s_[j], i + j < cnt, a.range0, a.range1);
         }
       } else
       for (uint32_t i = 0; __ballot(i < cnt) != 0ull; i++) {
