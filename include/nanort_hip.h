@@ -311,6 +311,13 @@ NRT_API nrt_status nrtTraverseCountDevice_f64(nrt_ctx *ctx, const nrt_ray_f64 *d
  * Synchronises with that work. */
 NRT_API float nrtLastTraverseMs(nrt_ctx *ctx);
 NRT_API float nrtLastBuildMs(nrt_ctx *ctx);
+/* By default every traversal launch is bracketed by a pair of timing events (what nrtLastTraverseMs reads) and followed
+ * by a completion event of its launch slot.  Event records between the kernels of a stream cost it idle time (measured:
+ * ~8 us each); a caller that enqueues launches back to back and does not read their times switches them off (on = 0:
+ * "lean" launches) and back on when it wants a measurement.  While off, nrtLastTraverseMs keeps reporting the last timed
+ * launch, and whatever must wait for launches in flight (nrtBuild / nrtSetMesh / nrtSetTree / nrtDestroy, a fifth stream
+ * launching concurrently) synchronises the whole device instead of one event.  (No reference counterpart.) */
+NRT_API nrt_status nrtSetLaunchTiming(nrt_ctx *ctx, int on);
 /* Name of the traversal kernel variant the most recent traversal launch of this context used, spelled as
  * rocprofv3 prints it without the argument list (static storage; "" before the first launch).  bench.py
  * reports it in `roofline.kernel` and matches the counter rows of its PMC passes against it. */

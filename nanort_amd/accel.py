@@ -170,6 +170,12 @@ class BVHAccel:
     def LastTraverseMs(self):
         return float(self._L.nrtLastTraverseMs(self._h))
 
+    def SetLaunchTiming(self, on):
+        """Per-launch events on / off (nrtSetLaunchTiming): off ("lean" launches) saves the idle time the event records cost
+        a stream of back-to-back launches; LastTraverseMs() then keeps reporting the last timed launch, and a rebuild waits
+        for launches in flight with a device-wide synchronisation."""
+        self._check(self._L.nrtSetLaunchTiming(self._h, 1 if on else 0))
+
     def LastKernelName(self):
         """The traversal kernel variant the most recent launch used (as rocprofv3 names it)."""
         return self._L.nrtLastKernelName(self._h).decode()

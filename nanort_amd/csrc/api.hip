@@ -98,6 +98,7 @@ struct nrt_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr; // timing of the slot's last launch (per slot: launches on different streams overlap)
     hipStream_t stream = nullptr; // stream of that launch
     bool used = false;
+    bool done_pending = false;    // the slot's last launch was a lean one: no `done` event was recorded for it (see slot_done)
   };
   static constexpr int kSlots = 4;
   LaunchSlot slots[kSlots];
@@ -137,6 +138,7 @@ struct nrt_ctx {
   hipEvent_t ev_build_state = nullptr; // the builder's state block has reached build_state
   void *build_state = nullptr;         // page-locked, kBuildPinnedBytes
   int last_timed_slot = -1; // slot of the most recent timed traversal launch (nrtLastTraverseMs)
+  int launch_timing = 1;    // record a pair of timing events around every traversal launch (nrtSetLaunchTiming, env NRT_LAUNCH_TIMING)
   bool have_build_time = false;
   const char *last_kernel = ""; // variant of the most recent traversal launch (nrtLastKernelName)
 };
@@ -171,11 +173,27 @@ static nrt_status ensure(nrt_ctx *c, DevBuf &b, size_t bytes) {
 // nrtSetTree / nrtBuild) first waits for the traversal launches still in flight on the CALLER's streams: they read
 // b_nodes / b_tris / b_wide, which the rebuild reuses without reallocating (a per-frame "trace asynchronously on my
 // stream, then rebuild" loop is therefore safe without a synchronisation of the caller's own).
+// Event records between two kernels of a stream keep the second from starting for several microseconds each (measured:
+// the three records per launch — a timing pair and the slot's `done` — held C3 at 24 us of idle time per launch).  With
+// launch timing switched off (nrtSetLaunchTiming(ctx, 0): "lean" launches) none is recorded.  The `done` event is only
+// needed when somebody has to wait for a slot's last launch — another stream taking the slot over, a rebuild, destroy —
+// and a lean launch cannot provide it afterwards (the caller's stream may be gone by then), so those waits fall back to a
+// device-wide synchronisation.
+static hipError_t slot_done(nrt_ctx *c, nrt_ctx::LaunchSlot &sl) {
+  if (!sl.used || !sl.done_pending) return hipSuccess;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return e;
+  sl.done_pending = false;
+  return hipEventRecord(sl.done, c->stream); // (everything has completed: later waits on the event return at once)
+}
+
 static hipError_t wait_for_launches(nrt_ctx *c) {
   std::lock_guard<std::mutex> lock(c->launch_mutex);
   for (nrt_ctx::LaunchSlot &sl : c->slots)
     if (sl.used && sl.done) {
-      const hipError_t e = hipEventSynchronize(sl.done);
+      hipError_t e = slot_done(c, sl);
+      if (e != hipSuccess) return e;
+      e = hipEventSynchronize(sl.done);
       if (e != hipSuccess) return e;
     }
   return hipStreamSynchronize(c->stream);
@@ -271,6 +289,7 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   if (const char *e = getenv("NRT_WIDE")) c->wide = atoi(e) != 0;
   if (const char *e = getenv("NRT_SPLIT")) c->split = atoi(e) != 0;
   if (const char *e = getenv("NRT_WIDE4")) c->wide4 = atoi(e) != 0;
+  if (const char *e = getenv("NRT_LAUNCH_TIMING")) c->launch_timing = atoi(e) != 0;
   if (const char *e = getenv("NRT_HOST_PIPELINE")) c->host_pipeline = atoi(e) != 0;
   if (const char *e = getenv("NRT_DRAIN_STEPS")) c->drain_steps = (unsigned)std::max(1, atoi(e));
   if (const char *e = getenv("NRT_SPLIT_BUSY")) c->split_busy = (unsigned)std::min(64, std::max(0, atoi(e)));
@@ -287,7 +306,7 @@ void nrtDestroy(nrt_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (nrt_ctx::LaunchSlot &sl : c->slots) { // launches still in flight on the caller's streams
-    if (sl.used && sl.done) (void)hipEventSynchronize(sl.done);
+    if (sl.used && sl.done && slot_done(c, sl) == hipSuccess) (void)hipEventSynchronize(sl.done);
     if (sl.d_cursor) (void)hipFree(sl.d_cursor);
     if (sl.spill.p) (void)hipFree(sl.spill.p);
     if (sl.spill_tmin.p) (void)hipFree(sl.spill_tmin.p);
@@ -674,6 +693,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   if (!slot) {
     slot = &c->slots[c->next_victim];
     c->next_victim = (c->next_victim + 1) % nrt_ctx::kSlots;
+    HIPCHK(c, slot_done(c, *slot));
     HIPCHK(c, hipStreamWaitEvent(s, slot->done, 0));
   }
 
@@ -773,6 +793,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.leaf_min = c->leaf_min;
 
   if (count || (c->debug_flags & (32u | 4096u))) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s));
+  timed = timed && c->launch_timing != 0;
   if (timed) HIPCHK(c, hipEventRecord(slot->t0, s));
   if (use_wide) {
     HIPCHK(c, launch_traverse_wide<T>(a, grid, c->wide_stack, c->prim_kind, s, &c->last_kernel));
@@ -787,7 +808,12 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
     HIPCHK(c, hipEventRecord(slot->t1, s));
     c->last_timed_slot = (int)(slot - c->slots);
   }
-  HIPCHK(c, hipEventRecord(slot->done, s));
+  if (c->launch_timing) {
+    HIPCHK(c, hipEventRecord(slot->done, s));
+    slot->done_pending = false;
+  } else {
+    slot->done_pending = true; // lean launch: whoever has to wait for it synchronises the device (slot_done)
+  }
   slot->parity ^= 1u;
   slot->stream = s;
   slot->used = true;
@@ -1031,6 +1057,16 @@ nrt_status nrtTraverseCountDevice_f32(nrt_ctx *c, const nrt_ray_f32 *r, uint64_t
 nrt_status nrtTraverseCountDevice_f64(nrt_ctx *c, const nrt_ray_f64 *r, uint64_t n, const nrt_trace_options *o,
                                       nrt_trace_counters *out) {
   return traverse_count<double>(c, r, n, o, out);
+}
+
+// Events around every traversal launch (the timing pair nrtLastTraverseMs reads, the slot's completion event) are on by
+// default; a caller that enqueues launches back to back and does not read the times can switch them off and save the idle
+// time they cost the stream (see slot_done for what then changes).
+nrt_status nrtSetLaunchTiming(nrt_ctx *c, int on) {
+  if (!c) return NRT_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->launch_mutex);
+  c->launch_timing = on ? 1 : 0;
+  return NRT_OK;
 }
 
 float nrtLastTraverseMs(nrt_ctx *c) {
