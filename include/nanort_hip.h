@@ -306,27 +306,40 @@ NRT_API nrt_status nrtTraverseCountDevice_f64(nrt_ctx *ctx, const nrt_ray_f64 *d
                                               uint64_t num_rays, const nrt_trace_options *options,
                                               nrt_trace_counters *counters_out);
 
-/* Device time (ms, HIP events on the launch stream) of the most recent
- * traversal launch / build on this context; < 0 if none has completed.
+/* Device time (ms) of the most recent traversal launch (the kernel's own start / end stamps, or HIP events on the
+ * launch stream: see nrtSetLaunchTiming) / build (HIP events) on this context; < 0 if none has completed.
  * Synchronises with that work. */
 NRT_API float nrtLastTraverseMs(nrt_ctx *ctx);
 NRT_API float nrtLastBuildMs(nrt_ctx *ctx);
-/* By default every traversal launch is bracketed by a pair of timing events (what nrtLastTraverseMs reads) and followed
- * by a completion event of its launch slot.  Event records between the kernels of a stream cost it idle time (measured:
- * ~8 us each); a caller that enqueues launches back to back and does not read their times switches them off (on = 0:
- * "lean" launches) and back on when it wants a measurement.  While off, nrtLastTraverseMs keeps reporting the last timed
- * launch, and whatever must wait for launches in flight (nrtBuild / nrtSetMesh / nrtSetTree / nrtDestroy, a fifth stream
- * launching concurrently) synchronises the whole device instead of one event.  (No reference counterpart.) */
+/* By default a traversal launch records NO event in the caller's stream (an event record between two kernels of a stream
+ * keeps the second from starting for ~8 us; three per launch cost C3 6.5 % of a step): the kernel's last wave publishes a
+ * completion record — sequence number, start and end stamps — in page-locked memory.  nrtLastTraverseMs reads those stamps
+ * (first block started -> last wave finished), and whatever must wait for launches in flight (nrtBuild / nrtSetMesh /
+ * nrtSetTree / nrtDestroy, a fifth stream launching concurrently on one context) waits for exactly those launches by polling
+ * their records.  on = 1 brackets every launch with a pair of timing events and follows it with a completion event instead
+ * (nrtLastTraverseMs then reports the event time, dispatch included) — a cross-check, not the fast path.  Launches that are
+ * followed by a post pass (sphere and cylinder primitives) and the literal BVHNode kernel always use events.
+ * (No reference counterpart.) */
 NRT_API nrt_status nrtSetLaunchTiming(nrt_ctx *ctx, int on);
+/* Traversal / build tunables by name (no reference counterpart; the library's defaults are the measured optimum on MI355X):
+ * "refill_min", "trav_min", "leaf_min", "chunk", "parts", "static_pct", "blocks_per_cu", "lds_stack", "wide_stack" (scheduling of
+ * the persistent traversal kernel), "wide", "wide4" (which walk), "ray_sort" (coherence pre-pass of a batch), "morton" (builder
+ * pre-pass), "launch_timing" (== nrtSetLaunchTiming), "host_pipeline", "debug" (profiling bit mask), "wide_scramble" (layout probe).
+ * Values are clamped to the tunable's range; an unknown name is NRT_ERR_INVALID.  Tunables that shape the private tree layout
+ * ("wide4", "wide_scramble", "morton") take effect with the next nrtBuild / nrtSetTree.  The environment variable
+ * NRT_<NAME> (upper case) overrides a default at nrtCreate — a debugging aid; programs use these calls. */
+NRT_API nrt_status nrtSetTunable(nrt_ctx *ctx, const char *name, long long value);
+NRT_API nrt_status nrtGetTunable(nrt_ctx *ctx, const char *name, long long *value_out);
 /* Name of the traversal kernel variant the most recent traversal launch of this context used, spelled as
  * rocprofv3 prints it without the argument list (static storage; "" before the first launch).  bench.py
  * reports it in `roofline.kernel` and matches the counter rows of its PMC passes against it. */
 NRT_API const char *nrtLastKernelName(const nrt_ctx *ctx);
-/* Profiling aid: loop-occupancy counters of the last traversal launched with the environment variable
- * NRT_DEBUG bit 32 set (a separately instantiated, slower kernel).  out8[0..6] = phase-1 wave iterations,
- * sum of active lanes, sum of lanes walking inner nodes, phase-2 iterations, sum of lanes testing a
- * triangle, refill events, lanes refilled.  Returns 0 on success. */
-NRT_API int nrtDebugCounters(nrt_ctx *ctx, unsigned long long *out8);
+/* Profiling aid: loop-occupancy counters of the last traversal launched with the tunable "debug" bit 32 set (a separately
+ * instantiated, slower kernel).  out16[0..7] = inner-node-phase wave iterations, sum of active lanes, idle lanes at leaf-phase
+ * entry, leaf-phase trips, sum of lanes testing a (first) record, refill events, lanes refilled, leaf-phase entries;
+ * [8..10] = shader-clock ticks the waves spent refilling / in the inner-node phase / in the leaf phase; [11] = lanes
+ * with a second record in a leaf trip.  Returns 0 on success. */
+NRT_API int nrtDebugCounters(nrt_ctx *ctx, unsigned long long *out16);
 /* Profiling aid: with NRT_DEBUG bit 8192 every wave of a traversal launch records when it started, ran out of rays and
  * finished (100 MHz realtime ticks, 3 x u64 per wave).  Copies up to `cap` records of the most recent launch; returns
  * the number of waves of that launch, or -1 (tools/drain_probe.py). */

@@ -171,10 +171,18 @@ class BVHAccel:
         return float(self._L.nrtLastTraverseMs(self._h))
 
     def SetLaunchTiming(self, on):
-        """Per-launch events on / off (nrtSetLaunchTiming): off ("lean" launches) saves the idle time the event records cost
-        a stream of back-to-back launches; LastTraverseMs() then keeps reporting the last timed launch, and a rebuild waits
-        for launches in flight with a device-wide synchronisation."""
+        """nrtSetLaunchTiming: on = bracket every launch with timing events (+ a completion event); off (the default) = no event
+        in the stream, the kernel publishes a completion record whose stamps LastTraverseMs() reads."""
         self._check(self._L.nrtSetLaunchTiming(self._h, 1 if on else 0))
+
+    def SetTunable(self, name, value):
+        """nrtSetTunable: scheduling / layout tunables by name (include/nanort_hip.h lists them)."""
+        self._check(self._L.nrtSetTunable(self._h, name.encode(), int(value)))
+
+    def GetTunable(self, name):
+        v = ctypes.c_longlong(0)
+        self._check(self._L.nrtGetTunable(self._h, name.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def LastKernelName(self):
         """The traversal kernel variant the most recent launch used (as rocprofv3 names it)."""

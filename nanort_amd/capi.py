@@ -24,7 +24,7 @@ SYMBOLS = [
     "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64",
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
-    "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtLastBuildMs", "nrtLastKernelName", "nrtDebugCounters", "nrtDebugWaveClocks", "nrtHostAlloc", "nrtHostFree",
+    "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtDebugCounters", "nrtDebugWaveClocks", "nrtHostAlloc", "nrtHostFree",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
     "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32",
 ]
@@ -138,6 +138,10 @@ def lib():
     L.nrtHostFree.restype = None
     L.nrtSetLaunchTiming.argtypes = [vp, ctypes.c_int]
     L.nrtSetLaunchTiming.restype = ctypes.c_int
+    L.nrtSetTunable.argtypes = [vp, ctypes.c_char_p, ctypes.c_longlong]
+    L.nrtSetTunable.restype = i32
+    L.nrtGetTunable.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)]
+    L.nrtGetTunable.restype = i32
     L.nrtLastTraverseMs.argtypes = [vp]
     L.nrtLastTraverseMs.restype = ctypes.c_float
     L.nrtLastBuildMs.argtypes = [vp]

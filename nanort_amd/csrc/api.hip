@@ -9,9 +9,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ctype.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -34,7 +38,7 @@ hipError_t launch_cylinder_post(const nrt_ray_f32 *, const nrt_hit_f32 *, const 
                                 uint8_t *, hipStream_t);
 template <typename T>
 hipError_t launch_make_wide(const typename Wire<T>::Node *, uint32_t, uint32_t packed, uint32_t *scratch, WideNode<T> *, Wide4Node<T> *,
-                            hipStream_t);
+                            uint32_t scramble_mod, hipStream_t);
 template <typename T>
 hipError_t launch_gather_leaf_tris(const uint32_t *, const uint32_t *, const T *, LeafTri<T> *,
                                    uint32_t, hipStream_t);
@@ -94,18 +98,24 @@ struct nrt_ctx {
     unsigned parity = 0;
     DevBuf spill, spill_tmin;
     DevBuf cyl_hits, cyl_bits;    // cylinder kind: compact records + {hit, cap} bits between the traversal and its post pass
-    hipEvent_t done = nullptr;    // recorded after the slot's last launch
-    hipEvent_t t0 = nullptr, t1 = nullptr; // timing of the slot's last launch (per slot: launches on different streams overlap)
+    hipEvent_t done = nullptr;    // recorded after the slot's last launch (launches that do not publish a completion record)
+    hipEvent_t t0 = nullptr, t1 = nullptr; // event timing of the slot's last launch (per slot: launches on different streams overlap)
     hipStream_t stream = nullptr; // stream of that launch
     bool used = false;
-    bool done_pending = false;    // the slot's last launch was a lean one: no `done` event was recorded for it (see slot_done)
+    // completion record (common.h, DoneRec): page-locked, written by the last wave of a launch — no event in the stream
+    DoneRec *h_done = nullptr, *d_done = nullptr; // host / device address of the same record
+    DoneCount *d_count = nullptr;                 // the device words that go with it
+    uint32_t seq = 0;             // sequence number of the slot's last launch that publishes a record
+    bool rec_pending = false;     // the slot's last launch publishes a record and nobody has seen it complete yet
+    bool last_has_rec = false;    // the slot's last launch publishes a record (nrtLastTraverseMs reads its stamps)
+    bool last_timed = false;      // ... or was bracketed by the t0 / t1 events
   };
   static constexpr int kSlots = 4;
   LaunchSlot slots[kSlots];
   unsigned next_victim = 0;
   std::mutex launch_mutex; // slot selection + launch (nrtTraverseBatchDevice may be called from several host threads)
   std::mutex host_mutex;   // the host-buffer traversal calls share one set of staging buffers: one at a time
-  unsigned long long *d_counters = nullptr;  // 8 x u64 (counting pass / profiling instantiation only)
+  unsigned long long *d_counters = nullptr;  // 16 x u64 (counting pass / profiling instantiation only)
   DevBuf st_rays, st_hits, st_mask;
   // host entry point with page-locked caller buffers: upload / trace / download pipelined over three streams
   hipStream_t copy_in = nullptr, copy_out = nullptr;
@@ -121,6 +131,7 @@ struct nrt_ctx {
   unsigned debug_flags = 0;
   int morton = 0; // Morton-order the primitive records before the build (env NRT_MORTON=1): measured +0.4 ms at 1M tris for an identical tree, so off by default
   unsigned static_pct = 75; // share of a batch handed out statically, percent (env NRT_STATIC_PCT)
+  unsigned static_bands = 8; // ... as up to this many slices per wave, one in each band of the static region
   unsigned max_blocks_per_cu = 0; // env NRT_BLOCKS_PER_CU caps the persistent grid
   int wide = 1, wide_stack = 10; // production path: WideNode kernel (env NRT_WIDE=0 selects the binary kernel)
   // Work splitting in the drain of a launch (traverse.hip, k_traverse_wide<..., SPLIT>): exact, soaked, and MEASURED TO
@@ -130,6 +141,7 @@ struct nrt_ctx {
   // Two tree levels per step (Wide4Node records, traverse.hip NRT_STEP_NODE4): the production walk of fp32 triangle trees
   // whose child boxes lie inside their parents'.  env NRT_WIDE4=0 goes back to one level per step.
   int wide4 = 1;
+  int wide_scramble = 0; // probe (tunable wide_scramble): the private node records in a pseudo-random order instead of pre-order
   unsigned wide4_blocks_per_cu = 0;
   unsigned drain_steps = 8, split_busy = 8; // hand-out policy (env NRT_DRAIN_STEPS, NRT_SPLIT_BUSY)
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
@@ -138,7 +150,7 @@ struct nrt_ctx {
   hipEvent_t ev_build_state = nullptr; // the builder's state block has reached build_state
   void *build_state = nullptr;         // page-locked, kBuildPinnedBytes
   int last_timed_slot = -1; // slot of the most recent timed traversal launch (nrtLastTraverseMs)
-  int launch_timing = 1;    // record a pair of timing events around every traversal launch (nrtSetLaunchTiming, env NRT_LAUNCH_TIMING)
+  int launch_timing = 0;    // 1: bracket every traversal launch with timing events and follow it with a completion event (nrtSetLaunchTiming); 0: completion records
   bool have_build_time = false;
   const char *last_kernel = ""; // variant of the most recent traversal launch (nrtLastKernelName)
 };
@@ -174,28 +186,44 @@ static nrt_status ensure(nrt_ctx *c, DevBuf &b, size_t bytes) {
 // b_nodes / b_tris / b_wide, which the rebuild reuses without reallocating (a per-frame "trace asynchronously on my
 // stream, then rebuild" loop is therefore safe without a synchronisation of the caller's own).
 // Event records between two kernels of a stream keep the second from starting for several microseconds each (measured:
-// the three records per launch — a timing pair and the slot's `done` — held C3 at 24 us of idle time per launch).  With
-// launch timing switched off (nrtSetLaunchTiming(ctx, 0): "lean" launches) none is recorded.  The `done` event is only
-// needed when somebody has to wait for a slot's last launch — another stream taking the slot over, a rebuild, destroy —
-// and a lean launch cannot provide it afterwards (the caller's stream may be gone by then), so those waits fall back to a
-// device-wide synchronisation.
+// the three records per launch — a timing pair and the slot's `done` — held C3 at 24 us of idle time per launch).  So the
+// triangle launches of the production kernel record NONE by default: the kernel's last wave publishes a completion record
+// (sequence number + start / end stamps) in page-locked memory, and whoever has to wait for the launch — a rebuild, destroy,
+// another stream taking the slot over, nrtLastTraverseMs — polls that record: precise, and nothing else on the device is
+// waited for.  Launches followed by a post pass (spheres, cylinders) and the literal kernel keep the events.
+static hipError_t wait_record(nrt_ctx::LaunchSlot &sl) {
+  if (!sl.rec_pending) return hipSuccess;
+  volatile uint32_t *seq = &sl.h_done->seq;
+  const auto t_start = std::chrono::steady_clock::now();
+  for (unsigned long spins = 0; *seq != sl.seq; spins++) {
+    if (spins < 4000) continue; // (a launch lasts a fraction of a millisecond)
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+    if ((spins & 1023) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) {
+      // something is wrong (a faulted launch never writes its record): let the runtime report it
+      hipError_t e = hipDeviceSynchronize();
+      if (e != hipSuccess) return e;
+      if (*seq != sl.seq) return hipErrorUnknown;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  sl.rec_pending = false;
+  return hipSuccess;
+}
+
+// The slot's last launch is over (host-side wait).
 static hipError_t slot_done(nrt_ctx *c, nrt_ctx::LaunchSlot &sl) {
-  if (!sl.used || !sl.done_pending) return hipSuccess;
-  hipError_t e = hipDeviceSynchronize();
-  if (e != hipSuccess) return e;
-  sl.done_pending = false;
-  return hipEventRecord(sl.done, c->stream); // (everything has completed: later waits on the event return at once)
+  (void)c;
+  if (!sl.used) return hipSuccess;
+  if (sl.last_has_rec) return wait_record(sl);
+  return sl.done ? hipEventSynchronize(sl.done) : hipSuccess;
 }
 
 static hipError_t wait_for_launches(nrt_ctx *c) {
   std::lock_guard<std::mutex> lock(c->launch_mutex);
-  for (nrt_ctx::LaunchSlot &sl : c->slots)
-    if (sl.used && sl.done) {
-      hipError_t e = slot_done(c, sl);
-      if (e != hipSuccess) return e;
-      e = hipEventSynchronize(sl.done);
-      if (e != hipSuccess) return e;
-    }
+  for (nrt_ctx::LaunchSlot &sl : c->slots) {
+    hipError_t e = slot_done(c, sl);
+    if (e != hipSuccess) return e;
+  }
   return hipStreamSynchronize(c->stream);
 }
 
@@ -215,6 +243,59 @@ static void free_mesh(nrt_ctx *c) {
   c->d_faces = nullptr;
   c->d_radii = nullptr;
   c->num_faces = c->num_verts = 0;
+}
+
+// ---------------------------------------------------------------------------
+// Tunables (nrtSetTunable / nrtGetTunable; the environment variable NRT_<NAME> overrides the default at nrtCreate).
+// ---------------------------------------------------------------------------
+struct TunableDesc {
+  const char *name;
+  long long lo, hi;
+  long long (*get)(const nrt_ctx *);
+  void (*set)(nrt_ctx *, long long);
+};
+#define NRT_TUNABLE(name_, lo_, hi_, field_, type_)                                                          \
+  {name_, lo_, hi_, [](const nrt_ctx *c) -> long long { return (long long)c->field_; },                      \
+   [](nrt_ctx *c, long long v) { c->field_ = (type_)v; }}
+static const TunableDesc kTunables[] = {
+    NRT_TUNABLE("refill_min", 1, 64, refill_min, unsigned),       // idle lanes of a wave before it claims more rays
+    NRT_TUNABLE("trav_min", 1, 64, trav_min, unsigned),           // lanes still walking below which the inner-node phase ends
+    NRT_TUNABLE("leaf_min", 1, 64, leaf_min, unsigned),           // lanes at a leaf below which a due refill goes first
+    NRT_TUNABLE("chunk", 16, 1 << 20, chunk, unsigned),           // rays claimed per atomic
+    NRT_TUNABLE("parts", 1, kMaxParts, num_parts, unsigned),      // ray partitions (== XCDs)
+    NRT_TUNABLE("static_pct", 0, 100, static_pct, unsigned),      // share of a batch owned statically, percent
+    NRT_TUNABLE("static_bands", 1, 64, static_bands, unsigned),   // ... in up to this many slices per wave, one per band
+    NRT_TUNABLE("blocks_per_cu", 0, 8, max_blocks_per_cu, unsigned), // cap on the persistent grid (0: occupancy)
+    NRT_TUNABLE("debug", 0, 0x7FFFFFFF, debug_flags, unsigned),   // profiling bit mask
+    NRT_TUNABLE("morton", 0, 1, morton, int),                     // Morton pre-pass of the builder (next build)
+    NRT_TUNABLE("wide", 0, 1, wide, int),                         // 0: the literal BVHNode loop
+    NRT_TUNABLE("wide4", 0, 1, wide4, int),                       // two tree levels per step (next build / set_tree)
+    NRT_TUNABLE("split", 0, 1, split, int),                       // drain-time work splitting
+    NRT_TUNABLE("drain_steps", 1, 1 << 20, drain_steps, unsigned),
+    NRT_TUNABLE("split_busy", 0, 64, split_busy, unsigned),
+    NRT_TUNABLE("launch_timing", 0, 1, launch_timing, int),       // == nrtSetLaunchTiming
+    NRT_TUNABLE("host_pipeline", 0, 1, host_pipeline, int),       // pipelined host entry point
+    NRT_TUNABLE("wide_scramble", 0, 1, wide_scramble, int),       // probe: WideNode / Wide4Node records in a pseudo-random order (next build)
+    {"lds_stack", 16, 32, [](const nrt_ctx *c) -> long long { return c->lds_stack; },
+     [](nrt_ctx *c, long long v) { if (v == 16 || v == 24 || v == 32) c->lds_stack = (int)v; }},
+    {"wide_stack", 8, 16, [](const nrt_ctx *c) -> long long { return c->wide_stack; },
+     [](nrt_ctx *c, long long v) { if (v == 8 || v == 10 || v == 12 || v == 16) c->wide_stack = (int)v; }},
+};
+#undef NRT_TUNABLE
+
+static const TunableDesc *tunable_find(const char *name) {
+  if (!name) return nullptr;
+  for (const TunableDesc &d : kTunables)
+    if (!strcmp(d.name, name)) return &d;
+  return nullptr;
+}
+static bool tunable_set(nrt_ctx *c, const char *name, long long v) {
+  const TunableDesc *d = tunable_find(name);
+  if (!d) return false;
+  d->set(c, std::min(d->hi, std::max(d->lo, v)));
+  // the occupancy figures depend on the variant the tunables select: recompute on the next launch
+  c->blocks_per_cu = c->wide_blocks_per_cu = c->wide4_blocks_per_cu = c->sphere_blocks_per_cu = 0;
+  return true;
 }
 
 extern "C" {
@@ -255,7 +336,7 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
       (e = hipEventCreate(&c->ev_b0)) != hipSuccess || (e = hipEventCreate(&c->ev_b1)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_build_state, hipEventDisableTiming)) != hipSuccess ||
       (e = hipHostMalloc(&c->build_state, kBuildPinnedBytes, hipHostMallocDefault)) != hipSuccess ||
-      (e = hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) {
+      (e = hipMalloc((void **)&c->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess) {
     fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
     nrtDestroy(c);
     return NRT_ERR_DEVICE;
@@ -264,38 +345,27 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
     if ((e = hipMalloc((void **)&sl.d_cursor, 2 * kCursorStrideWords * 4 * kMaxParts)) != hipSuccess ||
         (e = hipMemset(sl.d_cursor, 0, 2 * kCursorStrideWords * 4 * kMaxParts)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreate(&sl.t0)) != hipSuccess || (e = hipEventCreate(&sl.t1)) != hipSuccess) {
+        (e = hipEventCreate(&sl.t0)) != hipSuccess || (e = hipEventCreate(&sl.t1)) != hipSuccess ||
+        (e = hipHostMalloc((void **)&sl.h_done, sizeof(DoneRec), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipHostGetDevicePointer((void **)&sl.d_done, sl.h_done, 0)) != hipSuccess ||
+        (e = hipMalloc((void **)&sl.d_count, sizeof(DoneCount))) != hipSuccess ||
+        (e = hipMemset(sl.d_count, 0xFF, sizeof(DoneCount))) != hipSuccess || (e = hipMemset(sl.d_count, 0, 8)) != hipSuccess) {
       fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
       nrtDestroy(c);
       return NRT_ERR_DEVICE;
     }
   }
+  for (nrt_ctx::LaunchSlot &sl : c->slots) memset(sl.h_done, 0, sizeof(DoneRec));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     c->num_cus = prop.multiProcessorCount;
-  if (const char *e = getenv("NRT_LDS_STACK")) {
-    int v = atoi(e);
-    if (v == 16 || v == 24 || v == 32) c->lds_stack = v;
-  }
-  if (const char *e = getenv("NRT_REFILL_MIN")) c->refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
-  if (const char *e = getenv("NRT_TRAV_MIN")) c->trav_min = (unsigned)std::min(64, std::max(1, atoi(e)));
-  if (const char *e = getenv("NRT_LEAF_MIN")) c->leaf_min = (unsigned)std::min(64, std::max(1, atoi(e)));
-  if (const char *e = getenv("NRT_CHUNK")) c->chunk = (unsigned)std::max(16, atoi(e));
-  if (const char *e = getenv("NRT_PARTS")) c->num_parts = (unsigned)std::min((int)kMaxParts, std::max(1, atoi(e)));
-  if (const char *e = getenv("NRT_DEBUG")) c->debug_flags = (unsigned)atoi(e);
-  if (const char *e = getenv("NRT_MORTON")) c->morton = atoi(e) != 0;
-  if (const char *e = getenv("NRT_STATIC_PCT")) c->static_pct = (unsigned)std::min(100, std::max(0, atoi(e)));
-  if (const char *e = getenv("NRT_BLOCKS_PER_CU")) c->max_blocks_per_cu = (unsigned)std::max(0, atoi(e));
-  if (const char *e = getenv("NRT_WIDE")) c->wide = atoi(e) != 0;
-  if (const char *e = getenv("NRT_SPLIT")) c->split = atoi(e) != 0;
-  if (const char *e = getenv("NRT_WIDE4")) c->wide4 = atoi(e) != 0;
-  if (const char *e = getenv("NRT_LAUNCH_TIMING")) c->launch_timing = atoi(e) != 0;
-  if (const char *e = getenv("NRT_HOST_PIPELINE")) c->host_pipeline = atoi(e) != 0;
-  if (const char *e = getenv("NRT_DRAIN_STEPS")) c->drain_steps = (unsigned)std::max(1, atoi(e));
-  if (const char *e = getenv("NRT_SPLIT_BUSY")) c->split_busy = (unsigned)std::min(64, std::max(0, atoi(e)));
-  if (const char *e = getenv("NRT_WIDE_STACK")) {
-    int v = atoi(e);
-    if (v == 8 || v == 10 || v == 12 || v == 16) c->wide_stack = v;
+  // Environment overrides (debugging aid): NRT_<NAME> for every tunable of nrtSetTunable, applied once at creation.
+  for (const TunableDesc &d : kTunables) {
+    char env[64] = "NRT_";
+    size_t k = 4;
+    for (const char *p = d.name; *p && k + 1 < sizeof(env); p++) env[k++] = (char)toupper((unsigned char)*p);
+    env[k] = 0;
+    if (const char *e = getenv(env)) (void)tunable_set(c, d.name, atoll(e));
   }
   *out = c;
   return NRT_OK;
@@ -306,8 +376,10 @@ void nrtDestroy(nrt_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (nrt_ctx::LaunchSlot &sl : c->slots) { // launches still in flight on the caller's streams
-    if (sl.used && sl.done && slot_done(c, sl) == hipSuccess) (void)hipEventSynchronize(sl.done);
+    if (sl.h_done || sl.done) (void)slot_done(c, sl);
     if (sl.d_cursor) (void)hipFree(sl.d_cursor);
+    if (sl.d_count) (void)hipFree(sl.d_count);
+    if (sl.h_done) (void)hipHostFree(sl.h_done);
     if (sl.spill.p) (void)hipFree(sl.spill.p);
     if (sl.spill_tmin.p) (void)hipFree(sl.spill_tmin.p);
     if (sl.cyl_hits.p) (void)hipFree(sl.cyl_hits.p);
@@ -483,7 +555,8 @@ static nrt_status finish_wide(nrt_ctx *c) {
     c->d_wide4 = c->b_wide4.p;
   }
   HIPCHK(c, launch_make_wide<T>((const typename Wire<T>::Node *)c->d_nodes, (uint32_t)c->num_nodes, c->packed_leaves,
-                                (uint32_t *)c->b_wide_scratch.p, (WideNode<T> *)c->d_wide, (Wide4Node<T> *)c->d_wide4, c->stream));
+                                (uint32_t *)c->b_wide_scratch.p, (WideNode<T> *)c->d_wide, (Wide4Node<T> *)c->d_wide4,
+                                c->wide_scramble ? c->num_branch_records : 0u, c->stream));
   return NRT_OK;
 }
 
@@ -693,8 +766,10 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   if (!slot) {
     slot = &c->slots[c->next_victim];
     c->next_victim = (c->next_victim + 1) % nrt_ctx::kSlots;
-    HIPCHK(c, slot_done(c, *slot));
-    HIPCHK(c, hipStreamWaitEvent(s, slot->done, 0));
+    if (slot->last_has_rec)
+      HIPCHK(c, wait_record(*slot)); // (the host waits: a fifth concurrent stream is the rare case)
+    else
+      HIPCHK(c, hipStreamWaitEvent(s, slot->done, 0));
   }
 
   // persistent grid: every block resident (occupancy of the chosen variant)
@@ -707,7 +782,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
   // two levels per step: closest-hit walks of nested fp32 triangle trees, outside the profiling / splitting variants
   const bool use_wide4 = use_wide && !spheres && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch &&
-                         !c->split && !(c->debug_flags & (32u | 8192u));
+                         !c->split && !(c->debug_flags & 8192u);
   if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, c->split != 0, false);
   if (use_wide4 && c->wide4_blocks_per_cu == 0) c->wide4_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(kWide4LdsStack, kPrimTriangles, false, true);
   if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, false, false);
@@ -721,7 +796,10 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   const uint32_t total_threads = grid * kTraverseBlock;
   const uint32_t total_waves = grid * (kTraverseBlock / kWave);
   // static share: a multiple of 64 rays per wave, c->static_pct percent of the batch in total
-  const uint32_t static_per_wave = (uint32_t)(((uint64_t)n * c->static_pct / 100) / total_waves / 64) * 64;
+  // ... cut into up to `static_bands` slices of whole 64-ray groups, one in each band of the static region (traverse.hip, Claim)
+  const uint32_t static_share = (uint32_t)(((uint64_t)n * c->static_pct / 100) / total_waves / 64); // 64-ray groups per wave
+  const uint32_t static_bands = std::min<uint32_t>(c->static_bands, static_share);
+  const uint32_t static_per_wave = static_bands ? (static_share / static_bands) * 64u : 0u;
   // deepest possible stack: one pending sibling per level of the path — three per TWO levels when a step covers two
   const uint32_t max_entries = use_wide4 ? 3u * (c->tree_depth / 2u + 1u) + 2u : c->tree_depth + 2u;
   const uint32_t levels = max_entries > (uint32_t)stack_entries ? max_entries - stack_entries : 0;
@@ -777,7 +855,8 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.next_cursor = slot->d_cursor + (size_t)(slot->parity ^ 1u) * kCursorStrideWords * kMaxParts;
   a.num_parts = parts;
   a.static_per_wave = static_per_wave;
-  a.dyn_begin = static_per_wave * total_waves;
+  a.static_bands = static_bands;
+  a.dyn_begin = static_bands * static_per_wave * total_waves;
   a.blocks_per_part = grid / parts;
   a.counters = c->d_counters;
   a.wave_clock = nullptr;
@@ -792,8 +871,13 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.trav_min = c->trav_min;
   a.leaf_min = c->leaf_min;
 
-  if (count || (c->debug_flags & (32u | 4096u))) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), s));
-  timed = timed && c->launch_timing != 0;
+  if (count || (c->debug_flags & (32u | 4096u))) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), s));
+  // completion record instead of events: the traversal kernel is the launch's last kernel and events were not asked for
+  const bool use_rec = use_wide && !spheres && !count && !c->launch_timing;
+  a.done_rec = use_rec ? slot->d_done : nullptr;
+  a.done_count = slot->d_count;
+  a.done_seq = use_rec ? slot->seq + 1u : 0u;
+  timed = timed && !use_rec;
   if (timed) HIPCHK(c, hipEventRecord(slot->t0, s));
   if (use_wide) {
     HIPCHK(c, launch_traverse_wide<T>(a, grid, c->wide_stack, c->prim_kind, s, &c->last_kernel));
@@ -804,16 +888,16 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   if (d_cyl_hits)
     HIPCHK(c, launch_cylinder_post((const nrt_ray_f32 *)d_rays, (const nrt_hit_f32 *)slot->cyl_hits.p, (const uint8_t *)slot->cyl_bits.p,
                                    (const float *)c->d_verts, (uint32_t)n, d_cyl_hits, d_mask, s));
-  if (timed) {
-    HIPCHK(c, hipEventRecord(slot->t1, s));
-    c->last_timed_slot = (int)(slot - c->slots);
-  }
-  if (c->launch_timing) {
-    HIPCHK(c, hipEventRecord(slot->done, s));
-    slot->done_pending = false;
+  if (timed) HIPCHK(c, hipEventRecord(slot->t1, s));
+  if (use_rec) {
+    slot->seq++;
+    slot->rec_pending = true;
   } else {
-    slot->done_pending = true; // lean launch: whoever has to wait for it synchronises the device (slot_done)
+    HIPCHK(c, hipEventRecord(slot->done, s));
   }
+  slot->last_has_rec = use_rec;
+  slot->last_timed = timed;
+  if (timed || use_rec) c->last_timed_slot = (int)(slot - c->slots);
   slot->parity ^= 1u;
   slot->stream = s;
   slot->used = true;
@@ -869,7 +953,12 @@ static nrt_status traverse_host(nrt_ctx *c, const typename Wire<T>::Ray *rays, u
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_in[b], 0));
       if (piece >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_out[b], 0));
       st = traverse_device<T>(c, d_r, m, opt, d_h, d_m, c->stream, false, true);
-      if (st) return st;
+      if (st) { // (copies into the caller's buffers may still be in flight: let them land before the call returns)
+        (void)hipStreamSynchronize(c->copy_in);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->copy_out);
+        return st;
+      }
       HIPCHK(c, hipEventRecord(c->ev_tr[b], c->stream));
       HIPCHK(c, hipStreamWaitEvent(c->copy_out, c->ev_tr[b], 0));
       HIPCHK(c, hipMemcpyAsync(hits + off, d_h, m * sizeof(Hit), hipMemcpyDeviceToHost, c->copy_out));
@@ -1069,14 +1158,38 @@ nrt_status nrtSetLaunchTiming(nrt_ctx *c, int on) {
   return NRT_OK;
 }
 
+// Traversal / build tunables by name (the table above).  Values are clamped to the tunable's range; a tunable that shapes
+// the private tree layout (wide4, wide_scramble, morton) takes effect with the next nrtBuild / nrtSetTree.
+nrt_status nrtSetTunable(nrt_ctx *c, const char *name, long long value) {
+  if (!c) return NRT_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->launch_mutex);
+  if (!tunable_set(c, name, value)) return fail(c, NRT_ERR_INVALID, "nrtSetTunable: unknown tunable '%s'", name ? name : "(null)");
+  return NRT_OK;
+}
+nrt_status nrtGetTunable(nrt_ctx *c, const char *name, long long *value_out) {
+  if (!c || !value_out) return NRT_ERR_INVALID;
+  const TunableDesc *d = tunable_find(name);
+  if (!d) return fail(c, NRT_ERR_INVALID, "nrtGetTunable: unknown tunable '%s'", name ? name : "(null)");
+  std::lock_guard<std::mutex> lock(c->launch_mutex);
+  *value_out = d->get(c);
+  return NRT_OK;
+}
+
 float nrtLastTraverseMs(nrt_ctx *c) {
   if (!c) return -1.f;
   hipEvent_t t0, t1;
   {
     std::lock_guard<std::mutex> lock(c->launch_mutex);
     if (c->last_timed_slot < 0) return -1.f;
-    t0 = c->slots[c->last_timed_slot].t0;
-    t1 = c->slots[c->last_timed_slot].t1;
+    nrt_ctx::LaunchSlot &sl = c->slots[c->last_timed_slot];
+    if (sl.last_has_rec) { // the kernel's own stamps: first block started -> last wave finished (100 MHz realtime ticks)
+      if (wait_record(sl) != hipSuccess) return -1.f;
+      const unsigned long long b = sl.h_done->t_begin, e = sl.h_done->t_end;
+      return e >= b ? (float)((double)(e - b) * 1e-5) : -1.f;
+    }
+    if (!sl.last_timed) return -1.f;
+    t0 = sl.t0;
+    t1 = sl.t1;
   }
   if (hipEventSynchronize(t1) != hipSuccess) return -1.f;
   float ms = -1.f;
@@ -1094,7 +1207,7 @@ int nrtDebugCounters(nrt_ctx *c, unsigned long long *out) {
   if (!c || !out) return 1;
   if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
   if (hipDeviceSynchronize() != hipSuccess) return 1;
-  return hipMemcpy(out, c->d_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+  return hipMemcpy(out, c->d_counters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 
 // Profiling aid (not part of the public header): with NRT_DEBUG bit 8192 every wave of a traversal launch records when

@@ -181,6 +181,22 @@ struct SceneTraceArgs {
   uint32_t refill_min;        // free lanes of a wave before it claims more rays
 };
 
+// Completion record of a launch slot, in page-locked host memory the device writes to: the last wave of a traversal
+// launch to finish stores the launch's start / end stamps (100 MHz s_memrealtime ticks) and then its sequence number
+// (system-scope release).  Whoever must know that a launch is over (a rebuild, destroy, another stream taking the slot
+// over, nrtLastTraverseMs) polls `seq` — no event is recorded in the stream, so consecutive launches run back to back.
+struct DoneRec {
+  uint32_t seq;
+  uint32_t pad;
+  unsigned long long t_begin, t_end;
+};
+// Device-side words that go with it (one set per slot, zero / ~0 between launches).
+struct DoneCount {
+  uint32_t exited; // waves of the current launch that have finished
+  uint32_t pad;
+  unsigned long long t_begin; // earliest start stamp seen (atomicMin)
+};
+
 template <typename T>
 struct TraverseArgs {
   const typename Wire<T>::Node *nodes;
@@ -213,7 +229,8 @@ struct TraverseArgs {
   uint32_t *ray_cursor;              // persistent-thread work counters, one per ray partition, 4 KiB apart, zero at launch
   uint32_t *next_cursor;             // the set the NEXT launch of this slot will use: block 0 zeroes it (no memset launch)
   uint32_t num_parts;                // ray partitions (== XCDs): contiguous ranges of the ray array, one home range per XCD
-  uint32_t static_per_wave;          // rays [rank*static_per_wave, +static_per_wave) belong to wave `rank` without any atomic
+  uint32_t static_per_wave;          // rays per static slice: slice `rank` of band b = [(b*waves + rank)*static_per_wave, +static_per_wave) belongs to wave `rank` without any atomic
+  uint32_t static_bands;             // bands of the static region (0: no static share)
   uint32_t dyn_begin;                // rays [dyn_begin, num_rays) are claimed dynamically (per-partition cursors)
   uint32_t blocks_per_part;          // gridDim.x / num_parts
   unsigned long long *counters;      // 4 x u64 when counting
@@ -222,6 +239,9 @@ struct TraverseArgs {
   uint32_t refill_min;               // refill idle lanes once this many are idle (1..64)
   uint32_t trav_min;                 // leave the inner-node loop when fewer lanes than this are walking
   uint32_t leaf_min;                 // with fewer lanes than this waiting at a leaf, refill first (if a refill is due) and test triangles later
+  DoneRec *done_rec;                 // completion record of this launch's slot (device-visible host memory), or null: none
+  DoneCount *done_count;             // its device-side words
+  uint32_t done_seq;                 // sequence number of this launch within its slot
 };
 
 } // namespace nrt

@@ -390,9 +390,15 @@ __device__ __forceinline__ unsigned lane_id() {
 //    microsecond on this part, hence the static share and the modest chunk count.
 //    (Round 2 re-measured the whole family with per-wave time stamps — static share 0-75 %, chunks of 16-128 rays,
 //    claims issued one chunk ahead of need: nothing beats 75 % / 128; profiles/r02d_scheduling_sweep.txt.)
+//  * Round 3: the static share of a wave is no longer ONE slice but `static_bands` of them, one in each of as many equal
+//    bands of the static region (band b = rays [b * waves * static_per_wave, +waves * static_per_wave), inside it wave
+//    `rank` owns slice `rank`): every wave then samples the whole batch — an image whose cost per ray varies from region to
+//    region (C2: 40 % sky) no longer leaves one XCD with the expensive rows — and all waves of an XCD sit in the same band
+//    at the same time, which narrows the part of the tree an L2 sees at any moment.
 struct Claim {
   uint32_t next, end; // claimed, not yet handed out: [next, end)
   uint32_t part, tried;
+  uint32_t rank, band; // static share: this wave's rank, the band its current slice lies in
   bool exhausted;
 };
 
@@ -400,8 +406,10 @@ template <typename T>
 __device__ __forceinline__ void claim_init(const TraverseArgs<T> &a, Claim &c) {
   const uint32_t part = blockIdx.x % a.num_parts;
   const uint32_t rank = (part * a.blocks_per_part + blockIdx.x / a.num_parts) * (kTraverseBlock / kWave) + threadIdx.x / kWave;
+  c.rank = rank;
+  c.band = 0;
   c.next = rank * a.static_per_wave;
-  c.end = c.next + a.static_per_wave;
+  c.end = a.static_bands ? c.next + a.static_per_wave : c.next;
   c.part = part;
   c.tried = 0;
   c.exhausted = false;
@@ -410,6 +418,12 @@ __device__ __forceinline__ void claim_init(const TraverseArgs<T> &a, Claim &c) {
 // All lanes of the wave call this (uniform control flow); `leader` is any active lane index.
 template <typename T>
 __device__ __forceinline__ bool claim_chunk(const TraverseArgs<T> &a, Claim &c, unsigned lane, int leader) {
+  if (c.band + 1u < a.static_bands) { // the wave's slice of the next band (no atomic)
+    c.band++;
+    c.next = (c.band * (gridDim.x * (kTraverseBlock / kWave)) + c.rank) * a.static_per_wave;
+    c.end = c.next + a.static_per_wave;
+    return true;
+  }
   const uint32_t dyn = a.num_rays - a.dyn_begin;
   const uint32_t per = dyn / a.num_parts, extra = dyn % a.num_parts; // first `extra` parts hold one more ray
   while (c.tried < a.num_parts) {
@@ -448,6 +462,31 @@ __device__ __forceinline__ void store_hit_nt(typename Wire<T>::Hit *p, const typ
   u32x4 *dst = reinterpret_cast<u32x4 *>(p);
 #pragma unroll
   for (unsigned k = 0; k < sizeof(h) / 16; k++) __builtin_nontemporal_store(src[k], dst + k);
+}
+
+// Completion record of a launch (common.h, DoneRec): no event is recorded in the stream for it.  Start — one thread of each
+// of the first eight blocks (one per XCD) stamps the time; end — every wave counts itself out once its stores are on their
+// way, and the last one publishes the two stamps and then the launch's sequence number to the page-locked record.
+template <typename T>
+__device__ __forceinline__ void done_begin(const TraverseArgs<T> &a) {
+  if (a.done_rec != nullptr && threadIdx.x == 0u && blockIdx.x < 8u)
+    atomicMin(&a.done_count->t_begin, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+template <typename T>
+__device__ __forceinline__ void done_end(const TraverseArgs<T> &a, unsigned lane) {
+  if (a.done_rec == nullptr) return;
+  __threadfence(); // this wave's stores (results, overflow stack) are out before it counts itself out
+  if (lane == 0u) {
+    const uint32_t waves = gridDim.x * (kTraverseBlock / kWave);
+    if (atomicAdd(&a.done_count->exited, 1u) == waves - 1u) { // the last wave of the launch
+      const unsigned long long t0 = atomicExch(&a.done_count->t_begin, ~0ull); // (both words handed on clean to the slot's next launch)
+      (void)atomicExch(&a.done_count->exited, 0u);
+      DoneRec *r = a.done_rec;
+      r->t_begin = t0;
+      r->t_end = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+      __hip_atomic_store(&r->seq, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // Lane states of the while-while loop.
@@ -1002,7 +1041,7 @@ struct FoldRec { // one per thread slot, used by the slot's lane when it owns a 
 // WIDTH: 2 = one WideNode (two boxes) per step, 4 = one Wide4Node (two levels, four boxes) per step.
 template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool SPLIT = false, bool CLOCK = false, int WIDTH = 2>
 __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((WIDTH == 4 && sizeof(T) == 4) ? NRT_W4_WAVES : 1)) void k_traverse_wide(const TraverseArgs<T> a) {
-  static_assert(WIDTH == 2 || (WIDTH == 4 && !SPLIT && !STATS && KIND == kPrimTriangles), "the two-level step is a triangle closest-hit variant");
+  static_assert(WIDTH == 2 || (WIDTH == 4 && !SPLIT && KIND == kPrimTriangles), "the two-level step is a triangle closest-hit variant");
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
   __shared__ FoldRec<T> s_fold[SPLIT ? kTraverseBlock : 1];
@@ -1037,9 +1076,12 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
   Claim ck;
   claim_init<T>(a, ck);
   if (blockIdx.x == 0 && threadIdx.x < kMaxParts) a.next_cursor[kCursorStrideWords * threadIdx.x] = 0u;
+  done_begin<T>(a);
   // STATS (profiling instantiation only): wave-level loop occupancy
   unsigned long long st_it1 = 0, st_act1 = 0, st_idle2 = 0, st_it2 = 0, st_act2 = 0, st_refills = 0, st_refilled = 0, st_entries2 = 0;
   uint32_t st_steps = 0, st_tris = 0; // per ray; with debug flag 64 they replace u, v of the hit record
+  // ... and where the wave's time goes (shader-clock ticks): refill (claim, result stores, ray loads, lane set-up), inner-node phase, leaf phase
+  unsigned long long st_t_refill = 0, st_t_p1 = 0, st_t_p2 = 0, st_act2b = 0, st_stamp = 0;
 
   // PostTraversal (nanort.h:1205-1211) with the strict final predicate (:2552).  Finished lanes keep
   // their result in registers until the lane is refilled (or the wave runs out of rays), so the
@@ -1087,6 +1129,7 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
 
   for (;;) {
     // ---- refill idle lanes ---------------------------------------------------------
+    if (STATS) st_stamp = __builtin_amdgcn_s_memtime();
     unsigned long long idle = __ballot(state == W_IDLE);
     if (!ck.exhausted && (unsigned)__builtin_popcountll(idle) >= a.refill_min) {
       // lanes that still hold a result and lanes that never had a ray are both W_IDLE
@@ -1144,6 +1187,11 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
 
     // ---- phase 1: inner nodes / stack pops ---------------------------------------------
     // (lanes that leave the loop are invisible to its ballots: the wave counts those waiting at a leaf itself)
+    if (STATS) {
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();
+      st_t_refill += now_ - st_stamp;
+      st_stamp = now_;
+    }
     unsigned n_wait_leaf = (unsigned)__builtin_popcountll(__ballot(state == W_LEAF));
     while (state == W_TRAV || state == W_POP) {
       if (STATS) {
@@ -1193,6 +1241,11 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
     // their first leaves while these lanes wait, and the triangle loop then runs with many more
     // lanes.  (Every skip is followed by a refill that hands out at least one ray or marks the
     // claim exhausted, so this always makes progress.)
+    if (STATS) {
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();
+      st_t_p1 += now_ - st_stamp;
+      st_stamp = now_;
+    }
     const unsigned n_leaf = (unsigned)__builtin_popcountll(__ballot(state == W_LEAF));
     const bool refill_due = !ck.exhausted && (unsigned)__builtin_popcountll(__ballot(state == W_IDLE)) >= a.refill_min;
     if (n_leaf != 0u && !(n_leaf < a.leaf_min && refill_due)) {
@@ -1212,12 +1265,18 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
         st_entries2++;
         st_idle2 += (unsigned)__builtin_popcountll(__ballot(state == W_IDLE));
       }
-      if constexpr (!SPLIT && !STATS && KIND == kPrimTriangles && (WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL) > 1) {
+      if constexpr (!SPLIT && KIND == kPrimTriangles && (WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL) > 1) {
         // several records per trip, all fetched before any is tested (same tests in the same order; fewer dependent
         // round trips per leaf — this variant has the registers for it)
         constexpr uint32_t U_ = WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL;
         for (uint32_t i = 0; __ballot(i < cnt) != 0ull; i += U_) {
           LeafTri<T> t_[U_];
+          if (STATS) {
+            st_it2++;
+            st_act2 += (unsigned)__builtin_popcountll(__ballot(i < cnt));
+            st_act2b += (unsigned)__builtin_popcountll(__ballot(i + 1u < cnt));
+            if (i < cnt) st_tris += (i + 1u < cnt) ? 2u : 1u;
+          }
 #pragma unroll
           for (uint32_t j = 0; j < U_; j++) t_[j] = a.tris[first + (i + j < cnt ? i + j : 0u)];
 #pragma unroll
@@ -1250,6 +1309,7 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
       if (a.any_hit) sp = (state == W_LEAF && L.hit_t < L.max_t) ? 0 : sp;
       state = (state == W_LEAF) ? W_POP : state;
     }
+    if (STATS) st_t_p2 += __builtin_amdgcn_s_memtime() - st_stamp;
   }
   // ---- the drain: this wave found every work cursor empty ------------------------------------------------------
   // It holds at most 64 - refill_min rays, the survivors of its last refill — by construction the long ones — and
@@ -1496,6 +1556,7 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
   if (rid != kInvalid) NRT_WRITE_RESULT(); // results still held in registers
 #undef NRT_WRITE_RESULT
 #undef NRT_TEST_PRIM
+  done_end<T>(a, lane);
   if (clocked && lane == 0u) { // one record per wave, reduced on the host (atomics on one line would serialise the exits)
     unsigned long long *rec = a.wave_clock + 3ull * (size_t)(gslot / kWave);
     const unsigned long long clk_end = __builtin_amdgcn_s_memrealtime();
@@ -1512,6 +1573,10 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
     atomicAdd(&a.counters[5], st_refills);
     atomicAdd(&a.counters[6], st_refilled);
     atomicAdd(&a.counters[7], st_entries2);
+    atomicAdd(&a.counters[8], st_t_refill); // [8..10]: shader-clock ticks of the wave spent refilling / in the inner-node phase / in the leaf phase
+    atomicAdd(&a.counters[9], st_t_p1);
+    atomicAdd(&a.counters[10], st_t_p2);
+    atomicAdd(&a.counters[11], st_act2b);   // leaf loop, two records per trip: lanes with a second record
   }
 }
 
@@ -1784,7 +1849,7 @@ __global__ __launch_bounds__(256) void k_wide_scan_tiles(uint32_t *tile_count, u
 template <typename T>
 __global__ __launch_bounds__(256) void k_wide_index(const typename Wire<T>::Node *__restrict__ nodes, uint32_t n,
                                                     const uint32_t *__restrict__ tile_base,
-                                                    uint32_t *__restrict__ dense_of) {
+                                                    uint32_t *__restrict__ dense_of, uint32_t scramble_mod) {
   __shared__ uint32_t s_wave[4];
   const uint32_t base = blockIdx.x * 1024u + threadIdx.x * 4u;
   uint32_t flags[4], c = 0;
@@ -1795,7 +1860,9 @@ __global__ __launch_bounds__(256) void k_wide_index(const typename Wire<T>::Node
   uint32_t total;
   uint32_t ex = tile_base[blockIdx.x] + block_exclusive_scan_256(c, s_wave, total);
   for (uint32_t k = 0; k < 4; k++) {
-    if (base + k < n) dense_of[base + k] = ex;
+    // (layout probe, tunable wide_scramble: record j of the pre-order goes to slot j * P mod #records — a bijection that
+    // keeps the root at 0 and tears every subtree apart; how much the walk slows down bounds what any re-ordering can win)
+    if (base + k < n) dense_of[base + k] = scramble_mod ? (uint32_t)(((uint64_t)ex * 2654435761ull) % scramble_mod) : ex;
     ex += flags[k];
   }
 }
@@ -1993,7 +2060,9 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
   }
   if (args.wide4) { // two tree levels per step (the caller checked what that needs)
     if constexpr (sizeof(T) == 4) {
-      if (args.plain_options)
+      if (args.debug_flags & 32u)
+        NRT_LAUNCH_WIDE(kWide4LdsStack, true, kPrimTriangles, true, false, false, 4); // profiling instantiation (default trace options only)
+      else if (args.plain_options)
         NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, false, false, 4);
       else
         NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, false, false, false, 4);
@@ -2061,13 +2130,13 @@ int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool split, bool w
 // scratch: tile counts (ceil(n/1024) u32) followed by dense_of (n u32)
 template <typename T>
 hipError_t launch_make_wide(const typename Wire<T>::Node *nodes, uint32_t n, uint32_t packed, uint32_t *scratch,
-                            WideNode<T> *wide, Wide4Node<T> *wide4, hipStream_t s) {
+                            WideNode<T> *wide, Wide4Node<T> *wide4, uint32_t scramble_mod, hipStream_t s) {
   if (n == 0) return hipSuccess;
   const uint32_t tiles = (n + 1023u) / 1024u;
   uint32_t *tile_count = scratch, *dense_of = scratch + tiles;
   hipLaunchKernelGGL((k_wide_count<T>), dim3(tiles), dim3(256), 0, s, nodes, n, tile_count);
   hipLaunchKernelGGL(k_wide_scan_tiles, dim3(1), dim3(256), 0, s, tile_count, tiles);
-  hipLaunchKernelGGL((k_wide_index<T>), dim3(tiles), dim3(256), 0, s, nodes, n, tile_count, dense_of);
+  hipLaunchKernelGGL((k_wide_index<T>), dim3(tiles), dim3(256), 0, s, nodes, n, tile_count, dense_of, scramble_mod);
   hipLaunchKernelGGL((k_make_wide<T>), dim3((n + 255u) / 256u), dim3(256), 0, s, nodes, n, dense_of, packed, wide, wide4);
   return hipGetLastError();
 }
@@ -2120,9 +2189,9 @@ template hipError_t launch_gather_leaf_spheres<float>(const uint32_t *, const fl
 template hipError_t launch_gather_leaf_spheres<double>(const uint32_t *, const double *, const double *,
                                                        LeafSphere<double> *, uint32_t, hipStream_t);
 template hipError_t launch_make_wide<float>(const nrt_node_f32 *, uint32_t, uint32_t, uint32_t *, WideNode<float> *,
-                                            Wide4Node<float> *, hipStream_t);
+                                            Wide4Node<float> *, uint32_t, hipStream_t);
 template hipError_t launch_make_wide<double>(const nrt_node_f64 *, uint32_t, uint32_t, uint32_t *, WideNode<double> *,
-                                             Wide4Node<double> *, hipStream_t);
+                                             Wide4Node<double> *, uint32_t, hipStream_t);
 template int traverse_blocks_per_cu<float>(int);
 template int traverse_blocks_per_cu<double>(int);
 template hipError_t launch_gather_leaf_tris<float>(const uint32_t *, const uint32_t *, const float *,

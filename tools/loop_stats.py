@@ -1,22 +1,48 @@
-import os, sys, ctypes
+"""Loop occupancy and time split of the traversal kernel (profiling instantiation, tunable debug = 32) on a bench config:
+per phase the wave iterations per 64 rays and the average number of active lanes, and which share of a wave's clock
+ticks goes to refilling, the inner-node phase and the leaf phase.
+
+    python tools/loop_stats.py [C3] [refill_min=32 static_bands=1 ...]      (name=value: nrtSetTunable)
+"""
+import ctypes
+import sys
+
 import numpy as np
-sys.path.insert(0, '.')
-os.environ['NRT_DEBUG'] = '32'
-for a in sys.argv[1:]:
-    k, v = a.split('='); os.environ[k] = v
-import torch
-from nanort_amd import BVHAccel, TriangleMesh, scenes, capi
-v, f = scenes.plane(1000, 500); mesh = TriangleMesh(v, f)
-rays1 = scenes.camera_rays(1920, 1080)
-a = BVHAccel(np.float32); a.Build(mesh.num_faces, mesh)
-h1, m1 = a.TraverseBatch(rays1)
-rays2 = scenes.secondary_rays("bounce", v, f, rays1, h1, m1)
-L = capi.lib(); L.nrtDebugCounters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-for name, rays in (('primary', rays1), ('bounce', rays2)):
-    d = torch.from_numpy(rays.view(np.uint8)).cuda(); o = torch.empty(len(rays) * 16, dtype=torch.uint8, device='cuda')
-    a.TraverseBatchDevice(d, o); ms = a.LastTraverseMs()
-    c = np.zeros(8, dtype=np.uint64); L.nrtDebugCounters(a._h, c.ctypes.data_as(ctypes.c_void_p))
-    it1, act1, idle2, it2, act2, refills, refilled, ent2 = [int(x) for x in c[:8]]
-    n = len(rays)
-    print(name, 'ms %.3f' % ms, 'phase1: wave-iters/ray-group %.1f' % (it1 / (n / 64)), 'avg active lanes %.1f' % (act1 / it1),
-          '| phase2: wave-iters/ray-group %.1f avg active %.1f' % (it2 / (n / 64), act2 / max(1, it2)), 'entries/group %.2f idle lanes at entry %.1f' % (ent2 / (n / 64), idle2 / max(1, ent2)), '| refills/group %.2f lanes/refill %.1f' % (refills / (n / 64), refilled / max(1, refills)))
+
+sys.path.insert(0, ".")
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from nanort_amd import capi  # noqa: E402
+
+cfg = [a for a in sys.argv[1:] if "=" not in a] or ["C3"]
+tun = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
+L = capi.lib()
+L.nrtDebugCounters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+for name in cfg:
+    wl = bench.Workload(name, builds=1)
+    a = wl.accel
+    for k, v in tun.items():
+        a.SetTunable(k, int(v))
+    for wave, d, o, n in (("primary", wl.d_rays1, wl.d_hits1, wl.n1), ("bounce", wl.d_rays2, wl.d_hits2, wl.n2)):
+        a.SetTunable("debug", 0)
+        ts = []
+        for _ in range(5):
+            a.TraverseBatchDevice(d, o)
+            ts.append(a.LastTraverseMs())
+        a.SetTunable("debug", 32)
+        a.TraverseBatchDevice(d, o)
+        ms_stats = a.LastTraverseMs()
+        c = np.zeros(16, dtype=np.uint64)
+        L.nrtDebugCounters(a._h, c.ctypes.data_as(ctypes.c_void_p))
+        it1, act1, idle2, it2, act2, refills, refilled, ent2, t_ref, t_p1, t_p2, act2b = [int(x) for x in c[:12]]
+        g = n / 64.0
+        tt = max(1, t_ref + t_p1 + t_p2)
+        print("%s %-8s %s  production %.4f ms (profiling variant %.4f ms, %s)" % (name, wave, tun, float(np.median(ts)), ms_stats, a.LastKernelName()))
+        print("    inner-node phase: %.1f wave-iterations per 64 rays, %.1f lanes active | leaf phase: %.1f trips per 64 rays, %.1f lanes with a "
+              "first record, %.1f with a second; entered %.2f times per 64 rays with %.1f lanes idle | refills %.2f per 64 rays, %.1f lanes each"
+              % (it1 / g, act1 / max(1, it1), it2 / g, act2 / max(1, it2), act2b / max(1, it2), ent2 / g, idle2 / max(1, ent2), refills / g, refilled / max(1, refills)))
+        print("    wave time: refill %.1f %%, inner-node phase %.1f %%, leaf phase %.1f %%  (ticks per 64 rays: %.0f / %.0f / %.0f; per refill %.0f, per inner iteration %.0f, per leaf trip %.0f)"
+              % (100.0 * t_ref / tt, 100.0 * t_p1 / tt, 100.0 * t_p2 / tt, t_ref / g, t_p1 / g, t_p2 / g, t_ref / max(1, refills), t_p1 / max(1, it1), t_p2 / max(1, it2)), flush=True)
+    del wl
+    torch.cuda.empty_cache()
