@@ -356,7 +356,9 @@ NRT_API long nrtDebugWaveClocks(nrt_ctx *ctx, unsigned long long *out, long cap)
  * only when strictly nearer.  Nodes entered at exactly the same distance are visited in node order (the
  * reference: in the order its std::priority_queue pops them), which only shows when several COINCIDENT
  * instances produce the same hit record: either may be named in node_id.  A node is a built nrt_ctx (f32) plus nanosg's T[4][4] local transform
- * (row 3 = translation, nanosg.h:232-240); the mesh contexts must outlive the scene. */
+ * (row 3 = translation, nanosg.h:232-240); the mesh contexts must outlive the scene, and nrtSceneCommit caches where their trees
+ * live: after nrtBuild / nrtSetMesh / nrtSetTree on a mesh context the scene has to be committed again (until then
+ * nrtSceneTraverseBatch* fail with NRT_ERR_INVALID instead of walking the old buffers). */
 typedef struct nrt_scene nrt_scene;
 typedef struct {
   float t;
@@ -381,8 +383,9 @@ NRT_API nrt_status nrtSceneTraverseBatch_f32(nrt_scene *scene, const nrt_ray_f32
                                              nrt_scene_hit_f32 *hits_out, uint8_t *hit_mask_out);
 
 /* The same traversal with rays and results resident in HBM (device pointers; d_mask_out may be NULL): no PCIe traffic.
- * The call is still SYNCHRONOUS — it reads one small counter array back per list position to size the per-node
- * launches — and runs on the scene's own stream: the caller makes sure `d_rays` is complete before calling. */
+ * Two launches on the scene's own stream (the listing over the top-level BVH, then one trace kernel for the whole batch)
+ * and one synchronisation at the end: the call is SYNCHRONOUS (the scene owns the per-ray lists), and the caller makes
+ * sure `d_rays` is complete before calling. */
 NRT_API nrt_status nrtSceneTraverseBatchDevice_f32(nrt_scene *scene, const nrt_ray_f32 *d_rays, uint64_t num_rays,
                                                    nrt_scene_hit_f32 *d_hits_out, uint8_t *d_mask_out);
 

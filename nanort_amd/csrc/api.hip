@@ -89,6 +89,7 @@ struct nrt_ctx {
   uint32_t root_is_branch = 0; // node 0 has flag == 0
   uint32_t tree_nested = 1;    // every child box lies inside its parent's (always true of trees built here; checked for adopted ones)
   nrt_build_stats stats = {0, 0, 0, 0.f};
+  uint64_t generation = 0; // bumped whenever the tree or the primitives are replaced (free_tree)
 
   // traversal scratch.  Every launch owns one LaunchSlot (work cursors + overflow stacks) until it
   // completes, so launches issued on different streams may overlap on the GPU: the drain tail of one
@@ -131,7 +132,8 @@ struct nrt_ctx {
   unsigned debug_flags = 0;
   int morton = 0; // Morton-order the primitive records before the build (env NRT_MORTON=1): measured +0.4 ms at 1M tris for an identical tree, so off by default
   unsigned static_pct = 75; // share of a batch handed out statically, percent (env NRT_STATIC_PCT)
-  unsigned static_bands = 8; // ... as up to this many slices per wave, one in each band of the static region
+  unsigned static_bands = 8; // ... as up to this many slices per wave, one in each band of the batch
+  unsigned static_slice_groups = 2; // ... each of at least this many 64-ray groups
   unsigned max_blocks_per_cu = 0; // env NRT_BLOCKS_PER_CU caps the persistent grid
   int wide = 1, wide_stack = 10; // production path: WideNode kernel (env NRT_WIDE=0 selects the binary kernel)
   // Work splitting in the drain of a launch (traverse.hip, k_traverse_wide<..., SPLIT>): exact, soaked, and MEASURED TO
@@ -229,6 +231,7 @@ static hipError_t wait_for_launches(nrt_ctx *c) {
 
 // Forget the current tree (the buffers stay allocated for the next one).
 static void free_tree(nrt_ctx *c) {
+  c->generation++; // whoever cached device addresses / flags of the old tree (a committed nrt_scene) can tell
   c->d_wide = nullptr;
   c->d_wide4 = nullptr;
   c->d_nodes = nullptr;
@@ -265,6 +268,7 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("parts", 1, kMaxParts, num_parts, unsigned),      // ray partitions (== XCDs)
     NRT_TUNABLE("static_pct", 0, 100, static_pct, unsigned),      // share of a batch owned statically, percent
     NRT_TUNABLE("static_bands", 1, 64, static_bands, unsigned),   // ... in up to this many slices per wave, one per band
+    NRT_TUNABLE("static_slice_groups", 1, 64, static_slice_groups, unsigned), // ... of at least this many 64-ray groups each
     NRT_TUNABLE("blocks_per_cu", 0, 8, max_blocks_per_cu, unsigned), // cap on the persistent grid (0: occupancy)
     NRT_TUNABLE("debug", 0, 0x7FFFFFFF, debug_flags, unsigned),   // profiling bit mask
     NRT_TUNABLE("morton", 0, 1, morton, int),                     // Morton pre-pass of the builder (next build)
@@ -349,7 +353,8 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
         (e = hipHostMalloc((void **)&sl.h_done, sizeof(DoneRec), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
         (e = hipHostGetDevicePointer((void **)&sl.d_done, sl.h_done, 0)) != hipSuccess ||
         (e = hipMalloc((void **)&sl.d_count, sizeof(DoneCount))) != hipSuccess ||
-        (e = hipMemset(sl.d_count, 0xFF, sizeof(DoneCount))) != hipSuccess || (e = hipMemset(sl.d_count, 0, 8)) != hipSuccess) {
+        (e = hipMemset(sl.d_count, 0, sizeof(DoneCount))) != hipSuccess ||
+        (e = hipMemset((char *)sl.d_count + offsetof(DoneCount, t_begin), 0xFF, sizeof(unsigned long long))) != hipSuccess) {
       fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
       nrtDestroy(c);
       return NRT_ERR_DEVICE;
@@ -680,9 +685,14 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   c->d_indices = (uint32_t *)c->b_indices.p;
   c->num_indices = c->num_faces;
   nrt_status fst = finish_leaf_records<T>(c);
-  if (fst) return fst;
-  if ((e = gpu_build_result(c->build_state, c->ev_build_state, &res)) != hipSuccess)
+  if (fst) {
+    free_tree(c); // (no half-built tree is left behind: a later traversal call then reports "no tree")
+    return fst;
+  }
+  if ((e = gpu_build_result(c->build_state, c->ev_build_state, &res)) != hipSuccess) {
+    free_tree(c);
     return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s", hipGetErrorString(e));
+  }
   c->num_nodes = res.num_nodes;
   c->tree_depth = res.max_depth;
   c->max_leaf_count = res.max_leaf_count;
@@ -691,7 +701,10 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   c->min_leaf_count = 1; // the GPU builder never emits an empty leaf
   c->tree_nested = 1;    // a branch's box is the exact union of its children's
   fst = finish_wide<T>(c); // WideNode arrays: part of the build
-  if (fst) return fst;
+  if (fst) {
+    free_tree(c);
+    return fst;
+  }
   HIPCHK(c, hipEventRecord(c->ev_b1, c->stream));
   HIPCHK(c, hipEventSynchronize(c->ev_b1));
   c->have_build_time = true;
@@ -725,8 +738,10 @@ nrt_status nrt_internal_tree_view(nrt_ctx *c, nrt::TreeViewF32 *out) {
   out->tree_nested = c->tree_nested;
   out->prim_kind = (uint32_t)c->prim_kind;
   out->tree_depth = c->tree_depth;
+  out->generation = c->generation;
   return NRT_OK;
 }
+uint64_t nrt_internal_generation(const nrt_ctx *c) { return c ? c->generation : 0; }
 
 // ---------------------------------------------------------------------------
 // traverse
@@ -782,7 +797,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
   // two levels per step: closest-hit walks of nested fp32 triangle trees, outside the profiling / splitting variants
   const bool use_wide4 = use_wide && !spheres && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch &&
-                         !c->split && !(c->debug_flags & 8192u);
+                         !c->split;
   if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, c->split != 0, false);
   if (use_wide4 && c->wide4_blocks_per_cu == 0) c->wide4_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(kWide4LdsStack, kPrimTriangles, false, true);
   if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, false, false);
@@ -795,11 +810,18 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   grid = ((grid + parts - 1) / parts) * parts; // whole blocks per partition (ranks are partition-major)
   const uint32_t total_threads = grid * kTraverseBlock;
   const uint32_t total_waves = grid * (kTraverseBlock / kWave);
-  // static share: a multiple of 64 rays per wave, c->static_pct percent of the batch in total
-  // ... cut into up to `static_bands` slices of whole 64-ray groups, one in each band of the static region (traverse.hip, Claim)
+  // Work distribution (traverse.hip, Claim).  Static share: c->static_pct percent of the batch, in whole 64-ray groups per
+  // wave, cut into up to `static_bands` slices — one at the head of each of as many equal bands of the batch; the rest of
+  // each band (a whole number of chunks) and the tail behind the last band are claimed dynamically.
   const uint32_t static_share = (uint32_t)(((uint64_t)n * c->static_pct / 100) / total_waves / 64); // 64-ray groups per wave
-  const uint32_t static_bands = std::min<uint32_t>(c->static_bands, static_share);
-  const uint32_t static_per_wave = static_bands ? (static_share / static_bands) * 64u : 0u;
+  // (a slice shorter than two 64-ray groups makes the waves of an XCD drift apart over the bands within one refill, and its
+  // L2 then holds several strips of the scene at once: measured on C3, 64-ray slices in 4 bands cost 3 %; two bands of 128
+  // cost nothing and still take 8 % off C2, whose sky rows otherwise leave one XCD with the whole sphere: profiles/r03d_*)
+  const uint32_t bands = std::max<uint32_t>(1u, std::min<uint32_t>(c->static_bands, static_share / c->static_slice_groups));
+  const uint32_t static_per_wave = (static_share / bands) * 64u;
+  const uint32_t band_static = static_per_wave * total_waves;
+  const uint32_t dyn_per_band = static_per_wave ? (uint32_t)(((uint64_t)n / bands - band_static) / c->chunk) * c->chunk : 0u;
+  const uint32_t band_len = band_static + dyn_per_band;
   // deepest possible stack: one pending sibling per level of the path — three per TWO levels when a step covers two
   const uint32_t max_entries = use_wide4 ? 3u * (c->tree_depth / 2u + 1u) + 2u : c->tree_depth + 2u;
   const uint32_t levels = max_entries > (uint32_t)stack_entries ? max_entries - stack_entries : 0;
@@ -855,8 +877,14 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.next_cursor = slot->d_cursor + (size_t)(slot->parity ^ 1u) * kCursorStrideWords * kMaxParts;
   a.num_parts = parts;
   a.static_per_wave = static_per_wave;
-  a.static_bands = static_bands;
-  a.dyn_begin = static_bands * static_per_wave * total_waves;
+  a.static_bands = static_per_wave ? bands : 0u;
+  a.band_len = band_len;
+  a.band_static = band_static;
+  a.dyn_per_band = dyn_per_band;
+  a.dyn_banded = a.static_bands * dyn_per_band;
+  a.tail_begin = a.static_bands * band_len;
+  a.dyn_total = a.dyn_banded + ((uint32_t)n - a.tail_begin);
+  a.dyn_per_part = (a.dyn_total / parts / c->chunk) * c->chunk;
   a.blocks_per_part = grid / parts;
   a.counters = c->d_counters;
   a.wave_clock = nullptr;

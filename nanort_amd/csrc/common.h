@@ -150,6 +150,7 @@ struct TreeViewF32 {
   const void *prims;             // leaf-ordered primitive records (LeafTri<float> for triangle contexts)
   uint32_t num_nodes, num_indices;
   uint32_t packed_leaves, root_is_branch, tree_nested, prim_kind, tree_depth;
+  uint64_t generation;           // counts the context's rebuilds: a view is stale once the context's generation has moved on
 };
 
 // ---- two-level (instanced) traversal: one kernel for a whole ray batch (traverse.hip k_scene_trace) -------------
@@ -192,9 +193,10 @@ struct DoneRec {
 };
 // Device-side words that go with it (one set per slot, zero / ~0 between launches).
 struct DoneCount {
-  uint32_t exited; // waves of the current launch that have finished
+  uint32_t exited;   // block groups of the current launch that have finished
   uint32_t pad;
   unsigned long long t_begin; // earliest start stamp seen (atomicMin)
+  uint32_t group[8]; // blocks of group g = blockIdx % 8 that have finished (eight words instead of one: same-address atomics serialise)
 };
 
 template <typename T>
@@ -229,9 +231,16 @@ struct TraverseArgs {
   uint32_t *ray_cursor;              // persistent-thread work counters, one per ray partition, 4 KiB apart, zero at launch
   uint32_t *next_cursor;             // the set the NEXT launch of this slot will use: block 0 zeroes it (no memset launch)
   uint32_t num_parts;                // ray partitions (== XCDs): contiguous ranges of the ray array, one home range per XCD
-  uint32_t static_per_wave;          // rays per static slice: slice `rank` of band b = [(b*waves + rank)*static_per_wave, +static_per_wave) belongs to wave `rank` without any atomic
-  uint32_t static_bands;             // bands of the static region (0: no static share)
-  uint32_t dyn_begin;                // rays [dyn_begin, num_rays) are claimed dynamically (per-partition cursors)
+  // work distribution (traverse.hip, Claim): `static_bands` bands of band_len rays + a tail
+  uint32_t static_per_wave;          // rays per static slice: slice `rank` of band b = [b*band_len + rank*static_per_wave, +static_per_wave) belongs to wave `rank` without any atomic (0: no static share)
+  uint32_t static_bands;             // bands
+  uint32_t band_len;                 // rays per band
+  uint32_t band_static;              // static part of a band = waves * static_per_wave; the rest of the band is dynamic
+  uint32_t dyn_per_band;             // = band_len - band_static, a whole number of chunks
+  uint32_t dyn_banded;               // = static_bands * dyn_per_band: virtual dynamic rays below this lie in the bands, the others in the tail
+  uint32_t tail_begin;               // = static_bands * band_len: rays [tail_begin, num_rays) are dynamic
+  uint32_t dyn_total;                // all dynamic rays = dyn_banded + num_rays - tail_begin
+  uint32_t dyn_per_part;             // virtual dynamic rays per partition cursor (whole chunks; the last partition takes the rest)
   uint32_t blocks_per_part;          // gridDim.x / num_parts
   unsigned long long *counters;      // 4 x u64 when counting
   unsigned long long *wave_clock;    // profiling (NRT_DEBUG bit 8192): 3 x u64 per wave {start, out of rays, done}, 100 MHz ticks; else null

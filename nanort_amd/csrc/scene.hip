@@ -30,6 +30,7 @@
 
 struct nrt_ctx;
 nrt_status nrt_internal_tree_view(nrt_ctx *c, nrt::TreeViewF32 *out); // api.hip
+uint64_t nrt_internal_generation(const nrt_ctx *c);                      // api.hip: counts the context's rebuilds
 namespace nrt {
 hipError_t launch_scene_trace(const SceneTraceArgs &args, unsigned grid, hipStream_t s); // traverse.hip
 int scene_trace_blocks_per_cu();
@@ -296,6 +297,8 @@ struct nrt_scene {
   std::vector<Inst> insts;
   std::vector<NodeDev> host_nodes;
   bool committed = false;
+  std::vector<std::pair<nrt_ctx *, uint64_t> > mesh_gens; // the distinct mesh contexts and their generations at Commit (the
+                                                          // per-instance table caches their device addresses and flags)
   nrt_ctx *top = nullptr;        // top-level BVH over the nodes' world boxes (scenes of more than kScanMaxNodes nodes)
   nrt::TreeViewF32 top_view;
   bool use_top = false;
@@ -451,6 +454,8 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
       return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level build: %s", nrtLastError(s->top));
     s->use_top = s->top_view.tree_depth + 2 < (uint32_t)kTopStack; // (else: the scan)
   }
+  s->mesh_gens.clear();
+  for (size_t m = 0; m < meshes.size(); m++) s->mesh_gens.push_back(std::make_pair(meshes[m].first, meshes[m].second.tv.generation));
   s->committed = true;
   return NRT_OK;
 }
@@ -500,6 +505,11 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   if (n64 == 0) return NRT_OK;
   if (!rays || !hits_out) return sfail(s, NRT_ERR_INVALID, "nrtSceneTraverseBatch: NULL rays/hits");
   if (n64 > 0x7FFFFFFFull) return sfail(s, NRT_ERR_INVALID, "nrtSceneTraverseBatch: too many rays in one call");
+  // the instance table holds device addresses, layout flags and stack depths of the mesh contexts' trees as they were at
+  // Commit: a context rebuilt or re-set since then may have moved or re-shaped them — refuse instead of walking stale memory
+  for (size_t m = 0; m < s->mesh_gens.size(); m++)
+    if (nrt_internal_generation(s->mesh_gens[m].first) != s->mesh_gens[m].second)
+      return sfail(s, NRT_ERR_INVALID, "nrtSceneTraverseBatch: a mesh context was rebuilt or re-set since nrtSceneCommit (commit the scene again)");
   const uint32_t n = (uint32_t)n64, num_nodes = (uint32_t)s->insts.size();
   const uint32_t cap = std::min<uint32_t>(kMaxList, num_nodes);
   SCHK(s, hipSetDevice(s->device));

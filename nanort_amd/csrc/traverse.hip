@@ -380,21 +380,21 @@ __device__ __forceinline__ unsigned lane_id() {
 }
 
 // Work distribution of the persistent kernels.
-//  * A static share of the rays needs no atomics at all: wave `rank` owns
-//    [rank * static_per_wave, +static_per_wave).  Ranks are XCD-major (the dispatcher places
-//    block b on XCD b % 8 — used for L2 affinity only, never for correctness), so each XCD
-//    walks one contiguous band of the ray array and its L2 keeps one part of the tree.
-//  * The rest, [dyn_begin, num_rays), is cut into `num_parts` ranges with one cursor each
-//    (4 KiB apart); a wave drains its home range first and then steals from the others,
-//    `chunk` rays per atomicAdd.  Device-scope atomics on one word saturate near 100 per
-//    microsecond on this part, hence the static share and the modest chunk count.
-//    (Round 2 re-measured the whole family with per-wave time stamps — static share 0-75 %, chunks of 16-128 rays,
-//    claims issued one chunk ahead of need: nothing beats 75 % / 128; profiles/r02d_scheduling_sweep.txt.)
-//  * Round 3: the static share of a wave is no longer ONE slice but `static_bands` of them, one in each of as many equal
-//    bands of the static region (band b = rays [b * waves * static_per_wave, +waves * static_per_wave), inside it wave
-//    `rank` owns slice `rank`): every wave then samples the whole batch — an image whose cost per ray varies from region to
-//    region (C2: 40 % sky) no longer leaves one XCD with the expensive rows — and all waves of an XCD sit in the same band
-//    at the same time, which narrows the part of the tree an L2 sees at any moment.
+//  * The batch is cut into `static_bands` equal bands (+ a short tail).  The first part of every band is handed out
+//    STATICALLY, without any atomic: slice `rank` of band b, rays [b * band_len + rank * static_per_wave, +static_per_wave),
+//    belongs to wave `rank`.  Ranks are XCD-major (the dispatcher places block b on XCD b % 8 — used for L2 affinity only,
+//    never for correctness), so at any moment the waves of an XCD walk neighbouring slices of one band and its L2 keeps one
+//    part of the tree.  Every wave samples every band: an image whose cost per ray varies from region to region (C2: 40 %
+//    sky) does not leave one XCD with the expensive rows.
+//  * The rest of every band (and the tail) is claimed DYNAMICALLY, `chunk` rays per atomicAdd.  These rays form one virtual
+//    array (band 0's dynamic part, band 1's, ..., the tail) that is cut into `num_parts` ranges with one cursor each (4 KiB
+//    apart); a wave drains its home range first and then steals from the others.  Band parts and ranges are whole chunks, so a
+//    chunk never straddles two bands.  Because the dynamic rays come from all over the batch too (round 2: the last quarter
+//    of the array — for a camera wave the bottom of the image), what is left to balance the end of a launch is a sample of the
+//    whole batch, not its cheapest corner.
+//    (Device-scope atomics on one word saturate near 100 per microsecond on this part, hence the static share and the modest
+//    chunk count.  Round 2 re-measured static share 0-75 %, chunks of 16-128 rays, claims issued one chunk ahead of need:
+//    nothing beats 75 % / 128; profiles/r02d_scheduling_sweep.txt.)
 struct Claim {
   uint32_t next, end; // claimed, not yet handed out: [next, end)
   uint32_t part, tried;
@@ -405,11 +405,14 @@ struct Claim {
 template <typename T>
 __device__ __forceinline__ void claim_init(const TraverseArgs<T> &a, Claim &c) {
   const uint32_t part = blockIdx.x % a.num_parts;
-  const uint32_t rank = (part * a.blocks_per_part + blockIdx.x / a.num_parts) * (kTraverseBlock / kWave) + threadIdx.x / kWave;
+  // (readfirstlane: the compiler cannot see that threadIdx.x / 64 is the same in every lane; told so, it keeps the whole
+  // claim state in scalar registers)
+  const uint32_t rank = (part * a.blocks_per_part + blockIdx.x / a.num_parts) * (kTraverseBlock / kWave) +
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
   c.rank = rank;
   c.band = 0;
   c.next = rank * a.static_per_wave;
-  c.end = a.static_bands ? c.next + a.static_per_wave : c.next;
+  c.end = c.next + a.static_per_wave; // (static_per_wave == 0: nothing is owned statically)
   c.part = part;
   c.tried = 0;
   c.exhausted = false;
@@ -418,23 +421,29 @@ __device__ __forceinline__ void claim_init(const TraverseArgs<T> &a, Claim &c) {
 // All lanes of the wave call this (uniform control flow); `leader` is any active lane index.
 template <typename T>
 __device__ __forceinline__ bool claim_chunk(const TraverseArgs<T> &a, Claim &c, unsigned lane, int leader) {
-  if (c.band + 1u < a.static_bands) { // the wave's slice of the next band (no atomic)
+  if (a.static_per_wave != 0u && c.band + 1u < a.static_bands) { // the wave's slice of the next band (no atomic)
     c.band++;
-    c.next = (c.band * (gridDim.x * (kTraverseBlock / kWave)) + c.rank) * a.static_per_wave;
+    c.next = c.band * a.band_len + c.rank * a.static_per_wave;
     c.end = c.next + a.static_per_wave;
     return true;
   }
-  const uint32_t dyn = a.num_rays - a.dyn_begin;
-  const uint32_t per = dyn / a.num_parts, extra = dyn % a.num_parts; // first `extra` parts hold one more ray
   while (c.tried < a.num_parts) {
-    const uint32_t lo = a.dyn_begin + c.part * per + (c.part < extra ? c.part : extra);
-    const uint32_t len = per + (c.part < extra ? 1u : 0u);
+    const uint32_t lo = c.part * a.dyn_per_part; // range of this part in the virtual array of dynamic rays
+    const uint32_t len = (c.part + 1u == a.num_parts) ? a.dyn_total - lo : a.dyn_per_part;
     uint32_t base = 0;
     if (lane == (unsigned)leader) base = atomicAdd(a.ray_cursor + kCursorStrideWords * c.part, a.chunk);
     base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
     if (base < len) {
-      c.next = lo + base;
-      c.end = (len - base < a.chunk) ? lo + len : c.next + a.chunk;
+      const uint32_t v = lo + base, cnt = (len - base < a.chunk) ? len - base : a.chunk;
+      uint32_t real;
+      if (v < a.dyn_banded) { // inside band b's dynamic part
+        const uint32_t b = v / a.dyn_per_band;
+        real = b * a.band_len + a.band_static + (v - b * a.dyn_per_band);
+      } else { // the tail behind the last band
+        real = a.tail_begin + (v - a.dyn_banded);
+      }
+      c.next = real;
+      c.end = real + cnt;
       return true;
     }
     c.part = (c.part + 1 == a.num_parts) ? 0 : c.part + 1;
@@ -465,28 +474,36 @@ __device__ __forceinline__ void store_hit_nt(typename Wire<T>::Hit *p, const typ
 }
 
 // Completion record of a launch (common.h, DoneRec): no event is recorded in the stream for it.  Start — one thread of each
-// of the first eight blocks (one per XCD) stamps the time; end — every wave counts itself out once its stores are on their
-// way, and the last one publishes the two stamps and then the launch's sequence number to the page-locked record.
+// of the first eight blocks stamps the time; end — the waves of a block count themselves out in LDS, the block's last wave
+// counts the block out of its group (blockIdx % 8: eight counters, so that the atomics of ~1300 blocks do not queue on one
+// word), a group's last block counts the group out, and the last group publishes the two stamps and then the launch's
+// sequence number to the page-locked record.  Nothing is fenced: a waiter learns that every wave has stopped READING the
+// tree and the slot's scratch (what a rebuild or the slot's next launch must know), not that the hit records have landed —
+// for that the caller synchronises its stream as usual.  Every word a later launch depends on is handed on by an atomic
+// (performed at the memory side, visible to every XCD), not left dirty in one XCD's L2.
 template <typename T>
-__device__ __forceinline__ void done_begin(const TraverseArgs<T> &a) {
+__device__ __forceinline__ void done_begin(const TraverseArgs<T> &a, uint32_t *s_exit) {
+  if (threadIdx.x == 0u) *s_exit = 0u;
+  __syncthreads(); // (the only barrier of the kernel: all waves are at their first instructions)
   if (a.done_rec != nullptr && threadIdx.x == 0u && blockIdx.x < 8u)
     atomicMin(&a.done_count->t_begin, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 template <typename T>
-__device__ __forceinline__ void done_end(const TraverseArgs<T> &a, unsigned lane) {
-  if (a.done_rec == nullptr) return;
-  __threadfence(); // this wave's stores (results, overflow stack) are out before it counts itself out
-  if (lane == 0u) {
-    const uint32_t waves = gridDim.x * (kTraverseBlock / kWave);
-    if (atomicAdd(&a.done_count->exited, 1u) == waves - 1u) { // the last wave of the launch
-      const unsigned long long t0 = atomicExch(&a.done_count->t_begin, ~0ull); // (both words handed on clean to the slot's next launch)
-      (void)atomicExch(&a.done_count->exited, 0u);
-      DoneRec *r = a.done_rec;
-      r->t_begin = t0;
-      r->t_end = (unsigned long long)__builtin_amdgcn_s_memrealtime();
-      __hip_atomic_store(&r->seq, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
+__device__ __forceinline__ void done_end(const TraverseArgs<T> &a, unsigned lane, uint32_t *s_exit) {
+  if (a.done_rec == nullptr || lane != 0u) return;
+  if (atomicAdd(s_exit, 1u) != (uint32_t)(kTraverseBlock / kWave) - 1u) return; // not the block's last wave
+  const uint32_t groups = gridDim.x < 8u ? gridDim.x : 8u, g = blockIdx.x % 8u;
+  const uint32_t group_blocks = (gridDim.x - g + 7u) / 8u;
+  DoneCount *cnt = a.done_count;
+  if (atomicAdd(&cnt->group[g], 1u) != group_blocks - 1u) return; // not the group's last block
+  (void)atomicExch(&cnt->group[g], 0u); // (handed on clean to the slot's next launch)
+  if (atomicAdd(&cnt->exited, 1u) != groups - 1u) return; // not the launch's last group
+  (void)atomicExch(&cnt->exited, 0u);
+  const unsigned long long t0 = atomicExch(&cnt->t_begin, ~0ull);
+  DoneRec *r = a.done_rec;
+  __hip_atomic_store(&r->t_begin, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&r->t_end, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&r->seq, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Lane states of the while-while loop.
@@ -1075,8 +1092,11 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
   if (clocked) clk_begin = __builtin_amdgcn_s_memrealtime();
   Claim ck;
   claim_init<T>(a, ck);
-  if (blockIdx.x == 0 && threadIdx.x < kMaxParts) a.next_cursor[kCursorStrideWords * threadIdx.x] = 0u;
-  done_begin<T>(a);
+  // (an atomic store: performed at the memory side, so that the slot's next launch sees it wherever and whenever it runs)
+  if (blockIdx.x == 0 && threadIdx.x < kMaxParts)
+    __hip_atomic_store(a.next_cursor + kCursorStrideWords * threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __shared__ uint32_t s_exit; // waves of this block that have finished (done_end)
+  done_begin<T>(a, &s_exit);
   // STATS (profiling instantiation only): wave-level loop occupancy
   unsigned long long st_it1 = 0, st_act1 = 0, st_idle2 = 0, st_it2 = 0, st_act2 = 0, st_refills = 0, st_refilled = 0, st_entries2 = 0;
   uint32_t st_steps = 0, st_tris = 0; // per ray; with debug flag 64 they replace u, v of the hit record
@@ -1556,7 +1576,7 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
   if (rid != kInvalid) NRT_WRITE_RESULT(); // results still held in registers
 #undef NRT_WRITE_RESULT
 #undef NRT_TEST_PRIM
-  done_end<T>(a, lane);
+  done_end<T>(a, lane, &s_exit);
   if (clocked && lane == 0u) { // one record per wave, reduced on the host (atomics on one line would serialise the exits)
     unsigned long long *rec = a.wave_clock + 3ull * (size_t)(gslot / kWave);
     const unsigned long long clk_end = __builtin_amdgcn_s_memrealtime();
@@ -2062,6 +2082,8 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
     if constexpr (sizeof(T) == 4) {
       if (args.debug_flags & 32u)
         NRT_LAUNCH_WIDE(kWide4LdsStack, true, kPrimTriangles, true, false, false, 4); // profiling instantiation (default trace options only)
+      else if (args.wave_clock)
+        NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, false, true, 4); // per-wave time stamps (default trace options only)
       else if (args.plain_options)
         NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, false, false, 4);
       else

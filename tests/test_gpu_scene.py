@@ -80,6 +80,15 @@ def test_scene_error_paths_and_empty_scene(c1_mesh):
     # identity instance: the hit mask equals the single-level traversal's, and node_id is 0 on every hit
     h1, m1 = a.TraverseBatch(scenes.camera_rays(64, 64))
     assert np.array_equal(m, m1) and (h["node_id"][m == 1] == 0).all()
+    # a mesh context rebuilt after Commit: the scene's cached view of its tree is stale -> refused until committed again
+    v2, f2 = scenes.sphere(32, 16)
+    assert a.Build(f2.shape[0], TriangleMesh(v2, f2))
+    with pytest.raises(NrtError, match="commit the scene again"):
+        sc.TraverseBatch(scenes.camera_rays(8, 8))
+    assert sc.Commit()
+    h2, m2 = sc.TraverseBatch(scenes.camera_rays(64, 64))
+    h3, m3 = a.TraverseBatch(scenes.camera_rays(64, 64))
+    assert np.array_equal(m2, m3)
 
 
 def test_node_state_matches_the_reference(golden_dir, oracle):

@@ -236,6 +236,27 @@ def test_lean_launches_give_the_same_records_and_rebuilds_still_wait():
     torch.cuda.synchronize()
 
 
+def test_work_distribution_tunables_cover_every_ray():
+    """The static bands / dynamic chunks of the persistent kernel (traverse.hip, Claim) under odd settings: every ray of the
+    batch is traced exactly once, whatever the split — the records equal the default configuration's."""
+    v, f = scenes.plane(120, 60)
+    a = BVHAccel(np.float32)
+    assert a.Build(f.shape[0], TriangleMesh(v, f))
+    for w, h_ in ((640, 361), (97, 13), (1, 1)):
+        rays = scenes.camera_rays(w, h_)
+        ref, refm = a.TraverseBatch(rays)
+        for combo in (dict(static_pct=0), dict(static_pct=100), dict(static_bands=1), dict(static_bands=64, static_pct=90),
+                      dict(chunk=16, parts=3), dict(chunk=1000, parts=16, static_pct=10), dict(blocks_per_cu=1, static_bands=3),
+                      dict(refill_min=1, trav_min=1, leaf_min=1), dict(refill_min=64, trav_min=64, leaf_min=64)):
+            saved = {k: a.GetTunable(k) for k in combo}
+            for k, val in combo.items():
+                a.SetTunable(k, val)
+            h, m = a.TraverseBatch(rays)
+            for k, val in saved.items():
+                a.SetTunable(k, val)
+            assert h.tobytes() == ref.tobytes() and np.array_equal(m, refm), (w, h_, combo)
+
+
 def test_loaded_tree_with_unreachable_records(oracle, c1):
     """A loaded node array may carry records no path reaches (the reference's Load() takes any array,
     nanort.h:2219-2275); they must be ignored, whatever they contain."""
