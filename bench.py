@@ -33,9 +33,14 @@ Extra objects on the JSON line:
                 (52N + 40*nodes + 4N) over its device time.  The top-level bound/achieved/peak/frac/traffic
                 fields are the HBM figures (every frac <= 1).
   cpu_baseline  the UNMODIFIED reference (oracle/_ref, OpenMP, host cores) on a bounded sample of the same ray
-                buffers, with the parity check of the same run; falls back to the single-thread C port.
-  configs       (default line only) {Mrays/s, build_ms, parity} for C2, the C4 tile and C5, each with the
-                reference's answer on a bounded sample in the same run.
+                buffers (best of 3), with the parity check of the same run; falls back to the single-thread C port.
+  end_to_end    the host entry point nrtTraverseBatch_f32 (H2D rays + kernel + D2H hits) on the primary wave: pageable
+                buffers, page-locked buffers in one piece, page-locked buffers pipelined — Mrays/s and GB/s each way.
+  configs       (default line only) {Mrays/s, build_ms, parity, roofline} for C2, the C4 tile and C5, each with the
+                reference's answer on a bounded sample and its own hardware counters in the same run.
+  next_rows     (default line only) one figure + one same-run parity sample for each SURVEY §8(f) row (bench_rows.py).
+  strong_c4     (N > 1, default config) BASELINE.json's strong-scaling case beside the weak-scaled headline: the fixed
+                4096x4096 frame over the 10M-triangle plane, cut into N row-interleaved tiles.
 """
 import argparse
 import csv
@@ -155,13 +160,13 @@ def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, width, gpu_
             _, _, secs = R.traverse(probe, threads=t, chunk=width)
             if probe.shape[0] / secs > rate:
                 best_t, rate = t, probe.shape[0] / secs
-        frac = min(1.0, budget_s * rate / total)
+        frac = min(1.0, budget_s / 3.0 * rate / total)  # three passes over the sample share the budget
         rows1 = max(8, int(rays1.shape[0] // width * frac))
         step = max(1, (rays1.shape[0] // width) // rows1)
         s1 = rays1.reshape(-1, width)[::step].reshape(-1)
         s2 = rays2[:: max(1, step)]
         best = 1e30
-        for _ in range(2):
+        for _ in range(3):
             rh1, rm1, t1 = R.traverse(s1, threads=best_t, chunk=width)
             rh2, rm2, t2 = R.traverse(s2, threads=best_t, chunk=width)
             best = min(best, t1 + t2)
@@ -170,7 +175,7 @@ def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, width, gpu_
             "value": round(value, 4), "unit": "Mrays/s", "cores": int(best_t), "kind": "reference",
             "sample": "unmodified nanort.h (g++ -O3 -fopenmp, own parallel Build: %d nodes, depth %d), "
                       "every %d-th row of wave 1 (%d rays) + every %d-th wave-2 ray (%d rays), omp dynamic row loop, "
-                      "best of 2; %d OpenMP threads = best of %s (host: %d logical CPUs, cgroup quota %s)" % (
+                      "best of 3; %d OpenMP threads = best of %s (host: %d logical CPUs, cgroup quota %s)" % (
                           st["num_leaf_nodes"] + st["num_branch_nodes"], st["max_tree_depth"], step,
                           s1.shape[0], step, s2.shape[0], best_t, cands, hw, quota),
             "build_ms": round(build_ms, 1),
@@ -345,12 +350,14 @@ def pipelined(accel, torch, wave1, wave2, steps, rays_per_step, frames_in_flight
 # ---------------------------------------------------------------------------
 # hardware counters, collected in the same invocation (outside the timed region)
 # ---------------------------------------------------------------------------
+# Counter passes: one rocprofv3 --pmc invocation each (kernel trace only, as MI355X_MICROARCH.md prescribes).  The TCC block has
+# four counter slots (FETCH_SIZE takes 3, WRITE_SIZE 2), the TCP and SQ blocks have their own: three passes carry everything.
+# Each entry: (tag, counters, fallback passes tried when the combined pass fails or returns no rows).
 PMC_PASSES = [
-    ("fetch", "FETCH_SIZE"),
-    ("write", "WRITE_SIZE"),
-    ("sq", "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"),
-    ("tcc", "TCC_HIT_sum TCC_MISS_sum"),
-    ("tcp", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"),
+    ("fetch_tcp", "FETCH_SIZE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum",
+     [("fetch", "FETCH_SIZE"), ("tcp", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum")]),
+    ("write_tcc", "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum", [("write", "WRITE_SIZE"), ("tcc", "TCC_HIT_sum TCC_MISS_sum")]),
+    ("sq", "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE", []),
 ]
 # What the vector L1 (TCP) sustains in tag look-ups per second when every lane of every wave fetches scattered 16-byte
 # pieces, measured with tools/ubench/node_fetch.hip under the same counter (3145 M look-ups in 3.59 ms, table resident in
@@ -359,82 +366,130 @@ L1_PEAK_GACC_S = 876.0
 
 
 def pmc_child(args):
-    """The sub-run the counter passes profile: set-up, then (warmup + steps) x (primary, bounce) launches, nothing else."""
+    """The sub-run the counter passes profile: for every config named, the set-up (one primary launch) and then
+    (warmup + steps) x (primary, bounce) launches of THIS rank's share of the workload — nothing else."""
     import torch
 
-    wl = Workload(args.config, builds=1, mesh_path=args.mesh)
-    for _ in range(args.warmup + args.steps):
-        wl.accel.TraverseBatchDevice(wl.d_rays1, wl.d_hits1, wl.d_mask1)
-        wl.accel.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)
-    torch.cuda.synchronize()
-    print(json.dumps({"pmc_child": True, "kernel": wl.accel.LastKernelName(), "n1": wl.n1, "n2": wl.n2}), flush=True)
+    done = []
+    for name in args.pmc_configs.split(","):
+        wl = Workload(name, rank=args.pmc_rank, world=args.pmc_world, builds=1, mesh_path=args.mesh if name == "C2" else None)
+        for _ in range(args.warmup + args.steps):
+            wl.accel.TraverseBatchDevice(wl.d_rays1, wl.d_hits1, wl.d_mask1)
+            wl.accel.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)
+        torch.cuda.synchronize()
+        done.append({"name": name, "kernel": wl.accel.LastKernelName(), "n1": wl.n1, "n2": wl.n2})
+        del wl
+        torch.cuda.empty_cache()
+    print(json.dumps({"pmc_child": True, "configs": done}), flush=True)
 
 
 def _kernel_key(name):
     return name.replace("void ", "").split("(")[0].replace(" ", "")
 
 
-def pmc_collect(config, mesh_path, kernel_name, keep_dir=None, warmup=1, steps=3):
-    """Run the counter passes (one rocprofv3 --pmc invocation each, kernel trace only, as MI355X_MICROARCH.md
-    prescribes) over `bench.py --pmc-child` and return per-launch means for the primary and the bounce launches of
-    `kernel_name`.  Returns (dict, error string or None)."""
+def _pmc_pass(exe, tag, counters, child_args, out_root, env):
+    """One rocprofv3 invocation.  Returns (counter rows, kernel-trace rows, the child's config list, error or None)."""
+    out_dir = os.path.join(out_root, tag)
+    cmd = [exe, "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", out_dir, "-o", "p", "--",
+                                                                   sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child"] + child_args
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600, cwd="/tmp")
+    except Exception as e:  # pragma: no cover
+        return [], [], None, "%s: %r" % (tag, e)
+    if r.returncode != 0:
+        return [], [], None, "%s: rc %d: %s" % (tag, r.returncode, r.stdout[-300:])
+    child = None
+    for line in r.stdout.splitlines():
+        if line.startswith("{") and "pmc_child" in line:
+            child = json.loads(line)["configs"]
+    rows, trace = [], []
+    for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        rows += list(csv.DictReader(open(path)))
+    for path in glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"), recursive=True):
+        trace += list(csv.DictReader(open(path)))
+    if not rows or child is None:
+        return [], [], child, "%s: no counter rows" % tag
+    return rows, trace, child, None
+
+
+def pmc_collect(configs, mesh_path=None, rank=0, world=1, keep_dir=None, warmup=1, steps=3):
+    """Run the counter passes over `bench.py --pmc-child` (ONE sub-run per pass traces every config named, this rank's
+    share of it) and return {config: {"primary": {counter: per-launch mean}, "bounce": {...}, "profiled_us": {...}}}
+    plus an error string (or None).  Launches are attributed by kernel name and dispatch order: per config one set-up
+    launch (primary), then (primary, bounce) pairs."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    want = _kernel_key(kernel_name)
     tmp = keep_dir or tempfile.mkdtemp(prefix="nrt_pmc_", dir="/tmp")
     os.makedirs(tmp, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
-    per = {"primary": {}, "bounce": {}}
-    durs = {"primary": [], "bounce": []}
+    child_args = ["--pmc-configs", ",".join(configs), "--pmc-rank", str(rank), "--pmc-world", str(world), "--steps", str(steps), "--warmup", str(warmup)]
+    if mesh_path:
+        child_args += ["--mesh", mesh_path]
+    per_launch = 1 + 2 * (warmup + steps)
+    out = {c: {"primary": {}, "bounce": {}, "profiled_us": {"primary": None, "bounce": None}} for c in configs}
     errors = []
-    for tag, counters in PMC_PASSES:
-        out_dir = os.path.join(tmp, tag)
-        cmd = [exe, "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", out_dir, "-o", "p", "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", config, "--steps", str(steps), "--warmup", str(warmup)]
-        if mesh_path:
-            cmd += ["--mesh", mesh_path]
-        try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300, cwd="/tmp")
-        except Exception as e:  # pragma: no cover
-            errors.append("%s: %r" % (tag, e))
-            continue
-        if r.returncode != 0:
-            errors.append("%s: rc %d: %s" % (tag, r.returncode, r.stdout[-300:]))
-            continue
-        rows = []
-        for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
-            rows += [x for x in csv.DictReader(open(path)) if _kernel_key(x.get("Kernel_Name", "")) == want]
-        if not rows:
-            errors.append("%s: no counter rows for %s" % (tag, kernel_name))
-            continue
-        ids = sorted({int(x["Dispatch_Id"]) for x in rows})
-        order = {d: k for k, d in enumerate(ids)}  # launch 0 = the set-up's primary wave, then (primary, bounce) pairs
-        acc = {}
-        for x in rows:
-            k = order[int(x["Dispatch_Id"])]
-            if k == 0:
+
+    def absorb(rows, trace, child, with_durations):
+        by_kernel = {}
+        for c in child:  # configs in launch order, grouped by the kernel variant they ran
+            by_kernel.setdefault(_kernel_key(c["kernel"]), []).append(c["name"])
+        for key, names in by_kernel.items():
+            mine = [x for x in rows if _kernel_key(x.get("Kernel_Name", "")) == key]
+            ids = sorted({int(x["Dispatch_Id"]) for x in mine})
+            if len(ids) != per_launch * len(names):
+                errors.append("%s: %d dispatches of %s, expected %d" % (",".join(names), len(ids), key, per_launch * len(names)))
                 continue
-            wave = "primary" if k % 2 == 1 else "bounce"
-            acc.setdefault((wave, x["Counter_Name"], k), 0.0)
-            acc[(wave, x["Counter_Name"], k)] += float(x["Counter_Value"])
-        for (wave, cname, _k), v in acc.items():
-            per[wave].setdefault(cname, []).append(v)
-        for path in glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"), recursive=True):
-            tr = [x for x in csv.DictReader(open(path)) if _kernel_key(x.get("Kernel_Name", "")) == want]
-            tr.sort(key=lambda x: int(x["Start_Timestamp"]))
-            for k, x in enumerate(tr):
-                if k >= 1 and tag == "sq":
-                    durs["primary" if k % 2 == 1 else "bounce"].append((int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) * 1e-3)
-    out = {w: {c: float(np.mean(v)) for c, v in per[w].items()} for w in per}
-    out["profiled_us"] = {w: (float(np.mean(v)) if v else None) for w, v in durs.items()}
+            where = {d: (names[k // per_launch], k % per_launch) for k, d in enumerate(ids)}
+            acc = {}
+            for x in mine:
+                name, k = where[int(x["Dispatch_Id"])]
+                if k == 0:
+                    continue  # the set-up launch
+                wave = "primary" if k % 2 == 1 else "bounce"
+                acc[(name, wave, x["Counter_Name"], k)] = acc.get((name, wave, x["Counter_Name"], k), 0.0) + float(x["Counter_Value"])
+            lists = {}
+            for (name, wave, cname, _k), v in acc.items():
+                lists.setdefault((name, wave, cname), []).append(v)
+            for (name, wave, cname), v in lists.items():
+                out[name][wave][cname] = float(np.mean(v))
+            if with_durations:
+                tr = [x for x in trace if _kernel_key(x.get("Kernel_Name", "")) == key]
+                tr.sort(key=lambda x: int(x["Start_Timestamp"]))
+                if len(tr) == per_launch * len(names):
+                    for k, x in enumerate(tr):
+                        name, kk = names[k // per_launch], k % per_launch
+                        if kk:
+                            out[name].setdefault("_durs", {}).setdefault("primary" if kk % 2 == 1 else "bounce", []).append(
+                                (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) * 1e-3)
+
+    for tag, counters, fallback in PMC_PASSES:
+        rows, trace, child, err = _pmc_pass(exe, tag, counters, child_args, tmp, env)
+        if err and fallback:  # the combined pass was refused: the blocks one by one
+            errors.append(err + " (retried as %s)" % "+".join(t for t, _ in fallback))
+            for ftag, fcounters in fallback:
+                rows, trace, child, ferr = _pmc_pass(exe, ftag, fcounters, child_args, tmp, env)
+                if ferr:
+                    errors.append(ferr)
+                else:
+                    absorb(rows, trace, child, False)
+            continue
+        if err:
+            errors.append(err)
+            continue
+        absorb(rows, trace, child, tag == "sq")
+    for c in configs:
+        d = out[c].pop("_durs", {})
+        out[c]["profiled_us"] = {w: (float(np.mean(d[w])) if d.get(w) else None) for w in ("primary", "bounce")}
     if not keep_dir:
         shutil.rmtree(tmp, ignore_errors=True)
     return out, ("; ".join(errors) if errors else None)
 
 
-def roofline_from_counters(pmc, k_ms, n_cus):
-    """HBM and VALU rooflines of the primary / bounce launches from the in-run counter means (per launch)."""
+def roofline_from_counters(pmc, k_ms, n_cus, launch_ms=None):
+    """HBM, VALU and L1 rooflines of the primary / bounce launches from the in-run counter means (per launch).  The
+    fractions divide by the launch times `k_ms` (per wave) — or, for the top-level HBM figure of the headline, by
+    `launch_ms`, the average launch of the timed region itself."""
     simds = n_cus * 4
     lane_peak = simds * VALU_LANES_PER_SIMD * CLOCK_GHZ * 1e9  # lane-operations per second
     res = {"hbm": None, "valu": None, "l1": None}
@@ -442,11 +497,13 @@ def roofline_from_counters(pmc, k_ms, n_cus):
     if all("FETCH_SIZE" in pmc[w] and "WRITE_SIZE" in pmc[w] for w in waves):
         # rocprofv3 reports both in KiB; gfx950: FETCH_SIZE counts 128-B read requests as 64 B -> x2 (MI355X_MICROARCH.md §HBM)
         b = {w: pmc[w]["FETCH_SIZE"] * 1024.0 * 2.0 + pmc[w]["WRITE_SIZE"] * 1024.0 for w in waves}
-        tot_ms = sum(k_ms[w] for w in waves)
+        tot_ms = sum(k_ms[w] for w in waves) if launch_ms is None else 2.0 * launch_ms
         gbs = sum(b.values()) / (tot_ms * 1e-3) / 1e9
         res["hbm"] = {"bytes_per_launch": int(sum(b.values()) / 2), "achieved_GBs": round(gbs, 1), "peak_GBs": HBM_PEAK_GBS,
                       "frac": round(gbs / HBM_PEAK_GBS, 4),
+                      "time_base": "per-wave kernel times" if launch_ms is None else "average launch of the timed region",
                       "per_wave_bytes": {w: int(b[w]) for w in waves},
+                      "per_wave_frac": {w: round(b[w] / (k_ms[w] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for w in waves},
                       "formula": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024"}
         if all("TCC_HIT_sum" in pmc[w] for w in waves):
             h = sum(pmc[w]["TCC_HIT_sum"] for w in waves)
@@ -493,11 +550,98 @@ def roofline_from_counters(pmc, k_ms, n_cus):
     return res
 
 
+def compact_roofline(r, per_wave_counts):
+    """The per-config form of the counters: per wave {ms, hbm / valu / l1 fractions, lane utilisation, waiting share, L2 hit
+    rate is per config} — every number recomputable from the raw rows kept under --pmc-dir."""
+    out = {"waves": {}}
+    for w in ("primary", "bounce"):
+        e = dict(per_wave_counts.get(w, {}))
+        if r.get("hbm"):
+            e["hbm_bytes"] = r["hbm"]["per_wave_bytes"][w]
+            e["hbm_frac"] = r["hbm"]["per_wave_frac"][w]
+        if r.get("valu"):
+            pw = r["valu"]["per_wave"][w]
+            e.update({"valu_frac": pw["frac"], "lane_util": pw["lane_util"], "issue_busy": pw["issue_busy"]})
+            if "wait_frac_of_wave_cycles" in pw:
+                e["wait"] = pw["wait_frac_of_wave_cycles"]
+        if r.get("l1"):
+            e["l1_frac"] = r["l1"]["per_wave"][w]["frac"]
+            e["l1_requests_to_l2_per_lookup"] = r["l1"]["per_wave"][w].get("requests_to_l2_per_lookup")
+        out["waves"][w] = e
+    if r.get("hbm"):
+        out["hbm"] = {k: r["hbm"][k] for k in ("bytes_per_launch", "achieved_GBs", "frac") if k in r["hbm"]}
+        if "l2_hit_rate" in r["hbm"]:
+            out["l2_hit_rate"] = r["hbm"]["l2_hit_rate"]
+    if r.get("valu"):
+        out["valu"] = {k: r["valu"][k] for k in ("achieved_Tlaneops", "frac", "lane_util", "issue_busy")}
+    if r.get("l1"):
+        out["l1"] = {k: r["l1"][k] for k in ("achieved_Glookups_s", "frac")}
+    fr = {k: out[k]["frac"] for k in ("hbm", "valu", "l1") if k in out}
+    if fr:
+        out["most_loaded"] = max(fr, key=fr.get)
+    return out
+
+
+def end_to_end(wl, reps=5):
+    """the host entry point end to end — H2D rays + kernel + D2H hits and flags — on the primary wave
+    (nrtTraverseBatch_*): pageable caller buffers, page-locked buffers in one piece, page-locked buffers pipelined in
+    512K-ray pieces (the library's default for page-locked buffers).  Never `value`."""
+    import torch
+
+    a = wl.accel
+    rays = wl.rays1
+    n = rays.shape[0]
+    up, down = rays.nbytes, n * wl.HIT.itemsize + n
+    fn = getattr(a._L, "nrtTraverseBatch_" + ("f32" if wl.rb == 4 else "f64"))
+
+    def timed(call):
+        for _ in range(2):
+            call()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            call()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    def entry(secs):
+        return {"ms": round(secs * 1e3, 3), "Mrays_s": round(n / secs / 1e6, 1), "h2d_GBs": round(up / secs / 1e9, 2), "d2h_GBs": round(down / secs / 1e9, 2)}
+
+    res = {}
+    t = timed(lambda: a.TraverseBatch(rays))
+    res["pageable"] = entry(t)
+    pr = torch.empty(rays.nbytes, dtype=torch.uint8, pin_memory=True)
+    pr.numpy()[:] = rays.view(np.uint8)
+    ph = torch.empty(n * wl.HIT.itemsize, dtype=torch.uint8, pin_memory=True)
+    pm = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+
+    def call():
+        st = fn(a._h, pr.data_ptr(), n, None, ph.data_ptr(), pm.data_ptr())
+        assert st == 0
+
+    a.SetTunable("host_pipeline", 0)
+    res["page_locked"] = entry(timed(call))
+    a.SetTunable("host_pipeline", 1)
+    res["page_locked_pipelined"] = entry(timed(call))
+    res["records_identical_to_the_device_path"] = bool(ph.numpy().tobytes() == wl.hits1.tobytes() and pm.numpy().tobytes() == wl.mask1.tobytes())
+    return {"workload": "%d primary rays: %.1f MB of rays up, %.1f MB of records and flags down per call" % (n, up / 1e6, down / 1e6),
+            "unit": "Mrays/s end to end (never `value`)", **res}
+
+
 # ---------------------------------------------------------------------------
 # untimed extras: the other single-GPU configs of BASELINE.json
 # ---------------------------------------------------------------------------
+def per_wave_counts(wl, c1, c2, ms1, ms2):
+    """Work per ray of the two waves (the counting pass of the literal kernel: identical to the CPU oracle's counts)."""
+    return {"primary": {"ms": round(ms1, 4), "rays": wl.n1, "nodes_per_ray": round(c1["nodes_visited"] / max(1, wl.n1), 2),
+                        "tris_per_ray": round(c1["tris_tested"] / max(1, wl.n1), 2), "algorithmic_bytes": int(algorithmic_bytes(c1, wl.rb))},
+            "bounce": {"ms": round(ms2, 4), "rays": wl.n2, "nodes_per_ray": round(c2["nodes_visited"] / max(1, wl.n2), 2),
+                       "tris_per_ray": round(c2["tris_tested"] / max(1, wl.n2), 2), "algorithmic_bytes": int(algorithmic_bytes(c2, wl.rb))}}
+
+
 def measure_config(name, mesh_path=None, reps=5, parity_rays=200_000):
-    """{Mrays/s, build_ms, parity} for one config on GPU 0, with the reference's answer on a bounded sample."""
+    """{Mrays/s, build_ms, parity} for one config on GPU 0, with the reference's answer on a bounded sample.  The counters of
+    the config are attached by the caller (one profiled sub-run serves all configs)."""
     import torch
 
     wl = Workload(name, builds=3, mesh_path=mesh_path)
@@ -509,8 +653,7 @@ def measure_config(name, mesh_path=None, reps=5, parity_rays=200_000):
         a.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)
         t2.append(a.LastTraverseMs())
     ms1, ms2 = float(np.median(t1)), float(np.median(t2))
-    # the figure of merit as the headline measures it: lean launches back to back, one event pair around all of them
-    a.SetLaunchTiming(False)
+    # the figure of merit as the headline measures it: launches back to back, one event pair around all of them
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     torch.cuda.synchronize()
     ev[0].record()
@@ -519,15 +662,17 @@ def measure_config(name, mesh_path=None, reps=5, parity_rays=200_000):
         a.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)
     ev[1].record()
     torch.cuda.synchronize()
-    a.SetLaunchTiming(True)
     step_ms = float(ev[0].elapsed_time(ev[1])) / reps
+    c1, c2 = wl.counters()
     out = {"workload": wl.describe(), "dtype": wl.cfg["real"], "value": round((wl.n1 + wl.n2) / step_ms / 1e3, 1), "unit": "Mrays/s",
            "ms_per_step": round(step_ms, 4),
            "primary_ms": round(ms1, 4), "bounce_ms": round(ms2, 4), "primary_Mrays_s": round(wl.n1 / ms1 / 1e3, 1),
            "build_ms": round(float(np.median(wl.build_ms)), 4), "kernel": a.LastKernelName(),
            "bvh": {"nodes": wl.num_nodes, "max_depth": int(wl.stats["max_tree_depth"])},
            "roofline_build": {"bytes": int(build_bytes(wl.faces.shape[0], wl.num_nodes, wl.rb)),
-                              "frac": round(build_bytes(wl.faces.shape[0], wl.num_nodes, wl.rb) / (float(np.median(wl.build_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+                              "frac": round(build_bytes(wl.faces.shape[0], wl.num_nodes, wl.rb) / (float(np.median(wl.build_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+           "_k_ms": {"primary": ms1, "bounce": ms2},
+           "_counts": per_wave_counts(wl, c1, c2, ms1, ms2)}
     try:
         from oracle import bindings as ob
 
@@ -583,23 +728,147 @@ def self_spawn(args, argv):
     return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
+class Timed:
+    """The timed region of one workload on this rank's GPU: W warm-up steps, a short pass with an event pair around every
+    launch (per-wave kernel times, outside the timed region), then exactly K steps bracketed by barrier + synchronize —
+    max over ranks.  One step = wave 1 + wave 2 (+ for N > 1 the asynchronous, double-buffered gather of both waves' hit
+    records to rank 0, every gather completing inside the region)."""
+
+    def __init__(self, wl, steps, warmup, world, rank, dist, shared):
+        import torch
+
+        from nanort_amd import dist as nd
+
+        accel, n1, HIT = wl.accel, wl.n1, wl.HIT
+        comm_dev = "cpu" if shared else "cuda"
+        nbuf = 2 if world > 1 else 1
+        hit_bufs1 = [wl.d_hits1] + [torch.empty_like(wl.d_hits1) for _ in range(nbuf - 1)]
+        hit_bufs2 = [wl.d_hits2] + [torch.empty_like(wl.d_hits2) for _ in range(nbuf - 1)]
+        gathered1 = gathered2 = [None, None]
+        if world > 1 and rank == 0:
+            gathered1 = [torch.empty(world * n1 * HIT.itemsize, dtype=torch.uint8, device=comm_dev) for _ in range(2)]
+            gathered2 = [torch.empty(world * n1 * HIT.itemsize, dtype=torch.uint8, device=comm_dev) for _ in range(2)]
+        pending = [[None, None], [None, None]]  # [wave][buffer]
+        step_no = [0]
+
+        def step(ev=None):
+            b = step_no[0] % nbuf
+            step_no[0] += 1
+            if world > 1:
+                for w in (0, 1):
+                    if pending[w][b] is not None:
+                        pending[w][b].wait()  # the gathers that last used this buffer pair (two steps ago)
+                        pending[w][b] = None
+            if ev is not None:
+                ev[0].record()
+            accel.TraverseBatchDevice(wl.d_rays1, hit_bufs1[b], wl.d_mask1)
+            if ev is not None:
+                ev[1].record()
+            if world > 1:
+                src = hit_bufs1[b].cpu() if shared else hit_bufs1[b]  # (test hook: staged through the host for gloo)
+                _, pending[0][b] = nd.gather_hit_records(src, world, rank, dist, out=gathered1[b], async_op=True)
+            if ev is not None:
+                ev[2].record()
+            accel.TraverseBatchDevice(wl.d_rays2, hit_bufs2[b], wl.d_mask2)
+            if ev is not None:
+                ev[3].record()
+            if world > 1:
+                src = hit_bufs2[b].cpu() if shared else hit_bufs2[b]
+                _, pending[1][b] = nd.gather_hit_records(src, world, rank, dist, out=gathered2[b], async_op=True)
+
+        def drain():
+            for w in (0, 1):
+                for b in range(2):
+                    if pending[w][b] is not None:
+                        pending[w][b].wait()
+                        pending[w][b] = None
+
+        for _ in range(warmup):
+            step()
+        drain()
+        # Per-wave kernel times: a short pass with an event pair around every launch, OUTSIDE the timed region (an event record
+        # between two kernels of a stream keeps the second from starting for several microseconds).  The timed region itself
+        # carries one event pair around all of its 2 x steps launches; the library records no event of its own (completion records).
+        split_steps = 3
+        events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(split_steps)]
+        for k in range(split_steps):
+            step(events[k])
+        drain()
+        torch.cuda.synchronize()
+        self.k_ms1 = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+        self.k_ms2 = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
+        region = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        region[0].record()
+        for k in range(steps):
+            step()
+        region[1].record()
+        drain()  # every gather issued inside the timed region completes inside it
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        self.dt = time.perf_counter() - t0
+        self.kernel_name = accel.LastKernelName()
+        self.region_ms = float(region[0].elapsed_time(region[1]))  # HIP events on the launch stream over the timed region
+        self.steps = steps
+        self.rays_per_step = wl.n1 + wl.n2
+        self.per_rank = None
+        self.total_rays = float(self.rays_per_step)
+        if world > 1:
+            # a blocking gather of one wave's records, timed on its own (outside the timed region)
+            g0 = time.perf_counter()
+            src = hit_bufs1[0].cpu() if shared else hit_bufs1[0]
+            _, wk = nd.gather_hit_records(src, world, rank, dist, out=gathered1[0], async_op=True)
+            wk.wait()
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            t = torch.tensor([self.dt, float(self.rays_per_step), self.k_ms1, self.k_ms2, gather_ms, self.region_ms], dtype=torch.float64, device=comm_dev)
+            allt = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            allt = torch.stack(allt).cpu().numpy()
+            self.dt = float(allt[:, 0].max())
+            self.total_rays = float(allt[:, 1].sum())
+            self.per_rank = {"wall_ms_per_step": [round(float(x) / steps * 1e3, 4) for x in allt[:, 0]],
+                             "primary_kernel_ms": [round(float(x), 4) for x in allt[:, 2]],
+                             "bounce_kernel_ms": [round(float(x), 4) for x in allt[:, 3]],
+                             "kernel_ms_max": round(float((allt[:, 2] + allt[:, 3]).max()), 4),
+                             "kernel_ms_min": round(float((allt[:, 2] + allt[:, 3]).min()), 4),
+                             "launch_ms": [round(float(x) / (2 * steps), 4) for x in allt[:, 5]],
+                             "gather_ms_one_wave_blocking": [round(float(x), 4) for x in allt[:, 4]]}
+            self.gathered_bytes_per_step = int(2 * world * n1 * HIT.itemsize)
+        self.value = self.total_rays * steps / self.dt / 1e6
+        self.ms_per_step = self.dt / steps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="default: C3 (the config BASELINE.json's metric is quoted on; with --gpus N > 1 also its strong-scaling case C4 as `strong_c4`)")
     ap.add_argument("--mesh", default=None, help="C2: a .ply / .obj triangle mesh (e.g. Stanford bun_zipper.ply) instead of the procedural stand-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--builds", type=int, default=5)
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the untimed extras (2 frames in flight, primary+shadow): use for rocprofv3 runs, so that the "
-                         "kernel statistics hold the timed region's launches only")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (roofline.hbm/valu fall back to the committed file)")
+                    help="skip the untimed extras (2 frames in flight, primary+shadow, end_to_end, next_rows): use for rocprofv3 runs, so "
+                         "that the kernel statistics hold the timed region's launches only")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 counter passes (the line then says roofline UNMEASURED)")
     ap.add_argument("--no-configs", action="store_true", help="skip the untimed measurements of the other single-GPU configs")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the untimed figures of the SURVEY 8(f) rows")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1, default config: skip the strong-scaling C4 sub-object")
     ap.add_argument("--pmc-dir", default=None, help="keep the raw rocprofv3 counter CSVs here")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-configs", default="C3", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-rank", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-world", type=int, default=1, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    default_config = args.config is None
+    if default_config:
+        args.config = "C3"
     if args.mesh and args.config != "C2":
         raise SystemExit("--mesh applies to --config C2")
 
@@ -637,140 +906,74 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     comm_dev = "cpu" if shared else "cuda"
 
-    from nanort_amd import dist as nd
     from nanort_amd import scenes
 
     wl = Workload(args.config, rank, world, local_rank, args.builds, args.mesh)
     accel, n1, n2 = wl.accel, wl.n1, wl.n2
     HIT = wl.HIT
-    # rank 0 assembles the frame: it receives every rank's records over its 7 direct xGMI links at once (33 MB each per
-    # wave), the other ranks only send.  The records of BOTH waves are double-buffered so that the gather of wave 1
-    # (RCCL, its own stream) overlaps wave 2 of the same step and the gather of wave 2 overlaps the next step; a gather
-    # is waited for before its buffers are reused.
-    nbuf = 2 if world > 1 else 1
-    hit_bufs1 = [wl.d_hits1] + [torch.empty_like(wl.d_hits1) for _ in range(nbuf - 1)]
-    hit_bufs2 = [wl.d_hits2] + [torch.empty_like(wl.d_hits2) for _ in range(nbuf - 1)]
-    gathered1 = gathered2 = [None, None]
-    if world > 1 and rank == 0:
-        gathered1 = [torch.empty(world * n1 * HIT.itemsize, dtype=torch.uint8, device=comm_dev) for _ in range(2)]
-        gathered2 = [torch.empty(world * n1 * HIT.itemsize, dtype=torch.uint8, device=comm_dev) for _ in range(2)]
-    pending = [[None, None], [None, None]]  # [wave][buffer]
 
     # ---- work counters -> algorithmic bytes per launch ---------------------------
     c1, c2 = wl.counters()
     bytes1, bytes2 = algorithmic_bytes(c1, wl.rb), algorithmic_bytes(c2, wl.rb)
 
-    step_no = [0]
-
-    def step(ev=None):
-        b = step_no[0] % nbuf
-        step_no[0] += 1
-        if world > 1:
-            for w in (0, 1):
-                if pending[w][b] is not None:
-                    pending[w][b].wait()  # the gathers that last used this buffer pair (two steps ago)
-                    pending[w][b] = None
-        if ev is not None:
-            ev[0].record()
-        accel.TraverseBatchDevice(wl.d_rays1, hit_bufs1[b], wl.d_mask1)
-        if ev is not None:
-            ev[1].record()
-        if world > 1:
-            src = hit_bufs1[b].cpu() if shared else hit_bufs1[b]  # (test hook: staged through the host for gloo)
-            _, pending[0][b] = nd.gather_hit_records(src, world, rank, dist, out=gathered1[b], async_op=True)
-        if ev is not None:
-            ev[2].record()
-        accel.TraverseBatchDevice(wl.d_rays2, hit_bufs2[b], wl.d_mask2)
-        if ev is not None:
-            ev[3].record()
-        if world > 1:
-            src = hit_bufs2[b].cpu() if shared else hit_bufs2[b]
-            _, pending[1][b] = nd.gather_hit_records(src, world, rank, dist, out=gathered2[b], async_op=True)
-
-    def drain():
-        for w in (0, 1):
-            for b in range(2):
-                if pending[w][b] is not None:
-                    pending[w][b].wait()
-                    pending[w][b] = None
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    # Per-wave kernel times: a short pass with an event pair around every launch, OUTSIDE the timed region — an event
-    # record between two kernels of a stream keeps the second from starting for several microseconds (measured: 24 us per
-    # launch with the five records per launch the timed loop used to make), which is the benchmark's own overhead, not the
-    # path's.  The timed region itself carries one event pair around all of its 2 x steps launches.
-    split_steps = 3
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(split_steps)]
-    for k in range(split_steps):
-        step(events[k])
-    drain()
-    torch.cuda.synchronize()
-    k_ms1 = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    k_ms2 = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
-    accel.SetLaunchTiming(False)  # (the library's own per-launch event pair, nrtLastTraverseMs: same reason)
-    region = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    T = Timed(wl, args.steps, args.warmup, world, rank, dist, shared)
+    k_ms1, k_ms2, kernel_name, region_ms = T.k_ms1, T.k_ms2, T.kernel_name, T.region_ms
+    launch_ms = region_ms / (2 * args.steps)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    region[0].record()
-    for k in range(args.steps):
-        step()
-    region[1].record()
-    drain()  # every gather issued inside the timed region completes inside it
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    accel.SetLaunchTiming(True)
-    kernel_name = accel.LastKernelName()
-    region_ms = float(region[0].elapsed_time(region[1]))  # HIP events on the launch stream over the timed region
-    rays_per_step = n1 + n2
-    per_rank = None
-    gather_ms = None
-    if world > 1:
-        # a blocking gather of one wave's records, timed on its own (outside the timed region)
-        g0 = time.perf_counter()
-        src = hit_bufs1[0].cpu() if shared else hit_bufs1[0]
-        _, wk = nd.gather_hit_records(src, world, rank, dist, out=gathered1[0], async_op=True)
-        wk.wait()
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        t = torch.tensor([dt, float(rays_per_step), float(bytes1 + bytes2), k_ms1, k_ms2, gather_ms], dtype=torch.float64, device=comm_dev)
+        t = torch.tensor([float(bytes1 + bytes2)], dtype=torch.float64, device=comm_dev)
         allt = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
-        allt = torch.stack(allt).cpu().numpy()
-        dt = float(allt[:, 0].max())
-        total_rays = float(allt[:, 1].sum())
-        per_rank = {"wall_ms_per_step": [round(float(x) / args.steps * 1e3, 4) for x in allt[:, 0]],
-                    "primary_kernel_ms": [round(float(x), 4) for x in allt[:, 3]],
-                    "bounce_kernel_ms": [round(float(x), 4) for x in allt[:, 4]],
-                    "kernel_ms_max": round(float((allt[:, 3] + allt[:, 4]).max()), 4),
-                    "kernel_ms_min": round(float((allt[:, 3] + allt[:, 4]).min()), 4),
-                    "gather_ms_one_wave_blocking": [round(float(x), 4) for x in allt[:, 5]]}
-        agg_bytes = float(allt[:, 2].sum())
-        agg_ms = float((allt[:, 3] + allt[:, 4]).max())
+        agg_bytes = float(torch.stack(allt).sum())
+        agg_ms = T.per_rank["kernel_ms_max"]
     else:
-        total_rays = float(rays_per_step)
         agg_bytes = float(bytes1 + bytes2)
         agg_ms = k_ms1 + k_ms2
 
+    # ---- hardware counters of this run: rank 0's GPU, rank 0's share of the workload (every rank runs the same kernel on
+    # the same number of interleaved rows); all ranks wait at the barrier below meanwhile ------------------------------------
+    pmc_all, pmc_err = None, None
+    other_configs = ["C2", "C4tile", "C5"] if (world == 1 and not args.no_configs and default_config) else []
+    configs_out = {}
+    if rank == 0 and other_configs:
+        for name in other_configs:  # (before the counter passes: their own kernel times go into the fractions)
+            try:
+                configs_out[name] = measure_config(name)
+            except Exception as e:  # pragma: no cover
+                configs_out[name] = {"error": repr(e)}
+    if rank == 0 and not args.no_pmc:
+        keep = args.pmc_dir and os.path.abspath(args.pmc_dir)
+        pmc_all, pmc_err = pmc_collect([args.config] + [c for c in other_configs if "error" not in configs_out.get(c, {})],
+                                       args.mesh, rank=0, world=world, keep_dir=keep)
+    n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+
+    strong = None
+    if world > 1 and default_config and not args.no_strong:
+        # BASELINE.json's strong-scaling case beside the weak-scaled headline: every rank builds the 10M-triangle plane and
+        # traces its 4096/N interleaved rows of the fixed 4096x4096 frame
+        del wl.d_rays1, wl.d_rays2
+        torch.cuda.empty_cache()
+        wl4 = Workload("C4", rank, world, local_rank, 2, None)
+        T4 = Timed(wl4, max(2, args.steps // 4), 1, world, rank, dist, shared)
+        strong = {"config": "C4", "workload": wl4.describe(), "scaling": "strong", "value": round(T4.value, 3), "unit": "Mrays/s",
+                  "steps": T4.steps, "ms_per_step": round(T4.ms_per_step, 4), "rays_per_step": int(T4.total_rays),
+                  "build_ms": round(float(np.median(wl4.build_ms)), 4), "bvh": {"nodes": wl4.num_nodes, "max_depth": int(wl4.stats["max_tree_depth"])},
+                  "multi_gpu": T4.per_rank}
+        del wl4
+
     if rank == 0:
-        value = total_rays * args.steps / dt / 1e6
         k_ms = {"primary": k_ms1, "bounce": k_ms2}
         alg_gbs = agg_bytes / (agg_ms * 1e-3) / 1e9  # all ranks' algorithmic bytes over the slowest rank's two launches
         build_ms = float(np.median(wl.build_ms))
         bbytes = build_bytes(wl.faces.shape[0], wl.num_nodes, wl.rb)
         roof = {
             "kernel": kernel_name,
-            "limiting": "no single resource: per step, the latency of the dependent chain (node fetch -> slab tests -> next fetch; waves "
-                        "wait on L1/L2 ~40 % of their cycles), the vector L1's address work (~0.7 clk per scattered 16-byte lane access; "
-                        "see l1: look-ups against the measured peak) and VALU issue (~38 % busy) cost about the same (perturbation "
-                        "probes: profiles/r02g_sensitivity_probe.txt, r02g_node_fetch_ubench.txt); HBM is far from saturated: see "
-                        "valu / hbm; no MFMA in this path",
-            "launch_ms": round(region_ms / (2 * args.steps), 4),
+            "limiting": "the vector L1's address path and the latency of the dependent chain node fetch -> slab tests -> next fetch: in the bulk "
+                        "of a launch a CU completes one 128-byte node record per lane every ~0.7-1 clk (tools/ubench/node_fetch.hip: 0.7 clk per "
+                        "scattered 16-byte lane access is what the L1 sustains), waves wait on L1/L2 ~40 % of their cycles, VALU issue is ~38 % busy; "
+                        "the last quarter of a launch is the chain of its longest rays (tools/drain_probe.py, tools/tail_first_probe.py: an oracle "
+                        "ordering with the longest 1 % of the rays first takes 11 % off the bounce wave).  HBM is far from saturated: see hbm / "
+                        "valu / l1 (DESIGN.md 3.1, 5); no MFMA in this path",
+            "launch_ms": round(launch_ms, 4),
             "launch_ms_note": "HIP events on the launch stream around the whole timed region / (2 x steps): the average launch of the two "
                               "waves, idle time between launches included; per_wave.ms: event pairs around single launches in a 3-step "
                               "pass outside the timed region",
@@ -782,42 +985,29 @@ def main():
             "build": {"bytes": int(bbytes), "ms": round(build_ms, 4), "GBs": round(bbytes / (build_ms * 1e-3) / 1e9, 1),
                       "frac": round(bbytes / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                       "note": "compulsory traffic 52N + 40*nodes + 4N (SURVEY 8d) over the build's device time"},
-            "per_wave": {
-                "primary": {"ms": round(k_ms1, 4), "rays": n1, "nodes_per_ray": round(c1["nodes_visited"] / n1, 2),
-                            "tris_per_ray": round(c1["tris_tested"] / n1, 2), "algorithmic_bytes": int(bytes1)},
-                "bounce": {"ms": round(k_ms2, 4), "rays": n2, "nodes_per_ray": round(c2["nodes_visited"] / max(1, n2), 2),
-                           "tris_per_ray": round(c2["tris_tested"] / max(1, n2), 2), "algorithmic_bytes": int(bytes2)},
-            },
+            "per_wave": per_wave_counts(wl, c1, c2, k_ms1, k_ms2),
         }
-        # hardware counters of this run (rank 0's GPU; every rank runs the same kernel on the same kind of rows)
-        pmc, pmc_err, source = None, None, None
-        if not args.no_pmc and not shared:
-            keep = args.pmc_dir and os.path.abspath(args.pmc_dir)
-            pmc, pmc_err = pmc_collect(args.config, args.mesh, kernel_name, keep_dir=keep)
-        n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
-        if pmc is not None:
-            r = roofline_from_counters(pmc, k_ms, n_cus)
+        source = None
+        if pmc_all is not None and pmc_all.get(args.config, {}).get("primary"):
+            r = roofline_from_counters(pmc_all[args.config], k_ms, n_cus, launch_ms=launch_ms)
             if r["hbm"]:
-                roof["hbm"], source = r["hbm"], "in-run rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; 3 steps of the same workload)"
+                roof["hbm"], source = r["hbm"], "in-run rocprofv3 --pmc passes (3 steps of the same workload, this rank's share)"
             if r["valu"]:
                 roof["valu"] = r["valu"]
             if r["l1"]:
                 roof["l1"] = r["l1"]
         if pmc_err:
             roof["pmc_error"] = pmc_err
-        if "hbm" not in roof and args.config == "C3":
-            tf = os.path.join(ROOT, "profiles", "traffic_c3.json")
-            try:
-                traffic = float(json.load(open(tf)).get("hbm_bytes_per_launch"))
-                gbs = traffic / ((k_ms1 + k_ms2) / 2 * 1e-3) / 1e9
-                roof["hbm"] = {"bytes_per_launch": int(traffic), "achieved_GBs": round(gbs, 1), "peak_GBs": HBM_PEAK_GBS,
-                               "frac": round(gbs / HBM_PEAK_GBS, 4)}
-                source = "stale-file"
-            except Exception:
-                pass
         hb = roof.get("hbm")
         roof.update({"bound": "hbm", "achieved": hb["achieved_GBs"] if hb else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": hb["frac"] if hb else None, "traffic": hb["bytes_per_launch"] if hb else None, "traffic_source": source})
+                     "frac": hb["frac"] if hb else None, "traffic": hb["bytes_per_launch"] if hb else None,
+                     "traffic_source": source or "UNMEASURED (no counter pass in this run)"})
+        if hb and world > 1:
+            # per-rank fractions: this rank's measured bytes per launch (the ranks' shares are equally many interleaved rows of the
+            # same frame) over every rank's own average launch of the timed region
+            fr = [hb["bytes_per_launch"] / (x * 1e-3) / 1e9 / HBM_PEAK_GBS for x in T.per_rank["launch_ms"]]
+            roof["per_rank_hbm_frac"] = {"max": round(max(fr), 4), "min": round(min(fr), 4),
+                                         "note": "rank 0's counters (bytes per launch of its share) over each rank's own launch time"}
         cfg = wl.cfg
         par = "replicated BVH, interleaved image rows per GPU"
         if world > 1:
@@ -826,29 +1016,31 @@ def main():
                                                  if cfg["scaling"] == "strong" else "weak scaling: %dx%d rays per GPU" % (cfg["w"], wl.rows)))
         out = {
             "metric": METRIC,
-            "value": round(value, 3),
+            "value": round(T.value, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step": round(T.ms_per_step, 4),
             "higher_is_better": True,
             "scaling": cfg["scaling"] if "tile_of" not in cfg else "weak",
             "vs_baseline": None,
             "dtype": cfg["real"],
             "data": "synthetic" if not wl.mesh_note else "user mesh, synthetic rays",
-            "config": {"name": args.config, "workload": wl.describe(), "parallelism": par, "rays_per_step": int(total_rays)},
+            "config": {"name": args.config, "workload": wl.describe(), "parallelism": par, "rays_per_step": int(T.total_rays)},
             "build_ms": round(build_ms, 4),
             "bvh": {"nodes": wl.num_nodes, "max_depth": int(wl.stats["max_tree_depth"])},
             "roofline": roof,
         }
         if world > 1:
-            out["multi_gpu"] = dict(per_rank, rccl_ranks=world, backend="gloo (test hook)" if shared else "nccl (RCCL)",
-                                    gathered_bytes_per_step=int(2 * world * n1 * HIT.itemsize))
+            out["multi_gpu"] = dict(T.per_rank, rccl_ranks=world, backend="gloo (test hook)" if shared else "nccl (RCCL)",
+                                    gathered_bytes_per_step=T.gathered_bytes_per_step)
+            if strong is not None:
+                out["strong_c4"] = strong
         if world == 1 and not args.no_extras:
             # extras, outside the timed region: (a) the same K steps with two frames in flight (steps alternate
             # between two streams; a launch's drain tail is filled by the next frame's rays), (b) SURVEY 8(d)'s
-            # primary + shadow pair
+            # primary + shadow pair, (c) the host entry point end to end
             out["pipelined"] = pipelined(accel, torch, (wl.d_rays1, wl.d_hits1, wl.d_mask1), (wl.d_rays2, wl.d_hits2, wl.d_mask2), args.steps, n1 + n2)
             rays_s = scenes.secondary_rays("shadow", wl.verts32, wl.faces, wl.rays1_f32, wl.hits1_f32, wl.mask1)
             if wl.real != np.float32:
@@ -865,6 +1057,10 @@ def main():
             out["primary_plus_shadow"] = {"value": round((n1 + rays_s.shape[0]) / (k_ms1 + ms_s) / 1e3, 1), "unit": "Mrays/s",
                                           "shadow_ms": round(ms_s, 4), "shadow_rays": int(rays_s.shape[0])}
             del d_rs, d_hs
+            try:
+                out["end_to_end"] = end_to_end(wl)
+            except Exception as e:  # pragma: no cover
+                out["end_to_end"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             nodes, indices = accel.GetTree()
             # the timed region's own output buffers
@@ -872,15 +1068,24 @@ def main():
             accel.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)
             budget = 12.0 if args.config in ("C3", "C2") else 6.0
             out["cpu_baseline"] = cpu_baseline(wl.verts, wl.faces, wl.rays1, wl.rays2, nodes, indices, wl.width, wl.results(), budget_s=budget)
-        if world == 1 and not args.no_configs and args.config == "C3":
+        if configs_out:
+            out["configs"] = {}
+            for name, e in configs_out.items():
+                k_ms_c, counts = e.pop("_k_ms", None), e.pop("_counts", None)
+                if pmc_all is not None and k_ms_c and pmc_all.get(name, {}).get("primary"):
+                    e["roofline"] = compact_roofline(roofline_from_counters(pmc_all[name], k_ms_c, n_cus), counts)
+                elif counts:
+                    e["roofline"] = {"waves": counts, "note": "UNMEASURED (no counter pass in this run)"}
+                out["configs"][name] = e
+        if world == 1 and default_config and not args.no_next_rows and not args.no_extras:
             del wl
             torch.cuda.empty_cache()
-            out["configs"] = {}
-            for name in ("C2", "C4tile", "C5"):
-                try:
-                    out["configs"][name] = measure_config(name)
-                except Exception as e:  # pragma: no cover
-                    out["configs"][name] = {"error": repr(e)}
+            try:
+                import bench_rows
+
+                out["next_rows"] = bench_rows.next_rows()
+            except Exception as e:  # pragma: no cover
+                out["next_rows"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

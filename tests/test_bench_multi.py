@@ -35,6 +35,14 @@ def test_two_ranks_share_one_gpu_through_the_self_spawn_path():
     assert mg["kernel_ms_max"] >= mg["kernel_ms_min"] > 0
     assert out["roofline"]["algorithmic"]["bytes_per_launch"] > 0 and out["roofline"]["build"]["frac"] <= 1.0
     assert "cpu_baseline" not in out
+    # the default config with N > 1 also carries BASELINE.json's strong-scaling case: the fixed 4096x4096 frame in N tiles
+    sc = out["strong_c4"]
+    assert sc["scaling"] == "strong" and sc["rays_per_step"] > 2 * 4096 * 2048 * 0.9 and sc["value"] > 100.0
+    assert "4096x2048" in sc["workload"] and sc["bvh"]["nodes"] > 4_000_000 and len(sc["multi_gpu"]["wall_ms_per_step"]) == 2
+    # counters of rank 0's share, fractions against rank 0's own launch times
+    rf = out["roofline"]
+    assert rf["traffic_source"].startswith("in-run"), rf.get("pmc_error")
+    assert 0.0 < rf["frac"] <= 1.0 and 0.0 < rf["per_rank_hbm_frac"]["min"] <= rf["per_rank_hbm_frac"]["max"] <= 1.0
 
 
 @pytest.mark.gpu
@@ -46,6 +54,11 @@ def test_strong_scaling_config_splits_a_fixed_frame():
     assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["config"]["name"] == "C4"
     assert "4096x2048" in out["config"]["workload"]  # each of the two ranks traces half of the 4096 rows
     assert out["bvh"]["nodes"] > 4_000_000
+    # the counter sub-run traces THIS rank's share (4096x2048 rays), so the fractions stay fractions
+    rf = out["roofline"]
+    assert rf["traffic_source"].startswith("in-run"), rf.get("pmc_error")
+    assert 0.0 < rf["frac"] <= 1.0 and 0.0 < rf["valu"]["frac"] <= 1.0 and 0.0 < rf["l1"]["frac"] <= 1.0
+    assert abs(rf["per_wave"]["primary"]["rays"] - 4096 * 2048) == 0
 
 
 @pytest.mark.gpu
