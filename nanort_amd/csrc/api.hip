@@ -29,7 +29,7 @@ int traverse_blocks_per_cu(int lds_stack);
 template <typename T>
 hipError_t launch_traverse_wide(const TraverseArgs<T> &, unsigned grid, int lds_stack, int prim_kind, hipStream_t, const char **name_out);
 template <typename T>
-int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool split, bool wide4);
+int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool wide4);
 template <typename T>
 hipError_t launch_gather_leaf_spheres(const uint32_t *, const T *, const T *, LeafSphere<T> *, uint32_t, hipStream_t);
 template <typename T>
@@ -136,16 +136,11 @@ struct nrt_ctx {
   unsigned static_slice_groups = 2; // ... each of at least this many 64-ray groups
   unsigned max_blocks_per_cu = 0; // env NRT_BLOCKS_PER_CU caps the persistent grid
   int wide = 1, wide_stack = 10; // production path: WideNode kernel (env NRT_WIDE=0 selects the binary kernel)
-  // Work splitting in the drain of a launch (traverse.hip, k_traverse_wide<..., SPLIT>): exact, soaked, and MEASURED TO
-  // LOSE on C3 (profiles/r02c_split_*.txt: bounce wave 0.50 -> 0.51-0.59 ms depending on the hand-out policy), because
-  // under the while-while loop every helper adds leaf rounds that stall the very ray it helps.  Off unless NRT_SPLIT=1.
-  int split = 0;
   // Two tree levels per step (Wide4Node records, traverse.hip NRT_STEP_NODE4): the production walk of fp32 triangle trees
   // whose child boxes lie inside their parents'.  env NRT_WIDE4=0 goes back to one level per step.
   int wide4 = 1;
   int wide_scramble = 0; // probe (tunable wide_scramble): the private node records in a pseudo-random order instead of pre-order
   unsigned wide4_blocks_per_cu = 0;
-  unsigned drain_steps = 8, split_busy = 8; // hand-out policy (env NRT_DRAIN_STEPS, NRT_SPLIT_BUSY)
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
 
   hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;
@@ -274,9 +269,6 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("morton", 0, 1, morton, int),                     // Morton pre-pass of the builder (next build)
     NRT_TUNABLE("wide", 0, 1, wide, int),                         // 0: the literal BVHNode loop
     NRT_TUNABLE("wide4", 0, 1, wide4, int),                       // two tree levels per step (next build / set_tree)
-    NRT_TUNABLE("split", 0, 1, split, int),                       // drain-time work splitting
-    NRT_TUNABLE("drain_steps", 1, 1 << 20, drain_steps, unsigned),
-    NRT_TUNABLE("split_busy", 0, 64, split_busy, unsigned),
     NRT_TUNABLE("launch_timing", 0, 1, launch_timing, int),       // == nrtSetLaunchTiming
     NRT_TUNABLE("host_pipeline", 0, 1, host_pipeline, int),       // pipelined host entry point
     NRT_TUNABLE("wide_scramble", 0, 1, wide_scramble, int),       // probe: WideNode / Wide4Node records in a pseudo-random order (next build)
@@ -797,10 +789,10 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
   // two levels per step: closest-hit walks of nested fp32 triangle trees, outside the profiling / splitting variants
   const bool use_wide4 = use_wide && !spheres && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch &&
-                         !c->split;
-  if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, c->split != 0, false);
-  if (use_wide4 && c->wide4_blocks_per_cu == 0) c->wide4_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(kWide4LdsStack, kPrimTriangles, false, true);
-  if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, false, false);
+                         true;
+  if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, false);
+  if (use_wide4 && c->wide4_blocks_per_cu == 0) c->wide4_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(kWide4LdsStack, kPrimTriangles, true);
+  if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, false);
   unsigned blocks_per_cu = spheres ? c->sphere_blocks_per_cu : (use_wide4 ? c->wide4_blocks_per_cu : (use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu));
   if (c->max_blocks_per_cu && blocks_per_cu > c->max_blocks_per_cu) blocks_per_cu = c->max_blocks_per_cu;
   const int stack_entries = spheres ? 10 : (use_wide4 ? kWide4LdsStack : (use_wide ? c->wide_stack : c->lds_stack));
@@ -866,10 +858,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   // prim ids are < num_faces: nothing can be rejected by these options -> the kernel variant without the id tests
   a.plain_options = (opt->prim_ids_range[0] == 0u && opt->prim_ids_range[1] >= c->num_faces && opt->skip_prim_id >= c->num_faces &&
                      !opt->cull_back_face) ? 1u : 0u;
-  a.split = (c->split && use_wide && c->prim_kind == kPrimTriangles && !any_hit && c->root_is_branch && c->tree_nested) ? 1u : 0u;
   a.root_test = c->tree_nested ? 0u : 1u;
-  a.drain_steps = c->drain_steps;
-  a.split_busy = c->split_busy;
   a.spill = (uint32_t *)slot->spill.p;
   a.spill_stride = total_threads;
   a.spill_levels = levels;

@@ -193,10 +193,10 @@ struct DoneRec {
 };
 // Device-side words that go with it (one set per slot, zero / ~0 between launches).
 struct DoneCount {
-  uint32_t exited;   // block groups of the current launch that have finished
+  uint32_t exited;   // wave groups of the current launch that have finished
   uint32_t pad;
   unsigned long long t_begin; // earliest start stamp seen (atomicMin)
-  uint32_t group[8]; // blocks of group g = blockIdx % 8 that have finished (eight words instead of one: same-address atomics serialise)
+  uint32_t group[8]; // waves of group g = blockIdx % 8 that have finished (eight words instead of one: same-address atomics serialise)
 };
 
 template <typename T>
@@ -220,9 +220,6 @@ struct TraverseArgs {
   uint32_t cull_back_face;
   uint32_t any_hit;       // occlusion query (opt-in extension): a ray stops at the first primitive it accepts
   uint32_t plain_options; // the options above cannot reject any primitive of this tree (host-checked)
-  uint32_t split;         // work splitting in the drain (triangle closest-hit launches over a tree whose child boxes lie inside their parents')
-  uint32_t drain_steps;   // splitting launches: a round of hand-outs every this many trips through the outer loop once the wave is out of rays
-  uint32_t split_busy;    // ... and only while at most this many lanes of the wave are busy
   uint32_t root_test;     // node 0's box must be tested before its children (an adopted tree whose child boxes may stick out)
   uint32_t *spill;        // [spill_levels][spill_stride] overflow stack, may be null
   T *spill_tmin;          // same shape, entry t_min (wide kernel)

@@ -164,12 +164,9 @@ __device__ __forceinline__ bool slab_test(const Lane<T> &L, const T bmin[3], con
 // Written as one running predicate with select-style updates (the reference's early returns
 // in the same order): all loads of the record are issued together, and the lane state stays
 // in the same registers on every path.
-// CHECK (work splitting, see k_traverse_wide): `bad` collects "accepted a distance below the entry distance of the
-// leaf box it was found in (or a NaN)" — the one situation in which folding separately traversed subtrees could differ
-// from the sequential loop; such a ray is traced again sequentially.
-template <typename T, bool PLAIN = false, bool CHECK = false>
+template <typename T, bool PLAIN = false>
 __device__ __forceinline__ void tri_test(Lane<T> &L, const LeafTri<T> &tri, bool active, uint32_t range0,
-                                         uint32_t range1, uint32_t skip, bool cull, T leaf_tmin = T(0), bool *bad = nullptr) {
+                                         uint32_t range1, uint32_t skip, bool cull) {
   const uint32_t prim = tri.prim_id;
   bool ok = PLAIN ? active : (active & (prim >= range0) & (prim < range1) & (prim != skip)); // nanort.h:2387-2395
   if (PLAIN) cull = false;
@@ -207,7 +204,6 @@ __device__ __forceinline__ void tri_test(Lane<T> &L, const LeafTri<T> &tri, bool
     // `if (tt > t) return; if (tt < min_t) return;` — equality (and NaN) accepted (nanort.h:1133-1139)
     const bool acc = !(tt > L.hit_t) & !(tt < L.min_t);
     const T uu = V * rcp, vv = W * rcp;
-    if (CHECK) *bad = *bad | (acc & !(tt >= leaf_tmin));
     L.hit_t = acc ? tt : L.hit_t;
     L.u = acc ? uu : L.u;
     L.v = acc ? vv : L.v;
@@ -474,28 +470,25 @@ __device__ __forceinline__ void store_hit_nt(typename Wire<T>::Hit *p, const typ
 }
 
 // Completion record of a launch (common.h, DoneRec): no event is recorded in the stream for it.  Start — one thread of each
-// of the first eight blocks stamps the time; end — the waves of a block count themselves out in LDS, the block's last wave
-// counts the block out of its group (blockIdx % 8: eight counters, so that the atomics of ~1300 blocks do not queue on one
-// word), a group's last block counts the group out, and the last group publishes the two stamps and then the launch's
-// sequence number to the page-locked record.  Nothing is fenced: a waiter learns that every wave has stopped READING the
-// tree and the slot's scratch (what a rebuild or the slot's next launch must know), not that the hit records have landed —
-// for that the caller synchronises its stream as usual.  Every word a later launch depends on is handed on by an atomic
-// (performed at the memory side, visible to every XCD), not left dirty in one XCD's L2.
+// of the first eight blocks stamps the time; end — every wave counts itself out of its block's group (blockIdx % 8: eight
+// counters, so that the exit atomics of ~5000 waves do not queue on one word), a group's last wave counts the group out,
+// and the last group publishes the two stamps and then the launch's sequence number to the page-locked record.  No LDS
+// (the fp64 variants use all of it for their stacks), no barrier, nothing fenced: a waiter learns that every wave has
+// stopped READING the tree and the slot's scratch (what a rebuild or the slot's next launch must know), not that the hit
+// records have landed — for that the caller synchronises its stream as usual.  Every word a later launch depends on is
+// handed on by an atomic (performed at the memory side, visible to every XCD), not left dirty in one XCD's L2.
 template <typename T>
-__device__ __forceinline__ void done_begin(const TraverseArgs<T> &a, uint32_t *s_exit) {
-  if (threadIdx.x == 0u) *s_exit = 0u;
-  __syncthreads(); // (the only barrier of the kernel: all waves are at their first instructions)
+__device__ __forceinline__ void done_begin(const TraverseArgs<T> &a) {
   if (a.done_rec != nullptr && threadIdx.x == 0u && blockIdx.x < 8u)
     atomicMin(&a.done_count->t_begin, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 template <typename T>
-__device__ __forceinline__ void done_end(const TraverseArgs<T> &a, unsigned lane, uint32_t *s_exit) {
+__device__ __forceinline__ void done_end(const TraverseArgs<T> &a, unsigned lane) {
   if (a.done_rec == nullptr || lane != 0u) return;
-  if (atomicAdd(s_exit, 1u) != (uint32_t)(kTraverseBlock / kWave) - 1u) return; // not the block's last wave
   const uint32_t groups = gridDim.x < 8u ? gridDim.x : 8u, g = blockIdx.x % 8u;
-  const uint32_t group_blocks = (gridDim.x - g + 7u) / 8u;
+  const uint32_t group_waves = ((gridDim.x - g + 7u) / 8u) * (uint32_t)(kTraverseBlock / kWave);
   DoneCount *cnt = a.done_count;
-  if (atomicAdd(&cnt->group[g], 1u) != group_blocks - 1u) return; // not the group's last block
+  if (atomicAdd(&cnt->group[g], 1u) != group_waves - 1u) return; // not the group's last wave
   (void)atomicExch(&cnt->group[g], 0u); // (handed on clean to the slot's next launch)
   if (atomicAdd(&cnt->exited, 1u) != groups - 1u) return; // not the launch's last group
   (void)atomicExch(&cnt->exited, 0u);
@@ -901,7 +894,7 @@ struct StackEntry<double> {
 
 // The two per-lane moves of the WideNode walk, shared by k_traverse_wide and the two-level kernel k_scene_trace.  They
 // expand inside a kernel that has these names in scope: L (Lane<T>), cur, state, sp, tid, gslot, s_stack[STACK][block],
-// SE = StackEntry<T>, `a` with .spill / .spill_tmin / .spill_stride, the constant SPLIT and (when it is true) leaf_tmin.
+// SE = StackEntry<T>, `a` with .spill / .spill_tmin / .spill_stride.
 
 // One stack pop (a lane in W_POP): the entry is entered iff its t_min still beats the hit distance — the reference's
 // slab test at pop time (see the comment above the kernel); an empty stack finishes the ray.
@@ -918,7 +911,6 @@ do {                                                                            
   const uint32_t ref_ = SE::ref(e_);                                                                 \
   sp = s1_;                                                                                          \
   cur = enter_ ? (ref_ & ~kLeafBit) : cur;                                                           \
-  if (SPLIT) leaf_tmin = SE::tmin(e_);                                                               \
   state = fin_ ? W_IDLE : (enter_ ? ((ref_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP);                  \
 } while (0)
 
@@ -944,7 +936,6 @@ do {                                                                            
   /* both hit: the near one; one hit: that one */                                                    \
   const bool go1_ = both_ ? near1_ : sl_.h1;                                                         \
   const uint32_t next_ = go1_ ? (w_).c1 : (w_).c0;                                                   \
-  if (SPLIT) leaf_tmin = go1_ ? sl_.tm1 : sl_.tm0;                                                   \
   cur = any_ ? (next_ & ~kLeafBit) : cur;                                                            \
   state = any_ ? ((next_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP;                                     \
 } while (0)
@@ -1004,44 +995,12 @@ do {                                                                            
 // PLAIN: the launch uses trace options that cannot reject a primitive (full prim_ids_range, no skip_prim_id, no
 // back-face culling — the reference's defaults): the three id comparisons per triangle test are compiled out.
 //
-// SPLIT — work splitting in the drain of a launch.  Per-ray step counts are heavy-tailed (C3 bounce wave: mean 24
-// WideNode steps, maximum 174) and a ray advances one step per trip through the loop, so once the work cursors have
-// run dry the last long rays would keep a whole wave — and the launch — alive with a handful of busy lanes.  From that
-// moment a wave hands its rays' PENDING SUBTREES to its idle lanes: each round every busy lane may give away the
-// OLDEST entry of its stack (the subtree the reference loop, nanort.h:2526-2548, would reach LAST) to a free lane of
-// the same wave, which becomes a helper: a copy of the ray that starts in that subtree from the hit distance the donor
-// holds at that moment.  Helpers split on in the same way.  Results are folded in LDS, per original ray, with the
-// reference's acceptance rule (nanort.h:1133: a larger t is rejected, an equal t replaces): smallest t wins, among
-// equal t the segment that comes LATEST in the sequential order wins — every segment carries a 32-bit key for that
-// (a donor keeps the lower half of its key interval, the helper takes the upper half).
-// Exactness: a helper's start distance is never tighter than the distance the sequential loop would hold on reaching
-// that subtree, so it tests a superset of the sequential loop's triangles; by induction over the traversal order the
-// folded result equals the sequential one provided every triangle a helper accepts has t >= the entry distance of the
-// leaf box it was found in (child boxes lie inside their parents' — `a.split` is only set for such trees — and the
-// slab arithmetic is monotone, so that is also >= every ancestor's entry distance: the sequential loop could not have
-// culled it by a box and still hold a nearer hit).  Helpers test exactly that at every acceptance (one compare; it
-// also catches NaN distances); a ray with a violation is traced again by its owner lane, sequentially.  The rule is
-// soaked on the CPU against the restated reference loop by a sequential model of this scheme (tests/test_split_model.py:
-// hostile meshes where the violation does occur) and on the GPU by the bit-for-bit parity suites, which run with
-// splitting on (batches of every size end in a drain).
-enum : uint32_t {
-  kMetaOwnerMask = 0x3Fu,   // helper: lane (within the wave) of the ray's owner
-  kMetaHelper = 1u << 6,    // this lane traverses a subtree of another lane's ray
-  kMetaNoSplit = 1u << 7,   // owner re-running its ray sequentially: never donates
-  kMetaOwnerOpen = 1u << 8, // owner: a fold record is open (helpers were spawned)
-  kMetaMainDone = 1u << 9,  // owner: its own segment is folded into the record
-  kMetaBad = 1u << 10,      // helper: accepted a distance below its leaf box's entry distance (or NaN)
-  kMetaLevelShift = 11,     // 5 bits: how often this segment's key interval was halved
-  kMetaLevelMask = 31u << 11,
-  kMetaDonatedShift = 16,   // 16 bits: stack entries [0, donated) were given away (marked dead in place)
-};
-template <typename T>
-struct FoldRec { // one per thread slot, used by the slot's lane when it owns a split ray
-  T t, u, v;
-  uint32_t key, prim;
-  uint32_t pend; // helpers outstanding (low 16 bits) | 0x80000000: some helper reported a violation
-};
-
+// (Round 2 also carried a SPLIT variant here — exact work splitting in the drain of a launch: a busy lane handed the oldest
+// entry of its stack to an idle lane, results folded per ray by (smallest t, latest segment) — and a per-lane drain loop.
+// Both were exact and soaked; both were measured to lose (the variant's bulk loop ran 9 % slower than production through
+// register pressure and the extra checks, 13 % per step in all: profiles/r02c_split_*.txt, r03g_split_asis.txt) and were
+// removed in round 3.  What a launch waits for at its end is the dependent chain of its few longest rays
+// (tools/drain_probe.py, tools/tail_first_probe.py); DESIGN.md 3.1 and 10 keep the numbers.)
 #ifndef NRT_W4_TRI_UNROLL
 #define NRT_W4_TRI_UNROLL 2 // triangle records fetched per trip of the leaf loop in the WIDTH = 4 variants (1 or 2)
 #endif
@@ -1056,12 +1015,11 @@ struct FoldRec { // one per thread slot, used by the slot's lane when it owns a 
 #endif
 // CLOCK: profiling instantiation that stamps when each wave starts, runs dry and finishes (tools/drain_probe.py).
 // WIDTH: 2 = one WideNode (two boxes) per step, 4 = one Wide4Node (two levels, four boxes) per step.
-template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool SPLIT = false, bool CLOCK = false, int WIDTH = 2>
-__global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((WIDTH == 4 && sizeof(T) == 4) ? NRT_W4_WAVES : 1)) void k_traverse_wide(const TraverseArgs<T> a) {
-  static_assert(WIDTH == 2 || (WIDTH == 4 && !SPLIT && KIND == kPrimTriangles), "the two-level step is a triangle closest-hit variant");
+template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool CLOCK = false, int WIDTH = 2>
+__global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NRT_W4_WAVES : 1) void k_traverse_wide(const TraverseArgs<T> a) {
+  static_assert(WIDTH == 2 || (WIDTH == 4 && KIND == kPrimTriangles), "the two-level step is a triangle closest-hit variant");
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
-  __shared__ FoldRec<T> s_fold[SPLIT ? kTraverseBlock : 1];
 
   typedef typename Wire<T>::Node Node;
   typedef typename Wire<T>::Ray Ray;
@@ -1077,15 +1035,6 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
   uint32_t cur = 0;        // W_TRAV: WideNode index; W_LEAF: leaf reference without the leaf bit
   int state = W_IDLE;
   int sp = 0;
-  uint32_t meta = 0, key = 0; // SPLIT: role of this lane (kMeta*), position of its segment in the sequential order
-  T leaf_tmin = T(0);         // SPLIT: entry distance of the box of the leaf this lane is at
-  const bool split_on = SPLIT && a.split != 0u;
-  unsigned drain_round = 0u;
-  // (the sphere and cylinder kernels are left as they were: the extra loop body would cost them a wave per SIMD)
-  // (compiled into the splitting variants only — splitting lives in it.  In the production variants it measured neutral
-  // at run time, and its mere presence cost them 3 % through register allocation: profiles/r02f_variant_bisect.txt.)
-  constexpr bool kDrain = SPLIT && !STATS && KIND == kPrimTriangles;
-  const bool drain_on = kDrain && split_on; // see "the drain" below
   // (profiling, NRT_DEBUG bit 8192: when did this wave start, run out of rays, finish — 100 MHz realtime ticks)
   const bool clocked = CLOCK && a.wave_clock != nullptr;
   unsigned long long clk_begin = 0ull, clk_dry = 0ull;
@@ -1095,8 +1044,7 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
   // (an atomic store: performed at the memory side, so that the slot's next launch sees it wherever and whenever it runs)
   if (blockIdx.x == 0 && threadIdx.x < kMaxParts)
     __hip_atomic_store(a.next_cursor + kCursorStrideWords * threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __shared__ uint32_t s_exit; // waves of this block that have finished (done_end)
-  done_begin<T>(a, &s_exit);
+  done_begin<T>(a);
   // STATS (profiling instantiation only): wave-level loop occupancy
   unsigned long long st_it1 = 0, st_act1 = 0, st_idle2 = 0, st_it2 = 0, st_act2 = 0, st_refills = 0, st_refilled = 0, st_entries2 = 0;
   uint32_t st_steps = 0, st_tris = 0; // per ray; with debug flag 64 they replace u, v of the hit record
@@ -1133,14 +1081,7 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
       cylinder_test<T>(L, cy_, (act_), a.range0, a.range1, a.cyl_test_cap != 0u);                      \
     } else {                                                                                           \
       const LeafTri<T> tri_ = a.tris[(slot_)];                                                         \
-      if (SPLIT) {                                                                                     \
-        bool bad_ = false;                                                                             \
-        if (PLAIN)                                                                                     \
-          tri_test<T, true, true>(L, tri_, (act_), 0u, 0u, 0u, false, leaf_tmin, &bad_);               \
-        else                                                                                           \
-          tri_test<T, false, true>(L, tri_, (act_), a.range0, a.range1, a.skip_prim, cull, leaf_tmin, &bad_); \
-        meta |= bad_ ? kMetaBad : 0u; /* (only read in helper lanes) */                                \
-      } else if (PLAIN)                                                                                \
+      if (PLAIN)                                                                                       \
         tri_test<T, true>(L, tri_, (act_), 0u, 0u, 0u, false);                                         \
       else                                                                                             \
         tri_test<T>(L, tri_, (act_), a.range0, a.range1, a.skip_prim, cull);                           \
@@ -1166,10 +1107,6 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
           const Ray r = (a.debug_flags & 4u) ? a.rays[rid] : load_ray_nt<T>(a.rays + rid);
           lane_init<T>(L, r);
           sp = 0;
-          if (SPLIT) {
-            meta = 0u;
-            key = 0u;
-          }
           if (STATS) st_steps = st_tris = 0;
           // The reference pops and tests the root first (nanort.h:2526-2533).  For a branch root that test is implied by
           // the first step: a ray that misses the root's box misses both children's boxes (each lies inside it and the
@@ -1199,7 +1136,6 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
       idle = __ballot(state == W_IDLE);
     }
     if (clocked && ck.exhausted && clk_dry == 0ull) clk_dry = __builtin_amdgcn_s_memrealtime();
-    if (drain_on && ck.exhausted) break; // the last rays of this wave: the loop below
     if (idle == ~0ull) {
       if (ck.exhausted) break;
       continue;
@@ -1285,7 +1221,7 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
         st_entries2++;
         st_idle2 += (unsigned)__builtin_popcountll(__ballot(state == W_IDLE));
       }
-      if constexpr (!SPLIT && KIND == kPrimTriangles && (WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL) > 1) {
+      if constexpr (KIND == kPrimTriangles && (WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL) > 1) {
         // several records per trip, all fetched before any is tested (same tests in the same order; fewer dependent
         // round trips per leaf — this variant has the registers for it)
         constexpr uint32_t U_ = WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL;
@@ -1331,252 +1267,10 @@ __global__ __launch_bounds__(kTraverseBlock, (SPLIT && sizeof(T) == 4) ? 6 : ((W
     }
     if (STATS) st_t_p2 += __builtin_amdgcn_s_memtime() - st_stamp;
   }
-  // ---- the drain: this wave found every work cursor empty ------------------------------------------------------
-  // It holds at most 64 - refill_min rays, the survivors of its last refill — by construction the long ones — and
-  // nothing will ever fill its idle lanes again, so batching lanes per phase (the point of the loop above) has nothing
-  // left to win and only makes each ray wait for the others' leaf rounds: measured, a wave needed 84 us on average and
-  // up to 237 us to finish these rays on the C3 bounce wave, 30-45 % of the launch (profiles/r02c_split_drain_probe.txt).
-  // Here every lane does what it needs on every trip: pop, then one inner-node step OR one primitive test, the node and
-  // the primitive records of all lanes fetched up front so that the two latencies overlap.  Same operations per ray in the
-  // same order as above, hence the same records.
-  if constexpr (kDrain) if (drain_on && __ballot(state != W_IDLE) != 0ull) {
-    if (state == W_IDLE && rid != kInvalid) { // finished lanes: write now, the registers are needed no longer
-      NRT_WRITE_RESULT();
-      rid = kInvalid;
-    }
-    uint32_t li = 0u; // next record of the leaf this lane is at
-    for (;;) {
-      unsigned long long busy_lanes = __ballot(state != W_IDLE);
-      if (SPLIT && split_on) {
-        // Work splitting (see the comment above the kernel): every `drain_steps` trips — and whenever no lane is busy, to
-        // settle what the helpers left — finished helpers deliver, owners fold and settle, settled lanes write their
-        // records and become free, and (while at most `split_busy` lanes are busy) busy lanes hand their oldest pending
-        // subtree to free lanes.
-        const unsigned n_busy = (unsigned)__builtin_popcountll(busy_lanes);
-        if (busy_lanes == 0ull || drain_round % a.drain_steps == 0u) {
-          const bool hand_out = n_busy != 0u && n_busy <= a.split_busy;
-          const unsigned wbase = tid & ~63u; // this wave's slots of s_fold
-          // -- (a) finished helpers hand their result to the owner's record, one after the other
-          unsigned long long fh = __ballot(state == W_IDLE && rid != kInvalid && (meta & kMetaHelper) != 0u);
-          while (fh != 0ull) {
-            const unsigned h = (unsigned)__builtin_ctzll(fh);
-            fh &= fh - 1ull;
-            if (lane == h) {
-              FoldRec<T> &r = s_fold[wbase + (meta & kMetaOwnerMask)];
-              if (L.prim != kInvalid && (r.prim == kInvalid || L.hit_t < r.t || (L.hit_t == r.t && key > r.key))) {
-                r.t = L.hit_t;
-                r.u = L.u;
-                r.v = L.v;
-                r.key = key;
-                r.prim = L.prim;
-              }
-              r.pend = (r.pend - 1u) | ((meta & kMetaBad) ? 0x80000000u : 0u);
-              if (a.debug_flags & 4096u) atomicAdd(&a.counters[3], 1ull);
-              rid = kInvalid;
-              meta = 0u;
-            }
-          }
-          // -- (b) owners: fold the own segment once, then wait for the helpers; the last delivery settles the ray
-          if (state == W_IDLE && rid != kInvalid && (meta & kMetaOwnerOpen) != 0u) {
-            FoldRec<T> &r = s_fold[tid];
-            if (!(meta & kMetaMainDone)) {
-              if (L.prim != kInvalid && (r.prim == kInvalid || L.hit_t < r.t || (L.hit_t == r.t && key > r.key))) {
-                r.t = L.hit_t;
-                r.u = L.u;
-                r.v = L.v;
-                r.key = key;
-                r.prim = L.prim;
-              }
-              meta |= kMetaMainDone;
-            }
-            const uint32_t pend = r.pend;
-            if ((pend & 0xFFFFu) == 0u) {
-              if (a.debug_flags & 4096u) atomicAdd(&a.counters[(pend & 0x80000000u) ? 5 : 4], 1ull);
-              if (((pend & 0x80000000u) && !(a.debug_flags & 512u)) || (a.debug_flags & 1024u)) { // a helper saw t below its leaf box's entry distance: trace the ray again, sequentially
-                const Ray rr = load_ray_nt<T>(a.rays + rid);
-                lane_init<T>(L, rr);
-                sp = 0;
-                cur = 0u;
-                state = W_TRAV;
-                meta = kMetaNoSplit;
-                key = 0u;
-              } else {
-                const bool any_ = r.prim != kInvalid;
-                L.hit_t = any_ ? r.t : L.max_t;
-                L.u = r.u;
-                L.v = r.v;
-                L.prim = r.prim;
-                meta = 0u;
-              }
-            }
-          }
-          // -- (c) every lane that holds a settled result writes it now and becomes free
-          if (state == W_IDLE && rid != kInvalid && (meta & (kMetaHelper | kMetaOwnerOpen)) == 0u) {
-            NRT_WRITE_RESULT();
-            rid = kInvalid;
-          }
-          // -- (d) busy lanes give their oldest pending subtree to free lanes
-          const unsigned long long freel = __ballot(state == W_IDLE && rid == kInvalid);
-          const uint32_t donated = meta >> kMetaDonatedShift;
-          const uint32_t level = (meta & kMetaLevelMask) >> kMetaLevelShift;
-          const bool busy = state == W_TRAV || state == W_POP || state == W_LEAF;
-          // (a lane about to pop keeps the entry it is about to pop)
-          const bool can_give = busy && !(meta & kMetaNoSplit) && level < 31u && donated < 0xFFFFu &&
-                                (uint32_t)sp > donated + (state == W_POP ? 1u : 0u);
-          const unsigned long long donors = __ballot(can_give);
-          unsigned n_pair = (unsigned)__builtin_popcountll(donors);
-          const unsigned n_free = (unsigned)__builtin_popcountll(freel);
-          n_pair = n_pair < n_free ? n_pair : n_free;
-          if (a.debug_flags & 256u) n_pair = 0u; // (debugging: no donations)
-          if (!hand_out) n_pair = 0u; // (settling only)
-          if (n_pair != 0u) {
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const bool is_donor = can_give && (unsigned)__builtin_popcountll(donors & lt) < n_pair;
-            const bool is_recv = ((freel >> lane) & 1ull) != 0ull && (unsigned)__builtin_popcountll(freel & lt) < n_pair;
-            // receiver k takes from donor k: lane index of its source (scalar walk over the two masks; rare)
-            int src = (int)lane;
-            {
-              unsigned long long d = donors, f = freel;
-              for (unsigned k = 0; k < n_pair; k++) {
-                const int dl = __builtin_ctzll(d), fl = __builtin_ctzll(f);
-                d &= d - 1ull;
-                f &= f - 1ull;
-                src = ((int)lane == fl) ? dl : src;
-              }
-            }
-            // donor: take the oldest live entry off the bottom of its stack (it stays in place, marked dead)
-            typename SE::type e = SE::make(0u, T(0));
-            bool give = false;
-            uint32_t hkey = 0u, hmeta = 0u;
-            if (is_donor) {
-              if (donated < (uint32_t)STACK) {
-                e = s_stack[donated][tid];
-                s_stack[donated][tid] = SE::make(SE::ref(e), __builtin_nan(""));
-              } else {
-                const size_t o = (size_t)(donated - STACK) * a.spill_stride + gslot;
-                e = SE::make(a.spill[o], a.spill_tmin[o]);
-                a.spill_tmin[o] = __builtin_nan("");
-              }
-              give = SE::tmin(e) <= L.hit_t; // still alive?  (a dead or culled entry is just skipped)
-              const uint32_t nlevel = give ? level + 1u : level;
-              meta = (meta & ~(kMetaLevelMask | (0xFFFFu << kMetaDonatedShift))) | (nlevel << kMetaLevelShift) |
-                     ((donated + 1u) << kMetaDonatedShift);
-              hkey = give ? key + (1u << (32u - nlevel)) : 0u; // upper half of the donor's interval: after everything the donor still does
-              const uint32_t owner_lane = (meta & kMetaHelper) ? (meta & kMetaOwnerMask) : lane;
-              hmeta = kMetaHelper | owner_lane | (nlevel << kMetaLevelShift);
-              if (give) {
-                if (!(meta & (kMetaHelper | kMetaOwnerOpen))) { // first donation of an owner: open its record
-                  FoldRec<T> &r = s_fold[tid];
-                  r.prim = kInvalid;
-                  r.pend = 0u;
-                  meta |= kMetaOwnerOpen;
-                }
-              }
-            }
-            // (record initialisation above is ordered before the counting below: LDS operations of a wave execute in order)
-            if (is_donor && give) atomicAdd(&s_fold[wbase + (hmeta & kMetaOwnerMask)].pend, 1u);
-            if (a.debug_flags & 4096u) { // (debugging: event counts)
-              if (is_donor) atomicAdd(&a.counters[0], 1ull);
-              if (is_donor && give) atomicAdd(&a.counters[1], 1ull);
-            }
-            // receivers copy the ray and the entry from their source lane (value by value, each shuffle consumed at once:
-            // sources are busy lanes, receivers free ones, so overwriting in place never feeds a changed value to anyone)
-            // (every shuffle is a statement of its own, executed by the whole wave: inside `is_recv && __shfl(...)` the
-            // short-circuit would switch the source lanes off and the receivers would read nothing)
-            const int g_give = __shfl((int)(give ? 1 : 0), src);
-            const bool take = is_recv && g_give != 0;
-            if ((a.debug_flags & 4096u) && take) atomicAdd(&a.counters[2], 1ull);
-  // (the empty asm keeps the vectoriser from merging neighbouring values into one vector access, which would pin
-  // the lane's ray in scratch memory)
-#define NRT_TAKE(dst, val)                  \
-  do {                                      \
-    auto v_ = (val);                        \
-    asm volatile("" : "+v"(v_));            \
-    const auto g_ = __shfl(v_, src);        \
-    dst = take ? g_ : dst;                  \
-  } while (0)
-            {
-              const uint32_t g_pk = (uint32_t)__shfl((int)L.pk, src);
-              L.pk = take ? g_pk : L.pk;
-            }
-            {
-              const uint32_t g_ref = (uint32_t)__shfl((int)SE::ref(e), src);
-              cur = take ? (g_ref & ~kLeafBit) : cur;
-              state = take ? ((g_ref & kLeafBit) ? W_LEAF : W_TRAV) : state;
-            }
-            {
-              int r_ = (int)rid, k_ = (int)hkey, m_ = (int)hmeta;
-              const int g_r = __shfl(r_, src), g_k = __shfl(k_, src), g_m = __shfl(m_, src);
-              rid = take ? (uint32_t)g_r : rid;
-              key = take ? (uint32_t)g_k : key;
-              meta = take ? (uint32_t)g_m : meta;
-            }
-            NRT_TAKE(leaf_tmin, SE::tmin(e));
-            NRT_TAKE(L.org0, L.org0);
-            NRT_TAKE(L.org1, L.org1);
-            NRT_TAKE(L.org2, L.org2);
-            NRT_TAKE(L.inv0, L.inv0);
-            NRT_TAKE(L.inv1, L.inv1);
-            NRT_TAKE(L.inv2, L.inv2);
-            NRT_TAKE(L.min_t, L.min_t);
-            NRT_TAKE(L.max_t, L.max_t);
-            NRT_TAKE(L.hit_t, L.hit_t); // the donor's distance at this moment: never tighter than the sequential loop's on arrival here
-            NRT_TAKE(L.Sx, L.Sx);
-            NRT_TAKE(L.Sy, L.Sy);
-            NRT_TAKE(L.Sz, L.Sz);
-#undef NRT_TAKE
-            L.prim = take ? kInvalid : L.prim;
-            L.u = take ? T(0) : L.u;
-            L.v = take ? T(0) : L.v;
-            L.cap = take ? 0u : L.cap;
-            sp = take ? 0 : sp;
-            li = take ? 0u : li;
-            if (STATS && take) st_steps = st_tris = 0;
-          }
-
-          busy_lanes = __ballot(state != W_IDLE);
-        }
-        drain_round++;
-      }
-      if (busy_lanes == 0ull) break;
-      if (state == W_POP) {
-        NRT_POP_ENTRY();
-        li = 0u;
-      }
-      const bool tw = state == W_TRAV, tl = state == W_LEAF;
-      uint32_t cnt = 1u, first = 0u;
-      if (tl) {
-        if (a.packed_leaves) {
-          cnt = (cur >> kPackedFirstBits) + 1u;
-          first = cur & kPackedFirstMask;
-        } else {
-          const Node *nd = a.nodes + cur;
-          cnt = nd->data[0];
-          first = nd->data[1];
-        }
-      }
-      if (a.debug_flags & 1u) cnt = 0u;
-      WideNode<T> w;
-      if (tw) w = a.wide[cur];
-      const bool tp = tl && li < cnt; // (an empty leaf of an adopted tree: nothing to test)
-      if (tp) NRT_TEST_PRIM(first + li, true);
-      if (tw) {
-        NRT_STEP_NODE(w);
-        li = 0u;
-      }
-      if (tl) {
-        li++;
-        if (li >= cnt) {
-          if (a.any_hit) sp = (L.hit_t < L.max_t) ? 0 : sp; // occlusion query: any accepted primitive settles the ray
-          state = W_POP;
-        }
-      }
-    }
-  }
   if (rid != kInvalid) NRT_WRITE_RESULT(); // results still held in registers
 #undef NRT_WRITE_RESULT
 #undef NRT_TEST_PRIM
-  done_end<T>(a, lane, &s_exit);
+  done_end<T>(a, lane);
   if (clocked && lane == 0u) { // one record per wave, reduced on the host (atomics on one line would serialise the exits)
     unsigned long long *rec = a.wave_clock + 3ull * (size_t)(gslot / kWave);
     const unsigned long long clk_end = __builtin_amdgcn_s_memrealtime();
@@ -1631,9 +1325,6 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
   typedef float T;
   typedef StackEntry<float> SE;
   __shared__ SE::type s_stack[STACK][kTraverseBlock];
-  constexpr bool SPLIT = false;
-  float leaf_tmin = 0.f; // (names the shared step / pop macros mention under SPLIT only)
-  (void)leaf_tmin;
 
   const unsigned tid = threadIdx.x;
   const unsigned lane = lane_id();
@@ -2048,81 +1739,73 @@ int traverse_blocks_per_cu(int lds_stack) {
 }
 
 // `name_out` (optional) receives the name of the variant launched, as rocprofv3 prints it without the argument list.
-static const char *variant_name(bool f32, int stack, bool stats, int kind, bool plain, bool split, bool clock, int width) {
+static const char *variant_name(bool f32, int stack, bool stats, int kind, bool plain, bool clock, int width) {
   static std::mutex m;
   static std::map<std::string, std::string> *names = new std::map<std::string, std::string>(); // (never destroyed: the pointers are handed out)
   char buf[160];
-  snprintf(buf, sizeof(buf), "nrt::k_traverse_wide<%s, %d, %s, %d, %s, %s, %s, %d>", f32 ? "float" : "double", stack,
-           stats ? "true" : "false", kind, plain ? "true" : "false", split ? "true" : "false", clock ? "true" : "false", width);
+  snprintf(buf, sizeof(buf), "nrt::k_traverse_wide<%s, %d, %s, %d, %s, %s, %d>", f32 ? "float" : "double", stack,
+           stats ? "true" : "false", kind, plain ? "true" : "false", clock ? "true" : "false", width);
   std::lock_guard<std::mutex> lock(m);
   return names->emplace(buf, buf).first->second.c_str();
 }
-#define NRT_LAUNCH_WIDE(STACK_, STATS_, KIND_, PLAIN_, SPLIT_, CLOCK_, WIDTH_)                                          \
+#define NRT_LAUNCH_WIDE(STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_)                                                  \
   do {                                                                                                                  \
-    hipLaunchKernelGGL((k_traverse_wide<T, STACK_, STATS_, KIND_, PLAIN_, SPLIT_, CLOCK_, WIDTH_>), dim3(grid),         \
+    hipLaunchKernelGGL((k_traverse_wide<T, STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_>), dim3(grid),                 \
                        dim3(kTraverseBlock), 0, s, args);                                                               \
-    if (name_out) *name_out = variant_name(sizeof(T) == 4, STACK_, STATS_, KIND_, PLAIN_, SPLIT_, CLOCK_, WIDTH_);      \
+    if (name_out) *name_out = variant_name(sizeof(T) == 4, STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_);              \
   } while (0)
 
 template <typename T>
 hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int lds_stack, int prim_kind, hipStream_t s,
                                 const char **name_out) {
   if (prim_kind == kPrimSpheres) { // one instantiation: 10 LDS entries (the caller sizes the overflow stack for it)
-    NRT_LAUNCH_WIDE(10, false, kPrimSpheres, false, false, false, 2);
+    NRT_LAUNCH_WIDE(10, false, kPrimSpheres, false, false, 2);
     if (args.hits)
       hipLaunchKernelGGL((k_sphere_uv<T>), dim3((args.num_rays + 255u) / 256u), dim3(256), 0, s, args.rays, args.hits,
                          args.centers, args.num_rays);
     return hipGetLastError();
   }
   if (prim_kind == kPrimCylinders) {
-    NRT_LAUNCH_WIDE(10, false, kPrimCylinders, false, false, false, 2);
+    NRT_LAUNCH_WIDE(10, false, kPrimCylinders, false, false, 2);
     return hipGetLastError();
   }
   if (args.wide4) { // two tree levels per step (the caller checked what that needs)
     if constexpr (sizeof(T) == 4) {
       if (args.debug_flags & 32u)
-        NRT_LAUNCH_WIDE(kWide4LdsStack, true, kPrimTriangles, true, false, false, 4); // profiling instantiation (default trace options only)
+        NRT_LAUNCH_WIDE(kWide4LdsStack, true, kPrimTriangles, true, false, 4); // profiling instantiation (default trace options only)
       else if (args.wave_clock)
-        NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, false, true, 4); // per-wave time stamps (default trace options only)
+        NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, true, 4); // per-wave time stamps (default trace options only)
       else if (args.plain_options)
-        NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, false, false, 4);
+        NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, false, 4);
       else
-        NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, false, false, false, 4);
+        NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, false, false, 4);
       return hipGetLastError();
     } else {
       return hipErrorInvalidValue;
     }
   }
   switch (lds_stack) {
-    case 8: NRT_LAUNCH_WIDE(8, false, kPrimTriangles, false, false, false, 2); break;
+    case 8: NRT_LAUNCH_WIDE(8, false, kPrimTriangles, false, false, 2); break;
     case 10:
       if (args.debug_flags & 32u) {
-        NRT_LAUNCH_WIDE(10, true, kPrimTriangles, false, false, false, 2);
+        NRT_LAUNCH_WIDE(10, true, kPrimTriangles, false, false, 2);
       } else if (args.wave_clock) { // profiling: per-wave time stamps (default trace options only)
-        if (args.split)
-          NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, true, true, 2);
-        else
-          NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, false, true, 2);
-      } else if (args.split) { // work splitting in the drain (a.split: see api.hip)
-        if (args.plain_options)
-          NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, true, false, 2);
-        else
-          NRT_LAUNCH_WIDE(10, false, kPrimTriangles, false, true, false, 2);
+        NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, true, 2);
       } else if (args.plain_options) {
-        NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, false, false, 2);
+        NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, false, 2);
       } else {
-        NRT_LAUNCH_WIDE(10, false, kPrimTriangles, false, false, false, 2);
+        NRT_LAUNCH_WIDE(10, false, kPrimTriangles, false, false, 2);
       }
       break;
-    case 12: NRT_LAUNCH_WIDE(12, false, kPrimTriangles, false, false, false, 2); break;
-    default: NRT_LAUNCH_WIDE(16, false, kPrimTriangles, false, false, false, 2); break;
+    case 12: NRT_LAUNCH_WIDE(12, false, kPrimTriangles, false, false, 2); break;
+    default: NRT_LAUNCH_WIDE(16, false, kPrimTriangles, false, false, 2); break;
   }
   return hipGetLastError();
 }
 #undef NRT_LAUNCH_WIDE
 
 template <typename T>
-int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool split, bool wide4) {
+int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool wide4) {
   int n = 0;
   hipError_t e = hipErrorInvalidValue;
   if (prim_kind == kPrimSpheres) {
@@ -2131,16 +1814,11 @@ int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool split, bool w
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimCylinders>, kTraverseBlock, 0);
   } else if (wide4) {
     if constexpr (sizeof(T) == 4)
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, kWide4LdsStack, false, kPrimTriangles, true, false, false, 4>, kTraverseBlock, 0);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, kWide4LdsStack, false, kPrimTriangles, true, false, 4>, kTraverseBlock, 0);
   } else {
     switch (lds_stack) {
       case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 8, false, kPrimTriangles>, kTraverseBlock, 0); break;
-      case 10:
-        if (split)
-          e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimTriangles, true, true>, kTraverseBlock, 0);
-        else
-          e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimTriangles, true, false>, kTraverseBlock, 0);
-        break;
+      case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimTriangles, true>, kTraverseBlock, 0); break;
       case 12: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 12, false, kPrimTriangles>, kTraverseBlock, 0); break;
       default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 16, false, kPrimTriangles>, kTraverseBlock, 0); break;
     }
@@ -2204,8 +1882,8 @@ template hipError_t launch_traverse<float>(const TraverseArgs<float> &, unsigned
 template hipError_t launch_traverse<double>(const TraverseArgs<double> &, unsigned, bool, int, hipStream_t);
 template hipError_t launch_traverse_wide<float>(const TraverseArgs<float> &, unsigned, int, int, hipStream_t, const char **);
 template hipError_t launch_traverse_wide<double>(const TraverseArgs<double> &, unsigned, int, int, hipStream_t, const char **);
-template int traverse_wide_blocks_per_cu<float>(int, int, bool, bool);
-template int traverse_wide_blocks_per_cu<double>(int, int, bool, bool);
+template int traverse_wide_blocks_per_cu<float>(int, int, bool);
+template int traverse_wide_blocks_per_cu<double>(int, int, bool);
 template hipError_t launch_gather_leaf_spheres<float>(const uint32_t *, const float *, const float *, LeafSphere<float> *,
                                                       uint32_t, hipStream_t);
 template hipError_t launch_gather_leaf_spheres<double>(const uint32_t *, const double *, const double *,

@@ -49,9 +49,6 @@ class Oracle:
             g = getattr(L, "orc_traverse_" + s)
             g.argtypes = [vp, vp, vp, sz, vp, vp, u64, vp, vp, vp, vp]
             g.restype = None
-            h = getattr(L, "orc_traverse_split_model_" + s)
-            h.argtypes = [vp, vp, vp, sz, vp, vp, u64, vp, u32, u32, ctypes.c_int, vp, vp, vp, vp]
-            h.restype = None
             w4 = getattr(L, "orc_traverse_wide4_model_" + s)
             w4.argtypes = [vp, vp, vp, sz, vp, vp, u64, vp, vp, vp, vp, vp, vp, u64, vp]
             w4.restype = None
@@ -110,29 +107,6 @@ class Oracle:
         if count:
             return hits, mask, counters
         return hits, mask
-
-    def traverse_split_model(self, nodes, indices, verts, faces, rays, opts=None, split_permille=300, seed=1, check_helpers=True):
-        """The sequential MODEL of the kernel's drain-time work splitting (oracle/split_model_body.inc).
-        Returns (hits, mask, flagged, splits)."""
-        real = verts.dtype
-        s = suffix(real)
-        assert nodes.dtype == node_dtype(real) and rays.dtype == ray_dtype(real)
-        faces = np.ascontiguousarray(faces, dtype=np.uint32)
-        indices = np.ascontiguousarray(indices, dtype=np.uint32)
-        nodes = np.ascontiguousarray(nodes)
-        rays = np.ascontiguousarray(rays)
-        n = rays.shape[0]
-        hits = np.zeros((n,), dtype=hit_dtype(real))
-        mask = np.zeros((n,), dtype=np.uint8)
-        flagged = np.zeros((n,), dtype=np.uint8)
-        splits = np.zeros((n,), dtype=np.uint32)
-        w = _trace_opt_words(opts)
-        getattr(self.L, "orc_traverse_split_model_" + s)(
-            _p(nodes), _p(indices), _p(verts), 3 * verts.dtype.itemsize, _p(faces), _p(rays), n, _p(w),
-            int(split_permille), int(seed), 1 if check_helpers else 0, _p(hits), _p(mask), _p(flagged), _p(splits),
-        )
-        return hits, mask, flagged, splits
-
 
     def traverse_wide4_model(self, nodes, indices, verts, faces, rays, opts=None, trail_cap=0):
         """The sequential MODEL of the kernel's two-levels-per-step walk (oracle/wide4_model_body.inc).

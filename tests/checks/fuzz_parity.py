@@ -50,8 +50,12 @@ while time.time() < t_end:
         opts["skip_prim_id"] = int(rng.integers(0, n))
     opts["cull_back_face"] = int(rng.random() < 0.3)
     mesh = TriangleMesh(v, f)
-    os.environ["NRT_SPLIT"] = "1" if rng.random() < 0.5 else "0"   # (read at context creation) drain-time work splitting on / off
     a = BVHAccel(real)
+    # random scheduling of the persistent kernel (the records must not depend on it): static share and its bands, chunk
+    # size, ray partitions, refill / phase thresholds, one or two tree levels per step
+    for k, choices in (("static_pct", (0, 40, 75, 100)), ("static_bands", (1, 2, 8)), ("static_slice_groups", (1, 2)), ("chunk", (16, 64, 128)),
+                       ("parts", (1, 3, 8)), ("refill_min", (1, 24, 48, 64)), ("trav_min", (1, 8, 32)), ("leaf_min", (1, 32)), ("wide4", (0, 1))):
+        a.SetTunable(k, int(rng.choice(choices)))
     gpu_built = rng.random() < 0.5
     if gpu_built:
         bo = default_build_options(real)

@@ -1,11 +1,11 @@
 """CPU soak of the two-levels-per-step walk (oracle/wide4_model_body.inc, the model of the traversal kernel's
-NRT_STEP_NODE4) against the restated reference loop on the hostile generator of fuzz_split_model.py: same hit records,
+NRT_STEP_NODE4) against the restated reference loop on the hostile generator of hostile.py: same hit records,
 same SEQUENCE of visited leaves, same numbers of leaf and triangle tests.
 Usage: python tests/checks/fuzz_wide4_model.py [seconds] [seed]     (needs no GPU)"""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/checks')
-from fuzz_split_model import hostile_case
+from hostile import hostile_case
 from oracle.bindings import Oracle
 
 

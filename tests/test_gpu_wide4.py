@@ -18,8 +18,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def width(kernel_name):
-    """Template arguments of k_traverse_wide: <T, STACK, STATS, KIND, PLAIN, SPLIT, CLOCK, WIDTH>."""
-    return int(kernel_name.split("<")[1].rstrip(">").split(", ")[7])
+    """Template arguments of k_traverse_wide: <T, STACK, STATS, KIND, PLAIN, CLOCK, WIDTH>."""
+    return int(kernel_name.split("<")[1].rstrip(">").split(", ")[6])
 
 
 def hostile_rays(v, n, seed):

@@ -36,7 +36,7 @@ def test_saved_cross_tree_cases_stay_documented():
     """The two residual cases of round 1's cross-tree fuzz (tests/golden/fuzz_case_r01_crosstree_*.npz):
     on these grid-aligned meshes the REFERENCE's own answer depends on the tree beyond exact ties (a triangle's t one ulp
     below its leaf box's entry distance; rays lying in a triangle's plane).  Same-tree parity is exact (GPU:
-    tests/test_gpu_split.py replays them); across trees the restatement agrees with itself on >= 99.8 % of the rays and
+    tests/test_gpu_fuzz_cases.py replays them); across trees the restatement agrees with itself on >= 99.8 % of the rays and
     NOT on all of them — if that ever becomes 100 % the documented caveat can go."""
     import glob
     import os
