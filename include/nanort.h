@@ -74,9 +74,7 @@ namespace detail {
 // what the process may actually use — the cgroup CPU quota when there is one (an OpenMP default of "every hardware
 // thread" inside a quota'd container collapses, and starves the HIP runtime's own threads), else the OpenMP / hardware
 // thread count — clamped to [1, 64].
-inline unsigned int HostThreads() {
-  static unsigned int cached = 0;
-  if (cached) return cached;
+inline unsigned int HostThreadsUncached() {
   unsigned int n = 1;
 #if defined(_OPENMP)
   n = static_cast<unsigned int>(std::max(1, omp_get_max_threads()));
@@ -98,7 +96,10 @@ inline unsigned int HostThreads() {
   }
   if (quota > 0 && period > 0 && static_cast<unsigned long>(quota / period) >= 1 && static_cast<unsigned long>(quota / period) < n)
     n = static_cast<unsigned int>(quota / period);
-  cached = std::min(64u, std::max(1u, n));
+  return std::min(64u, std::max(1u, n));
+}
+inline unsigned int HostThreads() {
+  static const unsigned int cached = HostThreadsUncached();  // (function-local static: initialised once, thread-safely)
   return cached;
 }
 

@@ -547,7 +547,7 @@ static nrt_status finish_wide(nrt_ctx *c) {
   const size_t tiles = (c->num_nodes + 1023) / 1024;
   if ((st = ensure(c, c->b_wide_scratch, (tiles + c->num_nodes + 1) * sizeof(uint32_t)))) return st;
   c->d_wide4 = nullptr;
-  if (c->wide4 && c->prim_kind == kPrimTriangles && sizeof(T) == 4) {
+  if (c->wide4 && sizeof(T) == 4) { // (every primitive kind: the step does not look at the leaves)
     if ((st = ensure(c, c->b_wide4, std::max<size_t>(1, c->num_branch_records) * sizeof(Wide4Node<T>)))) return st;
     c->d_wide4 = c->b_wide4.p;
   }
@@ -788,14 +788,13 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   const bool use_wide = (c->wide || spheres || any_hit) && !count && c->d_wide;
   if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
   // two levels per step: closest-hit walks of nested fp32 triangle trees, outside the profiling / splitting variants
-  const bool use_wide4 = use_wide && !spheres && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch &&
-                         true;
+  const bool use_wide4 = use_wide && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch;
   if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, false);
-  if (use_wide4 && c->wide4_blocks_per_cu == 0) c->wide4_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(kWide4LdsStack, kPrimTriangles, true);
-  if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, false);
+  if (use_wide4 && !spheres && c->wide4_blocks_per_cu == 0) c->wide4_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(kWide4LdsStack, kPrimTriangles, true);
+  if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, use_wide4); // (one kind and one walk per context)
   unsigned blocks_per_cu = spheres ? c->sphere_blocks_per_cu : (use_wide4 ? c->wide4_blocks_per_cu : (use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu));
   if (c->max_blocks_per_cu && blocks_per_cu > c->max_blocks_per_cu) blocks_per_cu = c->max_blocks_per_cu;
-  const int stack_entries = spheres ? 10 : (use_wide4 ? kWide4LdsStack : (use_wide ? c->wide_stack : c->lds_stack));
+  const int stack_entries = use_wide4 ? kWide4LdsStack : (spheres ? 10 : (use_wide ? c->wide_stack : c->lds_stack));
   uint64_t need_blocks = (n + kTraverseBlock - 1) / kTraverseBlock;
   unsigned grid = (unsigned)std::min<uint64_t>(need_blocks, (uint64_t)c->num_cus * blocks_per_cu);
   const unsigned parts = std::max(1u, std::min(c->num_parts, grid));

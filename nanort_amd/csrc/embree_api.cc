@@ -195,9 +195,7 @@ bool commit_locked(Scene *s) {
 
 // Host threads for the record conversion: what the process may use (cgroup CPU quota), at most 16 — never the OpenMP
 // default, which on a many-core host inside a quota'd container starves the HIP runtime's own threads.
-static int host_threads() {
-  static int cached = 0;
-  if (cached) return cached;
+static int host_threads_uncached() {
   long n = 8;
 #ifdef _OPENMP
   n = omp_get_num_procs();
@@ -208,7 +206,10 @@ static int host_threads() {
     if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0 && atol(q) / period >= 1) n = std::min(n, atol(q) / period);
     fclose(f);
   }
-  cached = (int)std::max(1l, std::min(16l, n));
+  return (int)std::max(1l, std::min(16l, n));
+}
+static int host_threads() {
+  static const int cached = host_threads_uncached();  // (function-local static: initialised once, thread-safely)
   return cached;
 }
 constexpr size_t kParallelMin = 1u << 16;
@@ -296,18 +297,23 @@ void trace(Scene *s, size_t n, bool occluded, Get get) {
   }
   const size_t pieces = (n + kPiece - 1) / kPiece;
   std::vector<char> good(pieces, 0);
+  std::vector<std::string> why(pieces);  // the scene's error text of a failed piece, captured by the thread that traced it
   std::thread worker;
+  nrt_scene *scene = s->scene;
   for (size_t k = 0; k <= pieces; k++) {
     if (k < pieces) convert(k * kPiece, std::min(n, (k + 1) * kPiece));
     if (worker.joinable()) worker.join();  // piece k-1 is traced
     if (k < pieces) {
       const size_t lo = k * kPiece, hi = std::min(n, (k + 1) * kPiece);
-      worker = std::thread([&good, &gpu, k, lo, hi]() { good[k] = gpu(lo, hi) ? 1 : 0; });
+      worker = std::thread([&good, &why, &gpu, scene, k, lo, hi]() {
+        good[k] = gpu(lo, hi) ? 1 : 0;
+        if (!good[k]) why[k] = nrtSceneLastError(scene);  // (read here: the next piece's trace may overwrite it)
+      });
     }
     if (k >= 1) {  // overlaps the trace of piece k
       if (!good[k - 1] && ok) {
         ok = false;
-        report(s->device, RTC_UNKNOWN_ERROR, "rtcIntersect/rtcOccluded: %s", nrtSceneLastError(s->scene));
+        report(s->device, RTC_UNKNOWN_ERROR, "rtcIntersect/rtcOccluded: %s", why[k - 1].c_str());
       }
       write_back((k - 1) * kPiece, std::min(n, k * kPiece), good[k - 1] != 0);
     }

@@ -1017,7 +1017,7 @@ do {                                                                            
 // WIDTH: 2 = one WideNode (two boxes) per step, 4 = one Wide4Node (two levels, four boxes) per step.
 template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool CLOCK = false, int WIDTH = 2>
 __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NRT_W4_WAVES : 1) void k_traverse_wide(const TraverseArgs<T> a) {
-  static_assert(WIDTH == 2 || (WIDTH == 4 && KIND == kPrimTriangles), "the two-level step is a triangle closest-hit variant");
+  static_assert(WIDTH == 2 || WIDTH == 4, "one or two tree levels per step");
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
 
@@ -1758,15 +1758,29 @@ static const char *variant_name(bool f32, int stack, bool stats, int kind, bool 
 template <typename T>
 hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int lds_stack, int prim_kind, hipStream_t s,
                                 const char **name_out) {
-  if (prim_kind == kPrimSpheres) { // one instantiation: 10 LDS entries (the caller sizes the overflow stack for it)
-    NRT_LAUNCH_WIDE(10, false, kPrimSpheres, false, false, 2);
+  if (prim_kind == kPrimSpheres) { // 10 LDS entries walking one level per step, kWide4LdsStack walking two (the caller sizes the overflow stack)
+    if constexpr (sizeof(T) == 4) {
+      if (args.wide4)
+        NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimSpheres, false, false, 4);
+      else
+        NRT_LAUNCH_WIDE(10, false, kPrimSpheres, false, false, 2);
+    } else {
+      NRT_LAUNCH_WIDE(10, false, kPrimSpheres, false, false, 2);
+    }
     if (args.hits)
       hipLaunchKernelGGL((k_sphere_uv<T>), dim3((args.num_rays + 255u) / 256u), dim3(256), 0, s, args.rays, args.hits,
                          args.centers, args.num_rays);
     return hipGetLastError();
   }
   if (prim_kind == kPrimCylinders) {
-    NRT_LAUNCH_WIDE(10, false, kPrimCylinders, false, false, 2);
+    if constexpr (sizeof(T) == 4) {
+      if (args.wide4)
+        NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimCylinders, false, false, 4);
+      else
+        NRT_LAUNCH_WIDE(10, false, kPrimCylinders, false, false, 2);
+    } else {
+      NRT_LAUNCH_WIDE(10, false, kPrimCylinders, false, false, 2);
+    }
     return hipGetLastError();
   }
   if (args.wide4) { // two tree levels per step (the caller checked what that needs)
@@ -1809,9 +1823,15 @@ int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool wide4) {
   int n = 0;
   hipError_t e = hipErrorInvalidValue;
   if (prim_kind == kPrimSpheres) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimSpheres>, kTraverseBlock, 0);
+    if constexpr (sizeof(T) == 4) {
+      if (wide4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, kWide4LdsStack, false, kPrimSpheres, false, false, 4>, kTraverseBlock, 0);
+    }
+    if (!wide4 || sizeof(T) != 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimSpheres>, kTraverseBlock, 0);
   } else if (prim_kind == kPrimCylinders) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimCylinders>, kTraverseBlock, 0);
+    if constexpr (sizeof(T) == 4) {
+      if (wide4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, kWide4LdsStack, false, kPrimCylinders, false, false, 4>, kTraverseBlock, 0);
+    }
+    if (!wide4 || sizeof(T) != 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, 10, false, kPrimCylinders>, kTraverseBlock, 0);
   } else if (wide4) {
     if constexpr (sizeof(T) == 4)
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_wide<T, kWide4LdsStack, false, kPrimTriangles, true, false, 4>, kTraverseBlock, 0);

@@ -41,7 +41,10 @@ def load_ply(path):
             raise ValueError("%s: not a PLY file" % path)
         fmt, elements = None, []
         while True:
-            t = f.readline().decode("ascii", "replace").split()
+            line = f.readline()
+            if not line:  # EOF before end_header: a truncated file
+                raise ValueError("%s: PLY header has no end_header" % path)
+            t = line.decode("ascii", "replace").split()
             if not t or t[0] == "comment" or t[0] == "obj_info":
                 continue
             if t[0] == "format":
