@@ -127,7 +127,7 @@ struct nrt_ctx {
 
   // traversal tuning (env NRT_LDS_STACK / NRT_REFILL_MIN / NRT_TRAV_MIN / NRT_CHUNK override)
   int lds_stack = kLdsStackDefault;
-  unsigned blocks_per_cu = 0, chunk = 128, refill_min = 48, trav_min = 8, leaf_min = 32;
+  unsigned blocks_per_cu = 0, chunk = 128, chunk_tail_pct = 0, refill_min = 48, trav_min = 8, leaf_min = 32;
   unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
   unsigned debug_flags = 0;
   int morton = 0; // Morton-order the primitive records before the build (env NRT_MORTON=1): measured +0.4 ms at 1M tris for an identical tree, so off by default
@@ -259,7 +259,7 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("refill_min", 1, 64, refill_min, unsigned),       // idle lanes of a wave before it claims more rays
     NRT_TUNABLE("trav_min", 1, 64, trav_min, unsigned),           // lanes still walking below which the inner-node phase ends
     NRT_TUNABLE("leaf_min", 1, 64, leaf_min, unsigned),           // lanes at a leaf below which a due refill goes first
-    NRT_TUNABLE("chunk", 16, 1 << 20, chunk, unsigned),           // rays claimed per atomic
+    NRT_TUNABLE("chunk_tail_pct", 0, 100, chunk_tail_pct, unsigned), // share of the dynamic rays handed out in half chunks (the end of a launch)
     NRT_TUNABLE("parts", 1, kMaxParts, num_parts, unsigned),      // ray partitions (== XCDs)
     NRT_TUNABLE("static_pct", 0, 100, static_pct, unsigned),      // share of a batch owned statically, percent
     NRT_TUNABLE("static_bands", 1, 64, static_bands, unsigned),   // ... in up to this many slices per wave, one per band
@@ -272,6 +272,8 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("launch_timing", 0, 1, launch_timing, int),       // == nrtSetLaunchTiming
     NRT_TUNABLE("host_pipeline", 0, 1, host_pipeline, int),       // pipelined host entry point
     NRT_TUNABLE("wide_scramble", 0, 1, wide_scramble, int),       // probe: WideNode / Wide4Node records in a pseudo-random order (next build)
+    {"chunk", 32, 1 << 20, [](const nrt_ctx *c) -> long long { return c->chunk; },
+     [](nrt_ctx *c, long long v) { c->chunk = (unsigned)(v / 32) * 32u; }}, // rays claimed per atomic (whole and half chunks are multiples of 16)
     {"lds_stack", 16, 32, [](const nrt_ctx *c) -> long long { return c->lds_stack; },
      [](nrt_ctx *c, long long v) { if (v == 16 || v == 24 || v == 32) c->lds_stack = (int)v; }},
     {"wide_stack", 8, 16, [](const nrt_ctx *c) -> long long { return c->wide_stack; },
@@ -883,6 +885,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
     c->wave_clock_waves = total_waves;
   }
   a.chunk = c->chunk;
+  a.chunk_tail_pct = c->chunk_tail_pct;
   a.refill_min = c->refill_min;
   a.trav_min = c->trav_min;
   a.leaf_min = c->leaf_min;

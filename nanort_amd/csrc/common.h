@@ -241,7 +241,8 @@ struct TraverseArgs {
   uint32_t blocks_per_part;          // gridDim.x / num_parts
   unsigned long long *counters;      // 4 x u64 when counting
   unsigned long long *wave_clock;    // profiling (NRT_DEBUG bit 8192): 3 x u64 per wave {start, out of rays, done}, 100 MHz ticks; else null
-  uint32_t chunk;                    // rays claimed per atomic
+  uint32_t chunk;                    // rays claimed per atomic (a multiple of 32)
+  uint32_t chunk_tail_pct;           // the last this-many percent of every partition's dynamic range go out in half chunks
   uint32_t refill_min;               // refill idle lanes once this many are idle (1..64)
   uint32_t trav_min;                 // leave the inner-node loop when fewer lanes than this are walking
   uint32_t leaf_min;                 // with fewer lanes than this waiting at a leaf, refill first (if a refill is due) and test triangles later

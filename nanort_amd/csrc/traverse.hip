@@ -426,11 +426,17 @@ __device__ __forceinline__ bool claim_chunk(const TraverseArgs<T> &a, Claim &c, 
   while (c.tried < a.num_parts) {
     const uint32_t lo = c.part * a.dyn_per_part; // range of this part in the virtual array of dynamic rays
     const uint32_t len = (c.part + 1u == a.num_parts) ? a.dyn_total - lo : a.dyn_per_part;
-    uint32_t base = 0;
-    if (lane == (unsigned)leader) base = atomicAdd(a.ray_cursor + kCursorStrideWords * c.part, a.chunk);
-    base = __builtin_amdgcn_readfirstlane(__shfl(base, leader));
-    if (base < len) {
-      const uint32_t v = lo + base, cnt = (len - base < a.chunk) ? len - base : a.chunk;
+    // The cursor counts CHUNKS: the first `main_chunks` are whole ones, the rest of the range goes out in half chunks — the
+    // last rays of a launch in finer portions, so that the waves run dry closer together (half chunks subdivide whole ones:
+    // still no chunk straddles two bands).
+    uint32_t idx = 0;
+    if (lane == (unsigned)leader) idx = atomicAdd(a.ray_cursor + kCursorStrideWords * c.part, 1u);
+    idx = __builtin_amdgcn_readfirstlane(__shfl(idx, leader));
+    const uint32_t main_chunks = (uint32_t)(((unsigned long long)(len / a.chunk) * (100u - a.chunk_tail_pct)) / 100u), half = a.chunk >> 1;
+    const uint32_t base = idx < main_chunks ? idx * a.chunk : main_chunks * a.chunk + (idx - main_chunks) * half;
+    const uint32_t want = idx < main_chunks ? a.chunk : half;
+    if (idx < 0x1000000u && base < len) {
+      const uint32_t v = lo + base, cnt = (len - base < want) ? len - base : want;
       uint32_t real;
       if (v < a.dyn_banded) { // inside band b's dynamic part
         const uint32_t b = v / a.dyn_per_band;
