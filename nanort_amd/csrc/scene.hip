@@ -62,7 +62,11 @@ __host__ __device__ inline void mult_v(float dst[3], const float m[4][4], const 
 // Does the ray enter node box `nd`, and over which interval?  First the BVH leaf's robust test
 // (IntersectRayAABB, nanort.h:2285-2325, hit_t == ray.max_t throughout ListNodeIntersections), then
 // NodeBBoxIntersector::Intersect (nanosg.h:603-639: plain reciprocal, no MaxMult, no clipping).
+__device__ inline bool node_interval_box(const nrt_ray_f32 &r, const float xbmin[3], const float xbmax[3], float &t_min_out);
 __device__ inline bool node_interval(const nrt_ray_f32 &r, const NodeDev &nd, float &t_min_out) {
+  return node_interval_box(r, nd.xbmin, nd.xbmax, t_min_out);
+}
+__device__ inline bool node_interval_box(const nrt_ray_f32 &r, const float xbmin[3], const float xbmax[3], float &t_min_out) {
   float tmin = r.min_t, tmax = r.max_t;
   float tn[3], tf[3];
 #pragma unroll
@@ -74,7 +78,7 @@ __device__ inline bool node_interval(const nrt_ray_f32 &r, const NodeDev &nd, fl
       inv_safe = __builtin_huge_valf() * (neg ? -1.0f : 1.0f);
     else
       inv_safe = 1.0f / d;
-    const float lo = neg ? nd.xbmax[k] : nd.xbmin[k], hi = neg ? nd.xbmin[k] : nd.xbmax[k];
+    const float lo = neg ? xbmax[k] : xbmin[k], hi = neg ? xbmin[k] : xbmax[k];
     const float t0 = (lo - r.org[k]) * inv_safe;
     const float t1 = (hi - r.org[k]) * inv_safe * 1.00000024f;
     tmin = (t0 > tmin) ? t0 : tmin;
@@ -93,6 +97,48 @@ __device__ inline bool node_interval(const nrt_ray_f32 &r, const NodeDev &nd, fl
   return true;
 }
 
+// A ray's candidate list while it is being collected: UNSORTED, at most `cap` entries — the cap nearest by (entry distance,
+// node id), which is what BVHAccel::ListNodeIntersections keeps (nanort.h:2608-2692: a priority queue of kMaxIntersections).
+// Adding a candidate is one store; only a ray that enters more than `cap` boxes pays for finding the farthest entry to
+// replace.  k_scene_trace picks the candidates in (distance, id) order as it needs them (round 2 kept the list sorted by
+// insertion in global memory: most of the listing kernel's time).
+struct ListTail {
+  uint32_t cnt = 0;
+  bool far_known = false; // far_* describe the farthest entry of a full list
+  float far_t = 0.0f;
+  uint32_t far_id = 0, far_pos = 0;
+};
+__device__ inline void list_farthest(ListTail &st, uint32_t cap, const float *list_t, const uint32_t *list_node, uint32_t n, uint32_t i) {
+  st.far_t = list_t[i];
+  st.far_id = list_node[i];
+  st.far_pos = 0;
+  for (uint32_t q = 1; q < cap; q++) {
+    const float qt = list_t[(size_t)q * n + i];
+    const uint32_t qk = list_node[(size_t)q * n + i];
+    if (qt > st.far_t || (qt == st.far_t && qk > st.far_id)) {
+      st.far_t = qt;
+      st.far_id = qk;
+      st.far_pos = q;
+    }
+  }
+  st.far_known = true;
+}
+__device__ inline void list_add(ListTail &st, float t, uint32_t k, uint32_t cap, float *__restrict__ list_t,
+                                uint32_t *__restrict__ list_node, uint32_t n, uint32_t i) {
+  if (st.cnt < cap) {
+    list_t[(size_t)st.cnt * n + i] = t;
+    list_node[(size_t)st.cnt * n + i] = k;
+    st.cnt++;
+    return;
+  }
+  if (!st.far_known) list_farthest(st, cap, list_t, list_node, n, i);
+  if (t < st.far_t || (t == st.far_t && k < st.far_id)) { // nearer than the farthest kept: takes its place
+    list_t[(size_t)st.far_pos * n + i] = t;
+    list_node[(size_t)st.far_pos * n + i] = k;
+    st.far_known = false;
+  }
+}
+
 // list_t / list_node: [kMaxList or num_nodes][n] (entry-major, so lane-consecutive accesses coalesce)
 __global__ __launch_bounds__(256) void k_scene_list(const nrt_ray_f32 *__restrict__ rays, uint32_t n,
                                                     const NodeDev *__restrict__ nodes, uint32_t num_nodes, uint32_t cap,
@@ -101,28 +147,13 @@ __global__ __launch_bounds__(256) void k_scene_list(const nrt_ray_f32 *__restric
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const nrt_ray_f32 r = rays[i];
-  uint32_t cnt = 0;
+  ListTail st;
   for (uint32_t k = 0; k < num_nodes; k++) {
     float t;
     if (!node_interval(r, nodes[k], t)) continue;
-    // insertion by (t_min, node id) into the sorted prefix kept in global memory; beyond `cap` the farthest drops
-    uint32_t pos = cnt < cap ? cnt : cap;
-    while (pos > 0) {
-      const float pt = list_t[(size_t)(pos - 1) * n + i];
-      if (pt <= t) break; // equal t_min: lower node id first (ids ascend with k)
-      if (pos < cap) {
-        list_t[(size_t)pos * n + i] = pt;
-        list_node[(size_t)pos * n + i] = list_node[(size_t)(pos - 1) * n + i];
-      }
-      pos--;
-    }
-    if (pos < cap) {
-      list_t[(size_t)pos * n + i] = t;
-      list_node[(size_t)pos * n + i] = k;
-    }
-    if (cnt < cap) cnt++;
+    list_add(st, t, k, cap, list_t, list_node, n, i);
   }
-  count[i] = cnt;
+  count[i] = st.cnt;
 }
 
 // The same listing through the top-level BVH: reference-format nodes over the instances' world boxes, leaves name the
@@ -162,7 +193,7 @@ __global__ __launch_bounds__(256) void k_scene_list_bvh(const nrt_ray_f32 *__res
   uint32_t stack[kTopStack];
   int sp = 0;
   stack[0] = 0u;
-  uint32_t cnt = 0;
+  ListTail st;
   while (sp >= 0) {
     const nrt_node_f32 nd = top_nodes[stack[sp]];
     sp--;
@@ -177,25 +208,127 @@ __global__ __launch_bounds__(256) void k_scene_list_bvh(const nrt_ray_f32 *__res
       const uint32_t k = top_indices[nd.data[1] + q];
       float t;
       if (!node_interval(r, nodes[k], t)) continue;
-      uint32_t pos = cnt < cap ? cnt : cap;
-      while (pos > 0) {
-        const float pt = list_t[(size_t)(pos - 1) * n + i];
-        const uint32_t pk = list_node[(size_t)(pos - 1) * n + i];
-        if (pt < t || (pt == t && pk < k)) break;
-        if (pos < cap) {
-          list_t[(size_t)pos * n + i] = pt;
-          list_node[(size_t)pos * n + i] = pk;
-        }
-        pos--;
-      }
-      if (pos < cap) {
-        list_t[(size_t)pos * n + i] = t;
-        list_node[(size_t)pos * n + i] = k;
-      }
-      if (cnt < cap) cnt++;
+      list_add(st, t, k, cap, list_t, list_node, n, i);
     }
   }
-  count[i] = cnt;
+  count[i] = st.cnt;
+}
+
+// The same listing through the top-level tree's Wide4Node records (two tree levels per 128-byte fetch: a third of the
+// dependent round trips of the walk above).  Which instances a ray lists does not depend on the walk: an instance is listed iff
+// node_interval passes on its world box, and the tree only prunes — a subtree is skipped when the ray misses its box by the
+// same IntersectRayAABB arithmetic, and a box that contains an entered box is entered (the slab arithmetic is monotone), so
+// testing the four grandchild boxes instead of child-then-grandchild prunes the same subtrees.  A leaf of one instance needs
+// no fetch at all: its slot's box IS the instance's world box (the builder's box of the zero-radius cylinder xbmin -> xbmax).
+// PRUNE: keep entry distances on the stack, walk front to back and skip what lies beyond a full list (scenes of many
+// instances, where rays enter more boxes than the list holds; on smaller scenes the bookkeeping costs 5-10 % and buys nothing).
+template <bool PRUNE>
+__global__ __launch_bounds__(256) void k_scene_list_w4(const nrt_ray_f32 *__restrict__ rays, uint32_t n,
+                                                       const nrt::Wide4Node<float> *__restrict__ wide4,
+                                                       const nrt_node_f32 *__restrict__ top_nodes, uint32_t packed_leaves,
+                                                       const uint32_t *__restrict__ top_indices,
+                                                       const NodeDev *__restrict__ nodes, uint32_t cap,
+                                                       float *__restrict__ list_t, uint32_t *__restrict__ list_node,
+                                                       uint32_t *__restrict__ count) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const nrt_ray_f32 r = rays[i];
+  float inv[3], pinv[3];
+  int sign[3];
+  bool tame = PRUNE; // every direction component is an ordinary non-zero number and the origin is finite: entry distances are monotone in the box
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float d = r.dir[k];
+    sign[k] = d < 0.0f ? 1 : 0;
+    inv[k] = (__builtin_fabsf(d) < 1.1920928955078125e-07f) ? __builtin_huge_valf() * (sign[k] ? -1.0f : 1.0f) : 1.0f / d;
+    pinv[k] = 1.0f / d; // NodeBBoxIntersector's plain reciprocal (nanosg.h:603-639)
+    tame = tame && (__builtin_fabsf(d) >= 1.1920928955078125e-07f) && (__builtin_fabsf(pinv[k]) < __builtin_huge_valf()) &&
+           (__builtin_fabsf(r.org[k]) < __builtin_huge_valf());
+  }
+  // entry distance of a box as node_interval computes it for an instance's box (unclipped, plain reciprocal): for a tame ray
+  // it can only grow from a box to a box inside it, so a subtree whose box is entered beyond the farthest entry of a FULL
+  // list holds nothing that could still make the list — the walk skips it (a ray through 100 000 instances lists its 64
+  // nearest without visiting the rest)
+  auto entry = [&](const float bmin[3], const float bmax[3]) -> float {
+    float a = -__builtin_huge_valf();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float lo = sign[k] ? bmax[k] : bmin[k];
+      const float t = (lo - r.org[k]) * pinv[k];
+      a = (t > a) ? t : a;
+    }
+    return a;
+  };
+  uint32_t stack[kTopStack];
+  float stack_t[PRUNE ? kTopStack : 1]; // entry distance of the pushed record's box (tame rays; else unused)
+  int sp = 0;
+  stack[0] = 0u; // record 0 == the root branch
+  stack_t[0] = -__builtin_huge_valf();
+  sp = 1;
+  ListTail st;
+  while (sp > 0) {
+    sp--;
+    if constexpr (PRUNE) {
+      if (tame && st.cnt == cap) { // the list is full: anything entered beyond its farthest entry cannot get in
+        if (!st.far_known) list_farthest(st, cap, list_t, list_node, n, i);
+        if (stack_t[sp] > st.far_t) continue;
+      }
+    }
+    const nrt::Wide4Node<float> w = wide4[stack[sp]];
+    uint32_t in_ref[4];
+    float in_t[4];
+    int nin = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t cj = w.c[j];
+      if (cj == nrt::kWide4Empty) continue;
+      const float bmin[3] = {w.bmin[0][j], w.bmin[1][j], w.bmin[2][j]}, bmax[3] = {w.bmax[0][j], w.bmax[1][j], w.bmax[2][j]};
+      if (!(cj & nrt::kLeafBit)) {
+        if (top_box_hit(r, inv, sign, bmin, bmax)) {
+          in_ref[nin] = cj;
+          in_t[nin] = PRUNE ? entry(bmin, bmax) : 0.0f;
+          nin++;
+        }
+        continue;
+      }
+      uint32_t lcount, lfirst;
+      if (packed_leaves) {
+        lcount = ((cj & ~nrt::kLeafBit) >> nrt::kPackedFirstBits) + 1u;
+        lfirst = cj & nrt::kPackedFirstMask;
+      } else {
+        const nrt_node_f32 &leaf = top_nodes[cj & ~nrt::kLeafBit];
+        lcount = leaf.data[0];
+        lfirst = leaf.data[1];
+      }
+      for (uint32_t q = 0; q < lcount; q++) {
+        const uint32_t k = top_indices[lfirst + q];
+        float t;
+        if (lcount == 1u) {
+          if (!node_interval_box(r, bmin, bmax, t)) continue;
+        } else if (!node_interval(r, nodes[k], t)) {
+          continue;
+        }
+        list_add(st, t, k, cap, list_t, list_node, n, i);
+      }
+    }
+    // nearest box on top of the stack: the walk runs roughly front to back, the list fills with near entries first and the
+    // far subtrees fall to the test above (insertion sort of at most four entries, farthest first)
+    for (int x = 1; PRUNE && x < nin; x++)
+      for (int y = x; y > 0 && in_t[y] > in_t[y - 1]; y--) {
+        const float tt = in_t[y];
+        in_t[y] = in_t[y - 1];
+        in_t[y - 1] = tt;
+        const uint32_t rr = in_ref[y];
+        in_ref[y] = in_ref[y - 1];
+        in_ref[y - 1] = rr;
+      }
+    for (int x = 0; x < nin; x++) {
+      stack[sp] = in_ref[x];
+      if constexpr (PRUNE) stack_t[sp] = in_t[x];
+      sp++;
+    }
+  }
+  count[i] = st.cnt;
 }
 
 // ---- host-side restatement of the per-node update (nanosg.h:92-241, 246-302, 397-437) ----------------
@@ -304,6 +437,7 @@ struct nrt_scene {
   bool use_top = false;
   uint32_t max_inst_depth = 0;   // deepest instance tree: sizes the overflow stack of k_scene_trace
   nrt::DevBuf d_nodes, d_insts, d_rays, d_list_t, d_list_node, d_count, d_best, d_mask, d_spill, d_spill_tmin, d_cursor;
+  unsigned prune_min = 32768; // scenes of at least this many instances are listed by the pruning walk (k_scene_list_w4<true>)
   unsigned trace_blocks_per_cu = 0, num_cus = 0, refill_min = 56; // persistent grid of k_scene_trace (env NRT_SCENE_REFILL; 16-48 measured slower on small scenes, 64 slower on 10 000 instances)
 };
 
@@ -526,6 +660,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     SCHK(s, hipGetDeviceProperties(&prop, s->device));
     s->num_cus = (unsigned)prop.multiProcessorCount;
     if (const char *e = getenv("NRT_SCENE_REFILL")) s->refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
+    if (const char *e = getenv("NRT_SCENE_PRUNE_MIN")) s->prune_min = (unsigned)std::max(0, atoi(e)); // (debugging / tests: the pruning walk on small scenes)
   }
   const unsigned trace_grid = std::min(grid, s->num_cus * s->trace_blocks_per_cu); // the trace kernel: every block resident
   const uint32_t levels = s->max_inst_depth + 2 > (uint32_t)nrt::kSceneLdsStack ? s->max_inst_depth + 2 - nrt::kSceneLdsStack : 0;
@@ -539,7 +674,19 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   const nrt_ray_f32 *d_rays = device ? rays : (const nrt_ray_f32 *)s->d_rays.p;
 
   if (!device) SCHK(s, hipMemcpyAsync(s->d_rays.p, rays, (size_t)n * sizeof(nrt_ray_f32), hipMemcpyHostToDevice, s->stream));
-  if (s->use_top)
+  if (s->use_top && s->top_view.wide4 && s->top_view.root_is_branch && s->top_view.tree_nested &&
+      3u * (s->top_view.tree_depth / 2u + 1u) + 2u < (uint32_t)kTopStack)
+  {
+    if (num_nodes >= s->prune_min) // (rays can enter more boxes than the list holds: the pruning walk)
+      hipLaunchKernelGGL(k_scene_list_w4<true>, dim3(grid), dim3(256), 0, s->stream, d_rays, n, (const nrt::Wide4Node<float> *)s->top_view.wide4,
+                         s->top_view.nodes, s->top_view.packed_leaves, s->top_view.indices, d_nodes, cap, (float *)s->d_list_t.p,
+                         (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p);
+    else
+      hipLaunchKernelGGL(k_scene_list_w4<false>, dim3(grid), dim3(256), 0, s->stream, d_rays, n, (const nrt::Wide4Node<float> *)s->top_view.wide4,
+                         s->top_view.nodes, s->top_view.packed_leaves, s->top_view.indices, d_nodes, cap, (float *)s->d_list_t.p,
+                         (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p);
+  }
+  else if (s->use_top)
     hipLaunchKernelGGL(k_scene_list_bvh, dim3(grid), dim3(256), 0, s->stream, d_rays, n, s->top_view.nodes, s->top_view.indices,
                        d_nodes, cap, (float *)s->d_list_t.p, (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p);
   else

@@ -1343,7 +1343,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
   uint32_t i = 0; // this lane's ray
   uint32_t cur = 0;
   int state = S_DONE, sp = 0;
-  uint32_t cnt = 0, j = 0, inst = 0;
+  uint32_t cnt = 0, j = 0, inst = 0; // candidates of this ray; how many of them have been taken; the instance being walked
+  float last_t = 0.0f;               // (entry distance, id) of the candidate taken last: the next one is the smallest above it
+  uint32_t last_id = 0u;
   float best_t = 3.402823466e+38f; // t_nearest = numeric_limits<T>::max(), nanosg.h:787
   bool has_hit = false;
   float worg[3] = {0.f, 0.f, 0.f}, wdir[3] = {0.f, 0.f, 0.f};
@@ -1375,6 +1377,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
           }
           cnt = a.count[i];
           j = 0;
+          last_t = 0.0f;
+          last_id = 0u;
           best_t = 3.402823466e+38f;
           has_hit = false;
           nrt_scene_hit_f32 h; // the miss record; overwritten by every strictly nearer hit
@@ -1411,46 +1415,65 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
           a.hits[i] = h;
         }
       }
-      j++;
       state = S_NEXT;
     }
     if (state == S_NEXT) {
       state = S_DONE;
-      while (j < cnt) {
-        const float t_min = a.list_t[(size_t)j * a.n + i];
-        if (best_t < t_min) { // early cull, nanosg.h:795
-          j++;
-          continue;
-        }
-        inst = a.list_node[(size_t)j * a.n + i];
-        const SceneInst &nd = a.insts[inst];
-        nrt_ray_f32 lr;
-        scene_mult_v(lr.org, nd.inv_xform, worg);   // nanosg.h:807
-        scene_mult_v(lr.dir, nd.inv_xform33, wdir); // nanosg.h:808
-        lr.min_t = 0.0f;                            // Ray() defaults (nanort.h:477-487): the world interval is not propagated
-        lr.max_t = 3.402823466e+38f;
-        lr.type = 0;
-        lane_init<float>(L, lr);
-        wide = (const WideNode<float> *)nd.wide;
-        wide4 = (const Wide4Node<float> *)nd.wide4;
-        tris = (const LeafTri<float> *)nd.tris;
-        nodes = nd.nodes;
-        packed = nd.packed_leaves;
-        sp = 0;
-        cur = 0u;
-        if (nd.root_is_branch && nd.tree_nested) {
-          state = W_TRAV; // (a ray that misses node 0's box misses both children's: see k_traverse_wide)
-        } else {
-          const nrt_node_f32 root = nodes[0];
-          const bool root_hit = slab_test<float>(L, root.bmin, root.bmax);
-          if (nd.root_is_branch) {
-            state = root_hit ? W_TRAV : W_POP;
-          } else { // single-leaf tree
-            cur = packed ? (((root.data[0] - 1u) << kPackedFirstBits) | root.data[1]) : 0u;
-            state = root_hit ? W_LEAF : W_POP;
+      // The ray's candidates — the (at most 64 nearest) instances whose world boxes it enters — lie UNSORTED in its list
+      // (scene.hip appends them as the top-level walk finds them).  The reference visits them in the order of (entry distance,
+      // id) and skips one whose entry distance lies beyond the nearest hit so far (nanosg.h:795) — and then every later one
+      // too, their entry distances being no smaller.  So: pick the smallest (t_min, id) above the one taken last; if the hit
+      // so far is nearer than that, the ray is done.  Rays take one or two candidates before that happens, so a selection scan
+      // per candidate taken costs far less than sorting every list (round 2: an insertion sort in global memory while listing).
+      if (j < cnt) {
+        float bt = 0.0f;
+        uint32_t bid = 0xFFFFFFFFu;
+        bool found = false;
+        for (uint32_t q = 0; q < cnt; q++) {
+          const float t = a.list_t[(size_t)q * a.n + i];
+          if (j != 0u && t < last_t) continue;
+          if (found && t > bt) continue;
+          const uint32_t id = a.list_node[(size_t)q * a.n + i];
+          if (j != 0u && t == last_t && id <= last_id) continue; // taken already (ids are unique)
+          if (!found || t < bt || id < bid) { // (here t <= bt: nearer, or as near with the lower id)
+            bt = t;
+            bid = id;
+            found = true;
           }
         }
-        break;
+        if (found && !(best_t < bt)) { // (else: early cull, nanosg.h:795 — for this candidate and all that follow)
+          last_t = bt;
+          last_id = bid;
+          j++;
+          inst = bid;
+          const SceneInst &nd = a.insts[inst];
+          nrt_ray_f32 lr;
+          scene_mult_v(lr.org, nd.inv_xform, worg);   // nanosg.h:807
+          scene_mult_v(lr.dir, nd.inv_xform33, wdir); // nanosg.h:808
+          lr.min_t = 0.0f;                            // Ray() defaults (nanort.h:477-487): the world interval is not propagated
+          lr.max_t = 3.402823466e+38f;
+          lr.type = 0;
+          lane_init<float>(L, lr);
+          wide = (const WideNode<float> *)nd.wide;
+          wide4 = (const Wide4Node<float> *)nd.wide4;
+          tris = (const LeafTri<float> *)nd.tris;
+          nodes = nd.nodes;
+          packed = nd.packed_leaves;
+          sp = 0;
+          cur = 0u;
+          if (nd.root_is_branch && nd.tree_nested) {
+            state = W_TRAV; // (a ray that misses node 0's box misses both children's: see k_traverse_wide)
+          } else {
+            const nrt_node_f32 root = nodes[0];
+            const bool root_hit = slab_test<float>(L, root.bmin, root.bmax);
+            if (nd.root_is_branch) {
+              state = root_hit ? W_TRAV : W_POP;
+            } else { // single-leaf tree
+              cur = packed ? (((root.data[0] - 1u) << kPackedFirstBits) | root.data[1]) : 0u;
+              state = root_hit ? W_LEAF : W_POP;
+            }
+          }
+        }
       }
       if (state == S_DONE && a.mask) a.mask[i] = has_hit ? 1 : 0; // this ray is finished
     }

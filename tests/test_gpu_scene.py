@@ -230,3 +230,51 @@ def test_ten_thousand_instances_through_the_top_level_bvh(oracle):
     assert 0.05 < om.mean() < 0.95
     assert np.array_equal(m, om)
     assert fields_equal(h, oh, ("t", "u", "v", "prim_id", "node_id"))
+
+
+@pytest.mark.parametrize("prune", [False, True], ids=["plain_walk", "pruning_walk"])
+def test_rays_that_enter_more_than_64_boxes_keep_the_64_nearest(oracle, monkeypatch, prune):
+    """kMaxIntersections (nanosg.h:782): of the node boxes a ray enters only the 64 nearest by (entry distance, id) are
+    considered.  200 small spheres strung along a line, rays shot down the line (entering all of them, from either end and
+    from the middle), plus a camera wave: every field equals the restatement's."""
+    from scene_fixture import xform
+
+    if prune:  # the front-to-back walk that skips what lies beyond a full list (by default only on scenes of >= 32768 instances)
+        monkeypatch.setenv("NRT_SCENE_PRUNE_MIN", "1")
+    sv, sf = scenes.sphere(16, 8)
+    sv = (sv - np.array([0, 5, 0], dtype=np.float32)).astype(np.float32)
+    a = BVHAccel(np.float32)
+    assert a.Build(sf.shape[0], TriangleMesh(sv, sf))
+    tree = a.GetTree()
+    sc = Scene()
+    O = ob.SceneOracle(oracle)
+    rng = np.random.default_rng(3)
+    N = 200
+    for k in range(N):
+        x = xform((0.02, 0.02, 0.02), rng.uniform(0, 6.28), rng.uniform(0, 6.28), (0.25 * k - 25.0, 5.0 + 0.01 * rng.uniform(-1, 1), 0.0))
+        sc.AddNode(a, x)
+        O.add_node(sv, sf, x, tree=tree)
+    assert sc.Commit() and O.commit()
+    from nanort_amd.wire import RAY_F32
+
+    m = 3000
+    rays = np.zeros(m, dtype=RAY_F32)
+    rays["org"][:, 0] = rng.choice([-30.0, 30.0, 0.1], m)
+    rays["org"][:, 1] = 5.0 + rng.uniform(-0.2, 0.2, m)
+    rays["org"][:, 2] = rng.uniform(-0.2, 0.2, m)
+    tgt = np.stack([rng.uniform(-25, 25, m), 5.0 + rng.uniform(-0.25, 0.25, m), rng.uniform(-0.25, 0.25, m)], axis=1)
+    d = tgt - rays["org"]
+    rays["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["max_t"] = 1.0e30
+    # exactly axis-parallel rays (zero direction components: the listing then prunes nothing), some with -0.0
+    rays["dir"][:60] = 0.0
+    rays["dir"][:60, 0] = np.where(rays["org"][:60, 0] > 0, -1.0, 1.0)
+    rays["dir"][:20, 1] = -0.0
+    rays["org"][:60, 1] = 5.0
+    rays["org"][:60, 2] = 0.0
+    rays = np.concatenate([rays, scenes.camera_rays(160, 90)])
+    h, mk = sc.TraverseBatch(rays)
+    oh, om = O.traverse(rays)
+    assert int(mk.sum()) > 500
+    assert np.array_equal(mk, om)
+    assert fields_equal(h, oh, ("t", "u", "v", "prim_id", "node_id"))
