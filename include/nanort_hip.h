@@ -317,8 +317,8 @@ NRT_API float nrtLastBuildMs(nrt_ctx *ctx);
  * (first block started -> last wave finished), and whatever must wait for launches in flight (nrtBuild / nrtSetMesh /
  * nrtSetTree / nrtDestroy, a fifth stream launching concurrently on one context) waits for exactly those launches by polling
  * their records.  on = 1 brackets every launch with a pair of timing events and follows it with a completion event instead
- * (nrtLastTraverseMs then reports the event time, dispatch included) — a cross-check, not the fast path.  Launches that are
- * followed by a post pass (sphere and cylinder primitives) and the literal BVHNode kernel always use events.
+ * (nrtLastTraverseMs then reports the event time, dispatch included) — a cross-check, not the fast path.  (For the sphere
+ * and cylinder kinds the record is closed by their post pass; the literal BVHNode kernel always uses events.)
  * (No reference counterpart.) */
 NRT_API nrt_status nrtSetLaunchTiming(nrt_ctx *ctx, int on);
 /* Traversal / build tunables by name (no reference counterpart; the library's defaults are the measured optimum on MI355X):

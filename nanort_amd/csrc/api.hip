@@ -35,7 +35,7 @@ hipError_t launch_gather_leaf_spheres(const uint32_t *, const T *, const T *, Le
 template <typename T>
 hipError_t launch_gather_leaf_cylinders(const uint32_t *, const T *, const T *, LeafCylinder<T> *, uint32_t, hipStream_t);
 hipError_t launch_cylinder_post(const nrt_ray_f32 *, const nrt_hit_f32 *, const uint8_t *, const float *, uint32_t, void *,
-                                uint8_t *, hipStream_t);
+                                uint8_t *, DoneRec *, DoneCount *, uint32_t, hipStream_t);
 template <typename T>
 hipError_t launch_make_wide(const typename Wire<T>::Node *, uint32_t, uint32_t packed, uint32_t *scratch, WideNode<T> *, Wide4Node<T> *,
                             uint32_t scramble_mod, hipStream_t);
@@ -187,7 +187,7 @@ static nrt_status ensure(nrt_ctx *c, DevBuf &b, size_t bytes) {
 // triangle launches of the production kernel record NONE by default: the kernel's last wave publishes a completion record
 // (sequence number + start / end stamps) in page-locked memory, and whoever has to wait for the launch — a rebuild, destroy,
 // another stream taking the slot over, nrtLastTraverseMs — polls that record: precise, and nothing else on the device is
-// waited for.  Launches followed by a post pass (spheres, cylinders) and the literal kernel keep the events.
+// waited for.  (Sphere and cylinder launches: their post pass closes the record.  The literal kernel keeps the events.)
 static hipError_t wait_record(nrt_ctx::LaunchSlot &sl) {
   if (!sl.rec_pending) return hipSuccess;
   volatile uint32_t *seq = &sl.h_done->seq;
@@ -892,10 +892,13 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
 
   if (count || (c->debug_flags & (32u | 4096u))) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), s));
   // completion record instead of events: the traversal kernel is the launch's last kernel and events were not asked for
-  const bool use_rec = use_wide && !spheres && !count && !c->launch_timing;
+  const bool use_rec = use_wide && !count && !c->launch_timing;
+  // (the sphere kind's u/v pass and the cylinder kind's normal pass run behind the traversal kernel and close the record in its place)
+  const bool post_pass = (c->prim_kind == kPrimSpheres && d_hits != nullptr) || d_cyl_hits != nullptr;
   a.done_rec = use_rec ? slot->d_done : nullptr;
   a.done_count = slot->d_count;
   a.done_seq = use_rec ? slot->seq + 1u : 0u;
+  a.done_publish = post_pass ? 0u : 1u;
   timed = timed && !use_rec;
   if (timed) HIPCHK(c, hipEventRecord(slot->t0, s));
   if (use_wide) {
@@ -906,7 +909,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   }
   if (d_cyl_hits)
     HIPCHK(c, launch_cylinder_post((const nrt_ray_f32 *)d_rays, (const nrt_hit_f32 *)slot->cyl_hits.p, (const uint8_t *)slot->cyl_bits.p,
-                                   (const float *)c->d_verts, (uint32_t)n, d_cyl_hits, d_mask, s));
+                                   (const float *)c->d_verts, (uint32_t)n, d_cyl_hits, d_mask, a.done_rec, a.done_count, a.done_seq, s));
   if (timed) HIPCHK(c, hipEventRecord(slot->t1, s));
   if (use_rec) {
     slot->seq++;

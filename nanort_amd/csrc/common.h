@@ -249,6 +249,7 @@ struct TraverseArgs {
   DoneRec *done_rec;                 // completion record of this launch's slot (device-visible host memory), or null: none
   DoneCount *done_count;             // its device-side words
   uint32_t done_seq;                 // sequence number of this launch within its slot
+  uint32_t done_publish;             // 1: the traversal kernel's last wave closes the record; 0: a post pass behind it does (sphere / cylinder kinds)
 };
 
 } // namespace nrt

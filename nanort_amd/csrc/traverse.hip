@@ -16,6 +16,7 @@
 //                            hit iff t_best < ray.max_t)
 #include "common.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <map>
 #include <mutex>
@@ -488,9 +489,27 @@ __device__ __forceinline__ void done_begin(const TraverseArgs<T> &a) {
   if (a.done_rec != nullptr && threadIdx.x == 0u && blockIdx.x < 8u)
     atomicMin(&a.done_count->t_begin, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
+// The same hand-off at the end of an ordinary (non-persistent) grid — the post passes of the sphere and cylinder kinds, which
+// then close the launch's record in place of the traversal kernel: every block counts itself out once all its threads are
+// past their reads.
+__device__ __forceinline__ void done_end_blocks(DoneRec *rec, DoneCount *cnt, uint32_t seq) {
+  if (rec == nullptr) return; // (uniform)
+  __syncthreads();
+  if (threadIdx.x != 0u) return;
+  const uint32_t groups = gridDim.x < 8u ? gridDim.x : 8u, g = blockIdx.x % 8u;
+  const uint32_t group_blocks = (gridDim.x - g + 7u) / 8u;
+  if (atomicAdd(&cnt->group[g], 1u) != group_blocks - 1u) return;
+  (void)atomicExch(&cnt->group[g], 0u);
+  if (atomicAdd(&cnt->exited, 1u) != groups - 1u) return;
+  (void)atomicExch(&cnt->exited, 0u);
+  const unsigned long long t0 = atomicExch(&cnt->t_begin, ~0ull);
+  __hip_atomic_store(&rec->t_begin, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&rec->t_end, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&rec->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 template <typename T>
 __device__ __forceinline__ void done_end(const TraverseArgs<T> &a, unsigned lane) {
-  if (a.done_rec == nullptr || lane != 0u) return;
+  if (a.done_rec == nullptr || !a.done_publish || lane != 0u) return; // (done_publish == 0: a post pass closes the record)
   const uint32_t groups = gridDim.x < 8u ? gridDim.x : 8u, g = blockIdx.x % 8u;
   const uint32_t group_waves = ((gridDim.x - g + 7u) / 8u) * (uint32_t)(kTraverseBlock / kWave);
   DoneCount *cnt = a.done_count;
@@ -702,11 +721,13 @@ enum : int { W_IDLE = 0, W_TRAV = 1, W_LEAF = 2, W_POP = 3 };
 template <typename T>
 __global__ __launch_bounds__(256) void k_sphere_uv(const typename Wire<T>::Ray *__restrict__ rays,
                                                    typename Wire<T>::Hit *__restrict__ hits,
-                                                   const T *__restrict__ centers, uint32_t n) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
+                                                   const T *__restrict__ centers, uint32_t n, DoneRec *done_rec,
+                                                   DoneCount *done_count, uint32_t done_seq) {
+  // (grid-stride: a bounded number of blocks, so that the completion hand-off at the end — one returning atomic per block —
+  // is paid a couple of thousand times, not once per 256 rays)
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
   typename Wire<T>::Hit h = hits[i];
-  if (h.prim_id == kInvalid) return;
+  if (h.prim_id == kInvalid) continue;
   const typename Wire<T>::Ray r = rays[i];
   const double kPi = 3.14159265358979323846;
   const T h0 = r.org[0] + h.t * r.dir[0], h1 = r.org[1] + h.t * r.dir[1], h2 = r.org[2] + h.t * r.dir[2];
@@ -722,6 +743,8 @@ __global__ __launch_bounds__(256) void k_sphere_uv(const typename Wire<T>::Ray *
   h.u = T(float(atan2(double(n0), double(n2)) + kPi) * 0.5f * float(1.0 / kPi));
   h.v = T(float(acos(double(n1)) / kPi));
   hits[i] = h;
+  }
+  done_end_blocks(done_rec, done_count, done_seq);
 }
 
 // CylinderIntersector::PostTraversal (examples/cylinder_primitive/main.cc:367-418) as a pass over the finished compact
@@ -737,9 +760,9 @@ static_assert(sizeof(CylHit32) == 28, "nrt_cyl_hit_f32");
 __global__ __launch_bounds__(256) void k_cylinder_post(const Wire<float>::Ray *__restrict__ rays,
                                                        const Wire<float>::Hit *__restrict__ compact,
                                                        const uint8_t *__restrict__ bits, const float *__restrict__ verts,
-                                                       uint32_t n, CylHit32 *__restrict__ out, uint8_t *__restrict__ mask) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
+                                                       uint32_t n, CylHit32 *__restrict__ out, uint8_t *__restrict__ mask,
+                                                       DoneRec *done_rec, DoneCount *done_count, uint32_t done_seq) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) { // (grid-stride: see k_sphere_uv)
   const Wire<float>::Hit h = compact[i];
   const uint8_t b = bits[i];
   CylHit32 o;
@@ -783,6 +806,8 @@ __global__ __launch_bounds__(256) void k_cylinder_post(const Wire<float>::Ray *_
   }
   out[i] = o;
   if (mask) mask[i] = b & 1u;
+  }
+  done_end_blocks(done_rec, done_count, done_seq);
 }
 
 // Both child boxes of one WideNode at once.  For fp32 the two boxes ride in the two halves of
@@ -1796,9 +1821,9 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
     } else {
       NRT_LAUNCH_WIDE(10, false, kPrimSpheres, false, false, 2);
     }
-    if (args.hits)
-      hipLaunchKernelGGL((k_sphere_uv<T>), dim3((args.num_rays + 255u) / 256u), dim3(256), 0, s, args.rays, args.hits,
-                         args.centers, args.num_rays);
+    if (args.hits) // (args.done_publish == 0: this pass closes the launch's completion record)
+      hipLaunchKernelGGL((k_sphere_uv<T>), dim3(std::min((args.num_rays + 255u) / 256u, 2048u)), dim3(256), 0, s, args.rays, args.hits,
+                         args.centers, args.num_rays, args.done_publish ? nullptr : args.done_rec, args.done_count, args.done_seq);
     return hipGetLastError();
   }
   if (prim_kind == kPrimCylinders) {
@@ -1920,10 +1945,11 @@ template hipError_t launch_gather_leaf_cylinders<double>(const uint32_t *, const
                                                          LeafCylinder<double> *, uint32_t, hipStream_t);
 
 hipError_t launch_cylinder_post(const nrt_ray_f32 *rays, const nrt_hit_f32 *compact, const uint8_t *bits, const float *verts,
-                                uint32_t n, void *out, uint8_t *mask, hipStream_t s) {
+                                uint32_t n, void *out, uint8_t *mask, DoneRec *done_rec, DoneCount *done_count, uint32_t done_seq,
+                                hipStream_t s) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_cylinder_post, dim3((n + 255u) / 256u), dim3(256), 0, s, rays, compact, bits, verts, n,
-                     (CylHit32 *)out, mask);
+  hipLaunchKernelGGL(k_cylinder_post, dim3(std::min((n + 255u) / 256u, 2048u)), dim3(256), 0, s, rays, compact, bits, verts, n,
+                     (CylHit32 *)out, mask, done_rec, done_count, done_seq);
   return hipGetLastError();
 }
 
