@@ -127,7 +127,7 @@ struct nrt_ctx {
 
   // traversal tuning (env NRT_LDS_STACK / NRT_REFILL_MIN / NRT_TRAV_MIN / NRT_CHUNK override)
   int lds_stack = kLdsStackDefault;
-  unsigned blocks_per_cu = 0, chunk = 128, chunk_tail_pct = 0, refill_min = 48, trav_min = 8, leaf_min = 32;
+  unsigned blocks_per_cu = 0, chunk = 128, chunk_tail_pct = 0, refill_min = 44, trav_min = 12, leaf_min = 32; // (trav_min: 8 until round 3; 12-14 is the optimum of the two-level walk, profiles/r03t_trav_min.txt)
   unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
   unsigned debug_flags = 0;
   int morton = 0; // Morton-order the primitive records before the build (env NRT_MORTON=1): measured +0.4 ms at 1M tris for an identical tree, so off by default
