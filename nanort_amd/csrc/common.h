@@ -134,7 +134,10 @@ struct alignas(16) Wide4Node {
 static_assert(sizeof(Wide4Node<float>) == 128, "Wide4Node<float>");
 static_assert(sizeof(Wide4Node<double>) == 224, "Wide4Node<double>");
 constexpr uint32_t kWide4Empty = 0xFFFFFFFFu;
-constexpr int kWide4LdsStack = 12; // per-lane LDS stack entries of the WIDTH = 4 variants (24 KiB per block: six blocks per CU)
+#ifndef NRT_W4_LDS_STACK
+#define NRT_W4_LDS_STACK 12
+#endif
+constexpr int kWide4LdsStack = NRT_W4_LDS_STACK; // per-lane LDS stack entries of the WIDTH = 4 variants (24 KiB per block: six blocks per CU)
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kPackedFirstBits = 27;
 constexpr uint32_t kPackedFirstMask = (1u << kPackedFirstBits) - 1u;
@@ -180,6 +183,7 @@ struct SceneTraceArgs {
   uint32_t spill_stride;
   uint32_t *cursor;           // work cursor (next unclaimed ray), zero at launch
   uint32_t refill_min;        // free lanes of a wave before it claims more rays
+  uint32_t trav_min;          // lanes still walking inner nodes below which the wave turns to the waiting leaves
 };
 
 // Completion record of a launch slot, in page-locked host memory the device writes to: the last wave of a traversal

@@ -438,6 +438,7 @@ struct nrt_scene {
   uint32_t max_inst_depth = 0;   // deepest instance tree: sizes the overflow stack of k_scene_trace
   nrt::DevBuf d_nodes, d_insts, d_rays, d_list_t, d_list_node, d_count, d_best, d_mask, d_spill, d_spill_tmin, d_cursor;
   unsigned prune_min = 32768; // scenes of at least this many instances are listed by the pruning walk (k_scene_list_w4<true>)
+  unsigned trav_min = 8;
   unsigned trace_blocks_per_cu = 0, num_cus = 0, refill_min = 56; // persistent grid of k_scene_trace (env NRT_SCENE_REFILL; 16-48 measured slower on small scenes, 64 slower on 10 000 instances)
 };
 
@@ -660,6 +661,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     SCHK(s, hipGetDeviceProperties(&prop, s->device));
     s->num_cus = (unsigned)prop.multiProcessorCount;
     if (const char *e = getenv("NRT_SCENE_REFILL")) s->refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
+    if (const char *e = getenv("NRT_SCENE_TRAV")) s->trav_min = (unsigned)std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_PRUNE_MIN")) s->prune_min = (unsigned)std::max(0, atoi(e)); // (debugging / tests: the pruning walk on small scenes)
   }
   const unsigned trace_grid = std::min(grid, s->num_cus * s->trace_blocks_per_cu); // the trace kernel: every block resident
@@ -707,6 +709,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   a.spill_stride = trace_grid * 256u;
   a.cursor = (uint32_t *)s->d_cursor.p;
   a.refill_min = s->refill_min;
+  a.trav_min = s->trav_min;
   SCHK(s, nrt::launch_scene_trace(a, trace_grid, s->stream));
   if (!device) {
     SCHK(s, hipMemcpyAsync(hits_out, s->d_best.p, (size_t)n * sizeof(nrt_scene_hit_f32), hipMemcpyDeviceToHost, s->stream));

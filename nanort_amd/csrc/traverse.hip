@@ -1524,7 +1524,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
         }
       }
       n_wait += (unsigned)__builtin_popcountll(__ballot(state == W_LEAF || state == S_FIN));
-      if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < 8u && n_wait != 0u) break;
+      if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < a.trav_min && n_wait != 0u) break;
     }
 
     // ---- phase 2: leaves -----------------------------------------------------------------------------------------

@@ -9,8 +9,8 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=
 cp nanort_amd/lib/libnanort_hip.so /tmp/libnanort_hip.keep
 trap 'cp /tmp/libnanort_hip.keep nanort_amd/lib/libnanort_hip.so' EXIT
 for flags in "$@"; do
-  (cd nanort_amd/csrc && /opt/rocm/bin/hipcc $F $flags -c traverse.hip -o /tmp/traverse_probe.o &&
-   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libnanort_hip.so api.o /tmp/traverse_probe.o build.o scene.o)
+  (cd nanort_amd/csrc && /opt/rocm/bin/hipcc $F $flags -c traverse.hip -o /tmp/traverse_probe.o && /opt/rocm/bin/hipcc $F $flags -c api.hip -o /tmp/api_probe.o &&
+   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libnanort_hip.so /tmp/api_probe.o /tmp/traverse_probe.o build.o scene.o)
   echo "== ${flags:-as shipped}" >> "$out"
   ROUNDS=3 python tools/tune_probe.py "$cfgs" "dict()" 2>&1 | grep -v amdgpu >> "$out"
 done
