@@ -181,7 +181,8 @@ struct SceneTraceArgs {
   uint32_t *spill;            // overflow stack [spill_levels][spill_stride], may be null
   float *spill_tmin;
   uint32_t spill_stride;
-  uint32_t *cursor;           // work cursor (next unclaimed ray), zero at launch
+  uint32_t *cursor;           // work cursors (next unclaimed ray of each partition), kCursorStrideWords apart, zero at launch
+  uint32_t num_parts;         // ray partitions (<= kMaxParts)
   uint32_t refill_min;        // free lanes of a wave before it claims more rays
   uint32_t trav_min;          // lanes still walking inner nodes below which the wave turns to the waiting leaves
 };

@@ -670,8 +670,8 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     SCHK(s, nrt::devbuf_ensure(&s->d_spill, (size_t)levels * trace_grid * 256u * sizeof(uint32_t)));
     SCHK(s, nrt::devbuf_ensure(&s->d_spill_tmin, (size_t)levels * trace_grid * 256u * sizeof(float)));
   }
-  SCHK(s, nrt::devbuf_ensure(&s->d_cursor, 256));
-  SCHK(s, hipMemsetAsync(s->d_cursor.p, 0, sizeof(uint32_t), s->stream));
+  SCHK(s, nrt::devbuf_ensure(&s->d_cursor, (size_t)nrt::kMaxParts * nrt::kCursorStrideWords * sizeof(uint32_t)));
+  SCHK(s, hipMemsetAsync(s->d_cursor.p, 0, (size_t)nrt::kMaxParts * nrt::kCursorStrideWords * sizeof(uint32_t), s->stream));
   const NodeDev *d_nodes = (const NodeDev *)s->d_nodes.p;
   const nrt_ray_f32 *d_rays = device ? rays : (const nrt_ray_f32 *)s->d_rays.p;
 
@@ -708,6 +708,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   a.spill_tmin = (float *)s->d_spill_tmin.p;
   a.spill_stride = trace_grid * 256u;
   a.cursor = (uint32_t *)s->d_cursor.p;
+  a.num_parts = std::max(1u, std::min(8u, trace_grid));
   a.refill_min = s->refill_min;
   a.trav_min = s->trav_min;
   SCHK(s, nrt::launch_scene_trace(a, trace_grid, s->stream));

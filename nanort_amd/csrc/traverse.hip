@@ -1380,6 +1380,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
   const nrt_node_f32 *nodes = nullptr;
   uint32_t packed = 1u;
   bool exhausted = false;
+  uint32_t part = blockIdx.x % a.num_parts, tried = 0u; // ray partition this wave claims from (its home first), partitions found empty
 
   for (;;) {
     // ---- refill free lanes -------------------------------------------------------------------------------------------
@@ -1387,11 +1388,24 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
       const unsigned long long free_lanes = __ballot(state == S_DONE);
       const unsigned want = (unsigned)__builtin_popcountll(free_lanes);
       if (!exhausted && want >= a.refill_min) {
-        uint32_t base = 0;
-        if (lane == (unsigned)__builtin_ctzll(free_lanes)) base = atomicAdd(a.cursor, want);
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(free_lanes));
-        exhausted = base + want >= a.n;
-        const uint32_t mine = base + (uint32_t)__builtin_popcountll(free_lanes & ((1ull << lane) - 1ull));
+        // one cursor per ray partition (== XCD, as in k_traverse_wide): a wave drains its home range first, so an XCD walks one
+        // band of the batch and its L2 keeps one part of the scene; then it steals from the others
+        const uint32_t per = a.n / a.num_parts;
+        uint32_t mine = a.n;
+        while (tried < a.num_parts) {
+          const uint32_t lo = part * per, len = (part + 1u == a.num_parts) ? a.n - lo : per;
+          uint32_t base = 0;
+          if (lane == (unsigned)__builtin_ctzll(free_lanes)) base = atomicAdd(a.cursor + kCursorStrideWords * part, want);
+          base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(free_lanes));
+          if (base < len) {
+            const uint32_t off = base + (uint32_t)__builtin_popcountll(free_lanes & ((1ull << lane) - 1ull));
+            mine = off < len ? lo + off : a.n;
+            break;
+          }
+          part = (part + 1u == a.num_parts) ? 0u : part + 1u;
+          tried++;
+        }
+        exhausted = tried >= a.num_parts;
         if (state == S_DONE && mine < a.n) {
           i = mine;
           const nrt_ray_f32 r = a.rays[i];
