@@ -4,7 +4,13 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -ffp-contract=off -DNANORT_USE_HIP_BACKEND -I../../include main.hip \
 //         -L../../nanort_amd/lib -lnanort_hip -Wl,-rpath,$PWD/../../nanort_amd/lib -o wavefront_gpu
-//   ./wavefront_gpu [--size W H] [--spp N] [--depth D] [--grid NX NY] [--out image.ppm]
+//   ./wavefront_gpu [--size W H] [--spp N] [--depth D] [--grid NX NY] [--out image.f32] [--streams 1|2]
+//
+// Two streams (the default): the shadow query of depth d and the path wave of depth d + 1 do not depend on each other — both come
+// out of k_shade(d) — so the shadow query and its resolve run on a second stream while the first goes on with the next wave.
+// One BVHAccel serves both (every launch owns a launch slot of the context); the end of one launch — a handful of long rays —
+// is filled by the other.  The shadow contributions then accumulate in an image of their own that is added at the end, so a
+// pixel's sum is associated differently than with --streams 1 (last-bit differences).
 //
 // Same scene, camera, light, sampler and per-pixel accumulation order as the host-shaded example (a pixel's path is a
 // pure function of (pixel, sample)); waves keep one slot per pixel — a dead path's slot holds a ray that cannot hit
@@ -203,6 +209,11 @@ __global__ void k_shade(int n, int spp, int depth, int max_depth, const float *v
   shadow_contrib[3 * (size_t)i + 2] = c2;
 }
 
+__global__ void k_add_images(int n3, float *image, const float *other) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (uint32_t)n3) image[i] += other[i];
+}
+
 __global__ void k_resolve_shadows(int n, int spp, const unsigned char *shadow_mask, const float *shadow_contrib, float *image) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (uint32_t)n || shadow_mask[i]) return;  // occluded (a dead shadow ray never hits and carries 0)
@@ -230,7 +241,7 @@ static void MakeGrid(std::vector<float> *vertices, std::vector<unsigned int> *fa
 }
 
 int main(int argc, char **argv) {
-  int W = 480, H = 270, spp = 2, depth = 3, nx = 400, ny = 200;
+  int W = 480, H = 270, spp = 2, depth = 3, nx = 400, ny = 200, streams = 2;
   std::string out;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--size") && i + 2 < argc) {
@@ -245,6 +256,8 @@ int main(int argc, char **argv) {
       ny = atoi(argv[++i]);
     } else if (!strcmp(argv[i], "--out") && i + 1 < argc) {
       out = argv[++i];
+    } else if (!strcmp(argv[i], "--streams") && i + 1 < argc) {
+      streams = atoi(argv[++i]) == 1 ? 1 : 2;
     }
   }
   std::vector<float> vertices;
@@ -258,24 +271,33 @@ int main(int argc, char **argv) {
     return 1;
   }
   const int n = W * H;
-  float *d_verts, *d_contrib, *d_image;
+  float *d_verts, *d_contrib[2], *d_image, *d_image2;
   unsigned int *d_faces;
-  Ray *d_rays, *d_shadow;
+  Ray *d_rays, *d_shadow[2];
   Hit *d_hits;
-  unsigned char *d_mask, *d_smask;
+  unsigned char *d_mask, *d_smask[2];
   PathState *d_paths;
-  hipStream_t stream;
+  hipStream_t stream, stream2;
+  hipEvent_t ev_shaded[2], ev_resolved[2]; // per shadow buffer: k_shade has filled it / its query has been resolved
   CHECK(hipStreamCreate(&stream));
+  CHECK(hipStreamCreate(&stream2));
+  for (int b = 0; b < 2; b++) {
+    CHECK(hipEventCreateWithFlags(&ev_shaded[b], hipEventDisableTiming));
+    CHECK(hipEventCreateWithFlags(&ev_resolved[b], hipEventDisableTiming));
+  }
   CHECK(hipMalloc(&d_verts, vertices.size() * 4));
   CHECK(hipMalloc(&d_faces, faces.size() * 4));
   CHECK(hipMalloc(&d_rays, (size_t)n * sizeof(Ray)));
-  CHECK(hipMalloc(&d_shadow, (size_t)n * sizeof(Ray)));
+  for (int b = 0; b < 2; b++) { // shadow rays, their flags and pending contributions: double-buffered across depths
+    CHECK(hipMalloc(&d_shadow[b], (size_t)n * sizeof(Ray)));
+    CHECK(hipMalloc(&d_smask[b], n));
+    CHECK(hipMalloc(&d_contrib[b], (size_t)n * 12));
+  }
   CHECK(hipMalloc(&d_hits, (size_t)n * sizeof(Hit)));
   CHECK(hipMalloc(&d_mask, n));
-  CHECK(hipMalloc(&d_smask, n));
   CHECK(hipMalloc(&d_paths, (size_t)n * sizeof(PathState)));
-  CHECK(hipMalloc(&d_contrib, (size_t)n * 12));
   CHECK(hipMalloc(&d_image, (size_t)n * 12));
+  CHECK(hipMalloc(&d_image2, (size_t)n * 12));
   CHECK(hipMemcpy(d_verts, vertices.data(), vertices.size() * 4, hipMemcpyHostToDevice));
   CHECK(hipMemcpy(d_faces, faces.data(), faces.size() * 4, hipMemcpyHostToDevice));
   const dim3 grid((n + 255) / 256), block(256);
@@ -283,23 +305,40 @@ int main(int argc, char **argv) {
   double best = 1e30;
   for (int rep = 0; rep < 3; rep++) {  // first repetition warms up; the image is the same every time
     CHECK(hipMemsetAsync(d_image, 0, (size_t)n * 12, stream));
+    CHECK(hipMemsetAsync(d_image2, 0, (size_t)n * 12, stream));
     CHECK(hipStreamSynchronize(stream));
     const auto t0 = std::chrono::steady_clock::now();
     rays_traced = 0;
+    hipStream_t shadow_stream = streams == 2 ? stream2 : stream;
+    float *shadow_image = streams == 2 ? d_image2 : d_image; // (one stream: the shadow terms join the pixel's sum in path order)
+    int wave = 0; // shadow buffers alternate from wave to wave
     for (int s = 0; s < spp; s++) {
       hipLaunchKernelGGL(k_camera, grid, block, 0, stream, W, H, s, d_rays, d_paths);
-      for (int d = 0; d <= depth; d++) {
+      for (int d = 0; d <= depth; d++, wave++) {
+        const int b = wave & 1;
         if (!Trace(accel, d_rays, n, d_hits, d_mask, stream)) {
           fprintf(stderr, "TraverseBatchDevice: %s\n", accel.LastBackendError().c_str());
           return 1;
         }
-        hipLaunchKernelGGL(k_shade, grid, block, 0, stream, n, spp, d, depth, d_verts, d_faces, d_rays, d_hits, d_mask, d_paths, d_shadow,
-                           d_contrib, d_image);
-        // shadow rays only ask "is anything in the way?": the opt-in occlusion query (same flags, early exit)
-        if (!accel.OccludedBatchDevice(reinterpret_cast<const nanort::Ray<float> *>(d_shadow), n, d_smask, stream)) return 1;
-        hipLaunchKernelGGL(k_resolve_shadows, grid, block, 0, stream, n, spp, d_smask, d_contrib, d_image);
+        // (k_shade overwrites shadow buffer b: the query that read it two waves ago must have been resolved)
+        if (streams == 2 && wave >= 2) CHECK(hipStreamWaitEvent(stream, ev_resolved[b], 0));
+        hipLaunchKernelGGL(k_shade, grid, block, 0, stream, n, spp, d, depth, d_verts, d_faces, d_rays, d_hits, d_mask, d_paths, d_shadow[b],
+                           d_contrib[b], d_image);
+        if (streams == 2) {
+          CHECK(hipEventRecord(ev_shaded[b], stream));
+          CHECK(hipStreamWaitEvent(shadow_stream, ev_shaded[b], 0));
+        }
+        // shadow rays only ask "is anything in the way?": the opt-in occlusion query (same flags, early exit) — on the second
+        // stream it overlaps the next path wave, which the first stream goes on with at once
+        if (!accel.OccludedBatchDevice(reinterpret_cast<const nanort::Ray<float> *>(d_shadow[b]), n, d_smask[b], shadow_stream)) return 1;
+        hipLaunchKernelGGL(k_resolve_shadows, grid, block, 0, shadow_stream, n, spp, d_smask[b], d_contrib[b], shadow_image);
+        if (streams == 2) CHECK(hipEventRecord(ev_resolved[b], shadow_stream));
         rays_traced += 2ull * n;
       }
+    }
+    if (streams == 2) {
+      CHECK(hipStreamSynchronize(stream2));
+      hipLaunchKernelGGL(k_add_images, dim3((3 * n + 255) / 256), block, 0, stream, 3 * n, d_image, d_image2);
     }
     CHECK(hipStreamSynchronize(stream));
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
