@@ -15,12 +15,6 @@ h, m = a.TraverseBatch(rays, opts)
 oh, om = Oracle().traverse(nodes, idx, v, f, rays, opts)
 bad = np.nonzero((m != om) | (h['t'].view(np.uint32 if v.dtype == np.float32 else np.uint64) != oh['t'].view(np.uint32 if v.dtype == np.float32 else np.uint64))
                  | (h['prim_id'] != oh['prim_id']) | (h['u'] != oh['u']) | (h['v'] != oh['v']))[0]
-import ctypes, os
-if int(os.environ.get("NRT_DEBUG", "0")) & 4096:
-    c8 = (ctypes.c_ulonglong * 8)()
-    a._L.nrtDebugCounters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    a._L.nrtDebugCounters(a._h, c8)
-    print("donor rounds %d, given %d, taken %d, delivered %d, settled clean %d, settled flagged %d" % tuple(c8[:6]))
 print("kernel", a.LastKernelName(), "rays", len(rays), "differing", len(bad))
 for i in bad[:12]:
     print(i, "dir", rays[i]['dir'], "gpu", m[i], h[i], "oracle", om[i], oh[i])
