@@ -317,7 +317,9 @@ NRT_API float nrtLastBuildMs(nrt_ctx *ctx);
  * (first block started -> last wave finished), and whatever must wait for launches in flight (nrtBuild / nrtSetMesh /
  * nrtSetTree / nrtDestroy, a fifth stream launching concurrently on one context) waits for exactly those launches by polling
  * their records.  on = 1 brackets every launch with a pair of timing events and follows it with a completion event instead
- * (nrtLastTraverseMs then reports the event time, dispatch included) — a cross-check, not the fast path.  (For the sphere
+ * (nrtLastTraverseMs then reports the event time, dispatch included) — a cross-check, not the fast path.  A launch made while
+ * its stream is being CAPTURED into a graph does not run, so its record never completes: capture traversal launches only on
+ * contexts that are not rebuilt or destroyed before the graph has been launched and has finished (or use on = 1 while capturing).  (For the sphere
  * and cylinder kinds the record is closed by their post pass; the literal BVHNode kernel always uses events.)
  * (No reference counterpart.) */
 NRT_API nrt_status nrtSetLaunchTiming(nrt_ctx *ctx, int on);
