@@ -64,6 +64,9 @@ static_assert(kHandoff <= kSmall && kHandoff >= 64, "hand-off size");
 #ifndef NRT_SUBTREE_REC_LDS
 #define NRT_SUBTREE_REC_LDS 0 // 1: k_subtree copies its node's primitive records into LDS (10 KB per wave: 10 waves per CU instead of 22; measured slower, profiles/r02j_build_subtree_ab.txt)
 #endif
+#ifndef NRT_BIN_PRELOAD
+#define NRT_BIN_PRELOAD 1 // k_bin requests a lane's records together instead of one by one (profiles/r03D_build_variants.txt: 10M-triangle build 14.5 -> 11.3 ms, 1M unchanged)
+#endif
 #ifndef NRT_BUILD_TILE
 #define NRT_BUILD_TILE 2048
 #endif
@@ -1012,10 +1015,15 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
     uint32_t pc[3] = {0, 0, 0};
     U pmin[3][3], pmax[3][3];
     const uint32_t p0 = begin + threadIdx.x * kPerLane;
-    for (uint32_t it = 0; it < kPerLane; it++) { // (requesting record it + 1 before binning record it was measured: slower, the LDS atomics are the bound)
-      const uint32_t p = p0 + it;
-      if (p >= end) break;
-      const PrimRec<T> r = recs[p];
+    auto flush = [&](int k) {
+      atomicAdd(&s_cnt[k][pb[k]], pc[k]);
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        atomicMin(&s_min[k][pb[k]][d], pmin[k][d]);
+        atomicMax(&s_max[k][pb[k]][d], pmax[k][d]);
+      }
+    };
+    auto bin_rec = [&](const PrimRec<T> &r) {
       U emin[3], emax[3];
 #pragma unroll
       for (int d = 0; d < 3; d++) {
@@ -1033,14 +1041,7 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
             pmax[k][d] = emax[d] > pmax[k][d] ? emax[d] : pmax[k][d];
           }
         } else {
-          if (pb[k] >= 0) {
-            atomicAdd(&s_cnt[k][pb[k]], pc[k]);
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-              atomicMin(&s_min[k][pb[k]][d], pmin[k][d]);
-              atomicMax(&s_max[k][pb[k]][d], pmax[k][d]);
-            }
-          }
+          if (pb[k] >= 0) flush(k);
           pb[k] = b;
           pc[k] = 1;
 #pragma unroll
@@ -1050,18 +1051,32 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
           }
         }
       }
-    }
+    };
+#if NRT_BIN_PRELOAD
+    // The lane's records are requested together, kHold at a time, before the first of them is binned: a chunk is about all
+    // the work a CU gets at the top levels (two blocks per CU), so a load issued right before its use is an exposed round
+    // trip — eight of them per lane where this pays one (fp64: two).
+    constexpr uint32_t kHold = sizeof(T) == 4 ? (kPerLane < 8u ? kPerLane : 8u) : (kPerLane < 4u ? kPerLane : 4u);
+    static_assert(kPerLane % kHold == 0, "k_bin: whole batches");
+    for (uint32_t h0 = 0; h0 < kPerLane; h0 += kHold) {
+      PrimRec<T> rr[kHold];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      if (pb[k] >= 0) {
-        atomicAdd(&s_cnt[k][pb[k]], pc[k]);
+      for (uint32_t q = 0; q < kHold; q++)
+        if (p0 + h0 + q < end) rr[q] = recs[p0 + h0 + q];
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-          atomicMin(&s_min[k][pb[k]][d], pmin[k][d]);
-          atomicMax(&s_max[k][pb[k]][d], pmax[k][d]);
-        }
-      }
+      for (uint32_t q = 0; q < kHold; q++)
+        if (p0 + h0 + q < end) bin_rec(rr[q]);
     }
+#else
+    for (uint32_t it = 0; it < kPerLane; it++) {
+      const uint32_t p = p0 + it;
+      if (p >= end) break;
+      bin_rec(recs[p]);
+    }
+#endif
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      if (pb[k] >= 0) flush(k);
   }
   __syncthreads();
   if (whole_node) { // the node's complete bins are in LDS: split it here (k_split skips it)
