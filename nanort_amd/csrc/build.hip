@@ -64,6 +64,9 @@ static_assert(kHandoff <= kSmall && kHandoff >= 64, "hand-off size");
 #ifndef NRT_SUBTREE_REC_LDS
 #define NRT_SUBTREE_REC_LDS 0 // 1: k_subtree copies its node's primitive records into LDS (10 KB per wave: 10 waves per CU instead of 22; measured slower, profiles/r02j_build_subtree_ab.txt)
 #endif
+#ifndef NRT_SUBTREE_ROWS
+#define NRT_SUBTREE_ROWS 1 // subtree phase: k_subtree_rows (up to four nodes per step, one per 16-lane row) instead of k_subtree (one node per step)
+#endif
 #ifndef NRT_BIN_PRELOAD
 #define NRT_BIN_PRELOAD 1 // k_bin requests a lane's records together instead of one by one (profiles/r03D_build_variants.txt: 10M-triangle build 14.5 -> 11.3 ms, 1M unchanged)
 #endif
@@ -1786,6 +1789,515 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
 #undef NRT_SUB_REC
 
 // ---------------------------------------------------------------------------
+// subtree phase, row form: up to four nodes of a subtree per step, one per 16-lane row
+// ---------------------------------------------------------------------------
+// k_subtree above spends about 700 wave instructions on an inner node whatever its size, and three quarters of a
+// subtree's inner nodes hold 16 primitives or fewer (5 to 16 of 64 lanes busy).  This form keeps the nodes that wait to be
+// split on an LDS stack and takes up to FOUR of them per step, one per 16-lane DPP row: lane == primitive for the binning
+// and the partition (16 at a time), lane == bin for the cut search (the three axes one after the other, the 16-lane
+// prefix / suffix scans are the ones k_subtree uses), the winner's data is handed to its row by ds_bpermute.  With one or
+// two nodes on the stack (the first steps of a subtree, where the nodes are large) a node gets 64 or 32 lanes instead.
+// Every decision is the one k_subtree takes — same bins, cost expression, tie rule (lowest axis, then lowest bin), leaf
+// rule and object-median fallback (including k_subtree's stack-depth guard, whose depth every node carries along) — and
+// min / max / counts do not depend on the order they are combined in, so the tree is the same.  Nodes are created in
+// step order, not in pre-order: they are written to the scratch array under their creation index (children c, c + 1
+// with c odd) and the wave finishes by computing each node's pre-order index from the parent links (subtree sizes by
+// walking up, then the index as the sum over the path to the root), which k_emit_small applies when it splices the
+// subtree into the tree (premap).
+struct RowEntry {
+  uint16_t lo, hi; // range in the permutation
+  uint16_t me;     // creation index of the node
+  uint8_t ldepth;  // depth below the subtree's root
+  uint8_t misc;    // bit 7: permutation buffer holding [lo, hi); bits 0..5: k_subtree's stack depth at this node
+};
+static_assert(sizeof(RowEntry) == 8, "RowEntry");
+constexpr int kRowStack = kHandoff / 2; // pending nodes are disjoint ranges of at least 2 primitives
+
+template <typename U>
+__device__ __forceinline__ U row_allmin(U x) { // every lane of a 16-lane row gets the row's minimum
+  x = umin_(x, dpp_mov<0xB1>((U) ~(U)0, x));
+  x = umin_(x, dpp_mov<0x4E>((U) ~(U)0, x));
+  x = umin_(x, dpp_mov<0x141>((U) ~(U)0, x));
+  x = umin_(x, dpp_mov<0x140>((U) ~(U)0, x));
+  return x;
+}
+template <typename U>
+__device__ __forceinline__ U row_allmax(U x) {
+  x = umax_(x, dpp_mov<0xB1>((U)0, x));
+  x = umax_(x, dpp_mov<0x4E>((U)0, x));
+  x = umax_(x, dpp_mov<0x141>((U)0, x));
+  x = umax_(x, dpp_mov<0x140>((U)0, x));
+  return x;
+}
+// (groups of 16, 32 or 64 lanes: shift = 4, 5, 6 — wave-uniform)
+template <typename U>
+__device__ __forceinline__ U group_allmin(U x, uint32_t shift) {
+  x = row_allmin<U>(x);
+  if (shift >= 5u) x = umin_(x, (U)__shfl_xor(x, 16));
+  if (shift >= 6u) x = umin_(x, (U)__shfl_xor(x, 32));
+  return x;
+}
+template <typename U>
+__device__ __forceinline__ U group_allmax(U x, uint32_t shift) {
+  x = row_allmax<U>(x);
+  if (shift >= 5u) x = umax_(x, (U)__shfl_xor(x, 16));
+  if (shift >= 6u) x = umax_(x, (U)__shfl_xor(x, 32));
+  return x;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_subtree_rows(TopNode<T> *top, const uint32_t *__restrict__ small_list,
+                                                     const PrimRec<T> *__restrict__ recs0,
+                                                     const PrimRec<T> *__restrict__ recs1, int K, uint32_t min_leaf,
+                                                     uint32_t max_depth, typename Wire<T>::Node *scratch_nodes,
+                                                     uint16_t *premap, uint32_t *indices, LevelInfo *info) {
+  typedef typename Wire<T>::Node Node;
+  typedef typename Ord<T>::U U;
+  __shared__ uint16_t s_perm[2][kHandoff];
+  __shared__ RowEntry s_stack[kRowStack];
+  __shared__ uint16_t s_parent[2 * kHandoff];
+  __shared__ uint32_t s_cnt[4][3][kSmallBins];
+  __shared__ U s_bmin[4][3][kSmallBins][3]; // (after the last step: the nodes' subtree sizes, 2 * kHandoff uint32)
+  __shared__ U s_bmax[4][3][kSmallBins][3];
+  static_assert(sizeof(U) * 4 * 3 * kSmallBins * 3 >= sizeof(uint32_t) * 2 * kHandoff, "sizes fit the bins");
+
+  const unsigned lane = threadIdx.x;
+  if (blockIdx.x >= info->num_small) return; // grid is an upper bound
+  TopNode<T> &task = top[small_list[blockIdx.x]];
+  const uint32_t L = task.l, n_all = task.r - task.l;
+  const PrimRec<T> *src = (task.buf ? recs1 : recs0) + L;
+  Node *out = scratch_nodes + 2 * (size_t)L;
+  uint16_t *map = premap + 2 * (size_t)L;
+  const uint32_t leaf_max = min_leaf > 1u ? min_leaf : 1u;
+  const uint32_t depth0 = task.depth;
+
+  if (n_all <= leaf_max || depth0 >= max_depth) { // the task is a leaf (nanort.h:1781-1783)
+    for (uint32_t i = lane; i < n_all; i += 64u) indices[L + i] = src[i].prim;
+    if (lane == 0) {
+      Node nd;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        nd.bmin[d] = task.bmin[d];
+        nd.bmax[d] = task.bmax[d];
+      }
+      nd.flag = 1;
+      nd.axis = 0;
+      nd.data[0] = n_all;
+      nd.data[1] = L;
+      out[0] = nd;
+      map[0] = 0;
+      task.size = 1;
+      atomicAdd(&info->num_leaves, 1u);
+      atomicMax(&info->max_depth, depth0);
+      atomicMax(&info->max_leaf_count, n_all);
+    }
+    return;
+  }
+
+  for (uint32_t i = lane; i < n_all; i += 64u) s_perm[0][i] = (uint16_t)i;
+  for (uint32_t q = lane; q < 4u * 3u * kSmallBins; q += 64u) { // bins start clean and are handed on clean by their readers
+    (&s_cnt[0][0][0])[q] = 0;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      (&s_bmin[0][0][0][0])[3 * q + d] = Ord<T>::highest();
+      (&s_bmax[0][0][0][0])[3 * q + d] = Ord<T>::lowest();
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      out[0].bmin[d] = task.bmin[d];
+      out[0].bmax[d] = task.bmax[d];
+    }
+    RowEntry e;
+    e.lo = 0;
+    e.hi = (uint16_t)n_all;
+    e.me = 0;
+    e.ldepth = 0;
+    e.misc = 0;
+    s_stack[0] = e;
+    s_parent[0] = 0;
+  }
+  uint32_t stack_n = 1, node_count = 1;                // wave-uniform
+  uint32_t leaves = 0, deepest = 0, biggest_leaf = 0;  // kept by the group leaders, combined at the end
+  __syncthreads();
+
+  for (uint32_t step = 0; stack_n > 0; step++) {
+    if (step > 4u * kHandoff) { // cannot happen (every step splits at least one node, a subtree has fewer than kHandoff inner nodes)
+      if (lane == 0) info->error = 1;
+      break;
+    }
+    const uint32_t m = stack_n < 4u ? stack_n : 4u;
+    const uint32_t shift = m == 1u ? 6u : (m == 2u ? 5u : 4u); // lanes per node: 64, 32 or 16
+    const uint32_t G = 1u << shift, g = lane >> shift, lg = lane & (G - 1u), gbase = g << shift;
+    const bool act = g < m;
+    RowEntry e = s_stack[act ? stack_n - 1u - g : 0u];
+    stack_n -= m;
+    const uint32_t lo = act ? e.lo : 0u, hi = act ? e.hi : 0u, n = hi - lo, me = e.me;
+    const uint32_t ldepth = e.ldepth, depth = depth0 + ldepth, pb = e.misc >> 7, vsp = e.misc & 63u;
+    // passes over the node: G primitives at a time; the wave runs the longest group's count
+    const uint32_t my_pass = (n + G - 1u) >> shift;
+    uint32_t npass = (uint32_t)__builtin_amdgcn_readlane((int)my_pass, 0);
+    {
+      const uint32_t p1 = (uint32_t)__builtin_amdgcn_readlane((int)my_pass, 16), p2 = (uint32_t)__builtin_amdgcn_readlane((int)my_pass, 32),
+                     p3 = (uint32_t)__builtin_amdgcn_readlane((int)my_pass, 48);
+      npass = npass > p1 ? npass : p1;
+      npass = npass > p2 ? npass : p2;
+      npass = npass > p3 ? npass : p3;
+      npass = npass < (uint32_t)(kHandoff >> 4) ? npass : (uint32_t)(kHandoff >> 4); // (a range never exceeds the subtree)
+    }
+
+    // ---- this lane's first element stays in registers for every pass; the node's centroid bounds --------------------
+    const uint32_t i0 = lo + lg;
+    const bool have0 = i0 < hi;
+    uint32_t id0 = 0;
+    PrimRec<T> r0;
+    if (have0) {
+      id0 = s_perm[pb][i0];
+      r0 = src[id0];
+    }
+    T cmn[3], cmx[3];
+    if (step == 0) { // the subtree's root: reduced by the top phase
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        cmn[k] = task.cmin[k];
+        cmx[k] = task.cmax[k];
+      }
+    } else {
+      U emn[3], emx[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        emn[k] = have0 ? Ord<T>::enc(r0.c[k]) : Ord<T>::highest();
+        emx[k] = have0 ? Ord<T>::enc(r0.c[k]) : Ord<T>::lowest();
+      }
+      for (uint32_t pass = 1; pass < npass; pass++) {
+        const uint32_t i = i0 + (pass << shift);
+        if (i < hi) {
+          const PrimRec<T> &r = src[s_perm[pb][i]];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const U ec = Ord<T>::enc(r.c[k]);
+            emn[k] = umin_(emn[k], ec);
+            emx[k] = umax_(emx[k], ec);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        cmn[k] = Ord<T>::dec(group_allmin<U>(emn[k], shift));
+        cmx[k] = Ord<T>::dec(group_allmax<U>(emx[k], shift));
+      }
+    }
+
+    // ---- LDS bin reduction into the group's bins ---------------------------------------------------------------------
+    T sc[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) sc[k] = bin_scale<T>(cmn[k], cmx[k], K);
+    for (uint32_t pass = 0; pass < npass; pass++) {
+      const uint32_t i = i0 + (pass << shift);
+      if (i < hi) {
+        PrimRec<T> r = r0;
+        if (pass) r = src[s_perm[pb][i]];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const int b = bin_of<T>(r.c[k], cmn[k], sc[k], K);
+          atomicAdd(&s_cnt[g][k][b], 1u);
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            atomicMin(&s_bmin[g][k][b][d], Ord<T>::enc(r.bmin[d]));
+            atomicMax(&s_bmax[g][k][b][d], Ord<T>::enc(r.bmax[d]));
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- cut search: the first 16 lanes of the group, lane == bin, one axis after the other ---------------------------
+    T best_cost = Lim<T>::inf();
+    int axis = 0;
+    uint32_t split_bin = kMedian, nleft = n >> 1;
+    T cl[3], ch[3], rl[3], rh[3]; // children AABBs
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      cl[d] = rl[d] = Lim<T>::max();
+      ch[d] = rh[d] = -Lim<T>::max();
+    }
+    const bool bin_lane = act && lg < (uint32_t)K && lg < 16u;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      uint32_t cnt = 0;
+      U pmn[3], pmx[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        pmn[d] = Ord<T>::highest();
+        pmx[d] = Ord<T>::lowest();
+      }
+      if (bin_lane) {
+        cnt = s_cnt[g][k][lg];
+        if (cnt) {
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            pmn[d] = s_bmin[g][k][lg][d];
+            pmx[d] = s_bmax[g][k][lg][d];
+          }
+          s_cnt[g][k][lg] = 0; // read: hand the bin on clean (made visible by the barrier that ends the step)
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            s_bmin[g][k][lg][d] = Ord<T>::highest();
+            s_bmax[g][k][lg][d] = Ord<T>::lowest();
+          }
+        }
+      }
+      uint32_t pc = cnt, sc_n = cnt; // inclusive prefix / suffix inside the 16-lane row (DPP row shifts)
+      U smn[3] = {pmn[0], pmn[1], pmn[2]}, smx[3] = {pmx[0], pmx[1], pmx[2]};
+      row_prefix_e<T>(pc, pmn, pmx);
+      row_suffix_e<T>(sc_n, smn, smx);
+      // candidate s = bin, s in 1..K-1: low side = bins [0, s), high side = bins [s, K)
+      const uint32_t nl = dpp_mov<0x111>(0u, pc);
+      U lmn[3], lmx[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        lmn[d] = dpp_mov<0x111>(Ord<T>::highest(), pmn[d]);
+        lmx[d] = dpp_mov<0x111>(Ord<T>::lowest(), pmx[d]);
+      }
+      T cost = Lim<T>::inf();
+      if (bin_lane && lg >= 1u && nl > 0 && sc_n > 0) {
+        T a0[3], a1[3], b0[3], b1[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          a0[d] = Ord<T>::dec(lmn[d]);
+          a1[d] = Ord<T>::dec(lmx[d]);
+          b0[d] = Ord<T>::dec(smn[d]);
+          b1[d] = Ord<T>::dec(smx[d]);
+        }
+        cost = T(nl) * half_area<T>(a0, a1) + T(sc_n) * half_area<T>(b0, b1);
+      }
+      if (!(cost == cost)) cost = Lim<T>::inf(); // a NaN cost never wins
+      const U ecost = Ord<T>::enc(cost);
+      const U rbest = row_allmin<U>(ecost);
+      const unsigned long long hit = __ballot(ecost == rbest);
+      // the group's first row holds its candidates: the row's best, ties -> lowest bin
+      const U gbest = (U)__shfl(rbest, (int)gbase);
+      const uint32_t who = (uint32_t)__builtin_ctz(((uint32_t)(hit >> gbase) & 0xFFFFu) | 0x10000u);
+      const int from = (int)(gbase + (who & 15u));
+      const uint32_t w_nl = (uint32_t)__shfl(nl, from);
+      U w_lmn[3], w_lmx[3], w_smn[3], w_smx[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        w_lmn[d] = (U)__shfl(lmn[d], from);
+        w_lmx[d] = (U)__shfl(lmx[d], from);
+        w_smn[d] = (U)__shfl(smn[d], from);
+        w_smx[d] = (U)__shfl(smx[d], from);
+      }
+      const T c = Ord<T>::dec(gbest);
+      if (c < best_cost) { // ties -> lowest axis
+        best_cost = c;
+        axis = k;
+        split_bin = who;
+        nleft = w_nl;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          cl[d] = Ord<T>::dec(w_lmn[d]);
+          ch[d] = Ord<T>::dec(w_lmx[d]);
+          rl[d] = Ord<T>::dec(w_smn[d]);
+          rh[d] = Ord<T>::dec(w_smx[d]);
+        }
+      }
+    }
+    // a pathological chain of lopsided SAH splits is cut off as in k_subtree: past kSubStackSafe pending nodes (there),
+    // balanced object-median splits
+    if (!(best_cost < Lim<T>::inf()) || vsp >= (uint32_t)kSubStackSafe) {
+      axis = 0;
+      split_bin = kMedian;
+      nleft = n >> 1;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        cl[d] = rl[d] = Lim<T>::max();
+        ch[d] = rh[d] = -Lim<T>::max();
+      }
+    }
+    const bool median = split_bin == kMedian;
+    const bool low_leaf = nleft <= leaf_max || depth + 1u >= max_depth, high_leaf = n - nleft <= leaf_max || depth + 1u >= max_depth;
+
+    // ---- stable partition of s_perm[pb][lo, hi) into s_perm[1 - pb] ---------------------------------------------------
+    {
+      const T clo = axis == 0 ? cmn[0] : (axis == 1 ? cmn[1] : cmn[2]);
+      const T scl = axis == 0 ? sc[0] : (axis == 1 ? sc[1] : sc[2]);
+      const unsigned long long gmask = (G == 64u ? ~0ull : ((1ull << G) - 1ull)), lt = (1ull << lg) - 1ull;
+      const bool any_median = __ballot(act && median) != 0ull;
+      uint32_t run_l = 0, run_r = 0;
+      for (uint32_t pass = 0; pass < npass; pass++) {
+        const uint32_t i = i0 + (pass << shift);
+        const bool valid = i < hi;
+        uint32_t id = id0;
+        PrimRec<T> r = r0;
+        if (valid && pass) {
+          id = s_perm[pb][i];
+          r = src[id];
+        }
+        bool left = false;
+        if (valid) {
+          if (median) {
+            left = (i - lo) < nleft;
+          } else {
+            const T c = axis == 0 ? r.c[0] : (axis == 1 ? r.c[1] : r.c[2]);
+            left = (uint32_t)bin_of<T>(c, clo, scl, K) < split_bin;
+          }
+        }
+        const unsigned long long bl = (__ballot(valid && left) >> gbase) & gmask, br = (__ballot(valid && !left) >> gbase) & gmask;
+        if (valid) {
+          const uint32_t d = left ? lo + run_l + (uint32_t)__builtin_popcountll(bl & lt)
+                                  : lo + nleft + run_r + (uint32_t)__builtin_popcountll(br & lt);
+          s_perm[1u - pb][d] = (uint16_t)id;
+          if (left ? low_leaf : high_leaf) indices[L + d] = r.prim; // index slots of the leaves emitted below, in partition order
+          if (median) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+              if (left) {
+                cl[k] = tmin(cl[k], r.bmin[k]);
+                ch[k] = tmax(ch[k], r.bmax[k]);
+              } else {
+                rl[k] = tmin(rl[k], r.bmin[k]);
+                rh[k] = tmax(rh[k], r.bmax[k]);
+              }
+            }
+          }
+        }
+        run_l += (uint32_t)__builtin_popcountll(bl);
+        run_r += (uint32_t)__builtin_popcountll(br);
+      }
+      if (any_median) { // (uniform: the reductions run for every group, only the median ones keep the result)
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          const T a = Ord<T>::dec(group_allmin<U>(Ord<T>::enc(cl[d]), shift)), b = Ord<T>::dec(group_allmax<U>(Ord<T>::enc(ch[d]), shift));
+          const T c = Ord<T>::dec(group_allmin<U>(Ord<T>::enc(rl[d]), shift)), e2 = Ord<T>::dec(group_allmax<U>(Ord<T>::enc(rh[d]), shift));
+          if (median) {
+            cl[d] = a;
+            ch[d] = b;
+            rl[d] = c;
+            rh[d] = e2;
+          }
+        }
+      }
+    }
+
+    // ---- the group's first lane writes the node and its children -----------------------------------------------------
+    {
+      const bool lead = act && lg == 0u;
+      const unsigned long long push_l = __ballot(lead && !low_leaf), push_h = __ballot(lead && !high_leaf);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (lead) {
+        const uint32_t c0 = node_count + 2u * g;
+        out[me].flag = 0;
+        out[me].axis = axis;
+        out[me].data[0] = c0;
+        out[me].data[1] = c0 + 1u;
+        s_parent[c0] = (uint16_t)me;
+        s_parent[c0 + 1u] = (uint16_t)me;
+        uint32_t slot = stack_n + (uint32_t)__builtin_popcountll(push_l & below) + (uint32_t)__builtin_popcountll(push_h & below);
+        Node lf;
+        lf.flag = 1;
+        lf.axis = 0;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          lf.bmin[d] = cl[d];
+          lf.bmax[d] = ch[d];
+        }
+        lf.data[0] = nleft;
+        lf.data[1] = L + lo;
+        if (low_leaf) {
+          out[c0] = lf;
+        } else {
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            out[c0].bmin[d] = cl[d];
+            out[c0].bmax[d] = ch[d];
+          }
+          RowEntry ne;
+          ne.lo = (uint16_t)lo;
+          ne.hi = (uint16_t)(lo + nleft);
+          ne.me = (uint16_t)c0;
+          ne.ldepth = (uint8_t)(ldepth + 1u);
+          ne.misc = (uint8_t)(((1u - pb) << 7) | (vsp + 1u)); // k_subtree descends into the low side with the high side pending
+          s_stack[slot++] = ne;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          lf.bmin[d] = rl[d];
+          lf.bmax[d] = rh[d];
+        }
+        lf.data[0] = n - nleft;
+        lf.data[1] = L + lo + nleft;
+        if (high_leaf) {
+          out[c0 + 1u] = lf;
+        } else {
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            out[c0 + 1u].bmin[d] = rl[d];
+            out[c0 + 1u].bmax[d] = rh[d];
+          }
+          RowEntry ne;
+          ne.lo = (uint16_t)(lo + nleft);
+          ne.hi = (uint16_t)hi;
+          ne.me = (uint16_t)(c0 + 1u);
+          ne.ldepth = (uint8_t)(ldepth + 1u);
+          ne.misc = (uint8_t)(((1u - pb) << 7) | vsp);
+          s_stack[slot] = ne;
+        }
+        if (low_leaf || high_leaf) {
+          leaves += (low_leaf ? 1u : 0u) + (high_leaf ? 1u : 0u);
+          deepest = depth + 1u > deepest ? depth + 1u : deepest;
+          const uint32_t big = (low_leaf ? nleft : 0u) > (high_leaf ? n - nleft : 0u) ? (low_leaf ? nleft : 0u) : (high_leaf ? n - nleft : 0u);
+          biggest_leaf = big > biggest_leaf ? big : biggest_leaf;
+        }
+      }
+      stack_n += (uint32_t)__builtin_popcountll(push_l) + (uint32_t)__builtin_popcountll(push_h);
+      node_count += 2u * m;
+    }
+    __syncthreads(); // the permutation, the reset bins, the stack and the parent links are visible to the next step
+  }
+
+  // ---- pre-order index of every node from the parent links ------------------------------------------------------------
+  uint32_t *s_size = reinterpret_cast<uint32_t *>(&s_bmin[0][0][0][0]);
+  const uint32_t N = node_count;
+  for (uint32_t x = lane; x < N; x += 64u) s_size[x] = 1u;
+  __syncthreads();
+  for (uint32_t x = lane; x < N; x += 64u) {
+    if (x == 0u) continue;
+    uint32_t p = s_parent[x];
+    for (uint32_t it = 0; it < 2u * kHandoff; it++) { // every ancestor counts this node
+      atomicAdd(&s_size[p], 1u);
+      if (p == 0u) break;
+      p = s_parent[p];
+    }
+  }
+  __syncthreads();
+  for (uint32_t x = lane; x < N; x += 64u) {
+    // pre-order: a low-side child (odd creation index) follows its parent, a high-side child follows the low side's subtree
+    uint32_t acc = 0, y = x;
+    for (uint32_t it = 0; it < 2u * kHandoff && y != 0u; it++) {
+      acc += 1u + ((y & 1u) ? 0u : s_size[y - 1u]);
+      y = s_parent[y];
+    }
+    map[x] = (uint16_t)acc;
+  }
+  // stats: the leaders' partial values
+  for (int off = 32; off > 0; off >>= 1) {
+    leaves += __shfl_xor(leaves, off);
+    const uint32_t dd = __shfl_xor(deepest, off), bb = __shfl_xor(biggest_leaf, off);
+    deepest = dd > deepest ? dd : deepest;
+    biggest_leaf = bb > biggest_leaf ? bb : biggest_leaf;
+  }
+  if (lane == 0) {
+    task.size = N;
+    atomicAdd(&info->num_leaves, leaves);
+    atomicAdd(&info->num_branches, N - leaves);
+    atomicMax(&info->max_depth, deepest);
+    atomicMax(&info->max_leaf_count, biggest_leaf);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // relayout: sizes bottom-up, DFS pre-order top-down (single block over the
 // small top array), then emission / splice
 // ---------------------------------------------------------------------------
@@ -1959,10 +2471,22 @@ template <typename T>
 __global__ __launch_bounds__(64) void k_emit_small(const TopNode<T> *__restrict__ top,
                                                    const uint32_t *__restrict__ small_list,
                                                    const typename Wire<T>::Node *__restrict__ scratch_nodes,
-                                                   typename Wire<T>::Node *nodes, const LevelInfo *info) {
+                                                   const uint16_t *__restrict__ premap, typename Wire<T>::Node *nodes,
+                                                   const LevelInfo *info) {
   if (blockIdx.x >= info->num_small) return;
   const TopNode<T> &t = top[small_list[blockIdx.x]];
   const typename Wire<T>::Node *src = scratch_nodes + 2 * (size_t)t.l;
+#if NRT_SUBTREE_ROWS
+  const uint16_t *map = premap + 2 * (size_t)t.l; // creation index -> pre-order index inside the subtree (k_subtree_rows)
+  for (uint32_t i = threadIdx.x; i < t.size; i += 64u) {
+    typename Wire<T>::Node nd = src[i];
+    if (nd.flag == 0) {
+      nd.data[0] = t.dfs + map[nd.data[0]];
+      nd.data[1] = t.dfs + map[nd.data[1]];
+    }
+    nodes[t.dfs + map[i]] = nd;
+  }
+#else
   for (uint32_t i = threadIdx.x; i < t.size; i += 64u) {
     typename Wire<T>::Node nd = src[i];
     if (nd.flag == 0) {
@@ -1971,6 +2495,7 @@ __global__ __launch_bounds__(64) void k_emit_small(const TopNode<T> *__restrict_
     }
     nodes[t.dfs + i] = nd;
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1982,7 +2507,7 @@ template <typename T>
 struct BuildPlan { // carve-up of the build workspace for n primitives
   size_t max_top, max_active, max_chunks;
   size_t off_recs0, off_recs1, off_scratch, off_top, off_child_acc, off_active, off_chunk_base, off_gbins,
-      off_chunk_hist, off_chunk_left, off_small, off_scene, off_info, off_sort, sort_blocks, total;
+      off_chunk_hist, off_chunk_left, off_small, off_scene, off_info, off_sort, off_premap, sort_blocks, total;
   BuildPlan(uint32_t n, size_t top_scale, bool tiny_top = false) {
     typedef typename Wire<T>::Node Node;
     max_active = (size_t)n / kHandoff + 2;
@@ -1998,6 +2523,7 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
     off_recs0 = take((size_t)n * sizeof(PrimRec<T>));
     off_recs1 = take((size_t)n * sizeof(PrimRec<T>));
     off_scratch = take(2 * (size_t)n * sizeof(Node));
+    off_premap = take(2 * (size_t)n * sizeof(uint16_t));
     off_top = take(max_top * sizeof(TopNode<T>));
     off_child_acc = take(2 * max_active * sizeof(BoundsAcc<T>));
     off_active = take(max_active * sizeof(uint32_t));
@@ -2054,6 +2580,7 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     char *base = (char *)workspace->p;
     PrimRec<T> *recs[2] = {(PrimRec<T> *)(base + plan.off_recs0), (PrimRec<T> *)(base + plan.off_recs1)};
     Node *scratch = (Node *)(base + plan.off_scratch);
+    uint16_t *premap = (uint16_t *)(base + plan.off_premap);
     TopNode<T> *top = (TopNode<T> *)(base + plan.off_top);
     BoundsAcc<T> *child_acc = (BoundsAcc<T> *)(base + plan.off_child_acc);
     uint32_t *active = (uint32_t *)(base + plan.off_active);
@@ -2144,8 +2671,13 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
 
     // ---- subtree phase + relayout + emission ---------------------------------------------------------
     if (num_small) {
+#if NRT_SUBTREE_ROWS
+      hipLaunchKernelGGL((k_subtree_rows<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
+                         min_leaf, max_depth, scratch, premap, indices, info);
+#else
       hipLaunchKernelGGL((k_subtree<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
                          min_leaf, max_depth, scratch, indices, info);
+#endif
     }
     BCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_layout<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)(2 * kLayoutLds * sizeof(uint32_t)))); // (per device: set on every build, it costs nothing)
@@ -2163,7 +2695,7 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     hipLaunchKernelGGL((k_emit_top<T>), dim3((unsigned)((plan.max_top + 255) / 256)), dim3(256), 0, s, top, info, recs[0], recs[1],
                        nodes, indices);
     if (num_small)
-      hipLaunchKernelGGL((k_emit_small<T>), dim3(num_small), dim3(64), 0, s, top, small_list, scratch, nodes, info);
+      hipLaunchKernelGGL((k_emit_small<T>), dim3(num_small), dim3(64), 0, s, top, small_list, scratch, premap, nodes, info);
     BCHK(hipGetLastError());
     return hipSuccess;
   }
