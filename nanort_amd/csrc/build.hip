@@ -911,6 +911,21 @@ __device__ __forceinline__ uint32_t find_task(const uint32_t *chunk_base, uint32
   return lo;
 }
 
+// The same search by one full wave, 64 probes per round (two rounds up to 4096 active nodes, where the binary search is a
+// chain of twelve dependent loads at the head of every k_bin / k_partition block).
+__device__ __forceinline__ uint32_t find_task_wave(const uint32_t *chunk_base, uint32_t num_active, uint32_t chunk, unsigned lane) {
+  uint32_t lo = 0, hi = num_active; // chunk_base[lo] <= chunk, and (hi == num_active or chunk_base[hi] > chunk)
+  while (hi - lo > 1) {
+    const uint32_t step = (hi - lo + 63u) >> 6;
+    const uint32_t idx = lo + lane * step;
+    const bool ok = idx < hi && chunk_base[idx] <= chunk; // true for a prefix of the lanes (lane 0 included)
+    const uint32_t j = (uint32_t)__builtin_popcountll(__ballot(ok)) - 1u;
+    lo += j * step;
+    hi = hi < lo + step ? hi : lo + step;
+  }
+  return lo;
+}
+
 // The cut search of one node by one full wave, lane == bin: prefix (left) and suffix (right) sweeps of count and AABB,
 // cost = nL*SA(L) + nR*SA(R) as in FindCutFromBinBuffer (nanort.h:1393-1422), argmin over 3 x (K-1) candidates (ties:
 // lowest axis, then lowest bin).  cnt3 / mn3 / mx3: this lane's bin of each axis (integer images; an empty bin's bounds
@@ -984,7 +999,10 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
   __shared__ U s_max[3][kMaxBins][3];
   __shared__ uint32_t s_task;
   const uint32_t chunk = blockIdx.x;
-  if (threadIdx.x == 0) s_task = find_task(chunk_base, num_active, chunk);
+  if (threadIdx.x < 64u) {
+    const uint32_t t = find_task_wave(chunk_base, num_active, chunk, threadIdx.x);
+    if (threadIdx.x == 0) s_task = t;
+  }
   for (int i = threadIdx.x; i < 3 * kMaxBins; i += 256) {
     const int k = i / kMaxBins, b = i % kMaxBins;
     s_cnt[k][b] = 0;
@@ -1017,7 +1035,9 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
     int pb[3] = {-1, -1, -1};
     uint32_t pc[3] = {0, 0, 0};
     U pmin[3][3], pmax[3][3];
-    const uint32_t p0 = begin + threadIdx.x * kPerLane;
+    // (a partly filled chunk — the usual case a few levels down — is still spread over all 256 lanes: fewer records per lane)
+    const uint32_t per = (end - begin + 255u) >> 8;
+    const uint32_t p0 = begin + threadIdx.x * per;
     auto flush = [&](int k) {
       atomicAdd(&s_cnt[k][pb[k]], pc[k]);
 #pragma unroll
@@ -1061,17 +1081,17 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
     // trip — eight of them per lane where this pays one (fp64: two).
     constexpr uint32_t kHold = sizeof(T) == 4 ? (kPerLane < 8u ? kPerLane : 8u) : (kPerLane < 4u ? kPerLane : 4u);
     static_assert(kPerLane % kHold == 0, "k_bin: whole batches");
-    for (uint32_t h0 = 0; h0 < kPerLane; h0 += kHold) {
+    for (uint32_t h0 = 0; h0 < per; h0 += kHold) {
       PrimRec<T> rr[kHold];
 #pragma unroll
       for (uint32_t q = 0; q < kHold; q++)
-        if (p0 + h0 + q < end) rr[q] = recs[p0 + h0 + q];
+        if (h0 + q < per && p0 + h0 + q < end) rr[q] = recs[p0 + h0 + q];
 #pragma unroll
       for (uint32_t q = 0; q < kHold; q++)
-        if (p0 + h0 + q < end) bin_rec(rr[q]);
+        if (h0 + q < per && p0 + h0 + q < end) bin_rec(rr[q]);
     }
 #else
-    for (uint32_t it = 0; it < kPerLane; it++) {
+    for (uint32_t it = 0; it < per; it++) {
       const uint32_t p = p0 + it;
       if (p >= end) break;
       bin_rec(recs[p]);
@@ -1231,7 +1251,10 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
   const uint32_t chunk = blockIdx.x;
   if (chunk >= info->num_chunks) return; // grids are upper bounds
   const uint32_t num_active = info->num_active;
-  if (tid == 0) s_task = find_task(chunk_base, num_active, chunk);
+  if (tid < 64u) {
+    const uint32_t t = find_task_wave(chunk_base, num_active, chunk, tid);
+    if (tid == 0) s_task = t;
+  }
   if (tid < 24) s_acc[tid / 12][tid % 12] = ((tid % 12) % 6 < 3) ? (U)Ord<T>::highest() : (U)Ord<T>::lowest();
   __syncthreads();
   const uint32_t a = s_task;
@@ -2017,10 +2040,11 @@ __global__ __launch_bounds__(64) void k_subtree_rows(TopNode<T> *top, const uint
     int axis = 0;
     uint32_t split_bin = kMedian, nleft = n >> 1;
     T cl[3], ch[3], rl[3], rh[3]; // children AABBs
+    U ecl[3], ech[3], erl[3], erh[3]; // (their integer images while the axes compete)
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-      cl[d] = rl[d] = Lim<T>::max();
-      ch[d] = rh[d] = -Lim<T>::max();
+      ecl[d] = erl[d] = Ord<T>::enc(Lim<T>::max());
+      ech[d] = erh[d] = Ord<T>::enc(-Lim<T>::max());
     }
     const bool bin_lane = act && lg < (uint32_t)K && lg < 16u;
 #pragma unroll
@@ -2078,31 +2102,41 @@ __global__ __launch_bounds__(64) void k_subtree_rows(TopNode<T> *top, const uint
       const unsigned long long hit = __ballot(ecost == rbest);
       // the group's first row holds its candidates: the row's best, ties -> lowest bin
       const U gbest = (U)__shfl(rbest, (int)gbase);
-      const uint32_t who = (uint32_t)__builtin_ctz(((uint32_t)(hit >> gbase) & 0xFFFFu) | 0x10000u);
-      const int from = (int)(gbase + (who & 15u));
-      const uint32_t w_nl = (uint32_t)__shfl(nl, from);
-      U w_lmn[3], w_lmx[3], w_smn[3], w_smx[3];
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        w_lmn[d] = (U)__shfl(lmn[d], from);
-        w_lmx[d] = (U)__shfl(lmx[d], from);
-        w_smn[d] = (U)__shfl(smn[d], from);
-        w_smx[d] = (U)__shfl(smx[d], from);
-      }
       const T c = Ord<T>::dec(gbest);
-      if (c < best_cost) { // ties -> lowest axis
-        best_cost = c;
-        axis = k;
-        split_bin = who;
-        nleft = w_nl;
+      const bool better = c < best_cost; // ties -> lowest axis
+      if (__ballot(better) != 0ull) {    // (uniform: the winner's data travels only when some group wants it)
+        const uint32_t who = (uint32_t)__builtin_ctz(((uint32_t)(hit >> gbase) & 0xFFFFu) | 0x10000u);
+        const int from = (int)(gbase + (who & 15u));
+        const uint32_t w_nl = (uint32_t)__shfl(nl, from);
+        U w_lmn[3], w_lmx[3], w_smn[3], w_smx[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          cl[d] = Ord<T>::dec(w_lmn[d]);
-          ch[d] = Ord<T>::dec(w_lmx[d]);
-          rl[d] = Ord<T>::dec(w_smn[d]);
-          rh[d] = Ord<T>::dec(w_smx[d]);
+          w_lmn[d] = (U)__shfl(lmn[d], from);
+          w_lmx[d] = (U)__shfl(lmx[d], from);
+          w_smn[d] = (U)__shfl(smn[d], from);
+          w_smx[d] = (U)__shfl(smx[d], from);
+        }
+        if (better) {
+          best_cost = c;
+          axis = k;
+          split_bin = who;
+          nleft = w_nl;
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            ecl[d] = w_lmn[d];
+            ech[d] = w_lmx[d];
+            erl[d] = w_smn[d];
+            erh[d] = w_smx[d];
+          }
         }
       }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      cl[d] = Ord<T>::dec(ecl[d]);
+      ch[d] = Ord<T>::dec(ech[d]);
+      rl[d] = Ord<T>::dec(erl[d]);
+      rh[d] = Ord<T>::dec(erh[d]);
     }
     // a pathological chain of lopsided SAH splits is cut off as in k_subtree: past kSubStackSafe pending nodes (there),
     // balanced object-median splits
@@ -2310,7 +2344,10 @@ __global__ __launch_bounds__(64) void k_subtree_rows(TopNode<T> *top, const uint
 // O(nodes x depth) operations and two barriers instead of two barriers per level.  Small top arrays (the usual case) keep
 // sizes and parents in LDS: one block does everything (k_layout).  Larger ones run the same three steps as grid-wide
 // kernels on the global arrays (k_layout_init / _sizes / _dfs).
-constexpr uint32_t kLayoutLds = 16384; // top arrays up to this many nodes are laid out from LDS (2 x 4 bytes per node, dynamic)
+#ifndef NRT_LAYOUT_LDS
+#define NRT_LAYOUT_LDS 16384
+#endif
+constexpr uint32_t kLayoutLds = NRT_LAYOUT_LDS; // top arrays up to this many nodes are laid out from LDS (2 x 4 bytes per node, dynamic)
 constexpr uint32_t kLayoutOwn = kLayoutLds / 1024;
 template <typename T>
 __device__ __forceinline__ uint32_t layout_contribution(const TopNode<T> &t) { return t.kind == KIND_SMALL ? t.size : 1u; }

@@ -7,7 +7,8 @@ import numpy as np
 sys.path.insert(0, '.')
 if sys.argv[1] == 'run':
     from nanort_amd import BVHAccel, TriangleMesh, scenes
-    v, f = scenes.plane(1000, 500)
+    gx, gy = (int(x) for x in os.environ.get('NRT_TRACE_GRID', '1000x500').split('x'))
+    v, f = scenes.plane(gx, gy)
     a = BVHAccel(np.float32); m = TriangleMesh(v, f)
     for _ in range(4):
         a.Build(m.num_faces, m)
