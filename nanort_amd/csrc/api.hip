@@ -49,7 +49,7 @@ struct BuildResult {
 // (build.hip) enqueues a whole build; its size and statistics arrive in `pinned` behind `ev`: gpu_build_result waits for them
 template <typename T>
 hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, bool cylinders, uint32_t num_faces,
-                     uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, bool morton_order,
+                     uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, unsigned build_flags, // (bit 0: Morton pre-pass, bit 1: one-node-per-step subtree kernel)
                      DevBuf *workspace, DevBuf *nodes_buf, DevBuf *indices_buf, void *pinned, hipEvent_t ev, std::string *err);
 hipError_t gpu_build_result(const void *pinned, hipEvent_t ev, BuildResult *res);
 } // namespace nrt
@@ -130,6 +130,7 @@ struct nrt_ctx {
   unsigned blocks_per_cu = 0, chunk = 128, chunk_tail_pct = 0, refill_min = 44, trav_min = 12, leaf_min = 32; // (trav_min: 8 until round 3; 12-14 is the optimum of the two-level walk, profiles/r03t_trav_min.txt)
   unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
   unsigned debug_flags = 0;
+  int subtree_rows = 1; // builder: subtree phase in row form (up to four nodes per step); 0: one node per step — same tree, the cross-check (tests/test_gpu_build.py)
   int morton = 0; // Morton-order the primitive records before the build (env NRT_MORTON=1): measured +0.4 ms at 1M tris for an identical tree, so off by default
   unsigned static_pct = 75; // share of a batch handed out statically, percent (env NRT_STATIC_PCT)
   unsigned static_bands = 8; // ... as up to this many slices per wave, one in each band of the batch
@@ -267,6 +268,7 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("blocks_per_cu", 0, 8, max_blocks_per_cu, unsigned), // cap on the persistent grid (0: occupancy)
     NRT_TUNABLE("debug", 0, 0x7FFFFFFF, debug_flags, unsigned),   // profiling bit mask
     NRT_TUNABLE("morton", 0, 1, morton, int),                     // Morton pre-pass of the builder (next build)
+    NRT_TUNABLE("subtree_rows", 0, 1, subtree_rows, int),         // 0: the builder's one-node-per-step subtree kernel (next build; same tree)
     NRT_TUNABLE("wide", 0, 1, wide, int),                         // 0: the literal BVHNode loop
     NRT_TUNABLE("wide4", 0, 1, wide4, int),                       // two tree levels per step (next build / set_tree)
     NRT_TUNABLE("launch_timing", 0, 1, launch_timing, int),       // == nrtSetLaunchTiming
@@ -671,7 +673,7 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   std::string err;
   HIPCHK(c, hipEventRecord(c->ev_b0, c->stream));
   hipError_t e = gpu_build<T>(c->stream, (const T *)c->d_verts, c->d_faces, (const T *)c->d_radii, c->prim_kind == kPrimCylinders, c->num_faces, min_leaf, max_depth,
-                              bin_size, c->morton != 0, &c->b_build_ws, &c->b_nodes, &c->b_indices, c->build_state, c->ev_build_state, &err);
+                              bin_size, (c->morton ? 1u : 0u) | (c->subtree_rows ? 0u : 2u), &c->b_build_ws, &c->b_nodes, &c->b_indices, c->build_state, c->ev_build_state, &err);
   if (e != hipSuccess) return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s (%s)", err.c_str(), hipGetErrorString(e));
   // everything is enqueued; the leaf-ordered primitive records need the index array only, so they are enqueued too before
   // the host waits for the tree's size (the GPU stays busy meanwhile)

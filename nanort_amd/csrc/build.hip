@@ -47,6 +47,8 @@
 
 namespace nrt {
 
+enum : unsigned { kBuildMorton = 1u, kBuildSubtreeDfs = 2u }; // gpu_build's build_flags
+
 struct BuildResult {
   uint64_t num_nodes;
   uint32_t max_depth, num_leaves, num_branches, max_leaf_count;
@@ -63,9 +65,6 @@ constexpr int kHandoff = NRT_BUILD_HANDOFF;
 static_assert(kHandoff <= kSmall && kHandoff >= 64, "hand-off size");
 #ifndef NRT_SUBTREE_REC_LDS
 #define NRT_SUBTREE_REC_LDS 0 // 1: k_subtree copies its node's primitive records into LDS (10 KB per wave: 10 waves per CU instead of 22; measured slower, profiles/r02j_build_subtree_ab.txt)
-#endif
-#ifndef NRT_SUBTREE_ROWS
-#define NRT_SUBTREE_ROWS 1 // subtree phase: k_subtree_rows (up to four nodes per step, one per 16-lane row) instead of k_subtree (one node per step)
 #endif
 #ifndef NRT_BIN_PRELOAD
 #define NRT_BIN_PRELOAD 1 // k_bin requests a lane's records together instead of one by one (profiles/r03D_build_variants.txt: 10M-triangle build 14.5 -> 11.3 ms, 1M unchanged)
@@ -2513,18 +2512,19 @@ __global__ __launch_bounds__(64) void k_emit_small(const TopNode<T> *__restrict_
   if (blockIdx.x >= info->num_small) return;
   const TopNode<T> &t = top[small_list[blockIdx.x]];
   const typename Wire<T>::Node *src = scratch_nodes + 2 * (size_t)t.l;
-#if NRT_SUBTREE_ROWS
-  const uint16_t *map = premap + 2 * (size_t)t.l; // creation index -> pre-order index inside the subtree (k_subtree_rows)
-  for (uint32_t i = threadIdx.x; i < t.size; i += 64u) {
-    typename Wire<T>::Node nd = src[i];
-    if (nd.flag == 0) {
-      nd.data[0] = t.dfs + map[nd.data[0]];
-      nd.data[1] = t.dfs + map[nd.data[1]];
+  if (premap) { // creation index -> pre-order index inside the subtree (k_subtree_rows)
+    const uint16_t *map = premap + 2 * (size_t)t.l;
+    for (uint32_t i = threadIdx.x; i < t.size; i += 64u) {
+      typename Wire<T>::Node nd = src[i];
+      if (nd.flag == 0) {
+        nd.data[0] = t.dfs + map[nd.data[0]];
+        nd.data[1] = t.dfs + map[nd.data[1]];
+      }
+      nodes[t.dfs + map[i]] = nd;
     }
-    nodes[t.dfs + map[i]] = nd;
+    return;
   }
-#else
-  for (uint32_t i = threadIdx.x; i < t.size; i += 64u) {
+  for (uint32_t i = threadIdx.x; i < t.size; i += 64u) { // (k_subtree wrote its nodes in pre-order)
     typename Wire<T>::Node nd = src[i];
     if (nd.flag == 0) {
       nd.data[0] += t.dfs;
@@ -2532,7 +2532,6 @@ __global__ __launch_bounds__(64) void k_emit_small(const TopNode<T> *__restrict_
     }
     nodes[t.dfs + i] = nd;
   }
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -2596,9 +2595,10 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
 // gpu_build returns once everything is enqueued; gpu_build_result() waits for the final state block.
 template <typename T>
 hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, bool cylinders, uint32_t n,
-                     uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, bool morton_order, DevBuf *workspace, DevBuf *nodes_buf,
+                     uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, unsigned build_flags, DevBuf *workspace, DevBuf *nodes_buf,
                      DevBuf *indices_buf, void *pinned, hipEvent_t ev, std::string *err) {
   typedef typename Wire<T>::Node Node;
+  const bool morton_order = (build_flags & kBuildMorton) != 0, subtree_rows = (build_flags & kBuildSubtreeDfs) == 0;
   static_assert(offsetof(LevelInfo, level_begin) <= kBuildPinnedBytes, "state block");
   const int K = (int)(bin_size < 2 ? 2 : (bin_size > (uint32_t)kMaxBins ? (uint32_t)kMaxBins : bin_size));
   const int Ks = K < kSmallBins ? K : kSmallBins;
@@ -2708,13 +2708,12 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
 
     // ---- subtree phase + relayout + emission ---------------------------------------------------------
     if (num_small) {
-#if NRT_SUBTREE_ROWS
-      hipLaunchKernelGGL((k_subtree_rows<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
-                         min_leaf, max_depth, scratch, premap, indices, info);
-#else
-      hipLaunchKernelGGL((k_subtree<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
-                         min_leaf, max_depth, scratch, indices, info);
-#endif
+      if (subtree_rows)
+        hipLaunchKernelGGL((k_subtree_rows<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
+                           min_leaf, max_depth, scratch, premap, indices, info);
+      else // (the one-node-per-step form: kept as the cross-check of the row form, tunable subtree_rows = 0)
+        hipLaunchKernelGGL((k_subtree<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
+                           min_leaf, max_depth, scratch, indices, info);
     }
     BCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_layout<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)(2 * kLayoutLds * sizeof(uint32_t)))); // (per device: set on every build, it costs nothing)
@@ -2732,7 +2731,8 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     hipLaunchKernelGGL((k_emit_top<T>), dim3((unsigned)((plan.max_top + 255) / 256)), dim3(256), 0, s, top, info, recs[0], recs[1],
                        nodes, indices);
     if (num_small)
-      hipLaunchKernelGGL((k_emit_small<T>), dim3(num_small), dim3(64), 0, s, top, small_list, scratch, premap, nodes, info);
+      hipLaunchKernelGGL((k_emit_small<T>), dim3(num_small), dim3(64), 0, s, top, small_list, scratch,
+                         subtree_rows ? premap : (uint16_t *)nullptr, nodes, info);
     BCHK(hipGetLastError());
     return hipSuccess;
   }
@@ -2752,8 +2752,8 @@ hipError_t gpu_build_result(const void *pinned, hipEvent_t ev, BuildResult *res)
 }
 
 template hipError_t gpu_build<float>(hipStream_t, const float *, const uint32_t *, const float *, bool, uint32_t, uint32_t,
-                                     uint32_t, uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, void *, hipEvent_t, std::string *);
+                                     uint32_t, uint32_t, unsigned, DevBuf *, DevBuf *, DevBuf *, void *, hipEvent_t, std::string *);
 template hipError_t gpu_build<double>(hipStream_t, const double *, const uint32_t *, const double *, bool, uint32_t, uint32_t,
-                                      uint32_t, uint32_t, bool, DevBuf *, DevBuf *, DevBuf *, void *, hipEvent_t, std::string *);
+                                      uint32_t, uint32_t, unsigned, DevBuf *, DevBuf *, DevBuf *, void *, hipEvent_t, std::string *);
 
 } // namespace nrt

@@ -366,3 +366,76 @@ def test_non_finite_vertices_build_a_walkable_tree(oracle, real, kind):
     assert np.array_equal(m, om)
     for k in ("t", "u", "v", "prim_id"):
         assert np.array_equal(h[k], oh[k], equal_nan=True), k
+
+
+def _two_subtree_kernels(real, v, f, **opt):
+    """The same mesh through the row form of the subtree phase (the default) and the one-node-per-step form."""
+    out = []
+    for rows in (1, 0):
+        a = BVHAccel(real)
+        a.SetTunable("subtree_rows", rows)
+        o = default_build_options(real)
+        for k, val in opt.items():
+            o[k] = val
+        assert a.Build(f.shape[0], TriangleMesh(v, f), o)
+        nodes, idx = a.GetTree()
+        out.append((nodes, idx, a.GetStatistics()))
+        a.close()
+    (n1, i1, s1), (n0, i0, s0) = out
+    assert n1.tobytes() == n0.tobytes(), "the two subtree kernels must emit the same node array"
+    assert np.array_equal(i1, i0)
+    for key in ("max_tree_depth", "num_leaf_nodes", "num_branch_nodes"):
+        assert s1[key] == s0[key], key
+    return n1, i1, s1
+
+
+def _sliver_chain(n, ratio, real):
+    """Tiny triangles whose centroids sit at ratio**i along x: every SAH split peels a handful of primitives off one end, a
+    chain of lopsided splits far deeper than log2(n) inside ONE subtree task — the case the subtree kernels cut off with
+    object-median splits once too many high-side children are pending (kSubStackSafe)."""
+    x = ratio ** np.arange(n, dtype=np.float64)
+    v = np.empty((3 * n, 3), dtype=np.float64)
+    s = 1e-3 * x
+    v[0::3] = np.stack([x, np.zeros(n), np.zeros(n)], 1)
+    v[1::3] = np.stack([x + s, s, np.zeros(n)], 1)
+    v[2::3] = np.stack([x, s, s], 1)
+    f = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    return v.astype(real), f
+
+
+@pytest.mark.parametrize("real,n,ratio,min_leaf", [
+    (np.float64, 256, 0.3, 1), (np.float64, 256, 0.5, 1), (np.float64, 200, 0.2, 2), (np.float32, 100, 0.45, 1),
+    (np.float64, 5000, 0.97, 1),
+])
+def test_the_two_subtree_kernels_agree_on_chains_of_lopsided_splits(real, n, ratio, min_leaf):
+    v, f = _sliver_chain(n, ratio, real)
+    nodes, idx, st = _two_subtree_kernels(real, v, f, min_leaf_primitives=min_leaf)
+    validate_bvh(nodes, idx, v, f, min_leaf=min_leaf, stats=st)
+    if n <= 256 and ratio <= 0.3:
+        assert st["max_tree_depth"] > 36, "the chain must be deep enough to reach the pending-children guard"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_the_two_subtree_kernels_agree_on_random_meshes_and_options(seed):
+    rng = np.random.default_rng(1000 + seed)
+    real = np.float32 if seed % 2 == 0 else np.float64
+    n = int(rng.choice([3, 17, 64, 255, 256, 257, 700, 5000, 40000]))
+    kind = seed % 3
+    if kind == 0:    # soup
+        c = rng.uniform(-1, 1, (n, 1, 3))
+        tri = c + rng.normal(0, 0.03, (n, 3, 3))
+    elif kind == 1:  # clusters of coincident centroids (median splits) next to spread-out ones
+        c = np.repeat(rng.uniform(-1, 1, (max(1, n // 7), 1, 3)), 7, axis=0)[:n]
+        if len(c) < n:
+            c = np.concatenate([c, rng.uniform(-1, 1, (n - len(c), 1, 3))])
+        d = rng.normal(0, 0.02, (n, 3, 3))
+        tri = c + d - d.mean(axis=1, keepdims=True)
+    else:            # flat along one axis, wildly different scales along another
+        c = rng.uniform(-1, 1, (n, 1, 3)) * np.array([1.0, 1e-6, 0.0])
+        tri = c + rng.normal(0, 0.01, (n, 3, 3)) * np.array([1.0, 1e-6, 1.0])
+    v = tri.reshape(-1, 3).astype(real)
+    f = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    opt = dict(min_leaf_primitives=int(rng.choice([1, 2, 4, 7, 16])), bin_size=int(rng.choice([2, 5, 16, 64])),
+               max_tree_depth=int(rng.choice([3, 9, 20, 256])))
+    nodes, idx, st = _two_subtree_kernels(real, v, f, **opt)
+    validate_bvh(nodes, idx, v, f, min_leaf=opt["min_leaf_primitives"], max_depth=opt["max_tree_depth"], stats=st)
