@@ -551,7 +551,7 @@ static nrt_status finish_wide(nrt_ctx *c) {
   const size_t tiles = (c->num_nodes + 1023) / 1024;
   if ((st = ensure(c, c->b_wide_scratch, (tiles + c->num_nodes + 1) * sizeof(uint32_t)))) return st;
   c->d_wide4 = nullptr;
-  if (c->wide4 && sizeof(T) == 4) { // (every primitive kind: the step does not look at the leaves)
+  if (c->wide4 && sizeof(T) == 4 && c->num_branch_records < (1ull << 25)) { // (every primitive kind: the step does not look at the leaves; the walk addresses the records with 32-bit byte offsets: below 4 GiB)
     if ((st = ensure(c, c->b_wide4, std::max<size_t>(1, c->num_branch_records) * sizeof(Wide4Node<T>)))) return st;
     c->d_wide4 = c->b_wide4.p;
   }

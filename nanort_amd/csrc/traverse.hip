@@ -83,8 +83,11 @@ struct Lane {
   T Sy;
   uint32_t prim;
   T Sz;
+  uint32_t so0; // 48 if dir[k] < 0 else 0: byte offset of the ray's NEAR plane row inside a Wide4Node (bmax rows sit 48 bytes after bmin rows)
   T u;
+  uint32_t so1;
   T v;
+  uint32_t so2;
   __device__ __forceinline__ int kx() const { return (int)(pk & 3u); }
   __device__ __forceinline__ int ky() const { return (int)((pk >> 2) & 3u); }
   __device__ __forceinline__ int kz() const { return (int)((pk >> 4) & 3u); }
@@ -135,6 +138,9 @@ __device__ __forceinline__ void lane_init(Lane<T> &L, const typename Wire<T>::Ra
   // Traverse prologue (nanort.h:2505-2516)
   pk |= (d0 < T(0) ? 64u : 0u) | (d1 < T(0) ? 128u : 0u) | (d2 < T(0) ? 256u : 0u);
   L.pk = pk;
+  L.so0 = d0 < T(0) ? 48u : 0u;
+  L.so1 = d1 < T(0) ? 48u : 0u;
+  L.so2 = d2 < T(0) ? 48u : 0u;
   L.inv0 = safe_inverse<T>(d0);
   L.inv1 = safe_inverse<T>(d1);
   L.inv2 = safe_inverse<T>(d2);
@@ -889,6 +895,49 @@ __device__ __forceinline__ Slab4<float> slab4(const Lane<float> &L, const Wide4N
   return r;
 }
 
+// The same four tests with the near / far plane rows fetched straight from where the ray's direction signs say they are
+// (a per-ray byte offset inside the record: Lane::so0..2) instead of fetching both rows of every axis and selecting per
+// value: the same values reach the same arithmetic, 24 selects per step do not.  `rec` = byte offset of the record in the
+// array (32 bits: arrays below 4 GiB).
+struct Wide4Tail { // bytes 96..127 of a Wide4Node<float>
+  uint32_t c[4];
+  int32_t axis0, axis1, axis2;
+  uint32_t pad;
+};
+__device__ __forceinline__ Slab4<float> slab4_presel(const Lane<float> &L, const char *base, uint32_t rec) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f2 mm = {Const<float>::maxmult(), Const<float>::maxmult()};
+  float tmin[4] = {L.min_t, L.min_t, L.min_t, L.min_t}, tmax[4] = {L.hit_t, L.hit_t, L.hit_t, L.hit_t};
+  const uint32_t rec48 = rec + 48u;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const uint32_t so = k == 0 ? L.so0 : (k == 1 ? L.so1 : L.so2);
+    const f4 lo4 = *reinterpret_cast<const f4 *>(base + (size_t)(rec + so) + 16 * k);   // bmin[k][0..3] or bmax[k][0..3]
+    const f4 hi4 = *reinterpret_cast<const f4 *>(base + (size_t)(rec48 - so) + 16 * k); // the other row
+    const f2 o = {L.org(k), L.org(k)};
+    const f2 iv = {L.inv(k), L.inv(k)};
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const f2 lo = {p ? lo4.z : lo4.x, p ? lo4.w : lo4.y};
+      const f2 hi = {p ? hi4.z : hi4.x, p ? hi4.w : hi4.y};
+      const f2 t0 = (lo - o) * iv;
+      const f2 t1 = ((hi - o) * iv) * mm;
+      tmin[2 * p] = Const<float>::fmax(t0.x, tmin[2 * p]); // see slab_test
+      tmin[2 * p + 1] = Const<float>::fmax(t0.y, tmin[2 * p + 1]);
+      tmax[2 * p] = Const<float>::fmin(t1.x, tmax[2 * p]);
+      tmax[2 * p + 1] = Const<float>::fmin(t1.y, tmax[2 * p + 1]);
+    }
+  }
+  Slab4<float> r;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    r.h[j] = tmin[j] <= tmax[j];
+    r.tm[j] = tmin[j];
+  }
+  return r;
+}
+
 __device__ __forceinline__ Slab4<double> slab4(const Lane<double> &L, const Wide4Node<double> &w) {
   Slab4<double> r;
 #pragma unroll
@@ -986,7 +1035,12 @@ do {                                                                            
 // The half of a leaf child has one slot (the other is marked empty and never hit).
 #define NRT_STEP_NODE4(w_)                                                                             \
 do {                                                                                                 \
-  const Slab4<T> sl_ = slab4(L, (w_));                                                               \
+  const Slab4<T> sl4_ = slab4(L, (w_));                                                              \
+  NRT_STEP_NODE4_SL(sl4_, (w_));                                                                     \
+} while (0)
+/* (sl_: the four box tests of the record; w_: anything with c[4], axis0, axis1, axis2) */
+#define NRT_STEP_NODE4_SL(sl_, w_)                                                                     \
+do {                                                                                                 \
   const bool sA_ = L.sign((w_).axis1) != 0, sB_ = L.sign((w_).axis2) != 0, s0_ = L.sign((w_).axis0) != 0; \
   const bool v1_ = (w_).c[1] != kWide4Empty, v3_ = (w_).c[3] != kWide4Empty;                         \
   const bool h0_ = sl_.h[0], h1_ = sl_.h[1] & v1_, h2_ = sl_.h[2], h3_ = sl_.h[3] & v3_;             \
@@ -1032,6 +1086,9 @@ do {                                                                            
 // register pressure and the extra checks, 13 % per step in all: profiles/r02c_split_*.txt, r03g_split_asis.txt) and were
 // removed in round 3.  What a launch waits for at its end is the dependent chain of its few longest rays
 // (tools/drain_probe.py, tools/tail_first_probe.py); DESIGN.md 3.1 and 10 keep the numbers.)
+#ifndef NRT_W4_PRESEL
+#define NRT_W4_PRESEL 1 // fp32 two-level walk: the near / far plane rows are fetched by the ray's signs (slab4_presel) instead of selected per value
+#endif
 #ifndef NRT_W4_TRI_UNROLL
 #define NRT_W4_TRI_UNROLL 2 // triangle records fetched per trip of the leaf loop in the WIDTH = 4 variants (1 or 2)
 #endif
@@ -1190,8 +1247,19 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
       if (state == W_TRAV) {
         if (STATS) st_steps++;
         if constexpr (WIDTH == 4) {
-          const Wide4Node<T> w = a.wide4[cur];
-          NRT_STEP_NODE4(w);
+#if NRT_W4_PRESEL
+          if constexpr (sizeof(T) == 4) {
+            const char *wb_ = reinterpret_cast<const char *>(a.wide4);
+            const uint32_t rec_ = cur << 7; // (api.hip keeps Wide4Node<float> arrays below 4 GiB)
+            const Slab4<float> sl = slab4_presel(L, wb_, rec_);
+            const Wide4Tail w = *reinterpret_cast<const Wide4Tail *>(wb_ + (size_t)rec_ + 96);
+            NRT_STEP_NODE4_SL(sl, w);
+          } else
+#endif
+          {
+            const Wide4Node<T> w = a.wide4[cur];
+            NRT_STEP_NODE4(w);
+          }
         } else {
 #ifdef NRT_PROBE_EXTRA_LOADS // sensitivity probe (tools/variant_ab.sh): N more 16-byte reads of the record about to be fetched
           typedef uint32_t u4v_ __attribute__((ext_vector_type(4)));
