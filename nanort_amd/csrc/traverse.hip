@@ -1054,9 +1054,22 @@ do {                                                                            
   const bool q0_ = s0_ ? bn_ : an_, q1_ = s0_ ? bf_ : af_, q2_ = s0_ ? an_ : bn_, q3_ = s0_ ? af_ : bf_; \
   const uint32_t r0_ = s0_ ? rbn_ : ran_, r1_ = s0_ ? rbf_ : raf_, r2_ = s0_ ? ran_ : rbn_, r3_ = s0_ ? raf_ : rbf_; \
   const T t1_ = s0_ ? tbf_ : taf_, t2_ = s0_ ? tan_ : tbn_, t3_ = s0_ ? taf_ : tbf_;                 \
-  NRT_PUSH_IF(q3_ & (q0_ | q1_ | q2_), r3_, t3_);                                                    \
-  NRT_PUSH_IF(q2_ & (q0_ | q1_), r2_, t2_);                                                          \
-  NRT_PUSH_IF(q1_ & q0_, r1_, t1_);                                                                  \
+  const bool p3_ = q3_ & (q0_ | q1_ | q2_), p2_ = q2_ & (q0_ | q1_), p1_ = q1_ & q0_;                \
+  if (NRT_W4_FAST_PUSH && __ballot(sp > STACK - 3) == 0ull) {                                         \
+    /* every stepping lane has room for three entries in LDS: the candidates are stored unconditionally, in push order, \
+       and the stack pointer moves past the ones that count — three stores and three adds instead of three guarded    \
+       blocks (compare, branch, room check, store, add) that nearly always run because SOME lane needs them */         \
+    s_stack[sp][tid] = SE::make(r3_, t3_);                                                           \
+    sp += p3_ ? 1 : 0;                                                                               \
+    s_stack[sp][tid] = SE::make(r2_, t2_);                                                           \
+    sp += p2_ ? 1 : 0;                                                                               \
+    s_stack[sp][tid] = SE::make(r1_, t1_);                                                           \
+    sp += p1_ ? 1 : 0;                                                                               \
+  } else {                                                                                           \
+    NRT_PUSH_IF(p3_, r3_, t3_);                                                                      \
+    NRT_PUSH_IF(p2_, r2_, t2_);                                                                      \
+    NRT_PUSH_IF(p1_, r1_, t1_);                                                                      \
+  }                                                                                                  \
   const bool any_ = q0_ | q1_ | q2_ | q3_;                                                           \
   const uint32_t next_ = q0_ ? r0_ : (q1_ ? r1_ : (q2_ ? r2_ : r3_));                                \
   cur = any_ ? (next_ & ~kLeafBit) : cur;                                                            \
@@ -1086,6 +1099,9 @@ do {                                                                            
 // register pressure and the extra checks, 13 % per step in all: profiles/r02c_split_*.txt, r03g_split_asis.txt) and were
 // removed in round 3.  What a launch waits for at its end is the dependent chain of its few longest rays
 // (tools/drain_probe.py, tools/tail_first_probe.py); DESIGN.md 3.1 and 10 keep the numbers.)
+#ifndef NRT_W4_FAST_PUSH
+#define NRT_W4_FAST_PUSH 1 // two-level step: unconditional stores of the three push candidates when every lane has room in LDS
+#endif
 #ifndef NRT_W4_PRESEL
 #define NRT_W4_PRESEL 1 // fp32 two-level walk: the near / far plane rows are fetched by the ray's signs (slab4_presel) instead of selected per value
 #endif
