@@ -967,12 +967,15 @@ def main():
         bbytes = build_bytes(wl.faces.shape[0], wl.num_nodes, wl.rb)
         roof = {
             "kernel": kernel_name,
-            "limiting": "the vector L1's address path and the latency of the dependent chain node fetch -> slab tests -> next fetch: in the bulk "
-                        "of a launch a CU completes one 128-byte node record per lane every ~0.7-1 clk (tools/ubench/node_fetch.hip: 0.7 clk per "
-                        "scattered 16-byte lane access is what the L1 sustains), waves wait on L1/L2 ~40 % of their cycles, VALU issue is ~38 % busy; "
-                        "the last quarter of a launch is the chain of its longest rays (tools/drain_probe.py, tools/tail_first_probe.py: an oracle "
-                        "ordering with the longest 1 % of the rays first takes 11 % off the bounce wave).  HBM is far from saturated: see hbm / "
-                        "valu / l1 (DESIGN.md 3.1, 5); no MFMA in this path",
+            "limiting": "the length of each wave's own instruction stream between two node fetches, and the fetch latency behind it: five waves "
+                        "per SIMD each issue their ~200 instructions per step in order, so the loop's speed follows the step's instruction count "
+                        "whatever unit executes it (round 3: 24 selects fewer per step = +2.7 %, three guarded pushes turned into stores = +2 %; "
+                        "six more unpacking instructions for one fetch fewer = -1.7 %; 19 vector instructions moved to 59 scalar ones = -1.2 %: "
+                        "profiles/r03K-r03R); waves wait on L1/L2 ~40 % of their cycles, the vector unit is ~38 % busy, a lane's eight 16-byte "
+                        "pieces of a node record cost the L1 ~0.7 clk each (tools/ubench/node_fetch.hip); the last quarter of a launch is the "
+                        "chain of its longest rays (tools/drain_probe.py, tools/tail_first_probe.py: an oracle ordering with the longest 1 % of "
+                        "the rays first takes 11 % off the bounce wave).  HBM is far from saturated: see hbm / valu / l1 (DESIGN.md 3.1, 5); no "
+                        "MFMA in this path",
             "launch_ms": round(launch_ms, 4),
             "launch_ms_note": "HIP events on the launch stream around the whole timed region / (2 x steps): the average launch of the two "
                               "waves, idle time between launches included; per_wave.ms: event pairs around single launches in a 3-step "
