@@ -892,7 +892,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.trav_min = c->trav_min;
   a.leaf_min = c->leaf_min;
 
-  if (count || (c->debug_flags & (32u | 4096u))) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), s));
+  if (count || (c->debug_flags & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), s));
   // completion record instead of events: the traversal kernel is the launch's last kernel and events were not asked for
   const bool use_rec = use_wide && !count && !c->launch_timing;
   // (the sphere kind's u/v pass and the cylinder kind's normal pass run behind the traversal kernel and close the record in its place)
