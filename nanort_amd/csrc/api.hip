@@ -839,6 +839,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.wide = (const WideNode<T> *)c->d_wide;
   a.wide4 = use_wide4 ? (const Wide4Node<T> *)c->d_wide4 : nullptr;
   a.packed_leaves = c->packed_leaves;
+  a.wide_below_4g = (uint64_t)c->num_branch_records * sizeof(WideNode<T>) < (1ull << 32) ? 1u : 0u;
   a.root_is_branch = c->root_is_branch;
   a.debug_flags = c->debug_flags;
   a.spill_tmin = (T *)slot->spill_tmin.p;

@@ -113,6 +113,17 @@ struct alignas(16) WideNode {
   int32_t axis;
   uint32_t pad;
 };
+// fp64: the same record component-major — mn[k][child], mx[k][child]: a 16-byte row per plane pair, so that the walk fetches
+// the near and far rows of each axis by the ray's direction sign (a per-ray byte offset, as for Wide4Node<float>:
+// traverse.hip slab_pair_presel) instead of fetching all twelve doubles and selecting six pairs.
+template <>
+struct alignas(16) WideNode<double> {
+  double mn[3][2]; // [component][child]
+  double mx[3][2];
+  uint32_t c0, c1;
+  int32_t axis;
+  uint32_t pad;
+};
 static_assert(sizeof(WideNode<float>) == 64, "WideNode<float>");
 static_assert(sizeof(WideNode<double>) == 112, "WideNode<double>");
 // Two levels of the tree in one record: the boxes of the (up to) four GRANDCHILDREN of a branch node, component-major
@@ -215,6 +226,7 @@ struct TraverseArgs {
   const WideNode<T> *wide; // may be null (binary kernel only)
   const Wide4Node<T> *wide4; // may be null: two tree levels per record (the WIDTH = 4 variants)
   uint32_t packed_leaves;  // leaf references of `wide` are PACKED (see WideNode)
+  uint32_t wide_below_4g;  // the WideNode array is smaller than 4 GiB: the fp64 walk may address it with 32-bit byte offsets (slab_pair_presel)
   uint32_t root_is_branch; // node 0 is a branch (every tree of more than one node)
   uint32_t debug_flags;    // profiling only (env NRT_DEBUG): 1 = skip triangle tests, 2 = skip traversal
   const typename Wire<T>::Ray *rays;

@@ -853,8 +853,42 @@ __device__ __forceinline__ SlabPair<float> slab_pair(const Lane<float> &L, const
 
 __device__ __forceinline__ SlabPair<double> slab_pair(const Lane<double> &L, const WideNode<double> &w) {
   SlabPair<double> r;
-  r.h0 = slab_test_tmin<double>(L, w.box0, r.tm0);
-  r.h1 = slab_test_tmin<double>(L, w.box1, r.tm1);
+  const double b0[6] = {w.mn[0][0], w.mn[1][0], w.mn[2][0], w.mx[0][0], w.mx[1][0], w.mx[2][0]};
+  const double b1[6] = {w.mn[0][1], w.mn[1][1], w.mn[2][1], w.mx[0][1], w.mx[1][1], w.mx[2][1]};
+  r.h0 = slab_test_tmin<double>(L, b0, r.tm0);
+  r.h1 = slab_test_tmin<double>(L, b1, r.tm1);
+  return r;
+}
+// The same two tests with the near / far rows of each axis fetched by the ray's direction signs (Lane::so0..2: 0 or 48,
+// the distance between the mn and mx rows of a WideNode<double>): the same values into slab_test_tmin's arithmetic,
+// twelve 64-bit selects per step fewer.  `rec` = byte offset of the record (32 bits: arrays below 4 GiB).
+struct WideTail { // bytes 96..111 of a WideNode<double>
+  uint32_t c0, c1;
+  int32_t axis;
+  uint32_t pad;
+};
+__device__ __forceinline__ SlabPair<double> slab_pair_presel(const Lane<double> &L, const char *base, uint32_t rec) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const double mm = Const<double>::maxmult();
+  double tmin0 = L.min_t, tmin1 = L.min_t, tmax0 = L.hit_t, tmax1 = L.hit_t;
+  const uint32_t rec48 = rec + 48u;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const uint32_t so = k == 0 ? L.so0 : (k == 1 ? L.so1 : L.so2);
+    const d2 lo = *reinterpret_cast<const d2 *>(base + (size_t)(rec + so) + 16 * k);
+    const d2 hi = *reinterpret_cast<const d2 *>(base + (size_t)(rec48 - so) + 16 * k);
+    const double t00 = (lo.x - L.org(k)) * L.inv(k), t01 = (lo.y - L.org(k)) * L.inv(k);
+    const double t10 = (hi.x - L.org(k)) * L.inv(k) * mm, t11 = (hi.y - L.org(k)) * L.inv(k) * mm;
+    tmin0 = Const<double>::fmax(t00, tmin0); // see slab_test
+    tmin1 = Const<double>::fmax(t01, tmin1);
+    tmax0 = Const<double>::fmin(t10, tmax0);
+    tmax1 = Const<double>::fmin(t11, tmax1);
+  }
+  SlabPair<double> r;
+  r.h0 = tmin0 <= tmax0;
+  r.h1 = tmin1 <= tmax1;
+  r.tm0 = tmin0;
+  r.tm1 = tmin1;
   return r;
 }
 
@@ -998,7 +1032,12 @@ do {                                                                            
 // pushed with its t_min, the near one (or the only one) entered.
 #define NRT_STEP_NODE(w_)                                                                              \
 do {                                                                                                 \
-  const SlabPair<T> sl_ = slab_pair(L, (w_));                                                        \
+  const SlabPair<T> sl2_ = slab_pair(L, (w_));                                                       \
+  NRT_STEP_NODE_SL(sl2_, (w_));                                                                      \
+} while (0)
+/* (sl_: the two box tests; w_: anything with c0, c1, axis) */
+#define NRT_STEP_NODE_SL(sl_, w_)                                                                      \
+do {                                                                                                 \
   const bool near1_ = L.sign((w_).axis) != 0; /* near child = data[dir_sign[axis]] (nanort.h:2538) */ \
   const bool both_ = sl_.h0 & sl_.h1, any_ = sl_.h0 | sl_.h1;                                        \
   if (both_) { /* the far child waits with its t_min */                                              \
@@ -1104,6 +1143,9 @@ do {                                                                            
 #endif
 #ifndef NRT_W4_PRESEL
 #define NRT_W4_PRESEL 1 // fp32 two-level walk: the near / far plane rows are fetched by the ray's signs (slab4_presel) instead of selected per value
+#endif
+#ifndef NRT_W2_F64_PRESEL
+#define NRT_W2_F64_PRESEL 1 // fp64 one-level walk: the plane rows of both children are fetched by the ray's signs (slab_pair_presel)
 #endif
 #ifndef NRT_W4_TRI_UNROLL
 #define NRT_W4_TRI_UNROLL 2 // triangle records fetched per trip of the leaf loop in the WIDTH = 4 variants (1 or 2)
@@ -1284,6 +1326,21 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
           for (int x_ = 1; x_ < NRT_PROBE_EXTRA_LOADS; x_++) // (same destination: the returns are in order)
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "+v"(d0_) : "v"(a.wide + cur) : "memory");
 #endif
+#if NRT_W2_F64_PRESEL
+          bool stepped_ = false;
+          if constexpr (sizeof(T) == 8) {
+            if (a.wide_below_4g) { // (wave-uniform)
+              const char *wb_ = reinterpret_cast<const char *>(a.wide);
+              const uint32_t rec_ = cur * (uint32_t)sizeof(WideNode<double>);
+              const SlabPair<double> sl = slab_pair_presel(L, wb_, rec_);
+              const WideTail w = *reinterpret_cast<const WideTail *>(wb_ + (size_t)rec_ + 96);
+              NRT_STEP_NODE_SL(sl, w);
+              stepped_ = true;
+            }
+          }
+          if (!stepped_)
+#endif
+          {
           const WideNode<T> w = a.wide[cur];
 #ifdef NRT_PROBE_EXTRA_VALU // ... N more dependent v_fma_f32 per step
           {
@@ -1293,6 +1350,7 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
           }
 #endif
           NRT_STEP_NODE(w);
+          }
 #ifdef NRT_PROBE_EXTRA_LOADS
           asm volatile("" :: "v"(d0_));
 #endif
@@ -1744,10 +1802,17 @@ __global__ __launch_bounds__(256) void k_make_wide(const typename Wire<T>::Node 
   WideNode<T> w;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    w.box0[k] = a.bmin[k];
-    w.box0[3 + k] = a.bmax[k];
-    w.box1[k] = b.bmin[k];
-    w.box1[3 + k] = b.bmax[k];
+    if constexpr (sizeof(T) == 8) { // (component-major: see WideNode<double>)
+      w.mn[k][0] = a.bmin[k];
+      w.mx[k][0] = a.bmax[k];
+      w.mn[k][1] = b.bmin[k];
+      w.mx[k][1] = b.bmax[k];
+    } else {
+      w.box0[k] = a.bmin[k];
+      w.box0[3 + k] = a.bmax[k];
+      w.box1[k] = b.bmin[k];
+      w.box1[3 + k] = b.bmax[k];
+    }
   }
   const uint32_t la = packed ? (((a.data[0] - 1u) << kPackedFirstBits) | a.data[1]) : nd.data[0];
   const uint32_t lb = packed ? (((b.data[0] - 1u) << kPackedFirstBits) | b.data[1]) : nd.data[1];
