@@ -127,7 +127,8 @@ struct nrt_ctx {
 
   // traversal tuning (env NRT_LDS_STACK / NRT_REFILL_MIN / NRT_TRAV_MIN / NRT_CHUNK override)
   int lds_stack = kLdsStackDefault;
-  unsigned blocks_per_cu = 0, chunk = 128, chunk_tail_pct = 0, refill_min = 44, trav_min = 12, leaf_min = 32; // (trav_min: 8 until round 3; 12-14 is the optimum of the two-level walk, profiles/r03t_trav_min.txt)
+  unsigned blocks_per_cu = 0, chunk = 128, chunk_tail_pct = 0, refill_min = 44, trav_min = 12, leaf_min = 32; // (trav_min: 8 until round 3; 12-14 was the optimum of the two-level walk before its inner loop ran two rounds per trip, profiles/r03t_trav_min.txt)
+  unsigned trav_min4 = 24; // the same threshold for the fp32 two-level walk, whose inner loop runs two pop + step rounds per trip (profiles/r03Z_threshold_resweep*.txt)
   unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
   unsigned debug_flags = 0;
   int subtree_rows = 1; // builder: subtree phase in row form (up to four nodes per step); 0: one node per step — same tree, the cross-check (tests/test_gpu_build.py)
@@ -258,7 +259,8 @@ struct TunableDesc {
    [](nrt_ctx *c, long long v) { c->field_ = (type_)v; }}
 static const TunableDesc kTunables[] = {
     NRT_TUNABLE("refill_min", 1, 64, refill_min, unsigned),       // idle lanes of a wave before it claims more rays
-    NRT_TUNABLE("trav_min", 1, 64, trav_min, unsigned),           // lanes still walking below which the inner-node phase ends
+    NRT_TUNABLE("trav_min", 1, 64, trav_min, unsigned),           // lanes still walking below which the inner-node phase ends (one level per step)
+    NRT_TUNABLE("trav_min4", 1, 64, trav_min4, unsigned),         // ... of the two-level walk
     NRT_TUNABLE("leaf_min", 1, 64, leaf_min, unsigned),           // lanes at a leaf below which a due refill goes first
     NRT_TUNABLE("chunk_tail_pct", 0, 100, chunk_tail_pct, unsigned), // share of the dynamic rays handed out in half chunks (the end of a launch)
     NRT_TUNABLE("parts", 1, kMaxParts, num_parts, unsigned),      // ray partitions (== XCDs)
@@ -890,7 +892,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.chunk = c->chunk;
   a.chunk_tail_pct = c->chunk_tail_pct;
   a.refill_min = c->refill_min;
-  a.trav_min = c->trav_min;
+  a.trav_min = use_wide4 ? c->trav_min4 : c->trav_min;
   a.leaf_min = c->leaf_min;
 
   if (count || (c->debug_flags & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), s));

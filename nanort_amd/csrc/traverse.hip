@@ -1138,6 +1138,9 @@ do {                                                                            
 // register pressure and the extra checks, 13 % per step in all: profiles/r02c_split_*.txt, r03g_split_asis.txt) and were
 // removed in round 3.  What a launch waits for at its end is the dependent chain of its few longest rays
 // (tools/drain_probe.py, tools/tail_first_probe.py); DESIGN.md 3.1 and 10 keep the numbers.)
+#ifndef NRT_W4_P1_UNROLL
+#define NRT_W4_P1_UNROLL 2 // fp32 two-level walk: pop + step rounds per trip of the inner-node loop
+#endif
 #ifndef NRT_W4_FAST_PUSH
 #define NRT_W4_FAST_PUSH 1 // two-level step: unconditional stores of the three push candidates when every lane has room in LDS
 #endif
@@ -1301,6 +1304,8 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
         st_act1 += (unsigned)__builtin_popcountll(__ballot(true));
       }
       // a lane that must pop does so first and, if the popped entry survives, steps into it in the same iteration
+#pragma unroll
+      for (int u_ = 0; u_ < ((WIDTH == 4 && sizeof(T) == 4 && !STATS) ? NRT_W4_P1_UNROLL : 1); u_++) { // (several pop + step rounds per trip: the loop's own bookkeeping — two ballots, the exit test — runs once per trip)
       if (state == W_POP) NRT_POP_ENTRY();
       if (state == W_TRAV) {
         if (STATS) st_steps++;
@@ -1355,6 +1360,7 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
           asm volatile("" :: "v"(d0_));
 #endif
         }
+      }
       }
       // Leave when only a few lanes still walk — unless nothing else could be done anyway: no lane waits at a leaf
       // and there are no rays left to hand out (the drain of a launch: the last long rays then stay in this

@@ -16,7 +16,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.parametrize("case", sorted(glob.glob(os.path.join(GOLDEN, "fuzz_case_*.npz"))), ids=os.path.basename)
-@pytest.mark.parametrize("tun", [dict(), dict(refill_min=1, trav_min=1, static_pct=0, chunk=16), dict(wide4=0, static_bands=1)], ids=["default", "eager", "one_level"])
+@pytest.mark.parametrize("tun", [dict(), dict(refill_min=1, trav_min=1, trav_min4=1, static_pct=0, chunk=16), dict(wide4=0, static_bands=1)], ids=["default", "eager", "one_level"])
 def test_saved_fuzz_cases(case, tun):
     from oracle.bindings import Oracle
 

@@ -247,7 +247,7 @@ def test_work_distribution_tunables_cover_every_ray():
         ref, refm = a.TraverseBatch(rays)
         for combo in (dict(static_pct=0), dict(static_pct=100), dict(static_bands=1), dict(static_bands=64, static_pct=90),
                       dict(chunk=16, parts=3), dict(chunk=1000, parts=16, static_pct=10), dict(blocks_per_cu=1, static_bands=3),
-                      dict(refill_min=1, trav_min=1, leaf_min=1), dict(refill_min=64, trav_min=64, leaf_min=64)):
+                      dict(refill_min=1, trav_min=1, trav_min4=1, leaf_min=1), dict(refill_min=64, trav_min=64, trav_min4=64, leaf_min=64)):
             saved = {k: a.GetTunable(k) for k in combo}
             for k, val in combo.items():
                 a.SetTunable(k, val)
