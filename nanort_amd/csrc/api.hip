@@ -127,7 +127,7 @@ struct nrt_ctx {
 
   // traversal tuning (env NRT_LDS_STACK / NRT_REFILL_MIN / NRT_TRAV_MIN / NRT_CHUNK override)
   int lds_stack = kLdsStackDefault;
-  unsigned blocks_per_cu = 0, chunk = 128, chunk_tail_pct = 0, refill_min = 44, trav_min = 12, leaf_min = 32; // (trav_min: 8 until round 3; 12-14 was the optimum of the two-level walk before its inner loop ran two rounds per trip, profiles/r03t_trav_min.txt)
+  unsigned blocks_per_cu = 0, chunk = 128, chunk_tail_pct = 0, refill_min = 44, trav_min = 16, leaf_min = 32; // (trav_min: 8 until round 3; 12-14 was the optimum of the two-level walk before its inner loop ran two rounds per trip, profiles/r03t_trav_min.txt; 16 with two rounds per trip in the fp64 walk, profiles/r03ZA)
   unsigned trav_min4 = 24; // the same threshold for the fp32 two-level walk, whose inner loop runs two pop + step rounds per trip (profiles/r03Z_threshold_resweep*.txt)
   unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
   unsigned debug_flags = 0;

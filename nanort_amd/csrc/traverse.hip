@@ -1138,6 +1138,9 @@ do {                                                                            
 // register pressure and the extra checks, 13 % per step in all: profiles/r02c_split_*.txt, r03g_split_asis.txt) and were
 // removed in round 3.  What a launch waits for at its end is the dependent chain of its few longest rays
 // (tools/drain_probe.py, tools/tail_first_probe.py); DESIGN.md 3.1 and 10 keep the numbers.)
+#ifndef NRT_W2_F64_P1_UNROLL
+#define NRT_W2_F64_P1_UNROLL 2 // ... of the fp64 one-level walk
+#endif
 #ifndef NRT_W4_P1_UNROLL
 #define NRT_W4_P1_UNROLL 2 // fp32 two-level walk: pop + step rounds per trip of the inner-node loop
 #endif
@@ -1305,7 +1308,7 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
       }
       // a lane that must pop does so first and, if the popped entry survives, steps into it in the same iteration
 #pragma unroll
-      for (int u_ = 0; u_ < ((WIDTH == 4 && sizeof(T) == 4 && !STATS) ? NRT_W4_P1_UNROLL : 1); u_++) { // (several pop + step rounds per trip: the loop's own bookkeeping — two ballots, the exit test — runs once per trip)
+      for (int u_ = 0; u_ < ((WIDTH == 4 && sizeof(T) == 4 && !STATS) ? NRT_W4_P1_UNROLL : ((WIDTH == 2 && sizeof(T) == 8 && !STATS) ? NRT_W2_F64_P1_UNROLL : 1)); u_++) { // (several pop + step rounds per trip: the loop's own bookkeeping — two ballots, the exit test — runs once per trip)
       if (state == W_POP) NRT_POP_ENTRY();
       if (state == W_TRAV) {
         if (STATS) st_steps++;
