@@ -1138,6 +1138,9 @@ do {                                                                            
 // register pressure and the extra checks, 13 % per step in all: profiles/r02c_split_*.txt, r03g_split_asis.txt) and were
 // removed in round 3.  What a launch waits for at its end is the dependent chain of its few longest rays
 // (tools/drain_probe.py, tools/tail_first_probe.py); DESIGN.md 3.1 and 10 keep the numbers.)
+#ifndef NRT_SCENE_P1_UNROLL
+#define NRT_SCENE_P1_UNROLL 2 // ... of the two-level scene kernel
+#endif
 #ifndef NRT_W2_F64_P1_UNROLL
 #define NRT_W2_F64_P1_UNROLL 2 // ... of the fp64 one-level walk
 #endif
@@ -1675,6 +1678,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
     // ---- phase 1: inner nodes / stack pops ---------------------------------------------------------------------
     unsigned n_wait = (unsigned)__builtin_popcountll(__ballot(state == W_LEAF || state == S_FIN));
     while (state == W_TRAV || state == W_POP) {
+#pragma unroll
+      for (int u_ = 0; u_ < NRT_SCENE_P1_UNROLL; u_++) { // (pop + step rounds per trip, as in k_traverse_wide)
       if (state == W_POP) {
         NRT_POP_ENTRY();
         state = (state == W_IDLE) ? S_FIN : state; // an empty stack ends this instance's walk
@@ -1687,6 +1692,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
           const WideNode<float> w = wide[cur];
           NRT_STEP_NODE(w);
         }
+      }
       }
       n_wait += (unsigned)__builtin_popcountll(__ballot(state == W_LEAF || state == S_FIN));
       if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < a.trav_min && n_wait != 0u) break;
