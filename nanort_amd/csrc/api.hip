@@ -128,6 +128,7 @@ struct nrt_ctx {
   // traversal tuning (env NRT_LDS_STACK / NRT_REFILL_MIN / NRT_TRAV_MIN / NRT_CHUNK override)
   int lds_stack = kLdsStackDefault;
   unsigned blocks_per_cu = 0, chunk = 128, chunk_tail_pct = 0, refill_min = 44, trav_min = 16, leaf_min = 32; // (trav_min: 8 until round 3; 12-14 was the optimum of the two-level walk before its inner loop ran two rounds per trip, profiles/r03t_trav_min.txt; 16 with two rounds per trip in the fp64 walk, profiles/r03ZA)
+  int f64_row_fetch = 1; // fp64 walk: fetch the plane rows of a WideNode<double> by the ray's signs (0: fetch the record and select; the path arrays of 4 GiB and more take)
   unsigned trav_min4 = 24; // the same threshold for the fp32 two-level walk, whose inner loop runs two pop + step rounds per trip (profiles/r03Z_threshold_resweep*.txt)
   unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
   unsigned debug_flags = 0;
@@ -261,6 +262,7 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("refill_min", 1, 64, refill_min, unsigned),       // idle lanes of a wave before it claims more rays
     NRT_TUNABLE("trav_min", 1, 64, trav_min, unsigned),           // lanes still walking below which the inner-node phase ends (one level per step)
     NRT_TUNABLE("trav_min4", 1, 64, trav_min4, unsigned),         // ... of the two-level walk
+    NRT_TUNABLE("f64_row_fetch", 0, 1, f64_row_fetch, int),       // 0: the fp64 walk reads whole WideNode records and selects the planes (what arrays >= 4 GiB do)
     NRT_TUNABLE("leaf_min", 1, 64, leaf_min, unsigned),           // lanes at a leaf below which a due refill goes first
     NRT_TUNABLE("chunk_tail_pct", 0, 100, chunk_tail_pct, unsigned), // share of the dynamic rays handed out in half chunks (the end of a launch)
     NRT_TUNABLE("parts", 1, kMaxParts, num_parts, unsigned),      // ray partitions (== XCDs)
@@ -841,7 +843,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.wide = (const WideNode<T> *)c->d_wide;
   a.wide4 = use_wide4 ? (const Wide4Node<T> *)c->d_wide4 : nullptr;
   a.packed_leaves = c->packed_leaves;
-  a.wide_below_4g = (uint64_t)c->num_branch_records * sizeof(WideNode<T>) < (1ull << 32) ? 1u : 0u;
+  a.wide_below_4g = (c->f64_row_fetch && (uint64_t)c->num_branch_records * sizeof(WideNode<T>) < (1ull << 32)) ? 1u : 0u;
   a.root_is_branch = c->root_is_branch;
   a.debug_flags = c->debug_flags;
   a.spill_tmin = (T *)slot->spill_tmin.p;

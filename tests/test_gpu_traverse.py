@@ -84,6 +84,11 @@ def test_fp64(oracle, c1_mesh):
     oh, om = oracle.traverse(nodes, idx, v64, f, rays)
     h, m = a.TraverseBatch(rays)
     assert_hits_identical(oh, om, h, m)
+    # the fp64 walk fetches a record's plane rows by the ray's signs; node arrays of 4 GiB and more read whole records and
+    # select (tunable f64_row_fetch = 0 forces that path): the same records
+    a.SetTunable("f64_row_fetch", 0)
+    h0, m0 = a.TraverseBatch(rays)
+    assert_hits_identical(oh, om, h0, m0)
 
 
 def test_deep_reference_tree_spills_past_the_lds_stack(oracle):
