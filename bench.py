@@ -969,7 +969,7 @@ def main():
             "kernel": kernel_name,
             "limiting": "the length of each wave's own instruction stream between two node fetches, and the fetch latency behind it: five waves "
                         "per SIMD each issue their ~200 instructions per step in order, so the loop's speed follows the step's instruction count "
-                        "whatever unit executes it (round 3: 24 selects fewer per step = +2.7 %, three guarded pushes turned into stores = +2 %; "
+                        "whatever unit executes it (round 3: 24 selects fewer per step = +2.7 %, three guarded pushes turned into stores = +2 %, the loop's own bookkeeping once per two steps = +1.8 %; "
                         "six more unpacking instructions for one fetch fewer = -1.7 %; 19 vector instructions moved to 59 scalar ones = -1.2 %: "
                         "profiles/r03K-r03R); waves wait on L1/L2 ~40 % of their cycles, the vector unit is ~38 % busy, a lane's eight 16-byte "
                         "pieces of a node record cost the L1 ~0.7 clk each (tools/ubench/node_fetch.hip); the last quarter of a launch is the "
