@@ -142,6 +142,7 @@ struct nrt_ctx {
   // Two tree levels per step (Wide4Node records, traverse.hip NRT_STEP_NODE4): the production walk of fp32 triangle trees
   // whose child boxes lie inside their parents'.  env NRT_WIDE4=0 goes back to one level per step.
   int wide4 = 1;
+  int order4 = 0; // two-level walk: slots of a record entered by entry distance (contract-level parity: prim_id may differ at exact-t ties); 0: the binary loop's order, bit-identical to the same-tree oracle
   int wide_scramble = 0; // probe (tunable wide_scramble): the private node records in a pseudo-random order instead of pre-order
   unsigned wide4_blocks_per_cu = 0;
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
@@ -275,6 +276,7 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("subtree_rows", 0, 1, subtree_rows, int),         // 0: the builder's one-node-per-step subtree kernel (next build; same tree)
     NRT_TUNABLE("wide", 0, 1, wide, int),                         // 0: the literal BVHNode loop
     NRT_TUNABLE("wide4", 0, 1, wide4, int),                       // two tree levels per step (next build / set_tree)
+    NRT_TUNABLE("order4", 0, 1, order4, int),                     // two-level walk: 1 = slots by entry distance (hit t bit-equal; prim_id / u / v may differ at exact-t ties), 0 = the reference's order
     NRT_TUNABLE("launch_timing", 0, 1, launch_timing, int),       // == nrtSetLaunchTiming
     NRT_TUNABLE("host_pipeline", 0, 1, host_pipeline, int),       // pipelined host entry point
     NRT_TUNABLE("wide_scramble", 0, 1, wide_scramble, int),       // probe: WideNode / Wide4Node records in a pseudo-random order (next build)
@@ -796,7 +798,13 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   const bool use_wide = (c->wide || spheres || any_hit) && !count && c->d_wide;
   if (c->blocks_per_cu == 0) c->blocks_per_cu = (unsigned)traverse_blocks_per_cu<T>(c->lds_stack);
   // two levels per step: closest-hit walks of nested fp32 triangle trees, outside the profiling / splitting variants
-  const bool use_wide4 = use_wide && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch;
+  // prim ids are < num_faces: nothing can be rejected by these options -> the kernel variant without the id tests
+  const bool plain_options = opt->prim_ids_range[0] == 0u && opt->prim_ids_range[1] >= c->num_faces && opt->skip_prim_id >= c->num_faces &&
+                             !opt->cull_back_face;
+  // (the profiling instantiations of the two-level walk are built for the default trace options only: with options that can
+  // reject a primitive a profiled launch walks one level per step, whose profiling variant honours them)
+  const bool prof_needs_w2 = (c->debug_flags & (32u | 8192u)) && !plain_options && !spheres;
+  const bool use_wide4 = use_wide && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch && !prof_needs_w2;
   if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, false);
   if (use_wide4 && !spheres && c->wide4_blocks_per_cu == 0) c->wide4_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(kWide4LdsStack, kPrimTriangles, true);
   if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, use_wide4); // (one kind and one walk per context)
@@ -863,10 +871,9 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.skip_prim = opt->skip_prim_id;
   a.cull_back_face = opt->cull_back_face ? 1u : 0u;
   a.any_hit = any_hit ? 1u : 0u;
-  // prim ids are < num_faces: nothing can be rejected by these options -> the kernel variant without the id tests
-  a.plain_options = (opt->prim_ids_range[0] == 0u && opt->prim_ids_range[1] >= c->num_faces && opt->skip_prim_id >= c->num_faces &&
-                     !opt->cull_back_face) ? 1u : 0u;
+  a.plain_options = plain_options ? 1u : 0u;
   a.root_test = c->tree_nested ? 0u : 1u;
+  a.order4 = (c->order4 && use_wide4 && !spheres && !any_hit && !(c->debug_flags & (32u | 8192u))) ? 1u : 0u;
   a.spill = (uint32_t *)slot->spill.p;
   a.spill_stride = total_threads;
   a.spill_levels = levels;
@@ -914,22 +921,27 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
     HIPCHK(c, launch_traverse<T>(a, grid, count, c->lds_stack, s));
     c->last_kernel = sizeof(T) == 4 ? "nrt::k_traverse<float>" : "nrt::k_traverse<double>";
   }
-  if (d_cyl_hits)
-    HIPCHK(c, launch_cylinder_post((const nrt_ray_f32 *)d_rays, (const nrt_hit_f32 *)slot->cyl_hits.p, (const uint8_t *)slot->cyl_bits.p,
-                                   (const float *)c->d_verts, (uint32_t)n, d_cyl_hits, d_mask, a.done_rec, a.done_count, a.done_seq, s));
-  if (timed) HIPCHK(c, hipEventRecord(slot->t1, s));
+  // The kernel is enqueued: the slot's state follows it NOW, before any later call of this function can fail — a launch
+  // that is in flight publishes seq + 1 and flips the cursor sets whatever happens to the calls behind it.
   if (use_rec) {
     slot->seq++;
     slot->rec_pending = true;
-  } else {
-    HIPCHK(c, hipEventRecord(slot->done, s));
   }
   slot->last_has_rec = use_rec;
-  slot->last_timed = timed;
-  if (timed || use_rec) c->last_timed_slot = (int)(slot - c->slots);
+  slot->last_timed = false;
   slot->parity ^= 1u;
   slot->stream = s;
   slot->used = true;
+  if (use_rec) c->last_timed_slot = (int)(slot - c->slots);
+  if (d_cyl_hits)
+    HIPCHK(c, launch_cylinder_post((const nrt_ray_f32 *)d_rays, (const nrt_hit_f32 *)slot->cyl_hits.p, (const uint8_t *)slot->cyl_bits.p,
+                                   (const float *)c->d_verts, (uint32_t)n, d_cyl_hits, d_mask, a.done_rec, a.done_count, a.done_seq, s));
+  if (timed) {
+    HIPCHK(c, hipEventRecord(slot->t1, s));
+    slot->last_timed = true;
+    c->last_timed_slot = (int)(slot - c->slots);
+  }
+  if (!use_rec) HIPCHK(c, hipEventRecord(slot->done, s));
   return NRT_OK;
 }
 
@@ -1177,9 +1189,9 @@ nrt_status nrtTraverseCountDevice_f64(nrt_ctx *c, const nrt_ray_f64 *r, uint64_t
   return traverse_count<double>(c, r, n, o, out);
 }
 
-// Events around every traversal launch (the timing pair nrtLastTraverseMs reads, the slot's completion event) are on by
-// default; a caller that enqueues launches back to back and does not read the times can switch them off and save the idle
-// time they cost the stream (see slot_done for what then changes).
+// on = 1: events around every traversal launch (a timing pair nrtLastTraverseMs reads, the slot's completion event) — the
+// cross-check of the default, which records no event at all: the kernel's last wave publishes a completion record with its
+// own start / end stamps (see slot_done / wait_record for who waits on what).
 nrt_status nrtSetLaunchTiming(nrt_ctx *c, int on) {
   if (!c) return NRT_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->launch_mutex);
@@ -1208,12 +1220,18 @@ float nrtLastTraverseMs(nrt_ctx *c) {
   if (!c) return -1.f;
   hipEvent_t t0, t1;
   {
-    std::lock_guard<std::mutex> lock(c->launch_mutex);
+    std::unique_lock<std::mutex> lock(c->launch_mutex);
     if (c->last_timed_slot < 0) return -1.f;
     nrt_ctx::LaunchSlot &sl = c->slots[c->last_timed_slot];
     if (sl.last_has_rec) { // the kernel's own stamps: first block started -> last wave finished (100 MHz realtime ticks)
       if (wait_record(sl) != hipSuccess) return -1.f;
       const unsigned long long b = sl.h_done->t_begin, e = sl.h_done->t_end;
+      // The record says that every wave has stopped reading; the hit records' non-temporal stores are not fenced by it
+      // (traverse.hip, done_end).  This call is documented as the caller's synchronisation point, so it also drains the
+      // launch's stream (the stamps are taken: the reported time is unaffected).
+      const hipStream_t s = sl.stream;
+      lock.unlock();
+      if (hipStreamSynchronize(s) != hipSuccess) return -1.f;
       return e >= b ? (float)((double)(e - b) * 1e-5) : -1.f;
     }
     if (!sl.last_timed) return -1.f;

@@ -1129,6 +1129,56 @@ do {                                                                            
   }                                                                                                  \
 } while (0)
 
+// The Wide4Node step with the four slots entered in order of their ENTRY DISTANCE (template parameter ORDER = 1; tunable
+// `order4`) instead of the binary loop's axis-sign order.  What this keeps and what it gives up:
+//  * culling is unchanged — a slot is entered iff its slab test passes now and, when it was pushed, iff its t_min still
+//    beats the hit distance at pop time — so the walk tests a subset of the primitives the reference can reach and every
+//    primitive whose box chain the final hit distance does not cull: the closest hit's t (and u, v, prim_id of the record
+//    that realises it) are the reference's, except that among several primitives at EXACTLY the same t the survivor is
+//    the one this order tests last, not the one the reference's order tests last (prim_id may differ at
+//    exact-t ties only; tests/helpers.py:assert_hits_match re-verifies every such ray);
+//  * the LEAF SEQUENCE is no longer the reference's, so records are not bit-identical to the same-tree oracle at ties.
+// Keys: a hit slot sorts by min(t_min, FLT_MAX) (a hit can carry t_min = +inf only while the hit distance is +inf: the
+// clamped key then still passes the pop test), a missed or empty slot by +inf — so hits always precede misses.  Five
+// compare-exchanges (a 4-input sorting network) order {key, reference}; the first hit is entered, the others are pushed
+// farthest first.
+#define NRT_CSWAP4(ka_, ra_, kb_, rb_)                                                                 \
+do {                                                                                                 \
+  const bool sw_ = kb_ < ka_;                                                                        \
+  const T klo_ = Const<T>::fmin(ka_, kb_), khi_ = Const<T>::fmax(ka_, kb_);                          \
+  const uint32_t rlo_ = sw_ ? rb_ : ra_, rhi_ = sw_ ? ra_ : rb_;                                     \
+  ka_ = klo_; kb_ = khi_; ra_ = rlo_; rb_ = rhi_;                                                    \
+} while (0)
+#define NRT_STEP_NODE4_DIST(sl_, w_)                                                                   \
+do {                                                                                                 \
+  const T inf_ = Const<T>::inf(), big_ = Const<T>::fltmax();                                         \
+  const bool h0_ = sl_.h[0], h1_ = sl_.h[1] & ((w_).c[1] != kWide4Empty);                            \
+  const bool h2_ = sl_.h[2], h3_ = sl_.h[3] & ((w_).c[3] != kWide4Empty);                            \
+  T k0_ = h0_ ? Const<T>::fmin(sl_.tm[0], big_) : inf_, k1_ = h1_ ? Const<T>::fmin(sl_.tm[1], big_) : inf_; \
+  T k2_ = h2_ ? Const<T>::fmin(sl_.tm[2], big_) : inf_, k3_ = h3_ ? Const<T>::fmin(sl_.tm[3], big_) : inf_; \
+  uint32_t r0_ = (w_).c[0], r1_ = (w_).c[1], r2_ = (w_).c[2], r3_ = (w_).c[3];                       \
+  NRT_CSWAP4(k0_, r0_, k1_, r1_);                                                                    \
+  NRT_CSWAP4(k2_, r2_, k3_, r3_);                                                                    \
+  NRT_CSWAP4(k0_, r0_, k2_, r2_);                                                                    \
+  NRT_CSWAP4(k1_, r1_, k3_, r3_);                                                                    \
+  NRT_CSWAP4(k1_, r1_, k2_, r2_);                                                                    \
+  const bool any_ = k0_ < inf_, p1_ = k1_ < inf_, p2_ = k2_ < inf_, p3_ = k3_ < inf_;                \
+  if (__ballot(sp > STACK - 3) == 0ull) {                                                             \
+    s_stack[sp][tid] = SE::make(r3_, k3_);                                                           \
+    sp += p3_ ? 1 : 0;                                                                               \
+    s_stack[sp][tid] = SE::make(r2_, k2_);                                                           \
+    sp += p2_ ? 1 : 0;                                                                               \
+    s_stack[sp][tid] = SE::make(r1_, k1_);                                                           \
+    sp += p1_ ? 1 : 0;                                                                               \
+  } else {                                                                                           \
+    NRT_PUSH_IF(p3_, r3_, k3_);                                                                      \
+    NRT_PUSH_IF(p2_, r2_, k2_);                                                                      \
+    NRT_PUSH_IF(p1_, r1_, k1_);                                                                      \
+  }                                                                                                  \
+  cur = any_ ? (r0_ & ~kLeafBit) : cur;                                                              \
+  state = any_ ? ((r0_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP;                                       \
+} while (0)
+
 // PLAIN: the launch uses trace options that cannot reject a primitive (full prim_ids_range, no skip_prim_id, no
 // back-face culling — the reference's defaults): the three id comparisons per triangle test are compiled out.
 //
@@ -1170,9 +1220,11 @@ do {                                                                            
 #endif
 // CLOCK: profiling instantiation that stamps when each wave starts, runs dry and finishes (tools/drain_probe.py).
 // WIDTH: 2 = one WideNode (two boxes) per step, 4 = one Wide4Node (two levels, four boxes) per step.
-template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool CLOCK = false, int WIDTH = 2>
+// ORDER (WIDTH = 4 only): 0 = the four slots in the binary loop's order (same leaf sequence as the reference), 1 = by entry distance.
+template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool CLOCK = false, int WIDTH = 2, int ORDER = 0>
 __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NRT_W4_WAVES : 1) void k_traverse_wide(const TraverseArgs<T> a) {
   static_assert(WIDTH == 2 || WIDTH == 4, "one or two tree levels per step");
+  static_assert(ORDER == 0 || (WIDTH == 4 && sizeof(T) == 4), "distance order is a variant of the fp32 two-level step");
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
 
@@ -1322,7 +1374,10 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
             const uint32_t rec_ = cur << 7; // (api.hip keeps Wide4Node<float> arrays below 4 GiB)
             const Slab4<float> sl = slab4_presel(L, wb_, rec_);
             const Wide4Tail w = *reinterpret_cast<const Wide4Tail *>(wb_ + (size_t)rec_ + 96);
-            NRT_STEP_NODE4_SL(sl, w);
+            if constexpr (ORDER == 1)
+              NRT_STEP_NODE4_DIST(sl, w);
+            else
+              NRT_STEP_NODE4_SL(sl, w);
           } else
 #endif
           {
@@ -1971,21 +2026,22 @@ int traverse_blocks_per_cu(int lds_stack) {
 }
 
 // `name_out` (optional) receives the name of the variant launched, as rocprofv3 prints it without the argument list.
-static const char *variant_name(bool f32, int stack, bool stats, int kind, bool plain, bool clock, int width) {
+static const char *variant_name(bool f32, int stack, bool stats, int kind, bool plain, bool clock, int width, int order) {
   static std::mutex m;
   static std::map<std::string, std::string> *names = new std::map<std::string, std::string>(); // (never destroyed: the pointers are handed out)
   char buf[160];
-  snprintf(buf, sizeof(buf), "nrt::k_traverse_wide<%s, %d, %s, %d, %s, %s, %d>", f32 ? "float" : "double", stack,
-           stats ? "true" : "false", kind, plain ? "true" : "false", clock ? "true" : "false", width);
+  snprintf(buf, sizeof(buf), "nrt::k_traverse_wide<%s, %d, %s, %d, %s, %s, %d, %d>", f32 ? "float" : "double", stack,
+           stats ? "true" : "false", kind, plain ? "true" : "false", clock ? "true" : "false", width, order);
   std::lock_guard<std::mutex> lock(m);
   return names->emplace(buf, buf).first->second.c_str();
 }
-#define NRT_LAUNCH_WIDE(STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_)                                                  \
+#define NRT_LAUNCH_WIDE_O(STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_, ORDER_)                                          \
   do {                                                                                                                  \
-    hipLaunchKernelGGL((k_traverse_wide<T, STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_>), dim3(grid),                 \
+    hipLaunchKernelGGL((k_traverse_wide<T, STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_, ORDER_>), dim3(grid),         \
                        dim3(kTraverseBlock), 0, s, args);                                                               \
-    if (name_out) *name_out = variant_name(sizeof(T) == 4, STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_);              \
+    if (name_out) *name_out = variant_name(sizeof(T) == 4, STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_, ORDER_);      \
   } while (0)
+#define NRT_LAUNCH_WIDE(STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_) NRT_LAUNCH_WIDE_O(STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_, 0)
 
 template <typename T>
 hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int lds_stack, int prim_kind, hipStream_t s,
@@ -2021,6 +2077,10 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
         NRT_LAUNCH_WIDE(kWide4LdsStack, true, kPrimTriangles, true, false, 4); // profiling instantiation (default trace options only)
       else if (args.wave_clock)
         NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, true, 4); // per-wave time stamps (default trace options only)
+      else if (args.order4 && args.plain_options) // slots entered by entry distance (tunable order4; contract-level parity: see NRT_STEP_NODE4_DIST)
+        NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, true, false, 4, 1);
+      else if (args.order4)
+        NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, false, false, 4, 1);
       else if (args.plain_options)
         NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, false, 4);
       else
@@ -2049,6 +2109,7 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
   return hipGetLastError();
 }
 #undef NRT_LAUNCH_WIDE
+#undef NRT_LAUNCH_WIDE_O
 
 template <typename T>
 int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool wide4) {
