@@ -336,6 +336,11 @@ NRT_API nrt_status nrtGetTunable(nrt_ctx *ctx, const char *name, long long *valu
  * rocprofv3 prints it without the argument list (static storage; "" before the first launch).  bench.py
  * reports it in `roofline.kernel` and matches the counter rows of its PMC passes against it. */
 NRT_API const char *nrtLastKernelName(const nrt_ctx *ctx);
+/* Test aid: copy out the private 8-wide compressed layout of the current fp32 tree (built when the tunable "wide8" is set
+ * before nrtBuild / nrtSetTree): 80-byte node records and 40-byte leaf records (nanort_amd/csrc/common.h: Wide8Node, W8Rec).
+ * Either output may be NULL; the counts are always returned.  tests/test_gpu_wide8.py compares the arrays with the CPU
+ * model's (oracle/wide8_model.inc).  (No reference counterpart.) */
+NRT_API nrt_status nrtGetWide8_f32(nrt_ctx *ctx, void *nodes_out, void *recs_out, uint64_t *num_nodes, uint64_t *num_recs);
 /* Profiling aid: loop-occupancy counters of the last traversal launched with the tunable "debug" bit 32 set (a separately
  * instantiated, slower kernel).  out16[0..7] = inner-node-phase wave iterations, sum of active lanes, idle lanes at leaf-phase
  * entry, leaf-phase trips, sum of lanes testing a (first) record, refill events, lanes refilled, leaf-phase entries;

@@ -24,7 +24,7 @@ SYMBOLS = [
     "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64",
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
-    "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtDebugCounters", "nrtDebugWaveClocks", "nrtHostAlloc", "nrtHostFree",
+    "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtDebugCounters", "nrtDebugWaveClocks", "nrtGetWide8_f32", "nrtHostAlloc", "nrtHostFree",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
     "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32",
 ]
@@ -146,6 +146,8 @@ def lib():
     L.nrtLastTraverseMs.restype = ctypes.c_float
     L.nrtLastBuildMs.argtypes = [vp]
     L.nrtLastBuildMs.restype = ctypes.c_float
+    L.nrtGetWide8_f32.argtypes = [vp, vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.nrtGetWide8_f32.restype = i32
     L.nrtLastKernelName.argtypes = [vp]
     L.nrtLastKernelName.restype = ctypes.c_char_p
     _LIB = L
