@@ -1333,7 +1333,12 @@ long nrtDebugWaveClocks(nrt_ctx *c, unsigned long long *out, long cap) {
 // Either output may be NULL; the counts are always returned.  NRT_ERR_INVALID when the context holds no such layout.
 nrt_status nrtGetWide8_f32(nrt_ctx *c, void *nodes_out, void *recs_out, uint64_t *num_nodes, uint64_t *num_recs) {
   if (!c) return NRT_ERR_INVALID;
-  if (!c->d_w8nodes) return fail(c, NRT_ERR_INVALID, "nrtGetWide8: no 8-wide layout (set the tunable wide8 before nrtBuild / nrtSetTree)");
+  if (!c->d_w8nodes) {
+    if (c->h_w8state)
+      return fail(c, NRT_ERR_INVALID, "nrtGetWide8: no 8-wide layout (last construction: failed=%u pending=%u head=%u tail=%u rec_tail=%u of %u branch records)",
+                  c->h_w8state->failed, c->h_w8state->pending, c->h_w8state->head, c->h_w8state->tail, c->h_w8state->rec_tail, c->num_branch_records);
+    return fail(c, NRT_ERR_INVALID, "nrtGetWide8: no 8-wide layout (set the tunable wide8 before nrtBuild / nrtSetTree)");
+  }
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (num_nodes) *num_nodes = c->num_w8_nodes;

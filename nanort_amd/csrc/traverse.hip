@@ -1809,7 +1809,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_w8(const TraverseAr
         if (start) {
           const LeafTri<float> bx = rp[0];
           const bool ok = slab_test<float>(L, bx.p0, bx.p1); // the reference's own test of the leaf's EXACT box (nanort.h:2285-2325)
-          lcnt = ok ? __float_as_uint(bx.p2[0]) : 0u;
+          lcnt = ok ? min(__float_as_uint(bx.p2[0]), lstride - 1u) : 0u; // (a block holds at most stride - 1 triangles)
           if (STATS) {
             st_leaves++;
             st_reject += ok ? 0u : 1u;

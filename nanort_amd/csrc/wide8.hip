@@ -206,7 +206,7 @@ __device__ void w8_make_node(const W8BuildArgs &a, uint32_t my, uint32_t root) {
     const int c = kid_in_slot[s];
     if (c < 0) continue;
     if (!is_leaf[c]) {
-      __hip_atomic_store(a.queue + child_base + ri, kids[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      (void)atomicExch(a.queue + child_base + ri, kids[c]);
       ri++;
     } else {
       W8Rec *r = a.recs + leaf_base + rl * stride;
@@ -227,21 +227,42 @@ __device__ void w8_make_node(const W8BuildArgs &a, uint32_t my, uint32_t root) {
 }
 
 __global__ __launch_bounds__(256) void k_w8_build(const W8BuildArgs a) {
-  uint32_t my = kW8Empty;
-  for (;;) {
-    if (my == kW8Empty) my = atomicAdd(&a.st->head, 1u);
-    if (my >= a.cap_nodes) break; // beyond any node this tree can have
-    const uint32_t root = __hip_atomic_load(a.queue + my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (root == kW8Empty) {
-      // not published (yet).  `pending` counts the nodes published or about to be and not finished: once it is zero every
-      // position that will ever be published has been processed, and this one never will be.
-      if (__hip_atomic_load(&a.st->pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
-      __builtin_amdgcn_s_sleep(8);
-      continue;
+  // One loop with ONE back edge, taken by the whole wave until every lane is done: a lane that polls and a lane that builds
+  // go through the same iteration.  (Written with a `continue` on the polling path the compiler nested the polling into an
+  // inner loop of its own, and the lane holding the root — masked off until that loop ends — never got to publish what the
+  // others were polling for.)
+  uint32_t my = kW8Empty, polls = 0;
+  bool alive = true;
+  while (__ballot(alive) != 0ull) {
+    uint32_t root = kW8Empty;
+    if (alive) {
+      if (my == kW8Empty) my = atomicAdd(&a.st->head, 1u);
+      if (my >= a.cap_nodes) {
+        alive = false; // beyond any node this tree can have
+      } else {
+        // (compare-and-swap as the polling read: performed at the memory side, so a value published from another CU or XCD
+        // is seen; an idempotent atomicOr / atomicAdd of 0 is folded into a load by the compiler)
+        root = atomicCAS(a.queue + my, kW8Empty, kW8Empty);
+        if (root == kW8Empty) {
+          // not published (yet).  `pending` counts the nodes published or about to be and not finished: once it is zero
+          // every position that will ever be published has been processed, and this one never will be.
+          // (looked at every 16th poll only: every waiting thread reads this ONE word, and same-address atomics serialise)
+          if ((++polls & 15u) == 0u && atomicCAS(&a.st->pending, 0xFFFFFFFFu, 0xFFFFFFFFu) == 0u) {
+            alive = false;
+          } else if (polls > (1u << 24)) { // (a safety net, never reached: give up instead of hanging the device)
+            atomicExch(&a.st->failed, 2u);
+            alive = false;
+          }
+        }
+      }
     }
-    w8_make_node(a, my, root);
-    (void)atomicSub(&a.st->pending, 1u);
-    my = kW8Empty;
+    const bool work = alive && root != kW8Empty;
+    if (work) {
+      w8_make_node(a, my, root);
+      (void)atomicSub(&a.st->pending, 1u);
+      my = kW8Empty;
+    }
+    if (__ballot(work) == 0ull) __builtin_amdgcn_s_sleep(16); // nobody in this wave had anything to do: back off
   }
 }
 
