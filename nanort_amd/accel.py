@@ -281,6 +281,30 @@ class BVHAccel:
         )
         return n
 
+    def TraverseBatchesDevice(self, batches, options=None, stream=None):
+        """nrtTraverseBatchesDevice: several independent batches — a list of (d_rays, d_hits, d_mask or None, n or None) torch
+        uint8 tensors — walked by ONE persistent launch (asynchronous on `stream`).  Returns the ray counts."""
+        import torch
+
+        rsz, hsz = ray_dtype(self.real).itemsize, hit_dtype(self.real).itemsize
+        nb = len(batches)
+        rays = (ctypes.c_void_p * nb)()
+        hits = (ctypes.c_void_p * nb)()
+        masks = (ctypes.c_void_p * nb)()
+        counts = (ctypes.c_uint64 * nb)()
+        for k, b in enumerate(batches):
+            d_rays, d_hits, d_mask = b[0], b[1], b[2]
+            n = b[3] if len(b) > 3 and b[3] is not None else d_rays.numel() * d_rays.element_size() // rsz
+            assert d_hits.numel() * d_hits.element_size() >= n * hsz
+            rays[k], hits[k], counts[k] = d_rays.data_ptr(), d_hits.data_ptr(), n
+            masks[k] = None if d_mask is None else d_mask.data_ptr()
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        if options is not None:
+            options = np.asarray(options, dtype=TRACE_OPTIONS).reshape(1)
+        self._check(getattr(self._L, "nrtTraverseBatchesDevice_" + self._s)(self._h, nb, rays, counts, _p(options), hits, masks, stream))
+        return [int(c) for c in counts]
+
     def OccludedBatch(self, rays, options=None):
         """Opt-in extension: only the hit flags of TraverseBatch(), each ray stopping at the first primitive it accepts."""
         rays = np.ascontiguousarray(rays, dtype=ray_dtype(self.real))

@@ -21,7 +21,7 @@ SYMBOLS = [
     "nrtGetTree_f32", "nrtGetTree_f64", "nrtTreeSize",
     "nrtSetTree_f32", "nrtSetTree_f64",
     "nrtTraverseBatch_f32", "nrtTraverseBatch_f64",
-    "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64",
+    "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64", "nrtTraverseBatchesDevice_f32", "nrtTraverseBatchesDevice_f64",
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
     "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtDebugCounters", "nrtDebugWaveClocks", "nrtGetWide8_f32", "nrtHostAlloc", "nrtHostFree",
@@ -95,6 +95,9 @@ def lib():
         f.restype = i32
         f = getattr(L, "nrtTraverseBatchDevice_" + s)
         f.argtypes = [vp, vp, u64, vp, vp, vp, vp]
+        f.restype = i32
+        f = getattr(L, "nrtTraverseBatchesDevice_" + s)
+        f.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
         f.restype = i32
         f = getattr(L, "nrtTraverseCountDevice_" + s)
         f.argtypes = [vp, vp, u64, vp, ctypes.POINTER(TraceCounters)]

@@ -803,11 +803,27 @@ uint64_t nrt_internal_generation(const nrt_ctx *c) { return c ? c->generation : 
 // ---------------------------------------------------------------------------
 static const nrt_trace_options kDefaultTrace = {{0u, 0x7FFFFFFFu}, 0xFFFFFFFFu, 0, {0, 0, 0}}; // nanort.h:617-623
 
+// Several batches for one launch (nrtTraverseBatchesDevice): fp32 triangle contexts on the WideNode kernels.
+template <typename T>
+struct TraverseBatches {
+  uint32_t nb;
+  const typename Wire<T>::Ray *rays[kMaxBatches];
+  typename Wire<T>::Hit *hits[kMaxBatches];
+  uint8_t *mask[kMaxBatches];
+  uint64_t count[kMaxBatches];
+};
+
 template <typename T>
 static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_rays, uint64_t n,
                                   const nrt_trace_options *opt, typename Wire<T>::Hit *d_hits, uint8_t *d_mask,
-                                  hipStream_t s, bool count, bool timed, void *d_cyl_hits = nullptr, bool any_hit = false) {
+                                  hipStream_t s, bool count, bool timed, void *d_cyl_hits = nullptr, bool any_hit = false,
+                                  const TraverseBatches<T> *mb = nullptr) {
   if (c->prec != (int)sizeof(T)) return fail(c, NRT_ERR_PRECISION, "nrtTraverseBatch: precision mismatch");
+  if (mb) { // (the caller checked that this context walks batches in one launch; n = all rays)
+    d_rays = mb->rays[0];
+    d_hits = mb->hits[0];
+    d_mask = mb->mask[0];
+  }
   if ((c->prim_kind == kPrimCylinders) != (d_cyl_hits != nullptr))
     return fail(c, NRT_ERR_INVALID, "cylinder primitives are traced with nrtTraverseBatchCylinders*_f32 (28-byte records), "
                                     "every other primitive kind with nrtTraverseBatch*");
@@ -925,6 +941,24 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
     a.mask = (uint8_t *)slot->cyl_bits.p;
   }
   a.num_rays = (uint32_t)n;
+  a.num_batches = 1u;
+  for (int k = 0; k < kMaxBatches; k++) {
+    a.batch_end[k] = (uint32_t)n;
+    a.batches[k] = BatchPtrs{nullptr, nullptr, nullptr, 0};
+  }
+  if (mb) {
+    if (!use_wide || sizeof(T) != 4 || spheres || count) return fail(c, NRT_ERR_INVALID, "internal: multi-batch launch on a context that cannot take it");
+    a.num_batches = mb->nb;
+    uint64_t start = 0;
+    for (uint32_t k = 0; k < mb->nb; k++) { // pointers addressed by the virtual index: base - start
+      a.batches[k].rays_v = mb->rays[k] - start;
+      a.batches[k].hits_v = mb->hits[k] ? mb->hits[k] - start : nullptr;
+      a.batches[k].mask_v = mb->mask[k] ? mb->mask[k] - start : nullptr;
+      start += mb->count[k];
+      a.batch_end[k] = (uint32_t)start;
+    }
+    for (uint32_t k = mb->nb; k < (uint32_t)kMaxBatches; k++) a.batch_end[k] = (uint32_t)start;
+  }
   a.range0 = opt->prim_ids_range[0];
   a.range1 = opt->prim_ids_range[1];
   a.skip_prim = opt->skip_prim_id;
@@ -1106,6 +1140,55 @@ static nrt_status traverse_count(nrt_ctx *c, const typename Wire<T>::Ray *d_rays
   return NRT_OK;
 }
 
+// One persistent launch over several independent batches (same trace options): the claim machinery hands out one virtual
+// array, so the waves that run dry at the end of one batch carry on with the next — one tail and one completion record for
+// all.  Contexts that cannot (fp64, custom primitives, the literal kernel) launch the batches one after the other on the
+// same stream: the records are the same either way.
+template <typename T>
+static nrt_status traverse_batches_device(nrt_ctx *c, uint32_t nb, const typename Wire<T>::Ray *const *d_rays, const uint64_t *counts,
+                                          const nrt_trace_options *opt, typename Wire<T>::Hit *const *d_hits,
+                                          uint8_t *const *d_masks, hipStream_t s) {
+  if (!c) return NRT_ERR_INVALID;
+  if (nb == 0) return NRT_OK;
+  if (!d_rays || !counts || !d_hits) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchesDevice: NULL argument");
+  TraverseBatches<T> mb;
+  mb.nb = 0;
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < nb; k++) {
+    if (counts[k] == 0) continue;
+    if (!d_rays[k]) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchesDevice: batch %u has no rays", k);
+    total += counts[k];
+  }
+  if (total == 0) return NRT_OK;
+  const bool one_launch = sizeof(T) == 4 && c->prec == 4 && c->prim_kind == kPrimTriangles && c->wide && c->d_wide && total <= 0x7FFFFFFFull;
+  uint32_t k = 0;
+  while (k < nb) { // groups of up to kMaxBatches non-empty batches per launch
+    mb.nb = 0;
+    uint64_t n = 0;
+    while (k < nb && mb.nb < (uint32_t)kMaxBatches) {
+      if (counts[k]) {
+        mb.rays[mb.nb] = d_rays[k];
+        mb.hits[mb.nb] = d_hits[k];
+        mb.mask[mb.nb] = d_masks ? d_masks[k] : nullptr;
+        mb.count[mb.nb] = counts[k];
+        n += counts[k];
+        mb.nb++;
+      }
+      k++;
+    }
+    if (mb.nb == 0) break;
+    nrt_status st;
+    if (one_launch && mb.nb > 1) {
+      st = traverse_device<T>(c, nullptr, n, opt, nullptr, nullptr, s, false, false, nullptr, false, &mb);
+      if (st) return st;
+    } else {
+      for (uint32_t j = 0; j < mb.nb; j++)
+        if ((st = traverse_device<T>(c, mb.rays[j], mb.count[j], opt, mb.hits[j], mb.mask[j], s, false, false))) return st;
+    }
+  }
+  return NRT_OK;
+}
+
 template <typename T>
 static nrt_status occluded_host(nrt_ctx *c, const typename Wire<T>::Ray *rays, uint64_t n, const nrt_trace_options *opt, uint8_t *mask) {
   if (!c) return NRT_ERR_INVALID;
@@ -1241,6 +1324,14 @@ nrt_status nrtTraverseBatchDevice_f64(nrt_ctx *c, const nrt_ray_f64 *r, uint64_t
   return traverse_device<double>(c, r, n, o, h, m, (hipStream_t)s, false, true);
 }
 
+nrt_status nrtTraverseBatchesDevice_f32(nrt_ctx *c, uint32_t nb, const nrt_ray_f32 *const *r, const uint64_t *n, const nrt_trace_options *o,
+                                        nrt_hit_f32 *const *h, uint8_t *const *m, void *s) {
+  return traverse_batches_device<float>(c, nb, r, n, o, h, m, (hipStream_t)s);
+}
+nrt_status nrtTraverseBatchesDevice_f64(nrt_ctx *c, uint32_t nb, const nrt_ray_f64 *const *r, const uint64_t *n, const nrt_trace_options *o,
+                                        nrt_hit_f64 *const *h, uint8_t *const *m, void *s) {
+  return traverse_batches_device<double>(c, nb, r, n, o, h, m, (hipStream_t)s);
+}
 nrt_status nrtTraverseCountDevice_f32(nrt_ctx *c, const nrt_ray_f32 *r, uint64_t n, const nrt_trace_options *o,
                                       nrt_trace_counters *out) {
   return traverse_count<float>(c, r, n, o, out);

@@ -250,6 +250,17 @@ struct DoneCount {
   uint32_t group[8]; // waves of group g = blockIdx % 8 that have finished (eight words instead of one: same-address atomics serialise)
 };
 
+// Several independent batches walked by ONE persistent launch (nrtTraverseBatchesDevice: one tail, one completion record for all):
+// the claim machinery sees one virtual ray array, the batches back to back; a lane resolves its virtual index to a batch when it
+// loads the ray and when it stores the result.  The pointers are pre-offset so that they are addressed BY THE VIRTUAL INDEX.
+constexpr int kMaxBatches = 8;
+struct BatchPtrs {
+  const void *rays_v;
+  void *hits_v;
+  uint8_t *mask_v; // may be null
+  uint64_t pad;
+};
+
 template <typename T>
 struct TraverseArgs {
   const typename Wire<T>::Node *nodes;
@@ -270,6 +281,9 @@ struct TraverseArgs {
   typename Wire<T>::Hit *hits; // may be null (counting pass)
   uint8_t *mask;               // may be null
   uint32_t num_rays;
+  uint32_t num_batches;             // > 1: the rays are `num_batches` batches back to back (fp32 WideNode kernels only): batches[] / batch_end[] instead of rays / hits / mask
+  uint32_t batch_end[kMaxBatches];  // virtual index one past the last ray of batch k
+  BatchPtrs batches[kMaxBatches];
   uint32_t range0, range1, skip_prim; // BVHTraceOptions
   uint32_t cull_back_face;
   uint32_t any_hit;       // occlusion query (opt-in extension): a ray stops at the first primitive it accepts

@@ -382,6 +382,24 @@ __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// Which batch a virtual ray index lies in (multi-batch launches: common.h BatchPtrs; the ends are wave-uniform scalars).
+template <typename T>
+__device__ __forceinline__ uint32_t batch_of(const TraverseArgs<T> &a, uint32_t rid) {
+  uint32_t b = 0;
+#pragma unroll
+  for (int k = 0; k + 1 < kMaxBatches; k++) b += ((uint32_t)(k + 1) < a.num_batches && rid >= a.batch_end[k]) ? 1u : 0u;
+  return b;
+}
+// ... and the batch table copied from the kernel arguments into LDS once per block, so that lanes can index it by their own batch.
+#define NRT_BATCH_TABLE_SETUP()                                                                        \
+  __shared__ BatchPtrs s_tbl[sizeof(T) == 4 ? kMaxBatches : 1];                                        \
+  const bool multi = sizeof(T) == 4 && a.num_batches > 1u; /* (wave-uniform) */                        \
+  if (multi) {                                                                                         \
+    _Pragma("unroll") for (int k_ = 0; k_ < kMaxBatches; k_++)                                         \
+      if (threadIdx.x == (unsigned)k_) s_tbl[sizeof(T) == 4 ? k_ : 0] = a.batches[k_];                 \
+    __syncthreads();                                                                                   \
+  }
+
 // Work distribution of the persistent kernels.
 //  * The batch is cut into `static_bands` equal bands (+ a short tail).  The first part of every band is handed out
 //    STATICALLY, without any atomic: slice `rank` of band b, rays [b * band_len + rank * static_per_wave, +static_per_wave),
@@ -1240,6 +1258,7 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
   const unsigned gslot = blockIdx.x * kTraverseBlock + tid;
   const bool cull = a.cull_back_face != 0;
 
+  NRT_BATCH_TABLE_SETUP();
   Lane<T> L;
   uint32_t rid = kInvalid; // ray whose result this lane holds (W_IDLE with rid valid: finished, not yet written)
   uint32_t cur = 0;        // W_TRAV: WideNode index; W_LEAF: leaf reference without the leaf bit
@@ -1276,8 +1295,15 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
     }                                                   \
     h_.t = hit_ ? L.hit_t : L.max_t;                    \
     h_.prim_id = hit_ ? L.prim : kInvalid;              \
-    if (a.hits) store_hit_nt<T>(a.hits + rid, h_);      \
-    if (a.mask) a.mask[rid] = hit_ ? (KIND == kPrimCylinders ? (uint8_t)(1u | (L.cap << 1)) : (uint8_t)1) : (uint8_t)0; \
+    Hit *hp_ = a.hits;                                  \
+    uint8_t *mp_ = a.mask;                              \
+    if (multi) {                                        \
+      const BatchPtrs bp_ = s_tbl[batch_of<T>(a, rid)]; \
+      hp_ = (Hit *)bp_.hits_v;                          \
+      mp_ = bp_.mask_v;                                 \
+    }                                                   \
+    if (hp_) store_hit_nt<T>(hp_ + rid, h_);            \
+    if (mp_) mp_[rid] = hit_ ? (KIND == kPrimCylinders ? (uint8_t)(1u | (L.cap << 1)) : (uint8_t)1) : (uint8_t)0; \
   } while (0)
 
   // One primitive record (slot `slot_` of the leaf-ordered arrays) against a lane's ray; `act_` false -> no effect.
@@ -1314,7 +1340,9 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
         if (state == W_IDLE && rank < take) {
           if (rid != kInvalid) NRT_WRITE_RESULT();
           rid = ck.next + rank;
-          const Ray r = (a.debug_flags & 4u) ? a.rays[rid] : load_ray_nt<T>(a.rays + rid);
+          const Ray *rp_ = a.rays;
+          if (multi) rp_ = (const Ray *)s_tbl[batch_of<T>(a, rid)].rays_v;
+          const Ray r = (a.debug_flags & 4u) ? rp_[rid] : load_ray_nt<T>(rp_ + rid);
           lane_init<T>(L, r);
           sp = 0;
           if (STATS) st_steps = st_tris = 0;
@@ -1580,6 +1608,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_w8(const TraverseAr
   const bool cull = a.cull_back_face != 0;
   uint32_t *const spill_y = reinterpret_cast<uint32_t *>(a.spill_tmin);
 
+  NRT_BATCH_TABLE_SETUP();
   Lane<float> L; // (so0..2 hold the bits of the ray's reciprocal direction with infinities replaced by +-2^100)
   uint32_t rid = kInvalid;
   uint32_t cur = 0;  // W_TRAV: record index; W_LEAF: leaf_base | stride << 27
@@ -1602,8 +1631,15 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_w8(const TraverseAr
     h_.v = hit_ ? L.v : T(0);                           \
     h_.t = hit_ ? L.hit_t : L.max_t;                    \
     h_.prim_id = hit_ ? L.prim : kInvalid;              \
-    if (a.hits) store_hit_nt<T>(a.hits + rid, h_);      \
-    if (a.mask) a.mask[rid] = hit_ ? (uint8_t)1 : (uint8_t)0; \
+    Hit *hp_ = a.hits;                                  \
+    uint8_t *mp_ = a.mask;                              \
+    if (multi) {                                        \
+      const BatchPtrs bp_ = s_tbl[batch_of<T>(a, rid)]; \
+      hp_ = (Hit *)bp_.hits_v;                          \
+      mp_ = bp_.mask_v;                                 \
+    }                                                   \
+    if (hp_) store_hit_nt<T>(hp_ + rid, h_);            \
+    if (mp_) mp_[rid] = hit_ ? (uint8_t)1 : (uint8_t)0; \
   } while (0)
 #define W8_STORE_ENTRY(at_, ex_, ey_)                                                                  \
   do {                                                                                                 \
@@ -1630,7 +1666,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_w8(const TraverseAr
         if (state == W_IDLE && rank < take) {
           if (rid != kInvalid) W8_WRITE_RESULT();
           rid = ck.next + rank;
-          const Ray r = load_ray_nt<T>(a.rays + rid);
+          const Ray *rp_ = a.rays;
+          if (multi) rp_ = (const Ray *)s_tbl[batch_of<T>(a, rid)].rays_v;
+          const Ray r = load_ray_nt<T>(rp_ + rid);
           lane_init<T>(L, r);
           oct = (L.pk >> 6) & 7u;
           {

@@ -426,3 +426,63 @@ def test_host_entry_point_from_several_threads(c1):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("real,mode", [(np.float32, "default"), (np.float32, "order4"), (np.float32, "wide8"), (np.float32, "one_level"), (np.float64, "default")])
+def test_several_batches_in_one_launch_equal_separate_launches(real, mode):
+    """nrtTraverseBatchesDevice: independent batches of unequal sizes (one empty, one without a mask) walked by ONE persistent
+    launch — the records of each batch are exactly those of its own nrtTraverseBatchDevice call (fp64 contexts launch the
+    batches one after the other: same contract)."""
+    import torch
+
+    from nanort_amd.wire import hit_dtype
+
+    v, f = scenes.plane(200, 100)
+    a = BVHAccel(real)
+    if mode == "wide8":
+        a.SetTunable("wide8", 1)
+    if mode == "one_level":
+        a.SetTunable("wide4", 0)
+    assert a.Build(f.shape[0], TriangleMesh(v.astype(real), f))
+    if mode == "order4":
+        a.SetTunable("order4", 1)
+    rays1 = scenes.camera_rays(480, 270)
+    h1, m1 = a.TraverseBatch(rays1 if real == np.float32 else widen_rays(rays1))
+    h1_32 = h1
+    if real != np.float32:
+        from nanort_amd.wire import HIT_F32
+
+        h1_32 = np.zeros(h1.shape[0], dtype=HIT_F32)
+        for k in ("t", "u", "v"):
+            h1_32[k] = h1[k].astype(np.float32)
+        h1_32["prim_id"] = h1["prim_id"]
+    rays2 = scenes.secondary_rays("bounce", v, f, rays1, h1_32, m1)
+    rays3 = scenes.secondary_rays("shadow", v, f, rays1, h1_32, m1)
+    sets = [rays1, rays2[:1000], rays2[:0], rays3, rays2]
+    if real != np.float32:
+        sets = [widen_rays(r) for r in sets]
+    HIT = hit_dtype(real)
+    want = [a.TraverseBatch(r) if r.shape[0] else (np.zeros(0, HIT), np.zeros(0, np.uint8)) for r in sets]
+    dev = []
+    for k, r in enumerate(sets):
+        d_r = torch.from_numpy(np.ascontiguousarray(r).view(np.uint8)).cuda() if r.shape[0] else torch.zeros(1, dtype=torch.uint8, device="cuda")
+        d_h = torch.full((max(1, r.shape[0]) * HIT.itemsize,), 0xCD, dtype=torch.uint8, device="cuda")
+        d_m = None if k == 3 else torch.full((max(1, r.shape[0]),), 0xCD, dtype=torch.uint8, device="cuda")
+        dev.append((d_r, d_h, d_m, r.shape[0]))
+    counts = a.TraverseBatchesDevice(dev)
+    torch.cuda.synchronize()
+    assert counts == [r.shape[0] for r in sets]
+    if real == np.float32:
+        assert ("k_traverse_w8" in a.LastKernelName()) == (mode == "wide8"), a.LastKernelName()
+    for k, ((d_r, d_h, d_m, n), (h, m)) in enumerate(zip(dev, want)):
+        got = d_h.cpu().numpy()[: n * HIT.itemsize].view(HIT)
+        assert all(got[f_].tobytes() == h[f_].tobytes() for f_ in ("t", "u", "v", "prim_id")), "batch %d" % k  # (fp64 records carry 4 padding bytes)
+        if d_m is not None and n:
+            assert np.array_equal(d_m.cpu().numpy()[:n], m), "batch %d mask" % k
+    # and again right behind it on the same stream (the slot's cursors and completion record are handed on)
+    a.TraverseBatchesDevice(dev[:2])
+    a.TraverseBatchDevice(dev[0][0], dev[0][1], dev[0][2])
+    torch.cuda.synchronize()
+    got = dev[0][1].cpu().numpy().view(HIT)
+    assert all(got[f_].tobytes() == want[0][0][f_].tobytes() for f_ in ("t", "u", "v", "prim_id"))
+    assert a.LastTraverseMs() > 0
