@@ -347,6 +347,40 @@ def pipelined(accel, torch, wave1, wave2, steps, rays_per_step, frames_in_flight
             "ms_per_step": round(dt / steps * 1e3, 4)}
 
 
+def multi_batch(accel, torch, wave1, wave2, steps, rays_per_step):
+    """The same K steps through nrtTraverseBatchesDevice — ONE stream, ONE persistent launch per step over both waves of the
+    frame (one launch tail instead of two), and over the waves of two frames (four batches per launch) — with the records
+    compared with the separate launches'.  Same work as the timed region; reported beside it, never as `value` (a step of
+    the headline is two single-batch launches)."""
+    (r1, h1, m1), (r2, h2, m2) = wave1, wave2
+    accel.TraverseBatchDevice(r1, h1, m1)
+    accel.TraverseBatchDevice(r2, h2, m2)
+    torch.cuda.synchronize()
+    ref1, ref2 = h1.clone(), h2.clone()
+    h1.zero_()
+    h2.zero_()
+    accel.TraverseBatchesDevice([(r1, h1, m1), (r2, h2, m2)])
+    torch.cuda.synchronize()
+    same = bool(torch.equal(ref1, h1) and torch.equal(ref2, h2))
+    h1b, m1b, h2b, m2b = torch.empty_like(h1), torch.empty_like(m1), torch.empty_like(h2), torch.empty_like(m2)
+
+    def timed(batches, frames):
+        for _ in range(2):
+            accel.TraverseBatchesDevice(batches)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(max(1, steps // frames)):
+            accel.TraverseBatchesDevice(batches)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (max(1, steps // frames) * frames)
+
+    one = timed([(r1, h1, m1), (r2, h2, m2)], 1)
+    two = timed([(r1, h1, m1), (r2, h2, m2), (r1, h1b, m1b), (r2, h2b, m2b)], 2)
+    return {"entry_point": "nrtTraverseBatchesDevice_f32 (one stream)", "value": round(rays_per_step / one / 1e6, 1), "unit": "Mrays/s",
+            "ms_per_step": round(one * 1e3, 4), "records_identical_to_separate_launches": same,
+            "two_frames_per_launch": {"value": round(rays_per_step / two / 1e6, 1), "ms_per_step": round(two * 1e3, 4)}}
+
+
 # ---------------------------------------------------------------------------
 # hardware counters, collected in the same invocation (outside the timed region)
 # ---------------------------------------------------------------------------
@@ -1045,6 +1079,9 @@ def main():
             # between two streams; a launch's drain tail is filled by the next frame's rays), (b) SURVEY 8(d)'s
             # primary + shadow pair, (c) the host entry point end to end
             out["pipelined"] = pipelined(accel, torch, (wl.d_rays1, wl.d_hits1, wl.d_mask1), (wl.d_rays2, wl.d_hits2, wl.d_mask2), args.steps, n1 + n2)
+            if n2:
+                out["multi_batch"] = multi_batch(accel, torch, (wl.d_rays1, wl.d_hits1, wl.d_mask1), (wl.d_rays2, wl.d_hits2[: n2 * HIT.itemsize], wl.d_mask2[:n2]),
+                                                 args.steps, n1 + n2)
             rays_s = scenes.secondary_rays("shadow", wl.verts32, wl.faces, wl.rays1_f32, wl.hits1_f32, wl.mask1)
             if wl.real != np.float32:
                 from nanort_amd.wire import widen_rays

@@ -4,7 +4,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -ffp-contract=off -DNANORT_USE_HIP_BACKEND -I../../include main.hip \
 //         -L../../nanort_amd/lib -lnanort_hip -Wl,-rpath,$PWD/../../nanort_amd/lib -o wavefront_gpu
-//   ./wavefront_gpu [--size W H] [--spp N] [--depth D] [--grid NX NY] [--out image.f32] [--streams 1|2]
+//   ./wavefront_gpu [--size W H] [--spp N] [--depth D] [--grid NX NY] [--out image.f32] [--streams 0|1|2]
 //
 // Two streams (the default): the shadow query of depth d and the path wave of depth d + 1 do not depend on each other — both come
 // out of k_shade(d) — so the shadow query and its resolve run on a second stream while the first goes on with the next wave.
@@ -241,7 +241,7 @@ static void MakeGrid(std::vector<float> *vertices, std::vector<unsigned int> *fa
 }
 
 int main(int argc, char **argv) {
-  int W = 480, H = 270, spp = 2, depth = 3, nx = 400, ny = 200, streams = 2;
+  int W = 480, H = 270, spp = 2, depth = 3, nx = 400, ny = 200, streams = 0;
   std::string out;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--size") && i + 2 < argc) {
@@ -257,7 +257,8 @@ int main(int argc, char **argv) {
     } else if (!strcmp(argv[i], "--out") && i + 1 < argc) {
       out = argv[++i];
     } else if (!strcmp(argv[i], "--streams") && i + 1 < argc) {
-      streams = atoi(argv[++i]) == 1 ? 1 : 2;
+      streams = atoi(argv[++i]);
+      if (streams < 0 || streams > 2) streams = 0;
     }
   }
   std::vector<float> vertices;
@@ -312,6 +313,40 @@ int main(int argc, char **argv) {
     hipStream_t shadow_stream = streams == 2 ? stream2 : stream;
     float *shadow_image = streams == 2 ? d_image2 : d_image; // (one stream: the shadow terms join the pixel's sum in path order)
     int wave = 0; // shadow buffers alternate from wave to wave
+    if (streams == 0) {
+      // ONE stream, ONE traversal launch per depth (the default): the shadow query of depth d and the path wave of depth d + 1 both
+      // come out of k_shade(d) and do not depend on each other — they go into one persistent launch as two waves
+      // (BVHAccel::TraverseBatchesDevice), which has one tail where two launches have two.  Per pixel the terms are added in
+      // the order of --streams 1 (shade(d), shadows(d), shade(d + 1), ...): the image is the same in every bit.
+      // (the camera wave of sample s + 1 does not depend on sample s either: it rides with the last shadow query of sample s)
+      hipLaunchKernelGGL(k_camera, grid, block, 0, stream, W, H, 0, d_rays, d_paths);
+      if (!Trace(accel, d_rays, n, d_hits, d_mask, stream)) {
+        fprintf(stderr, "TraverseBatchDevice: %s\n", accel.LastBackendError().c_str());
+        return 1;
+      }
+      rays_traced += n;
+      for (int s = 0; s < spp; s++) {
+        for (int d = 0; d <= depth; d++, wave++) {
+          const int b = wave & 1;
+          hipLaunchKernelGGL(k_shade, grid, block, 0, stream, n, spp, d, depth, d_verts, d_faces, d_rays, d_hits, d_mask, d_paths, d_shadow[b],
+                             d_contrib[b], d_image);
+          const bool next_wave = d < depth || s + 1 < spp; // the next path wave of this sample, or the camera wave of the next one
+          if (d == depth && s + 1 < spp) hipLaunchKernelGGL(k_camera, grid, block, 0, stream, W, H, s + 1, d_rays, d_paths);
+          const nanort::Ray<float> *waves[2] = {reinterpret_cast<const nanort::Ray<float> *>(d_shadow[b]),
+                                                reinterpret_cast<const nanort::Ray<float> *>(d_rays)};
+          nanort::TriangleIntersection<float> *recs[2] = {NULL, reinterpret_cast<nanort::TriangleIntersection<float> *>(d_hits)};
+          unsigned char *flags[2] = {d_smask[b], d_mask};
+          const size_t counts[2] = {(size_t)n, (size_t)n};
+          const unsigned char occlusion[2] = {1, 0};
+          if (!accel.TraverseBatchesDevice(next_wave ? 2 : 1, waves, counts, recs, flags, occlusion, stream)) {
+            fprintf(stderr, "TraverseBatchesDevice: %s\n", accel.LastBackendError().c_str());
+            return 1;
+          }
+          hipLaunchKernelGGL(k_resolve_shadows, grid, block, 0, stream, n, spp, d_smask[b], d_contrib[b], d_image);
+          rays_traced += next_wave ? 2ull * n : (uint64_t)n;
+        }
+      }
+    } else
     for (int s = 0; s < spp; s++) {
       hipLaunchKernelGGL(k_camera, grid, block, 0, stream, W, H, s, d_rays, d_paths);
       for (int d = 0; d <= depth; d++, wave++) {

@@ -967,6 +967,10 @@ struct HipApi<float> {
   static nrt_status TraverseDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, HitPod *h, uint8_t *m, void *s) {
     return nrtTraverseBatchDevice_f32(c, r, n, o, h, m, s);
   }
+  static nrt_status TraverseBatches(nrt_ctx *c, uint32_t nb, const RayPod *const *r, const uint64_t *n, const nrt_trace_options *o, HitPod *const *h,
+                                    uint8_t *const *m, const uint32_t *fl, void *s) {
+    return nrtTraverseBatchesDevice_f32(c, nb, r, n, o, h, m, fl, s);
+  }
   static nrt_status Occluded(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m) { return nrtOccludedBatch_f32(c, r, n, o, m); }
   static nrt_status OccludedDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m, void *s) {
     return nrtOccludedBatchDevice_f32(c, r, n, o, m, s);
@@ -987,6 +991,10 @@ struct HipApi<double> {
   }
   static nrt_status TraverseDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, HitPod *h, uint8_t *m, void *s) {
     return nrtTraverseBatchDevice_f64(c, r, n, o, h, m, s);
+  }
+  static nrt_status TraverseBatches(nrt_ctx *c, uint32_t nb, const RayPod *const *r, const uint64_t *n, const nrt_trace_options *o, HitPod *const *h,
+                                    uint8_t *const *m, const uint32_t *fl, void *s) {
+    return nrtTraverseBatchesDevice_f64(c, nb, r, n, o, h, m, fl, s);
   }
   static nrt_status Occluded(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m) { return nrtOccludedBatch_f64(c, r, n, o, m); }
   static nrt_status OccludedDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m, void *s) {
@@ -1187,6 +1195,37 @@ class BVHAccel {
     nrt_trace_options o;
     std::memcpy(&o, &options, sizeof(o));
     if (DeviceLaunch(ctx_.get(), d_rays, num_rays, &o, d_isects, d_hit, hip_stream) != NRT_OK) {
+      backend_error_ = nrtLastError(ctx_.get());
+      return false;
+    }
+    return true;
+  }
+  // Several independent device-resident waves in ONE launch (nrtTraverseBatchesDevice): `occlusion[k]` != 0 makes wave k an
+  // occlusion query (only d_hit[k] is written, d_isects[k] may be NULL).  One launch tail for all the waves — a renderer's
+  // shadow query and next path wave, without a second stream.  Records equal those of separate calls.  `occlusion` may be NULL.
+  bool TraverseBatchesDevice(size_t num_waves, const Ray<T> *const *d_rays, const size_t *num_rays, TriangleIntersection<T> *const *d_isects,
+                             unsigned char *const *d_hit, const unsigned char *occlusion, void *hip_stream,
+                             const BVHTraceOptions &options = BVHTraceOptions()) const {
+    typedef detail::HipApi<T> Api;
+    if (!ctx_ || device_tree_stale_ || device_prim_kind_ != 0) {
+      backend_error_ = "TraverseBatchesDevice: no triangle tree on the GPU";
+      return false;
+    }
+    nrt_trace_options o;
+    std::memcpy(&o, &options, sizeof(o));
+    std::vector<const typename Api::RayPod *> r(num_waves);
+    std::vector<typename Api::HitPod *> h(num_waves);
+    std::vector<uint8_t *> m(num_waves);
+    std::vector<uint64_t> n(num_waves);
+    std::vector<uint32_t> fl(num_waves);
+    for (size_t k = 0; k < num_waves; k++) {
+      r[k] = reinterpret_cast<const typename Api::RayPod *>(d_rays[k]);
+      h[k] = reinterpret_cast<typename Api::HitPod *>(d_isects ? d_isects[k] : NULL);
+      m[k] = d_hit ? d_hit[k] : NULL;
+      n[k] = num_rays[k];
+      fl[k] = (occlusion && occlusion[k]) ? NRT_BATCH_OCCLUSION : 0u;
+    }
+    if (Api::TraverseBatches(ctx_.get(), static_cast<uint32_t>(num_waves), r.data(), n.data(), &o, h.data(), m.data(), fl.data(), hip_stream) != NRT_OK) {
       backend_error_ = nrtLastError(ctx_.get());
       return false;
     }

@@ -297,17 +297,22 @@ NRT_API nrt_status nrtTraverseBatchDevice_f64(nrt_ctx *ctx, const nrt_ray_f64 *d
                                               void *hip_stream);
 
 /* Several independent HBM-resident batches in ONE launch (same trace options; arrays of `num_batches` device pointers and
- * counts, d_masks or any of its entries may be NULL).  The persistent kernel hands out the batches as one virtual ray array, so
- * the waves that run dry at the end of one batch carry on with the next: one launch tail instead of `num_batches` (a renderer's
- * shadow and bounce waves, or two tiles, without a second stream).  Records are exactly those of `num_batches` separate
- * nrtTraverseBatchDevice calls.  fp64, sphere and cylinder contexts launch the batches one after the other.  Asynchronous on
- * `hip_stream` like nrtTraverseBatchDevice.  (No reference counterpart: nanort.h traces one ray per call, :2487-2556.) */
+ * counts; d_masks or any of its entries may be NULL; batch_flags may be NULL).  The persistent kernel hands out the batches as
+ * one virtual ray array, so the waves that run dry at the end of one batch carry on with the next: one launch tail instead of
+ * `num_batches` (a renderer's shadow and bounce waves, or two tiles, without a second stream).  A batch flagged
+ * NRT_BATCH_OCCLUSION is an occlusion query (nrtOccludedBatchDevice's contract: its d_masks entry receives the flags, its
+ * d_hits entry is ignored).  Records are exactly those of separate nrtTraverseBatchDevice / nrtOccludedBatchDevice calls.
+ * fp64, sphere and cylinder contexts launch the batches one after the other.  Asynchronous on `hip_stream` like
+ * nrtTraverseBatchDevice.  (No reference counterpart: nanort.h traces one ray per call, :2487-2556.) */
+#define NRT_BATCH_OCCLUSION 1u
 NRT_API nrt_status nrtTraverseBatchesDevice_f32(nrt_ctx *ctx, uint32_t num_batches, const nrt_ray_f32 *const *d_rays,
                                                 const uint64_t *num_rays, const nrt_trace_options *options,
-                                                nrt_hit_f32 *const *d_hits_out, uint8_t *const *d_masks_out, void *hip_stream);
+                                                nrt_hit_f32 *const *d_hits_out, uint8_t *const *d_masks_out,
+                                                const uint32_t *batch_flags, void *hip_stream);
 NRT_API nrt_status nrtTraverseBatchesDevice_f64(nrt_ctx *ctx, uint32_t num_batches, const nrt_ray_f64 *const *d_rays,
                                                 const uint64_t *num_rays, const nrt_trace_options *options,
-                                                nrt_hit_f64 *const *d_hits_out, uint8_t *const *d_masks_out, void *hip_stream);
+                                                nrt_hit_f64 *const *d_hits_out, uint8_t *const *d_masks_out,
+                                                const uint32_t *batch_flags, void *hip_stream);
 
 /* Measurement aid: run the batch once on HBM-resident rays with the work
  * counters on (synchronous; results are not written).  Used by bench.py to

@@ -282,8 +282,9 @@ class BVHAccel:
         return n
 
     def TraverseBatchesDevice(self, batches, options=None, stream=None):
-        """nrtTraverseBatchesDevice: several independent batches — a list of (d_rays, d_hits, d_mask or None, n or None) torch
-        uint8 tensors — walked by ONE persistent launch (asynchronous on `stream`).  Returns the ray counts."""
+        """nrtTraverseBatchesDevice: several independent batches — a list of (d_rays, d_hits, d_mask or None, n or None[, "occlusion"])
+        torch uint8 tensors — walked by ONE persistent launch (asynchronous on `stream`).  A batch marked "occlusion" is an
+        occlusion query: only its d_mask is written (d_hits may be None).  Returns the ray counts."""
         import torch
 
         rsz, hsz = ray_dtype(self.real).itemsize, hit_dtype(self.real).itemsize
@@ -292,17 +293,20 @@ class BVHAccel:
         hits = (ctypes.c_void_p * nb)()
         masks = (ctypes.c_void_p * nb)()
         counts = (ctypes.c_uint64 * nb)()
+        flags = (ctypes.c_uint32 * nb)()
         for k, b in enumerate(batches):
             d_rays, d_hits, d_mask = b[0], b[1], b[2]
             n = b[3] if len(b) > 3 and b[3] is not None else d_rays.numel() * d_rays.element_size() // rsz
-            assert d_hits.numel() * d_hits.element_size() >= n * hsz
-            rays[k], hits[k], counts[k] = d_rays.data_ptr(), d_hits.data_ptr(), n
+            occ = len(b) > 4 and b[4] == "occlusion"
+            assert occ or d_hits.numel() * d_hits.element_size() >= n * hsz
+            flags[k] = 1 if occ else 0
+            rays[k], hits[k], counts[k] = d_rays.data_ptr(), (None if d_hits is None else d_hits.data_ptr()), n
             masks[k] = None if d_mask is None else d_mask.data_ptr()
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream
         if options is not None:
             options = np.asarray(options, dtype=TRACE_OPTIONS).reshape(1)
-        self._check(getattr(self._L, "nrtTraverseBatchesDevice_" + self._s)(self._h, nb, rays, counts, _p(options), hits, masks, stream))
+        self._check(getattr(self._L, "nrtTraverseBatchesDevice_" + self._s)(self._h, nb, rays, counts, _p(options), hits, masks, flags, stream))
         return [int(c) for c in counts]
 
     def OccludedBatch(self, rays, options=None):

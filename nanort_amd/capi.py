@@ -97,7 +97,7 @@ def lib():
         f.argtypes = [vp, vp, u64, vp, vp, vp, vp]
         f.restype = i32
         f = getattr(L, "nrtTraverseBatchesDevice_" + s)
-        f.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
+        f.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, vp]
         f.restype = i32
         f = getattr(L, "nrtTraverseCountDevice_" + s)
         f.argtypes = [vp, vp, u64, vp, ctypes.POINTER(TraceCounters)]

@@ -811,6 +811,7 @@ struct TraverseBatches {
   typename Wire<T>::Hit *hits[kMaxBatches];
   uint8_t *mask[kMaxBatches];
   uint64_t count[kMaxBatches];
+  uint32_t anyhit; // bit k: batch k is an occlusion query
 };
 
 template <typename T>
@@ -942,6 +943,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   }
   a.num_rays = (uint32_t)n;
   a.num_batches = 1u;
+  a.batch_anyhit = 0u;
   for (int k = 0; k < kMaxBatches; k++) {
     a.batch_end[k] = (uint32_t)n;
     a.batches[k] = BatchPtrs{nullptr, nullptr, nullptr, 0};
@@ -949,6 +951,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   if (mb) {
     if (!use_wide || sizeof(T) != 4 || spheres || count) return fail(c, NRT_ERR_INVALID, "internal: multi-batch launch on a context that cannot take it");
     a.num_batches = mb->nb;
+    a.batch_anyhit = mb->anyhit;
     uint64_t start = 0;
     for (uint32_t k = 0; k < mb->nb; k++) { // pointers addressed by the virtual index: base - start
       a.batches[k].rays_v = mb->rays[k] - start;
@@ -1147,10 +1150,13 @@ static nrt_status traverse_count(nrt_ctx *c, const typename Wire<T>::Ray *d_rays
 template <typename T>
 static nrt_status traverse_batches_device(nrt_ctx *c, uint32_t nb, const typename Wire<T>::Ray *const *d_rays, const uint64_t *counts,
                                           const nrt_trace_options *opt, typename Wire<T>::Hit *const *d_hits,
-                                          uint8_t *const *d_masks, hipStream_t s) {
+                                          uint8_t *const *d_masks, const uint32_t *flags, hipStream_t s) {
   if (!c) return NRT_ERR_INVALID;
   if (nb == 0) return NRT_OK;
   if (!d_rays || !counts || !d_hits) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchesDevice: NULL argument");
+  for (uint32_t k = 0; k < nb; k++)
+    if (flags && (flags[k] & NRT_BATCH_OCCLUSION) && counts[k] && !(d_masks && d_masks[k]))
+      return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchesDevice: occlusion batch %u has no flag array", k);
   TraverseBatches<T> mb;
   mb.nb = 0;
   uint64_t total = 0;
@@ -1164,13 +1170,16 @@ static nrt_status traverse_batches_device(nrt_ctx *c, uint32_t nb, const typenam
   uint32_t k = 0;
   while (k < nb) { // groups of up to kMaxBatches non-empty batches per launch
     mb.nb = 0;
+    mb.anyhit = 0;
     uint64_t n = 0;
     while (k < nb && mb.nb < (uint32_t)kMaxBatches) {
       if (counts[k]) {
+        const bool occ = flags && (flags[k] & NRT_BATCH_OCCLUSION);
         mb.rays[mb.nb] = d_rays[k];
-        mb.hits[mb.nb] = d_hits[k];
+        mb.hits[mb.nb] = occ ? nullptr : d_hits[k]; // (an occlusion query writes the flags only)
         mb.mask[mb.nb] = d_masks ? d_masks[k] : nullptr;
         mb.count[mb.nb] = counts[k];
+        if (occ) mb.anyhit |= 1u << mb.nb;
         n += counts[k];
         mb.nb++;
       }
@@ -1183,7 +1192,8 @@ static nrt_status traverse_batches_device(nrt_ctx *c, uint32_t nb, const typenam
       if (st) return st;
     } else {
       for (uint32_t j = 0; j < mb.nb; j++)
-        if ((st = traverse_device<T>(c, mb.rays[j], mb.count[j], opt, mb.hits[j], mb.mask[j], s, false, false))) return st;
+        if ((st = traverse_device<T>(c, mb.rays[j], mb.count[j], opt, mb.hits[j], mb.mask[j], s, false, false, nullptr, ((mb.anyhit >> j) & 1u) != 0u)))
+          return st;
     }
   }
   return NRT_OK;
@@ -1325,12 +1335,12 @@ nrt_status nrtTraverseBatchDevice_f64(nrt_ctx *c, const nrt_ray_f64 *r, uint64_t
 }
 
 nrt_status nrtTraverseBatchesDevice_f32(nrt_ctx *c, uint32_t nb, const nrt_ray_f32 *const *r, const uint64_t *n, const nrt_trace_options *o,
-                                        nrt_hit_f32 *const *h, uint8_t *const *m, void *s) {
-  return traverse_batches_device<float>(c, nb, r, n, o, h, m, (hipStream_t)s);
+                                        nrt_hit_f32 *const *h, uint8_t *const *m, const uint32_t *fl, void *s) {
+  return traverse_batches_device<float>(c, nb, r, n, o, h, m, fl, (hipStream_t)s);
 }
 nrt_status nrtTraverseBatchesDevice_f64(nrt_ctx *c, uint32_t nb, const nrt_ray_f64 *const *r, const uint64_t *n, const nrt_trace_options *o,
-                                        nrt_hit_f64 *const *h, uint8_t *const *m, void *s) {
-  return traverse_batches_device<double>(c, nb, r, n, o, h, m, (hipStream_t)s);
+                                        nrt_hit_f64 *const *h, uint8_t *const *m, const uint32_t *fl, void *s) {
+  return traverse_batches_device<double>(c, nb, r, n, o, h, m, fl, (hipStream_t)s);
 }
 nrt_status nrtTraverseCountDevice_f32(nrt_ctx *c, const nrt_ray_f32 *r, uint64_t n, const nrt_trace_options *o,
                                       nrt_trace_counters *out) {

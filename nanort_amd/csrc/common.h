@@ -282,6 +282,7 @@ struct TraverseArgs {
   uint8_t *mask;               // may be null
   uint32_t num_rays;
   uint32_t num_batches;             // > 1: the rays are `num_batches` batches back to back (fp32 WideNode kernels only): batches[] / batch_end[] instead of rays / hits / mask
+  uint32_t batch_anyhit;            // bit k: batch k is an occlusion query (its rays stop at the first primitive they accept; only the flags are written)
   uint32_t batch_end[kMaxBatches];  // virtual index one past the last ray of batch k
   BatchPtrs batches[kMaxBatches];
   uint32_t range0, range1, skip_prim; // BVHTraceOptions

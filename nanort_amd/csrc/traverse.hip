@@ -1341,9 +1341,15 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
           if (rid != kInvalid) NRT_WRITE_RESULT();
           rid = ck.next + rank;
           const Ray *rp_ = a.rays;
-          if (multi) rp_ = (const Ray *)s_tbl[batch_of<T>(a, rid)].rays_v;
+          uint32_t bq_ = 0u; // this ray belongs to an occlusion-query batch
+          if (multi) {
+            const uint32_t b_ = batch_of<T>(a, rid);
+            rp_ = (const Ray *)s_tbl[b_].rays_v;
+            bq_ = (a.batch_anyhit >> b_) & 1u;
+          }
           const Ray r = (a.debug_flags & 4u) ? rp_[rid] : load_ray_nt<T>(rp_ + rid);
           lane_init<T>(L, r);
+          L.pk |= bq_ << 9;
           sp = 0;
           if (STATS) st_steps = st_tris = 0;
           // The reference pops and tests the root first (nanort.h:2526-2533).  For a branch root that test is implied by
@@ -1533,7 +1539,7 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
         NRT_TEST_PRIM(first + (i < cnt ? i : 0u), i < cnt);
       }
       // occlusion query: any accepted primitive settles the ray — drop what is left of its stack
-      if (a.any_hit) sp = (state == W_LEAF && L.hit_t < L.max_t) ? 0 : sp;
+      if (a.any_hit | a.batch_anyhit) sp = (state == W_LEAF && L.hit_t < L.max_t && (a.any_hit != 0u || (L.pk & 512u) != 0u)) ? 0 : sp;
       state = (state == W_LEAF) ? W_POP : state;
     }
     if (STATS) st_t_p2 += __builtin_amdgcn_s_memtime() - st_stamp;
@@ -1667,9 +1673,15 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_w8(const TraverseAr
           if (rid != kInvalid) W8_WRITE_RESULT();
           rid = ck.next + rank;
           const Ray *rp_ = a.rays;
-          if (multi) rp_ = (const Ray *)s_tbl[batch_of<T>(a, rid)].rays_v;
+          uint32_t bq_ = 0u;
+          if (multi) {
+            const uint32_t b_ = batch_of<T>(a, rid);
+            rp_ = (const Ray *)s_tbl[b_].rays_v;
+            bq_ = (a.batch_anyhit >> b_) & 1u;
+          }
           const Ray r = load_ray_nt<T>(rp_ + rid);
           lane_init<T>(L, r);
+          L.pk |= bq_ << 9;
           oct = (L.pk >> 6) & 7u;
           {
             const float big0 = __builtin_copysignf(NRT_W8_BIG, L.inv0), big1 = __builtin_copysignf(NRT_W8_BIG, L.inv1),
@@ -1863,7 +1875,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_w8(const TraverseAr
         }
         li += 2u;
       }
-      if (a.any_hit) sp = (mine && L.hit_t < L.max_t) ? 0 : sp;
+      if (a.any_hit | a.batch_anyhit) sp = (mine && L.hit_t < L.max_t && (a.any_hit != 0u || (L.pk & 512u) != 0u)) ? 0 : sp;
       state = mine ? W_POP : state;
     }
   }

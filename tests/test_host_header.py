@@ -424,6 +424,15 @@ def test_gpu_shaded_wavefront_path_tracer(tmp_path):
     d = np.abs(g - h)
     assert (d <= 2e-3).mean() > 0.995, (d > 2e-3).mean()
     assert d.mean() < 1e-3 and abs(float(g.sum()) - float(h.sum())) / float(h.sum()) < 1e-3
+    # the default mode puts a depth's shadow query and the next path wave into ONE launch (TraverseBatchesDevice); per pixel the
+    # terms are summed in the order of the one-stream mode, whose launches are separate: the two images are the same in every bit
+    one = subprocess.run([str(hip)] + args + ["--streams", "1", "--out", str(tmp_path / "gpu1.f32")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert one.returncode == 0, one.stdout
+    assert np.fromfile(str(tmp_path / "gpu1.f32"), dtype=np.float32).tobytes() == g.tobytes()
+    two = subprocess.run([str(hip)] + args + ["--streams", "2", "--out", str(tmp_path / "gpu2.f32")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert two.returncode == 0, two.stdout
+    g2 = np.fromfile(str(tmp_path / "gpu2.f32"), dtype=np.float32)
+    assert np.abs(g2 - g).max() < 1e-4  # (two streams: the shadow terms are summed separately, last-bit differences)
 
 
 SERIALIZE_SRC = r"""
