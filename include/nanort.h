@@ -971,6 +971,9 @@ struct HipApi<float> {
                                     uint8_t *const *m, const uint32_t *fl, void *s) {
     return nrtTraverseBatchesDevice_f32(c, nb, r, n, o, h, m, fl, s);
   }
+  static nrt_status TraverseMulti(nrt_ctx *const *cs, uint32_t nc, const RayPod *r, uint64_t n, uint64_t row, const nrt_trace_options *o, HitPod *h, uint8_t *m) {
+    return nrtTraverseBatchMulti_f32(cs, nc, r, n, row, o, h, m);
+  }
   static nrt_status Occluded(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m) { return nrtOccludedBatch_f32(c, r, n, o, m); }
   static nrt_status OccludedDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m, void *s) {
     return nrtOccludedBatchDevice_f32(c, r, n, o, m, s);
@@ -995,6 +998,9 @@ struct HipApi<double> {
   static nrt_status TraverseBatches(nrt_ctx *c, uint32_t nb, const RayPod *const *r, const uint64_t *n, const nrt_trace_options *o, HitPod *const *h,
                                     uint8_t *const *m, const uint32_t *fl, void *s) {
     return nrtTraverseBatchesDevice_f64(c, nb, r, n, o, h, m, fl, s);
+  }
+  static nrt_status TraverseMulti(nrt_ctx *const *cs, uint32_t nc, const RayPod *r, uint64_t n, uint64_t row, const nrt_trace_options *o, HitPod *h, uint8_t *m) {
+    return nrtTraverseBatchMulti_f64(cs, nc, r, n, row, o, h, m);
   }
   static nrt_status Occluded(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m) { return nrtOccludedBatch_f64(c, r, n, o, m); }
   static nrt_status OccludedDevice(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, uint8_t *m, void *s) {
@@ -1307,6 +1313,12 @@ class BVHAccel {
   const std::string &LastBackendError() const { return backend_error_; }
   // The C-ABI context behind this accel (NULL before a GPU Build()): what nrtSceneAddNode_f32 takes (include/nanosg_hip.h).
   nrt_ctx *HipContext() const { return device_tree_stale_ ? NULL : ctx_.get(); }
+  // Multi-GPU (environment variable NANORT_HIP_DEVICES = "all" or a list such as "0,1,2,3"; read by Build()): Build() makes a
+  // replica of the tree on every listed device (the build is deterministic: the replicas are bit-identical) and
+  // TraverseBatch() splits a host batch over them in interleaved rows of this many rays (default 4096; a renderer passes its
+  // image width).  Records are the single-device ones.
+  size_t NumHipDevices() const { return ctx_ ? 1 + peers_.size() : 0; }
+  void SetTraverseBatchRowLength(size_t rays_per_row) { batch_row_len_ = rays_per_row; }
 
  private:
   static nrt_status DeviceLaunch(nrt_ctx *c, const Ray<T> *r, size_t n, const nrt_trace_options *o, TriangleIntersection<T> *h,
@@ -1336,6 +1348,12 @@ class BVHAccel {
         backend_error_ = nodes_.empty() ? "TraverseBatch: empty tree" : nrtLastError(ctx_.get());
         return false;
       }
+      for (size_t k = 0; k < peers_.size(); k++) // (the replicas on the other devices adopt the same arrays)
+        if (Api::SetTree(peers_[k].get(), reinterpret_cast<const typename Api::NodePod *>(&nodes_[0]), nodes_.size(),
+                         indices_.empty() ? NULL : &indices_[0], indices_.size()) != NRT_OK) {
+          backend_error_ = nrtLastError(peers_[k].get());
+          return false;
+        }
       device_tree_stale_ = false;
     }
     if (num_rays == 0) return true;
@@ -1351,7 +1369,16 @@ class BVHAccel {
     }
     nrt_trace_options o;
     std::memcpy(&o, &options, sizeof(o));
-    if (Api::Traverse(ctx_.get(), reinterpret_cast<const typename Api::RayPod *>(rays), num_rays, &o, tmp, mask) != NRT_OK) {
+    if (!peers_.empty() && want_kind == 0) {
+      // NANORT_HIP_DEVICES: the batch is split row-interleaved over the replicas, one per device (nrtTraverseBatchMulti)
+      std::vector<nrt_ctx *> cs(1, ctx_.get());
+      for (size_t k = 0; k < peers_.size(); k++) cs.push_back(peers_[k].get());
+      if (Api::TraverseMulti(&cs[0], static_cast<uint32_t>(cs.size()), reinterpret_cast<const typename Api::RayPod *>(rays), num_rays, batch_row_len_,
+                             &o, reinterpret_cast<HitPod *>(tmp), mask) != NRT_OK) {
+        backend_error_ = nrtLastError(ctx_.get());
+        return false;
+      }
+    } else if (Api::Traverse(ctx_.get(), reinterpret_cast<const typename Api::RayPod *>(rays), num_rays, &o, tmp, mask) != NRT_OK) {
       backend_error_ = nrtLastError(ctx_.get());
       return false;
     }
@@ -1684,6 +1711,7 @@ class BVHAccel {
     // user primitives live on the host only: a device context left over from an earlier built-in Build() holds other
     // primitives and must not be traced against this tree
     ctx_.reset();
+    peers_.clear();
     device_tree_stale_ = false;
     device_prim_kind_ = -1;
 #endif
@@ -1728,15 +1756,40 @@ class BVHAccel {
     assert(options_.bin_size > 1);
     if (n == 0) return false;
     if (!ctx_) {
-      nrt_ctx *raw = NULL;
-      int device = 0;
-      if (const char *env = std::getenv("NANORT_HIP_DEVICE")) device = std::atoi(env);
-      if (nrtCreate(device, &raw) != NRT_OK) {
-        backend_error_ = nrtLastError(NULL);
-        fprintf(stderr, "[nanort] HIP backend unavailable: %s\n", backend_error_.c_str());
-        return false;
+      // devices: NANORT_HIP_DEVICES ("all" or a comma-separated list; the first is the primary) or the one of NANORT_HIP_DEVICE
+      std::vector<int> devices;
+      if (const char *list = std::getenv("NANORT_HIP_DEVICES")) {
+        if (std::strcmp(list, "all") == 0) {
+          for (int d = 0; d < nrtDeviceCount(); d++) devices.push_back(d);
+        } else {
+          for (const char *p = list; *p;) {
+            devices.push_back(std::atoi(p));
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+          }
+        }
       }
-      ctx_ = std::shared_ptr<nrt_ctx>(raw, detail::CtxDeleter());
+      if (devices.empty()) {
+        int device = 0;
+        if (const char *env = std::getenv("NANORT_HIP_DEVICE")) device = std::atoi(env);
+        devices.push_back(device);
+      }
+      for (size_t k = 0; k < devices.size(); k++) {
+        nrt_ctx *raw = NULL;
+        if (nrtCreate(devices[k], &raw) != NRT_OK) {
+          backend_error_ = nrtLastError(NULL);
+          if (k == 0) {
+            fprintf(stderr, "[nanort] HIP backend unavailable: %s\n", backend_error_.c_str());
+            return false;
+          }
+          fprintf(stderr, "[nanort] HIP device %d unavailable (%s): continuing with %zu device(s)\n", devices[k], backend_error_.c_str(), k);
+          break;
+        }
+        if (k == 0)
+          ctx_ = std::shared_ptr<nrt_ctx>(raw, detail::CtxDeleter());
+        else
+          peers_.push_back(std::shared_ptr<nrt_ctx>(raw, detail::CtxDeleter()));
+      }
     }
     nrt_ctx *c = ctx_.get();
     typename Api::BuildPod o;
@@ -1760,6 +1813,17 @@ class BVHAccel {
     stats_.num_leaf_nodes = st.num_leaf_nodes;
     stats_.num_branch_nodes = st.num_branch_nodes;
     stats_.build_secs = st.build_secs;
+    // replicas on the other devices: the same primitives, the same (deterministic) build
+    for (size_t k = 0; k < peers_.size(); k++) {
+      nrt_build_stats pst;
+      uint64_t pn = 0;
+      if (set_prims(peers_[k].get()) != NRT_OK || Api::Build(peers_[k].get(), &o, &pst, &pn) != NRT_OK || pn != num_nodes) {
+        backend_error_ = nrtLastError(peers_[k].get());
+        fprintf(stderr, "[nanort] HIP build of replica %zu failed (%s): tracing on one device\n", k + 1, backend_error_.c_str());
+        peers_.clear();
+        break;
+      }
+    }
     device_tree_stale_ = false;
     device_prim_kind_ = prim_kind;
     return true;
@@ -1773,6 +1837,8 @@ class BVHAccel {
   unsigned int pad0_;
 #ifdef NANORT_USE_HIP_BACKEND
   std::shared_ptr<nrt_ctx> ctx_;
+  std::vector<std::shared_ptr<nrt_ctx> > peers_;  // replicas on the other devices of NANORT_HIP_DEVICES
+  size_t batch_row_len_ = 0;                      // rays per interleaved row of a multi-device TraverseBatch (0: 4096)
   mutable bool device_tree_stale_ = false;
   int device_prim_kind_ = -1;  // what the device context was built over: 0 triangles, 1 spheres, 2 cylinders, -1 nothing usable
   const float *cyl_endpoints_ = NULL;  // cylinder primitive: what Build() was given

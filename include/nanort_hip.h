@@ -314,6 +314,25 @@ NRT_API nrt_status nrtTraverseBatchesDevice_f64(nrt_ctx *ctx, uint32_t num_batch
                                                 nrt_hit_f64 *const *d_hits_out, uint8_t *const *d_masks_out,
                                                 const uint32_t *batch_flags, void *hip_stream);
 
+/* One HOST batch spread over several contexts — typically one per GPU of the node (nrtDeviceCount), each holding the same
+ * tree: nrtBuild is deterministic, so building the same mesh on every context gives bit-identical replicas (or nrtSetTree the
+ * same arrays).  The batch is cut into rows of `row_len` rays (an image row; 0 = 4096) and row r is traced by context
+ * r % num_ctx — the interleaved image-tile split of SURVEY.md §8(e); each context is driven by its own host thread and its
+ * GPU copies its rows of the records (and flags, when hit_mask_out is not NULL) straight into the caller's arrays, which are
+ * written in full like nrtTraverseBatch's.  Records are exactly those of nrtTraverseBatch on one context.  Page-locked caller
+ * buffers (nrtHostAlloc) let the copies of different GPUs overlap at PCIe speed.  Errors: NRT_ERR_INVALID when a context is
+ * NULL, listed twice, of another precision, without a triangle tree or with another tree than context 0's.
+ * (No reference counterpart: the reference's only parallel loop is the example's OpenMP row loop,
+ * examples/path_tracer/main.cc:785-806.) */
+NRT_API nrt_status nrtTraverseBatchMulti_f32(nrt_ctx *const *ctxs, uint32_t num_ctx, const nrt_ray_f32 *rays, uint64_t num_rays,
+                                             uint64_t row_len, const nrt_trace_options *options, nrt_hit_f32 *hits_out,
+                                             uint8_t *hit_mask_out);
+NRT_API nrt_status nrtTraverseBatchMulti_f64(nrt_ctx *const *ctxs, uint32_t num_ctx, const nrt_ray_f64 *rays, uint64_t num_rays,
+                                             uint64_t row_len, const nrt_trace_options *options, nrt_hit_f64 *hits_out,
+                                             uint8_t *hit_mask_out);
+/* HIP devices visible to this process (0 when there is none or the runtime cannot be initialised). */
+NRT_API int nrtDeviceCount(void);
+
 /* Measurement aid: run the batch once on HBM-resident rays with the work
  * counters on (synchronous; results are not written).  Used by bench.py to
  * turn kernel time into algorithmic bytes per SURVEY.md §8(d). */
@@ -357,7 +376,7 @@ NRT_API const char *nrtLastKernelName(const nrt_ctx *ctx);
 /* Test aid: copy out the private 8-wide compressed layout of the current fp32 tree (built when the tunable "wide8" is set
  * before nrtBuild / nrtSetTree): 80-byte node records and 40-byte leaf records (nanort_amd/csrc/common.h: Wide8Node, W8Rec).
  * Either output may be NULL; the counts are always returned.  tests/test_gpu_wide8.py compares the arrays with the CPU
- * model's (oracle/wide8_model.inc).  (No reference counterpart.) */
+ * model's (the wide8 model under the test infrastructure).  (No reference counterpart.) */
 NRT_API nrt_status nrtGetWide8_f32(nrt_ctx *ctx, void *nodes_out, void *recs_out, uint64_t *num_nodes, uint64_t *num_recs);
 /* Profiling aid: loop-occupancy counters of the last traversal launched with the tunable "debug" bit 32 set (a separately
  * instantiated, slower kernel).  out16[0..7] = inner-node-phase wave iterations, sum of active lanes, idle lanes at leaf-phase

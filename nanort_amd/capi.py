@@ -22,6 +22,7 @@ SYMBOLS = [
     "nrtSetTree_f32", "nrtSetTree_f64",
     "nrtTraverseBatch_f32", "nrtTraverseBatch_f64",
     "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64", "nrtTraverseBatchesDevice_f32", "nrtTraverseBatchesDevice_f64",
+    "nrtTraverseBatchMulti_f32", "nrtTraverseBatchMulti_f64", "nrtDeviceCount",
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
     "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtDebugCounters", "nrtDebugWaveClocks", "nrtGetWide8_f32", "nrtHostAlloc", "nrtHostFree",
@@ -96,6 +97,9 @@ def lib():
         f = getattr(L, "nrtTraverseBatchDevice_" + s)
         f.argtypes = [vp, vp, u64, vp, vp, vp, vp]
         f.restype = i32
+        f = getattr(L, "nrtTraverseBatchMulti_" + s)
+        f.argtypes = [vp, u32, vp, u64, u64, vp, vp, vp]
+        f.restype = i32
         f = getattr(L, "nrtTraverseBatchesDevice_" + s)
         f.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, vp]
         f.restype = i32
@@ -151,6 +155,8 @@ def lib():
     L.nrtLastBuildMs.restype = ctypes.c_float
     L.nrtGetWide8_f32.argtypes = [vp, vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     L.nrtGetWide8_f32.restype = i32
+    L.nrtDeviceCount.argtypes = []
+    L.nrtDeviceCount.restype = i32
     L.nrtLastKernelName.argtypes = [vp]
     L.nrtLastKernelName.restype = ctypes.c_char_p
     _LIB = L

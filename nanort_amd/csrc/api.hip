@@ -1126,6 +1126,81 @@ static nrt_status traverse_host(nrt_ctx *c, const typename Wire<T>::Ray *rays, u
   return NRT_OK;
 }
 
+// One host batch spread over several contexts — one per GPU of the node, each holding the same tree (the build is
+// deterministic: replicas are bit-identical).  The batch is cut into rows of `row_len` rays (an image row; 4096 rays when 0) and
+// row r goes to context r % num_ctx — interleaved, so that no device gets the empty sky or the dense ground alone.  Every
+// context is driven by a host thread of its own: strided copy of its rows up (one 2-D copy), one launch, strided copies of its
+// records and flags straight into the caller's arrays.  No collective: the results are host-resident and every GPU writes its
+// own rows of them.  Records are exactly those of a single-context nrtTraverseBatch over the whole batch.
+template <typename T>
+static nrt_status traverse_share(nrt_ctx *c, uint32_t k, uint32_t num_ctx, const typename Wire<T>::Ray *rays, uint64_t n, uint64_t row_len,
+                                 const nrt_trace_options *opt, typename Wire<T>::Hit *hits, uint8_t *mask) {
+  typedef typename Wire<T>::Ray Ray;
+  typedef typename Wire<T>::Hit Hit;
+  const uint64_t rows_total = (n + row_len - 1) / row_len;
+  if (k >= rows_total) return NRT_OK;
+  const uint64_t my_rows = (rows_total - k + num_ctx - 1) / num_ctx; // rows k, k + num_ctx, ...
+  const uint64_t last_row = k + (my_rows - 1) * num_ctx;
+  const uint64_t last_len = (last_row == rows_total - 1) ? n - last_row * row_len : row_len; // only the batch's final row can be short
+  const uint64_t full_rows = last_len == row_len ? my_rows : my_rows - 1;
+  const uint64_t m = full_rows * row_len + (full_rows < my_rows ? last_len : 0);
+  std::lock_guard<std::mutex> host_lock(c->host_mutex);
+  HIPCHK(c, hipSetDevice(c->device));
+  nrt_status st;
+  if ((st = ensure(c, c->st_rays, m * sizeof(Ray))) || (st = ensure(c, c->st_hits, m * sizeof(Hit))) || (st = ensure(c, c->st_mask, m))) return st;
+  Ray *d_r = (Ray *)c->st_rays.p;
+  Hit *d_h = (Hit *)c->st_hits.p;
+  uint8_t *d_m = (uint8_t *)c->st_mask.p;
+  const size_t rb = (size_t)row_len * sizeof(Ray), hb = (size_t)row_len * sizeof(Hit), mbytes = (size_t)row_len;
+  if (full_rows) HIPCHK(c, hipMemcpy2DAsync(d_r, rb, rays + k * row_len, rb * num_ctx, rb, full_rows, hipMemcpyHostToDevice, c->stream));
+  if (full_rows < my_rows)
+    HIPCHK(c, hipMemcpyAsync(d_r + full_rows * row_len, rays + last_row * row_len, last_len * sizeof(Ray), hipMemcpyHostToDevice, c->stream));
+  if ((st = traverse_device<T>(c, d_r, m, opt, d_h, d_m, c->stream, false, false))) return st;
+  if (full_rows) {
+    HIPCHK(c, hipMemcpy2DAsync(hits + k * row_len, hb * num_ctx, d_h, hb, hb, full_rows, hipMemcpyDeviceToHost, c->stream));
+    if (mask) HIPCHK(c, hipMemcpy2DAsync(mask + k * row_len, mbytes * num_ctx, d_m, mbytes, mbytes, full_rows, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (full_rows < my_rows) {
+    HIPCHK(c, hipMemcpyAsync(hits + last_row * row_len, d_h + full_rows * row_len, last_len * sizeof(Hit), hipMemcpyDeviceToHost, c->stream));
+    if (mask) HIPCHK(c, hipMemcpyAsync(mask + last_row * row_len, d_m + full_rows * row_len, last_len, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NRT_OK;
+}
+
+template <typename T>
+static nrt_status traverse_multi(nrt_ctx *const *ctxs, uint32_t num_ctx, const typename Wire<T>::Ray *rays, uint64_t n, uint64_t row_len,
+                                 const nrt_trace_options *opt, typename Wire<T>::Hit *hits, uint8_t *mask) {
+  if (!ctxs || num_ctx == 0 || !ctxs[0]) return NRT_ERR_INVALID;
+  nrt_ctx *c0 = ctxs[0];
+  if (n == 0) return NRT_OK;
+  if (!rays || !hits) return fail(c0, NRT_ERR_INVALID, "nrtTraverseBatchMulti: NULL rays/hits");
+  for (uint32_t k = 0; k < num_ctx; k++) {
+    if (!ctxs[k]) return fail(c0, NRT_ERR_INVALID, "nrtTraverseBatchMulti: context %u is NULL", k);
+    for (uint32_t j = 0; j < k; j++)
+      if (ctxs[j] == ctxs[k]) return fail(c0, NRT_ERR_INVALID, "nrtTraverseBatchMulti: context %u is listed twice", k);
+    if (ctxs[k]->prec != (int)sizeof(T) || !ctxs[k]->d_nodes || ctxs[k]->prim_kind != kPrimTriangles)
+      return fail(c0, NRT_ERR_INVALID, "nrtTraverseBatchMulti: context %u holds no triangle tree of this precision", k);
+    if (ctxs[k]->num_nodes != c0->num_nodes || ctxs[k]->num_indices != c0->num_indices)
+      return fail(c0, NRT_ERR_INVALID, "nrtTraverseBatchMulti: context %u holds another tree (%llu nodes, context 0 has %llu)", k,
+                  (unsigned long long)ctxs[k]->num_nodes, (unsigned long long)c0->num_nodes);
+  }
+  if (row_len == 0) row_len = 4096;
+  if (num_ctx == 1) return traverse_host<T>(c0, rays, n, opt, hits, mask);
+  std::vector<nrt_status> st(num_ctx, NRT_OK);
+  std::vector<std::thread> th;
+  for (uint32_t k = 1; k < num_ctx; k++)
+    th.emplace_back([&, k]() { st[k] = traverse_share<T>(ctxs[k], k, num_ctx, rays, n, row_len, opt, hits, mask); });
+  st[0] = traverse_share<T>(c0, 0, num_ctx, rays, n, row_len, opt, hits, mask);
+  for (std::thread &t : th) t.join();
+  for (uint32_t k = 0; k < num_ctx; k++)
+    if (st[k]) {
+      if (k) c0->err = "context " + std::to_string(k) + ": " + ctxs[k]->err;
+      return st[k];
+    }
+  return NRT_OK;
+}
+
 template <typename T>
 static nrt_status traverse_count(nrt_ctx *c, const typename Wire<T>::Ray *d_rays, uint64_t n,
                                  const nrt_trace_options *opt, nrt_trace_counters *out) {
@@ -1334,6 +1409,22 @@ nrt_status nrtTraverseBatchDevice_f64(nrt_ctx *c, const nrt_ray_f64 *r, uint64_t
   return traverse_device<double>(c, r, n, o, h, m, (hipStream_t)s, false, true);
 }
 
+nrt_status nrtTraverseBatchMulti_f32(nrt_ctx *const *ctxs, uint32_t num_ctx, const nrt_ray_f32 *r, uint64_t n, uint64_t row_len,
+                                     const nrt_trace_options *o, nrt_hit_f32 *h, uint8_t *m) {
+  return traverse_multi<float>(ctxs, num_ctx, r, n, row_len, o, h, m);
+}
+nrt_status nrtTraverseBatchMulti_f64(nrt_ctx *const *ctxs, uint32_t num_ctx, const nrt_ray_f64 *r, uint64_t n, uint64_t row_len,
+                                     const nrt_trace_options *o, nrt_hit_f64 *h, uint8_t *m) {
+  return traverse_multi<double>(ctxs, num_ctx, r, n, row_len, o, h, m);
+}
+int nrtDeviceCount(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
 nrt_status nrtTraverseBatchesDevice_f32(nrt_ctx *c, uint32_t nb, const nrt_ray_f32 *const *r, const uint64_t *n, const nrt_trace_options *o,
                                         nrt_hit_f32 *const *h, uint8_t *const *m, const uint32_t *fl, void *s) {
   return traverse_batches_device<float>(c, nb, r, n, o, h, m, fl, (hipStream_t)s);

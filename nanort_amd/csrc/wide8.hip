@@ -10,7 +10,7 @@
 // by a renumbering only (tests/test_gpu_wide8.py compares with the CPU model record by record through `root`).
 //
 // The rules (greedy opening, slot affinity, outward quantisation in double) are restated one for one by the CPU model the
-// tests check against (oracle/wide8_model.inc).
+// tests check against (the wide8 model under the test infrastructure).
 #include "common.h"
 
 #include <algorithm>

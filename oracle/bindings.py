@@ -52,7 +52,7 @@ class Wide8Model:
         indices = np.ascontiguousarray(indices, dtype=np.uint32)
         self.h = L.orc_wide8_build_f32(_p(nodes), nodes.shape[0], _p(indices), _p(self.verts), 12, _p(self.faces), int(collapse_mode))
         if not self.h:
-            raise ValueError("wide8 model: node 0 must be a branch")
+            raise ValueError("wide8 model: node 0 must be a branch and every leaf must hold 1..30 primitives")
         self.num_nodes = int(L.orc_wide8_num_nodes(self.h))
         self.num_recs = int(L.orc_wide8_num_recs(self.h))
 

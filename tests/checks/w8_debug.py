@@ -1,5 +1,5 @@
 """Staged bring-up of the 8-wide walk (each stage under its own `timeout` on the GPU box):
-    python tools/w8_debug.py layout|trace [mesh]"""
+    python tests/checks/w8_debug.py layout|trace [mesh]"""
 import sys
 import time
 

@@ -1,6 +1,6 @@
 """CPU-side counts of the 8-wide compressed walk's MODEL (oracle/wide8_model.inc) against the two-level walk's model on a
 saved GPU-built tree (tools/dump_tree.py): steps per ray, leaves, triangle tests — what the kernel variants can win before
-any of them is built.   python tools/w8_model_probe.py gpurun_out/c3_tree.npz C3 [every]"""
+any of them is built.   python tests/checks/w8_model_probe.py gpurun_out/c3_tree.npz C3 [every]"""
 import sys
 import time
 

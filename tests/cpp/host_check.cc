@@ -97,7 +97,10 @@ static int trace(const char *mesh_path, const char *rays_path, const char *out_p
     mask[i] = accel.Traverse(rays[i], isector, &hits[i]) ? 1 : 0;
   }
 #ifdef NANORT_USE_HIP_BACKEND
-  // batched GPU path over the same (GPU-built) node array: must agree bit for bit
+  // batched GPU path over the same (GPU-built) node array: must agree bit for bit (with NANORT_HIP_DEVICES set the batch is
+  // split over one replica of the tree per listed device: BVHAccel::TraverseBatch -> nrtTraverseBatchMulti)
+  printf("hip_devices %zu\n", accel.NumHipDevices());
+  accel.SetTraverseBatchRowLength(320);
   std::vector<nanort::TriangleIntersection<T> > bhits(n);
   std::vector<unsigned char> bmask(n, 0);
   for (uint64_t i = 0; i < n; i++) {

@@ -358,7 +358,15 @@ def test_hip_backend_build_and_traverse_batch(tmp_path, oracle, f64):
     r = subprocess.run([str(exe), "trace", "f64" if f64 else "f32", mesh, rp, out], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
-    assert "batch_vs_per_ray_mismatches 0" in r.stdout and "device_variant_mismatches 0" in r.stdout
+    assert "batch_vs_per_ray_mismatches 0" in r.stdout and "device_variant_mismatches 0" in r.stdout and "hip_devices 1" in r.stdout
+    # the same program with the batch split over three replicas of the tree (three contexts on the one GPU of this box — the
+    # multi-GPU path of BVHAccel::TraverseBatch, NANORT_HIP_DEVICES): the same records, bit for bit
+    out3 = os.path.join(str(tmp_path), "out3.bin")
+    r3 = subprocess.run([str(exe), "trace", "f64" if f64 else "f32", mesh, rp, out3], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                        env=dict(os.environ, NANORT_HIP_DEVICES="0,0,0"))
+    assert r3.returncode == 0, r3.stdout
+    assert "batch_vs_per_ray_mismatches 0" in r3.stdout and "hip_devices 3" in r3.stdout
+    assert open(out3, "rb").read() == open(out, "rb").read()
     hits, mask, nodes, idx = read_output(out, rays.shape[0], f.shape[0], f64)
     validate_bvh(nodes, idx, v, f)
     onodes, oidx, _ = oracle.build(v, f)
