@@ -140,9 +140,28 @@ def host_threads():
     return quota
 
 
-def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, width, gpu_results=None, budget_s=12.0):
+def reference_order_results(wl):
+    """The two waves once more through the reference-order walk (tunable order4 = 0: every field bit-identical to the reference
+    on the same node array), into scratch buffers, outside every timed region.  Returns (hits1, mask1, hits2, mask2)."""
+    torch = wl.torch
+    a = wl.accel
+    was = a.GetTunable("order4")
+    a.SetTunable("order4", 0)
+    try:
+        h1, m1 = torch.empty_like(wl.d_hits1), torch.empty_like(wl.d_mask1)
+        h2, m2 = torch.empty_like(wl.d_hits2), torch.empty_like(wl.d_mask2)
+        a.TraverseBatchDevice(wl.d_rays1, h1, m1)
+        a.TraverseBatchDevice(wl.d_rays2, h2, m2)
+        torch.cuda.synchronize()
+        return (h1.cpu().numpy().view(wl.HIT), m1.cpu().numpy(), h2.cpu().numpy().view(wl.HIT)[:wl.n2], m2.cpu().numpy()[:wl.n2])
+    finally:
+        a.SetTunable("order4", was)
+
+
+def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, width, gpu_results=None, budget_s=12.0, gpu_results_ref_order=None):
     """Reference (or port) timed on the host cores over a bounded sample of the same buffers; with `gpu_results` =
-    (hits1, mask1, hits2, mask2) of the GPU also the parity check of the same run."""
+    (hits1, mask1, hits2, mask2) of the GPU's timed walk also the parity check of the same run (SURVEY 8d);
+    `gpu_results_ref_order`: the same waves through the reference-order walk (reference_order_results)."""
     from oracle import bindings as ob
 
     total = rays1.shape[0] + rays2.shape[0]
@@ -200,9 +219,17 @@ def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, width, gpu_
             th1, tm1, t1 = R.traverse(rays1, threads=best_t, chunk=width)
             th2, tm2, t2 = R.traverse(rays2, threads=best_t, chunk=width)
             out["value_on_gpu_built_tree"] = round(total / (t1 + t2) / 1e6, 4)
-            if gpu_results is not None:  # same node array: every field must be bit-identical
+            if gpu_results is not None:
+                # same node array, the timed (default) walk: hit flags and t bit-equal, prim_id / u / v may differ at exact-t ties only
                 gh1, gm1, gh2, gm2 = gpu_results
+                out["parity_same_tree"] = {"walk": "default (slots entered by entry distance)",
+                                           "primary": parity(th1, tm1, gh1, gm1), "bounce": parity(th2, tm2, gh2, gm2),
+                                           "t_and_hit_flags_bit_identical": bool(np.array_equal(tm1, gm1) and np.array_equal(tm2, gm2) and
+                                                                                 th1["t"].tobytes() == gh1["t"].tobytes() and th2["t"].tobytes() == gh2["t"].tobytes())}
+            if gpu_results_ref_order is not None or gpu_results is not None:  # same node array, reference-order walk: every field bit-identical
+                gh1, gm1, gh2, gm2 = gpu_results_ref_order if gpu_results_ref_order is not None else gpu_results
                 out["parity_same_tree_bit_identical"] = bit_identical(th1, tm1, gh1, gm1) and bit_identical(th2, tm2, gh2, gm2)
+                out["parity_same_tree_bit_identical_walk"] = "reference order (tunable order4 = 0), untimed launch" if gpu_results_ref_order is not None else "timed walk"
         return out
     O = ob.Oracle()
     t0 = time.time()
@@ -697,11 +724,12 @@ def measure_config(name, mesh_path=None, reps=5, parity_rays=200_000):
     ev[1].record()
     torch.cuda.synchronize()
     step_ms = float(ev[0].elapsed_time(ev[1])) / reps
+    timed_kernel = a.LastKernelName()  # (before the counting pass: that one launches the literal kernel)
     c1, c2 = wl.counters()
     out = {"workload": wl.describe(), "dtype": wl.cfg["real"], "value": round((wl.n1 + wl.n2) / step_ms / 1e3, 1), "unit": "Mrays/s",
            "ms_per_step": round(step_ms, 4),
            "primary_ms": round(ms1, 4), "bounce_ms": round(ms2, 4), "primary_Mrays_s": round(wl.n1 / ms1 / 1e3, 1),
-           "build_ms": round(float(np.median(wl.build_ms)), 4), "kernel": a.LastKernelName(),
+           "build_ms": round(float(np.median(wl.build_ms)), 4), "kernel": timed_kernel,
            "bvh": {"nodes": wl.num_nodes, "max_depth": int(wl.stats["max_tree_depth"])},
            "roofline_build": {"bytes": int(build_bytes(wl.faces.shape[0], wl.num_nodes, wl.rb)),
                               "frac": round(build_bytes(wl.faces.shape[0], wl.num_nodes, wl.rb) / (float(np.median(wl.build_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
@@ -711,6 +739,7 @@ def measure_config(name, mesh_path=None, reps=5, parity_rays=200_000):
         from oracle import bindings as ob
 
         gh1, gm1, gh2, gm2 = wl.results()
+        ro = reference_order_results(wl) if (wl.real == np.float32 and a.GetTunable("order4")) else (gh1, gm1, gh2, gm2)
         nodes, indices = a.GetTree()
         if ob.reference_available():
             R = ob.Reference(wl.verts, wl.faces)
@@ -722,7 +751,9 @@ def measure_config(name, mesh_path=None, reps=5, parity_rays=200_000):
             if R.load_tree(nodes, indices):
                 th1, tm1, _ = R.traverse(wl.rays1[::s1], threads=threads, chunk=4096)
                 th2, tm2, _ = R.traverse(wl.rays2[::s2], threads=threads, chunk=4096)
-                p["same_tree_bit_identical"] = bit_identical(th1, tm1, gh1[::s1], gm1[::s1]) and bit_identical(th2, tm2, gh2[::s2], gm2[::s2])
+                # the reference-order walk (order4 = 0; fp64 trees always): every field; the timed default walk: t and flags, ties in prim_id
+                p["same_tree_bit_identical"] = bit_identical(th1, tm1, ro[0][::s1], ro[1][::s1]) and bit_identical(th2, tm2, ro[2][::s2], ro[3][::s2])
+                p["same_tree_timed_walk"] = {"primary": parity(th1, tm1, gh1[::s1], gm1[::s1]), "bounce": parity(th2, tm2, gh2[::s2], gm2[::s2])}
                 p["same_tree_rays"] = int(th1.shape[0] + th2.shape[0])
             # (b) the reference on its own tree (its own Build): equal up to exact-t ties
             ok, st = R.build(parallel=True, threads=threads)
@@ -735,7 +766,7 @@ def measure_config(name, mesh_path=None, reps=5, parity_rays=200_000):
             O = ob.Oracle()
             s1 = max(1, wl.n1 // 20000)
             oh, om = O.traverse(nodes, indices, wl.verts, wl.faces, wl.rays1[::s1])
-            p = {"kind": "port", "same_tree_bit_identical": bit_identical(oh, om, gh1[::s1], gm1[::s1]), "same_tree_rays": int(oh.shape[0])}
+            p = {"kind": "port", "same_tree_bit_identical": bit_identical(oh, om, ro[0][::s1], ro[1][::s1]), "same_tree_rays": int(oh.shape[0])}
         out["parity"] = p
     except Exception as e:  # pragma: no cover
         out["parity"] = {"error": repr(e)}
@@ -1107,7 +1138,10 @@ def main():
             accel.TraverseBatchDevice(wl.d_rays1, wl.d_hits1, wl.d_mask1)
             accel.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)
             budget = 12.0 if args.config in ("C3", "C2") else 6.0
-            out["cpu_baseline"] = cpu_baseline(wl.verts, wl.faces, wl.rays1, wl.rays2, nodes, indices, wl.width, wl.results(), budget_s=budget)
+            timed_walk = wl.results()
+            ref_order = reference_order_results(wl) if accel.GetTunable("order4") and "k_traverse_wide" in accel.LastKernelName() and wl.real == np.float32 else None
+            out["cpu_baseline"] = cpu_baseline(wl.verts, wl.faces, wl.rays1, wl.rays2, nodes, indices, wl.width, timed_walk, budget_s=budget,
+                                               gpu_results_ref_order=ref_order)
         if configs_out:
             out["configs"] = {}
             for name, e in configs_out.items():

@@ -154,7 +154,7 @@ struct nrt_ctx {
   int wide4 = 1;
   int wide8 = 0; // the 8-wide compressed walk (next build / set_tree builds its layout; contract-level parity as order4)
   unsigned trav_min8 = 24, w8_blocks_per_cu = 0;
-  int order4 = 0; // two-level walk: slots of a record entered by entry distance (contract-level parity: prim_id may differ at exact-t ties); 0: the binary loop's order, bit-identical to the same-tree oracle
+  int order4 = 1; // two-level walk: slots of a record entered by entry distance — the default since round 4 (+2...5 % on every config; t / hit flags bit-equal to the reference on the same node array, prim_id / u / v may differ at exact-t ties); 0: the binary loop's order, every field bit-identical to the reference on the same node array
   int wide_scramble = 0; // probe (tunable wide_scramble): the private node records in a pseudo-random order instead of pre-order
   unsigned wide4_blocks_per_cu = 0;
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;

@@ -2,7 +2,12 @@
 meshes built to provoke the edge rules (grid-aligned vertices -> rays through edges and vertices -> exact zeros in the
 edge functions and exact t ties; degenerate and duplicated triangles; axis-parallel, zero, NaN and infinite ray
 components; random trace options), fp32 and fp64, GPU-built trees and adopted oracle-built trees, and the occlusion
-query's flags.  Usage: python tests/checks/fuzz_parity.py [seconds] [seed]"""
+query's flags.  Usage: python tests/checks/fuzz_parity.py [seconds] [seed] [--default-walk]
+--default-walk: the library's default two-level walk (slots entered by entry distance, tunable order4 = 1) instead of the
+reference-order walk.  Its contract is the cross-order one: hit flags and t bit-equal, prim_id / u / v free at exact-t ties; on
+this adversarial geometry the reference's own answer depends on the visiting order beyond exact ties in a few rays per
+thousand (a triangle whose computed t lies one ulp below its leaf box's entry distance; rays lying in a
+triangle's plane), so the check is statistical there and the exceptions are counted and printed."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -12,8 +17,11 @@ from bvh_check import validate_bvh
 from oracle.bindings import Oracle
 from helpers import assert_hits_identical
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+default_walk = "--default-walk" in sys.argv
+argv = [x for x in sys.argv if not x.startswith("--")]
+budget = float(argv[1]) if len(argv) > 1 else 60.0
+seed = int(argv[2]) if len(argv) > 2 else 1
+order_exceptions = order_ties = 0
 rng = np.random.default_rng(seed)
 orc = Oracle()
 t_end = time.time() + budget
@@ -56,6 +64,9 @@ while time.time() < t_end:
     for k, choices in (("static_pct", (0, 40, 75, 100)), ("static_bands", (1, 2, 8)), ("static_slice_groups", (1, 2)), ("chunk", (16, 64, 128)),
                        ("parts", (1, 3, 8)), ("refill_min", (1, 24, 48, 64)), ("trav_min", (1, 8, 32)), ("trav_min4", (1, 12, 24, 48)), ("leaf_min", (1, 32)), ("wide4", (0, 1))):
         a.SetTunable(k, int(rng.choice(choices)))
+    a.SetTunable("order4", 1 if default_walk else 0)
+    if default_walk:
+        a.SetTunable("wide4", 1)
     gpu_built = rng.random() < 0.5
     if gpu_built:
         bo = default_build_options(real)
@@ -72,7 +83,14 @@ while time.time() < t_end:
     h, mk = a.TraverseBatch(rays, opts)
     oh, om = orc.traverse(nodes, idx, v, f, rays, opts)
     try:
-        assert_hits_identical(oh, om, h, mk)
+        if default_walk and real == np.float32:
+            t_same = (h["t"] == oh["t"]) | (np.isnan(h["t"]) & np.isnan(oh["t"]))
+            exc = (mk != om) | ~t_same
+            assert exc.mean() <= 0.003, "the default walk differs from the restatement on %d of %d rays" % (int(exc.sum()), m)
+            order_exceptions += int(exc.sum())
+            order_ties += int((~exc & (h["prim_id"] != oh["prim_id"])).sum())
+        else:
+            assert_hits_identical(oh, om, h, mk)
         assert np.array_equal(a.OccludedBatch(rays, opts), om)
         if gpu_built and rounds % 4 == 0:  # a different (oracle-built) tree over the same mesh: same hit flags and distances
             on, oi, _ = orc.build(v, f)
@@ -92,4 +110,5 @@ while time.time() < t_end:
         print("MISMATCH round", rounds, "real", real.__name__, "n", n, "kind", int(kind), str(e)[:300], flush=True)
         sys.exit(1)
     rounds += 1; rays_total += m
-print("fuzz ok: %d rounds, %d rays, seed %d" % (rounds, rays_total, seed))
+print("fuzz ok: %d rounds, %d rays, seed %d" % (rounds, rays_total, seed) + (
+    "; default walk: %d rays named another primitive at an exact-t tie, %d rays differ beyond ties (order-dependent answers of the reference arithmetic on this geometry)" % (order_ties, order_exceptions) if default_walk else ""))

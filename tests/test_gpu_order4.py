@@ -28,10 +28,25 @@ def mesh_of(name):
     return scenes.plane(3, 2)
 
 
+def test_the_library_default_is_the_distance_order(monkeypatch, oracle):
+    monkeypatch.delenv("NRT_ORDER4", raising=False)  # (conftest.py starts this suite's contexts in the reference-order walk)
+    v, f = scenes.load_c1_mesh()
+    a = BVHAccel(np.float32)
+    assert a.GetTunable("order4") == 1
+    assert a.Build(f.shape[0], TriangleMesh(v, f))
+    rays = scenes.camera_rays(128, 128)
+    h, m = a.TraverseBatch(rays)
+    assert targs(a.LastKernelName())[6:] == ["4", "1"], a.LastKernelName()
+    nodes, idx = a.GetTree()
+    oh, om = oracle.traverse(nodes, idx, v, f, rays)
+    assert_hits_match(oh, om, h, m, oracle, nodes, idx, v, f, rays)
+
+
 @pytest.mark.parametrize("mesh", ["c1", "plane", "sphere", "tiny"])
 def test_distance_order_matches_the_oracle_up_to_exact_ties(mesh, oracle):
     v, f = mesh_of(mesh)
     a = BVHAccel(np.float32)
+    a.SetTunable("order4", 0)
     assert a.Build(f.shape[0], TriangleMesh(v, f))
     nodes, idx = a.GetTree()
     rays = np.concatenate([hostile_rays(v, 40000, seed=17), scenes.camera_rays(160, 120)])
