@@ -84,11 +84,24 @@ while time.time() < t_end:
     oh, om = orc.traverse(nodes, idx, v, f, rays, opts)
     try:
         if default_walk and real == np.float32:
-            t_same = (h["t"] == oh["t"]) | (np.isnan(h["t"]) & np.isnan(oh["t"]))
-            exc = (mk != om) | ~t_same
-            assert exc.mean() <= 0.003, "the default walk differs from the restatement on %d of %d rays" % (int(exc.sum()), m)
+            # the contract's bar: hit flags equal, t within 1e-5 relative, and a record that names another
+            # primitive (or another last bit of t: coplanar overlapping sheets) must be that primitive's own record in the
+            # reference arithmetic — checked by the restatement restricted to it.  Beyond that, a few rays per thousand whose
+            # answer depends on the visiting order in the reference's own arithmetic (header) are counted.
+            both = (mk == 1) & (om == 1)
+            nan_t = np.isnan(h["t"]) | np.isnan(oh["t"])
+            tol = np.abs(h["t"].astype(np.float64) - oh["t"].astype(np.float64)) <= 1e-5 * np.maximum(1.0, np.abs(oh["t"].astype(np.float64)))
+            exc = (mk != om) | (both & ~nan_t & ~tol) | (nan_t & ~(np.isnan(h["t"]) & np.isnan(oh["t"])))
+            assert exc.mean() <= 0.003, "the default walk differs from the restatement beyond the tolerance on %d of %d rays" % (int(exc.sum()), m)
+            differ = np.nonzero((mk == 1) & ((h["t"] != oh["t"]) | (h["prim_id"] != oh["prim_id"])) & ~np.isnan(h["t"]))[0]
+            for i in differ[:300]:
+                o = opts.copy()
+                p = int(h["prim_id"][i])
+                o["prim_ids_range"] = (max(p, int(opts["prim_ids_range"][0])), min(p + 1, int(opts["prim_ids_range"][1])))
+                h1, m1 = orc.traverse(nodes, idx, v, f, rays[i:i + 1], o)
+                assert m1[0] == 1 and h1.tobytes() == h[i:i + 1].tobytes(), "ray %d: the reported record is not primitive %d's in the reference arithmetic" % (i, p)
             order_exceptions += int(exc.sum())
-            order_ties += int((~exc & (h["prim_id"] != oh["prim_id"])).sum())
+            order_ties += int(differ.size) - int((exc & (mk == 1)).sum())
         else:
             assert_hits_identical(oh, om, h, mk)
         assert np.array_equal(a.OccludedBatch(rays, opts), om)
@@ -111,4 +124,4 @@ while time.time() < t_end:
         sys.exit(1)
     rounds += 1; rays_total += m
 print("fuzz ok: %d rounds, %d rays, seed %d" % (rounds, rays_total, seed) + (
-    "; default walk: %d rays named another primitive at an exact-t tie, %d rays differ beyond ties (order-dependent answers of the reference arithmetic on this geometry)" % (order_ties, order_exceptions) if default_walk else ""))
+    "; default walk: %d rays report another primitive's own record within the tolerance (ties, coplanar sheets), %d rays differ beyond it (order-dependent answers of the reference arithmetic on this geometry)" % (order_ties, order_exceptions) if default_walk else ""))
