@@ -1157,7 +1157,7 @@ def main():
             try:
                 import bench_rows
 
-                out["next_rows"] = bench_rows.next_rows()
+                out["next_rows"] = bench_rows.next_rows(counters=not args.no_pmc, pmc_dir=args.pmc_dir and os.path.abspath(args.pmc_dir))
             except Exception as e:  # pragma: no cover
                 out["next_rows"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)

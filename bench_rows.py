@@ -270,7 +270,127 @@ def wavefront_row():
         "parity": {"kind": "tests/test_host_header.py::test_gpu_shaded_wavefront_path_tracer (GPU-shaded image == host-shaded image)", "in_run": False}}
 
 
-def next_rows():
+# ---------------------------------------------------------------------------
+# hardware counters of a row's dominant kernel (outside every timed region): bench_rows.py --pmc-row NAME is re-run under
+# rocprofv3 --pmc (kernel trace only; one pass per counter set, as MI355X_MICROARCH.md prescribes)
+# ---------------------------------------------------------------------------
+ROW_KERNELS = {"scene_10k": "k_scene_trace", "scene_fixture": "k_scene_trace", "spheres_1m": "k_traverse_wide", "cylinders": "k_traverse_wide"}
+
+
+def pmc_row_child(name):
+    """The row's workload without its parity sample: set-up, then a few launches of the query (the rocprofv3 child)."""
+    import torch
+
+    from nanort_amd import BVHAccel, CylinderGeometry, Scene, SphereGeometry, TriangleMesh, scenes
+
+    if name in ("scene_10k", "scene_fixture"):
+        from nanort_amd.wire import SCENE_HIT_F32
+        from scene_fixture import instances, xform
+
+        rays = scenes.camera_rays(W, H)
+        sc, keep = Scene(), []
+        if name == "scene_fixture":
+            for v, f, x in instances(sphere_res=(264, 132), plane_res=(1000, 500)):
+                a = BVHAccel(np.float32)
+                assert a.Build(f.shape[0], TriangleMesh(v, f))
+                keep.append(a)
+                sc.AddNode(a, x)
+        else:
+            rng = np.random.default_rng(5)
+            sv, sf = scenes.sphere(48, 24)
+            sv = sv - np.array([0, 5, 0], dtype=np.float32)
+            a = BVHAccel(np.float32)
+            assert a.Build(sf.shape[0], TriangleMesh(sv, sf))
+            keep.append(a)
+            for _ in range(10000):
+                sc.AddNode(a, xform(tuple(rng.uniform(0.01, 0.04, 3)), rng.uniform(0, 6.28), rng.uniform(0, 6.28), tuple(rng.uniform(-9, 9, 3) + np.array([0, 5, 0]))))
+        assert sc.Commit()
+        d = torch.from_numpy(rays.view(np.uint8)).cuda()
+        o = torch.empty(len(rays) * SCENE_HIT_F32.itemsize, dtype=torch.uint8, device="cuda")
+        m = torch.empty(len(rays), dtype=torch.uint8, device="cuda")
+        run = lambda: sc.TraverseBatchDevice(d, o, m)  # noqa: E731
+    else:
+        rays = scenes.particle_camera_rays(W, H)
+        a = BVHAccel(np.float32)
+        if name == "spheres_1m":
+            c, r = scenes.random_spheres(1000000)
+            assert a.Build(1000000, SphereGeometry(c, r))
+            rec = 16
+        else:
+            v, r = scenes.random_cylinders(20000)
+            assert a.Build(20000, CylinderGeometry(v, r))
+            rec = 28
+        d = torch.from_numpy(rays.view(np.uint8)).cuda()
+        o = torch.empty(len(rays) * rec, dtype=torch.uint8, device="cuda")
+        m = torch.empty(len(rays), dtype=torch.uint8, device="cuda")
+        run = lambda: a.TraverseBatchDevice(d, o, m)  # noqa: E731
+    for _ in range(4):
+        run()
+    torch.cuda.synchronize()
+    print("pmc_row_child", name, len(rays), flush=True)
+
+
+def row_counters(name, keep_dir=None):
+    """{hbm_frac, l2_hit_rate, lane_util, wait_frac, l1_frac, ...} of the row's dominant kernel, mean per launch."""
+    import csv
+    import glob
+    import shutil
+
+    import bench
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    tmp = keep_dir or tempfile.mkdtemp(prefix="nrt_rowpmc_", dir="/tmp")
+    key = ROW_KERNELS[name]
+    acc, durs, errors = {}, [], []
+    for tag, counters, _fallback in bench.PMC_PASSES:
+        for sub, cs in ([(tag, counters)] if tag != "fetch_tcp" else [("fetch", "FETCH_SIZE"), ("tcp", "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum")]):
+            out_dir = os.path.join(tmp, name + "_" + sub)
+            cmd = [exe, "--kernel-trace", "--pmc"] + cs.split() + ["--output-format", "csv", "-d", out_dir, "-o", "p", "--", sys.executable,
+                                                                     os.path.join(ROOT, "bench_rows.py"), "--pmc-row", name]
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, TMPDIR="/tmp"), timeout=300, cwd="/tmp")
+            except Exception as e:  # pragma: no cover
+                errors.append("%s: %r" % (sub, e))
+                continue
+            if r.returncode != 0:
+                errors.append("%s: rc %d: %s" % (sub, r.returncode, r.stdout[-200:]))
+                continue
+            for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                for x in csv.DictReader(open(path)):
+                    if key in x.get("Kernel_Name", ""):
+                        acc.setdefault(x["Counter_Name"], {}).setdefault(int(x["Dispatch_Id"]), 0.0)
+                        acc[x["Counter_Name"]][int(x["Dispatch_Id"])] += float(x["Counter_Value"])
+            if sub == "sq":
+                for path in glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"), recursive=True):
+                    for x in csv.DictReader(open(path)):
+                        if key in x.get("Kernel_Name", ""):
+                            durs.append((int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) * 1e-9)
+    if not keep_dir:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if not acc or not durs:
+        return {"error": "; ".join(errors) or "no counter rows for " + key}
+    c = {k: float(np.mean(list(v.values()))) for k, v in acc.items()}
+    secs = float(np.mean(durs))  # (the launch under the counter profiler)
+    out = {"kernel_contains": key, "profiled_launch_ms": round(secs * 1e3, 4)}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        b = c["FETCH_SIZE"] * 1024.0 * 2.0 + c["WRITE_SIZE"] * 1024.0
+        out["hbm"] = {"bytes_per_launch": int(b), "frac": round(b / secs / 1e9 / bench.HBM_PEAK_GBS, 4)}
+    if "TCC_HIT_sum" in c:
+        out["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+        out["l1"] = {"lookups_per_launch": int(c["TCP_TOTAL_CACHE_ACCESSES_sum"]), "frac": round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / secs / 1e9 / bench.L1_PEAK_GACC_S, 4)}
+    if "SQ_INSTS_VALU" in c:
+        out["valu"] = {"wave_insts": int(c["SQ_INSTS_VALU"]), "lane_util": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]), 4)}
+        if c.get("SQ_WAVE_CYCLES"):
+            out["wait_frac_of_wave_cycles"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
+    if errors:
+        out["errors"] = errors
+    return out
+
+
+def next_rows(counters=True, pmc_dir=None):
     out = {}
     for name, fn in (("scenes", scene_rows), ("spheres_1m", spheres_row), ("cylinders", cylinders_row), ("embree_stream", embree_row),
                      ("wavefront_frame", wavefront_row)):
@@ -284,10 +404,22 @@ def next_rows():
         else:
             out[name] = r
         out.setdefault("_seconds", {})[name] = round(time.perf_counter() - t0, 1)
+    if counters:  # hardware counters of the rows' dominant kernels (three rocprofv3 passes each, outside every timed region)
+        for name in ("scene_10k", "spheres_1m", "cylinders"):
+            if name in out and "error" not in out[name]:
+                t0 = time.perf_counter()
+                try:
+                    out[name]["counters"] = row_counters(name, keep_dir=os.path.join(pmc_dir, "rows") if pmc_dir else None)
+                except Exception as e:  # pragma: no cover
+                    out[name]["counters"] = {"error": repr(e)}
+                out["_seconds"]["counters_" + name] = round(time.perf_counter() - t0, 1)
     return out
 
 
 if __name__ == "__main__":
     import json
 
-    print(json.dumps(next_rows(), indent=1))
+    if len(sys.argv) > 2 and sys.argv[1] == "--pmc-row":
+        pmc_row_child(sys.argv[2])
+    else:
+        print(json.dumps(next_rows(), indent=1))
