@@ -1128,6 +1128,29 @@ def main():
             out["primary_plus_shadow"] = {"value": round((n1 + rays_s.shape[0]) / (k_ms1 + ms_s) / 1e3, 1), "unit": "Mrays/s",
                                           "shadow_ms": round(ms_s, 4), "shadow_rays": int(rays_s.shape[0])}
             del d_rs, d_hs
+            # a SECOND bounce: rays generated from the bounce-1 hits by the same host generator, traced in the order the
+            # renderer produces them (how far does coherence decay with depth? — profiles/r03a_reorder_probe_*: a random
+            # order of the bounce-1 wave costs 25-46 %)
+            try:
+                if wl.real == np.float32 and n2:
+                    _, _, gh2, gm2 = wl.results()
+                    rays3 = scenes.secondary_rays("bounce", wl.verts32, wl.faces, wl.rays2, gh2, gm2, pixel_base=7 * n1)
+                    if rays3.shape[0]:
+                        d_r3 = torch.from_numpy(rays3.view(np.uint8)).cuda()
+                        d_h3 = torch.empty(rays3.shape[0] * HIT.itemsize, dtype=torch.uint8, device="cuda")
+                        ts = []
+                        for _ in range(5):
+                            accel.TraverseBatchDevice(d_r3, d_h3)
+                            ts.append(accel.LastTraverseMs())
+                        ms3 = float(np.median(ts))
+                        c3 = accel.TraverseCountDevice(d_r3)
+                        out["bounce2"] = {"rays": int(rays3.shape[0]), "ms": round(ms3, 4), "Mrays_s": round(rays3.shape[0] / ms3 / 1e3, 1),
+                                          "bounce1_Mrays_s": round(n2 / k_ms2 / 1e3, 1),
+                                          "nodes_per_ray": round(c3["nodes_visited"] / max(1, rays3.shape[0]), 2),
+                                          "tris_per_ray": round(c3["tris_tested"] / max(1, rays3.shape[0]), 2)}
+                        del d_r3, d_h3
+            except Exception as e:  # pragma: no cover
+                out["bounce2"] = {"error": repr(e)}
             try:
                 out["end_to_end"] = end_to_end(wl)
             except Exception as e:  # pragma: no cover
