@@ -1144,11 +1144,22 @@ def main():
                             ts.append(accel.LastTraverseMs())
                         ms3 = float(np.median(ts))
                         c3 = accel.TraverseCountDevice(d_r3)
+                        # the same number of bounce-1 rays (every k-th): what a batch this small reaches with bounce-1's coherence
+                        sub = np.ascontiguousarray(wl.rays2[:: max(1, n2 // rays3.shape[0])][: rays3.shape[0]])
+                        d_rsub = torch.from_numpy(sub.view(np.uint8)).cuda()
+                        ts = []
+                        for _ in range(5):
+                            accel.TraverseBatchDevice(d_rsub, d_h3)
+                            ts.append(accel.LastTraverseMs())
+                        ms_sub = float(np.median(ts))
                         out["bounce2"] = {"rays": int(rays3.shape[0]), "ms": round(ms3, 4), "Mrays_s": round(rays3.shape[0] / ms3 / 1e3, 1),
                                           "bounce1_Mrays_s": round(n2 / k_ms2 / 1e3, 1),
+                                          "bounce1_subsampled_to_the_same_batch_size_Mrays_s": round(sub.shape[0] / ms_sub / 1e3, 1),
+                                          "note": "the second bounce is slower per ray because the batch is small (the launch's ramp and tail), not because "
+                                                  "coherence is lost: profiles/r04i_bounce2_probe.txt (best re-ordering +2.4 %)",
                                           "nodes_per_ray": round(c3["nodes_visited"] / max(1, rays3.shape[0]), 2),
                                           "tris_per_ray": round(c3["tris_tested"] / max(1, rays3.shape[0]), 2)}
-                        del d_r3, d_h3
+                        del d_r3, d_h3, d_rsub
             except Exception as e:  # pragma: no cover
                 out["bounce2"] = {"error": repr(e)}
             try:
