@@ -345,7 +345,7 @@ NRT_API nrt_status nrtTraverseCountDevice_f64(nrt_ctx *ctx, const nrt_ray_f64 *d
 
 /* Device time (ms) of the most recent traversal launch (the kernel's own start / end stamps, or HIP events on the
  * launch stream: see nrtSetLaunchTiming) / build (HIP events) on this context; < 0 if none has completed.
- * Synchronises with that work. */
+ * Synchronises with that work: when it returns, the launch's stream has drained (the records have landed). */
 NRT_API float nrtLastTraverseMs(nrt_ctx *ctx);
 NRT_API float nrtLastBuildMs(nrt_ctx *ctx);
 /* By default a traversal launch records NO event in the caller's stream (an event record between two kernels of a stream
@@ -361,11 +361,19 @@ NRT_API float nrtLastBuildMs(nrt_ctx *ctx);
  * (No reference counterpart.) */
 NRT_API nrt_status nrtSetLaunchTiming(nrt_ctx *ctx, int on);
 /* Traversal / build tunables by name (no reference counterpart; the library's defaults are the measured optimum on MI355X):
- * "refill_min", "trav_min", "leaf_min", "chunk", "parts", "static_pct", "blocks_per_cu", "lds_stack", "wide_stack" (scheduling of
- * the persistent traversal kernel), "wide", "wide4" (which walk), "ray_sort" (coherence pre-pass of a batch), "morton" (builder
- * pre-pass), "launch_timing" (== nrtSetLaunchTiming), "host_pipeline", "debug" (profiling bit mask), "wide_scramble" (layout probe).
+ *   which walk        "wide" (0: the literal BVHNode loop), "wide4" (two tree levels per step; next build / set_tree),
+ *                     "order4" (1, the default: a record's four slots entered by entry distance — t and hit flags bit-equal to
+ *                     the reference on the same node array, prim_id / u / v may differ at exact-t ties; 0: the reference's own
+ *                     order, every field bit-identical), "wide8" (the 8-wide compressed walk, opt-in; next build / set_tree),
+ *                     "f64_row_fetch"
+ *   scheduling        "refill_min", "trav_min", "trav_min4", "trav_min8", "leaf_min", "chunk", "chunk_tail_pct", "parts",
+ *                     "static_pct", "static_bands", "static_slice_groups", "blocks_per_cu", "lds_stack", "wide_stack"
+ *   builder           "morton" (Morton pre-pass), "subtree_rows" (0: the one-node-per-step subtree kernel; same tree)
+ *   launches / host   "launch_timing" (== nrtSetLaunchTiming), "host_pipeline"
+ *   probes            "debug" (bit mask: 1 / 2 skip triangle tests / traversal, 4 plain ray loads; the profiling bits 32 / 64 / 8192
+ *                     act in libnanort_hip_prof.so only), "wide_scramble" (layout probe; next build)
  * Values are clamped to the tunable's range; an unknown name is NRT_ERR_INVALID.  Tunables that shape the private tree layout
- * ("wide4", "wide_scramble", "morton") take effect with the next nrtBuild / nrtSetTree.  The environment variable
+ * ("wide4", "wide8", "wide_scramble", "morton") take effect with the next nrtBuild / nrtSetTree.  The environment variable
  * NRT_<NAME> (upper case) overrides a default at nrtCreate — a debugging aid; programs use these calls. */
 NRT_API nrt_status nrtSetTunable(nrt_ctx *ctx, const char *name, long long value);
 NRT_API nrt_status nrtGetTunable(nrt_ctx *ctx, const char *name, long long *value_out);
@@ -378,16 +386,8 @@ NRT_API const char *nrtLastKernelName(const nrt_ctx *ctx);
  * Either output may be NULL; the counts are always returned.  tests/test_gpu_wide8.py compares the arrays with the CPU
  * model's (the wide8 model under the test infrastructure).  (No reference counterpart.) */
 NRT_API nrt_status nrtGetWide8_f32(nrt_ctx *ctx, void *nodes_out, void *recs_out, uint64_t *num_nodes, uint64_t *num_recs);
-/* Profiling aid: loop-occupancy counters of the last traversal launched with the tunable "debug" bit 32 set (a separately
- * instantiated, slower kernel).  out16[0..7] = inner-node-phase wave iterations, sum of active lanes, idle lanes at leaf-phase
- * entry, leaf-phase trips, sum of lanes testing a (first) record, refill events, lanes refilled, leaf-phase entries;
- * [8..10] = shader-clock ticks the waves spent refilling / in the inner-node phase / in the leaf phase; [11] = lanes
- * with a second record in a leaf trip.  Returns 0 on success. */
-NRT_API int nrtDebugCounters(nrt_ctx *ctx, unsigned long long *out16);
-/* Profiling aid: with NRT_DEBUG bit 8192 every wave of a traversal launch records when it started, ran out of rays and
- * finished (100 MHz realtime ticks, 3 x u64 per wave).  Copies up to `cap` records of the most recent launch; returns
- * the number of waves of that launch, or -1 (tools/drain_probe.py). */
-NRT_API long nrtDebugWaveClocks(nrt_ctx *ctx, unsigned long long *out, long cap);
+/* (The profiling entry points — loop-occupancy counters, per-wave time stamps — are not part of this library: they live in
+ * libnanort_hip_prof.so, declared in nanort_hip_prof.h, together with the counting / clocked kernel instantiations.) */
 
 /* ---- two-level scenes (instancing): replaces nanosg::Scene<float, M> -----------------------
  * examples/nanosg/nanosg.h — AddNode :682, Commit :700-760 (per-node world AABB / inverse

@@ -1,0 +1,32 @@
+/* include/nanort_hip_prof.h — profiling entry points of libnanort_hip_prof.so.
+ *
+ * libnanort_hip_prof.so is libnanort_hip.so built from the same sources with -DNRT_PROF (nanort_amd/csrc/Makefile): the whole
+ * C ABI of nanort_hip.h plus the two calls below and the kernel instantiations behind them (loop-occupancy counters, per-wave
+ * time stamps).  The product library carries neither; its tunable "debug" ignores bits 32, 64 and 8192.  Used by the scripts under tools/
+ * (NRT_USE_PROF_LIB=1 makes nanort_amd.capi load this library).  No reference counterpart.
+ */
+#ifndef NANORT_HIP_PROF_H_
+#define NANORT_HIP_PROF_H_
+
+#include "nanort_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Profiling aid: loop-occupancy counters of the last traversal launched with the tunable "debug" bit 32 set (a separately
+ * instantiated, slower kernel).  out16[0..7] = inner-node-phase wave iterations, sum of active lanes, idle lanes at leaf-phase
+ * entry, leaf-phase trips, sum of lanes testing a (first) record, refill events, lanes refilled, leaf-phase entries;
+ * [8..10] = shader-clock ticks the waves spent refilling / in the inner-node phase / in the leaf phase; [11] = lanes
+ * with a second record in a leaf trip.  Returns 0 on success. */
+NRT_API int nrtDebugCounters(nrt_ctx *ctx, unsigned long long *out, int capacity /* >= 16 */);
+/* Profiling aid: with NRT_DEBUG bit 8192 every wave of a traversal launch records when it started, ran out of rays and
+ * finished (100 MHz realtime ticks, 3 x u64 per wave).  Copies up to `cap` records of the most recent launch; returns
+ * the number of waves of that launch, or -1 (tools/drain_probe.py). */
+NRT_API long nrtDebugWaveClocks(nrt_ctx *ctx, unsigned long long *out, long cap);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NANORT_HIP_PROF_H_ */

@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnanort_hip.so")
+# (NRT_USE_PROF_LIB=1: the profiling build of the same sources — include/nanort_hip_prof.h — for tools/ that read loop counters
+# or per-wave time stamps; never set by the package, the tests or bench.py)
+LIB_PATH = os.path.join(_HERE, "lib", "libnanort_hip_prof.so" if os.environ.get("NRT_USE_PROF_LIB") == "1" else "libnanort_hip.so")
 
 NRT_OK, NRT_ERR_INVALID, NRT_ERR_EMPTY, NRT_ERR_DEVICE, NRT_ERR_PRECISION = 0, 1, 2, 3, 4
 
@@ -25,7 +27,7 @@ SYMBOLS = [
     "nrtTraverseBatchMulti_f32", "nrtTraverseBatchMulti_f64", "nrtDeviceCount",
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
-    "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtDebugCounters", "nrtDebugWaveClocks", "nrtGetWide8_f32", "nrtHostAlloc", "nrtHostFree",
+    "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtGetWide8_f32", "nrtHostAlloc", "nrtHostFree",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
     "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32",
 ]

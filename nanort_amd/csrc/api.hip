@@ -20,6 +20,9 @@
 #include <vector>
 
 #include "common.h"
+#ifdef NRT_PROF
+#include "../../include/nanort_hip_prof.h"
+#endif
 
 namespace nrt {
 template <typename T>
@@ -833,6 +836,11 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   if (!d_rays) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatch: NULL rays");
   if (n > 0x7FFFFFFFull) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatch: more than 2^31-1 rays in one call");
   if (!opt) opt = &kDefaultTrace;
+#ifdef NRT_PROF
+  const unsigned dbg = c->debug_flags;
+#else
+  const unsigned dbg = c->debug_flags & ~(32u | 64u | 8192u); // (the counting / clocked instantiations live in libnanort_hip_prof.so)
+#endif
   std::lock_guard<std::mutex> lock(c->launch_mutex);
   HIPCHK(c, hipSetDevice(c->device));
 
@@ -873,10 +881,10 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
                              !opt->cull_back_face;
   // (the profiling instantiations of the two-level walk are built for the default trace options only: with options that can
   // reject a primitive a profiled launch walks one level per step, whose profiling variant honours them)
-  const bool prof_needs_w2 = (c->debug_flags & (32u | 8192u)) && !plain_options && !spheres;
+  const bool prof_needs_w2 = (dbg & (32u | 8192u)) && !plain_options && !spheres;
   const bool use_wide4 = use_wide && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch && !prof_needs_w2;
   // the 8-wide compressed walk: closest-hit and occlusion walks of fp32 triangle trees that had the layout built
-  const bool use_w8 = use_wide && sizeof(T) == 4 && c->wide8 && c->d_w8nodes && !spheres && !(c->debug_flags & 8192u);
+  const bool use_w8 = use_wide && sizeof(T) == 4 && c->wide8 && c->d_w8nodes && !spheres && !(dbg & 8192u);
   if (use_w8 && c->w8_blocks_per_cu == 0) c->w8_blocks_per_cu = (unsigned)traverse_w8_blocks_per_cu();
   if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, false);
   if (use_wide4 && !spheres && c->wide4_blocks_per_cu == 0) c->wide4_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(kWide4LdsStack, kPrimTriangles, true);
@@ -929,7 +937,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.packed_leaves = c->packed_leaves;
   a.wide_below_4g = (c->f64_row_fetch && (uint64_t)c->num_branch_records * sizeof(WideNode<T>) < (1ull << 32)) ? 1u : 0u;
   a.root_is_branch = c->root_is_branch;
-  a.debug_flags = c->debug_flags;
+  a.debug_flags = dbg;
   a.spill_tmin = (T *)slot->spill_tmin.p;
   a.rays = d_rays;
   a.hits = d_hits;
@@ -969,7 +977,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.any_hit = any_hit ? 1u : 0u;
   a.plain_options = plain_options ? 1u : 0u;
   a.root_test = c->tree_nested ? 0u : 1u;
-  a.order4 = (c->order4 && use_wide4 && !spheres && !any_hit && !(c->debug_flags & (32u | 8192u))) ? 1u : 0u;
+  a.order4 = (c->order4 && use_wide4 && !spheres && !any_hit && !(dbg & (32u | 8192u))) ? 1u : 0u;
   a.spill = (uint32_t *)slot->spill.p;
   a.spill_stride = total_threads;
   a.spill_levels = levels;
@@ -988,19 +996,21 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.blocks_per_part = grid / parts;
   a.counters = c->d_counters;
   a.wave_clock = nullptr;
-  if (c->debug_flags & 8192u) { // profiling: per-wave time stamps of this launch (nrtDebugWaveClocks)
+#ifdef NRT_PROF
+  if (dbg & 8192u) { // profiling: per-wave time stamps of this launch (nrtDebugWaveClocks)
     nrt_status st = ensure(c, c->b_wave_clock, (size_t)total_waves * 3 * sizeof(unsigned long long));
     if (st) return st;
     a.wave_clock = (unsigned long long *)c->b_wave_clock.p;
     c->wave_clock_waves = total_waves;
   }
+#endif
   a.chunk = c->chunk;
   a.chunk_tail_pct = c->chunk_tail_pct;
   a.refill_min = c->refill_min;
   a.trav_min = use_w8 ? c->trav_min8 : (use_wide4 ? c->trav_min4 : c->trav_min);
   a.leaf_min = c->leaf_min;
 
-  if (count || (c->debug_flags & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), s));
+  if (count || (dbg & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), s));
   // completion record instead of events: the traversal kernel is the launch's last kernel and events were not asked for
   const bool use_rec = use_wide && !count && !c->launch_timing;
   // (the sphere kind's u/v pass and the cylinder kind's normal pass run behind the traversal kernel and close the record in its place)
@@ -1501,10 +1511,11 @@ float nrtLastTraverseMs(nrt_ctx *c) {
 // the argument list) — bench.py reports it instead of guessing.
 const char *nrtLastKernelName(const nrt_ctx *c) { return c ? c->last_kernel : ""; }
 
+#ifdef NRT_PROF // libnanort_hip_prof.so only (include/nanort_hip_prof.h)
 // Profiling aid (not part of the public header): loop-occupancy counters of the last launch made with
 // NRT_DEBUG bit 32 set.  out[0..6] = it1, act1, trav1, it2, act2, refills, refilled.
-int nrtDebugCounters(nrt_ctx *c, unsigned long long *out) {
-  if (!c || !out) return 1;
+int nrtDebugCounters(nrt_ctx *c, unsigned long long *out, int cap) {
+  if (!c || !out || cap < 16) return 1; // (sixteen counters are written)
   if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   return hipMemcpy(out, c->d_counters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
@@ -1520,6 +1531,8 @@ long nrtDebugWaveClocks(nrt_ctx *c, unsigned long long *out, long cap) {
   if (hipMemcpy(out, c->b_wave_clock.p, (size_t)n * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (long)c->wave_clock_waves;
 }
+
+#endif
 
 // Test aid: the 8-wide compressed layout of the current tree (tunable wide8), for the comparison with the CPU model.
 // Either output may be NULL; the counts are always returned.  NRT_ERR_INVALID when the context holds no such layout.

@@ -2432,11 +2432,14 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
   }
   if (args.wide4) { // two tree levels per step (the caller checked what that needs)
     if constexpr (sizeof(T) == 4) {
+#ifdef NRT_PROF // (the profiling instantiations exist in libnanort_hip_prof.so only: nanort_hip_prof.h)
       if (args.debug_flags & 32u)
         NRT_LAUNCH_WIDE(kWide4LdsStack, true, kPrimTriangles, true, false, 4); // profiling instantiation (default trace options only)
       else if (args.wave_clock)
         NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, true, 4); // per-wave time stamps (default trace options only)
-      else if (args.order4 && args.plain_options) // slots entered by entry distance (tunable order4; contract-level parity: see NRT_STEP_NODE4_DIST)
+      else
+#endif
+      if (args.order4 && args.plain_options) // slots entered by entry distance (tunable order4; contract-level parity: see NRT_STEP_NODE4_DIST)
         NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, true, false, 4, 1);
       else if (args.order4)
         NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, false, false, 4, 1);
@@ -2452,11 +2455,14 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
   switch (lds_stack) {
     case 8: NRT_LAUNCH_WIDE(8, false, kPrimTriangles, false, false, 2); break;
     case 10:
+#ifdef NRT_PROF
       if (args.debug_flags & 32u) {
         NRT_LAUNCH_WIDE(10, true, kPrimTriangles, false, false, 2);
       } else if (args.wave_clock) { // profiling: per-wave time stamps (default trace options only)
         NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, true, 2);
-      } else if (args.plain_options) {
+      } else
+#endif
+      if (args.plain_options) {
         NRT_LAUNCH_WIDE(10, false, kPrimTriangles, true, false, 2);
       } else {
         NRT_LAUNCH_WIDE(10, false, kPrimTriangles, false, false, 2);
@@ -2472,10 +2478,13 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
 
 // The 8-wide compressed walk (fp32 triangle trees; the caller checked what it needs).
 hipError_t launch_traverse_w8(const TraverseArgs<float> &args, unsigned grid, hipStream_t s, const char **name_out) {
+#ifdef NRT_PROF
   if (args.debug_flags & 32u) {
     hipLaunchKernelGGL((k_traverse_w8<true, true>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
     if (name_out) *name_out = "nrt::k_traverse_w8<true, true>";
-  } else if (args.plain_options) {
+  } else
+#endif
+  if (args.plain_options) {
     hipLaunchKernelGGL((k_traverse_w8<true, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
     if (name_out) *name_out = "nrt::k_traverse_w8<true, false>";
   } else {

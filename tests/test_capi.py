@@ -31,6 +31,24 @@ def test_library_exports_every_declared_symbol():
     assert exported == set(declared_symbols()), "exported C symbols differ from the header"
 
 
+def test_profiling_entry_points_live_in_the_profiling_library_only():
+    """libnanort_hip_prof.so = the same sources with -DNRT_PROF: the product ABI plus the two nrtDebug* calls of
+    include/nanort_hip_prof.h; the product library exports neither."""
+    prof = os.path.join(os.path.dirname(capi.LIB_PATH), "libnanort_hip_prof.so")
+    assert os.path.exists(prof), "make -C nanort_amd/csrc builds it"
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, text=True).stdout
+        return set(re.findall(r" T (nrt\w+)", out))
+
+    base = exported(os.path.join(os.path.dirname(capi.LIB_PATH), "libnanort_hip.so"))
+    assert not any(n.startswith("nrtDebug") for n in base)
+    hdr = open(os.path.join(ROOT, "include", "nanort_hip_prof.h")).read()
+    extra = set(re.findall(r"NRT_API\s+[\w\s\*]+?\b(nrt\w+)\s*\(", hdr))
+    assert extra == {"nrtDebugCounters", "nrtDebugWaveClocks"}
+    assert exported(prof) == base | extra
+
+
 def test_library_has_gfx950_code_object():
     data = open(capi.LIB_PATH, "rb").read()
     assert b"gfx950" in data and b"k_traverse" in data and b"k_subtree" in data

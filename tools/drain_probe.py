@@ -4,6 +4,9 @@ mean and longest drain (out of rays -> done), and the share of wave-time that is
 
     python tools/drain_probe.py [C3] [static_bands=1 ...]
 """
+import os
+
+os.environ["NRT_USE_PROF_LIB"] = "1"  # the profiling build of the library (include/nanort_hip_prof.h)
 import ctypes
 import sys
 

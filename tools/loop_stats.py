@@ -4,6 +4,9 @@ ticks goes to refilling, the inner-node phase and the leaf phase.
 
     python tools/loop_stats.py [C3] [refill_min=32 static_bands=1 ...]      (name=value: nrtSetTunable)
 """
+import os
+
+os.environ["NRT_USE_PROF_LIB"] = "1"  # the profiling build of the library (include/nanort_hip_prof.h)
 import ctypes
 import sys
 
@@ -18,7 +21,7 @@ from nanort_amd import capi  # noqa: E402
 cfg = [a for a in sys.argv[1:] if "=" not in a] or ["C3"]
 tun = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
 L = capi.lib()
-L.nrtDebugCounters.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+L.nrtDebugCounters.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 for name in cfg:
     wl = bench.Workload(name, builds=1)
     a = wl.accel
@@ -34,7 +37,7 @@ for name in cfg:
         a.TraverseBatchDevice(d, o)
         ms_stats = a.LastTraverseMs()
         c = np.zeros(16, dtype=np.uint64)
-        L.nrtDebugCounters(a._h, c.ctypes.data_as(ctypes.c_void_p))
+        L.nrtDebugCounters(a._h, c.ctypes.data_as(ctypes.c_void_p), 16)
         it1, act1, idle2, it2, act2, refills, refilled, ent2, t_ref, t_p1, t_p2, act2b = [int(x) for x in c[:12]]
         g = n / 64.0
         tt = max(1, t_ref + t_p1 + t_p2)

@@ -5,6 +5,9 @@ not know its costs — the answer bounds what any predictor-driven ordering coul
 
     python tools/tail_first_probe.py [C3 C2 C4tile]
 """
+import os
+
+os.environ["NRT_USE_PROF_LIB"] = "1"  # the profiling build of the library (include/nanort_hip_prof.h)
 import sys
 
 import numpy as np
