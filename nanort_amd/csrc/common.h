@@ -231,6 +231,9 @@ struct SceneTraceArgs {
   uint32_t num_parts;         // ray partitions (<= kMaxParts)
   uint32_t refill_min;        // free lanes of a wave before it claims more rays
   uint32_t trav_min;          // lanes still walking inner nodes below which the wave turns to the waiting leaves
+  uint32_t cand_min;          // lanes waiting between two instances (a local walk ended / the next candidate is due) before the wave runs
+                              // that — expensive, divergent — step for them; fewer wait while `cand_busy_max` or more lanes still walk
+  uint32_t cand_busy_max;
 };
 
 // Completion record of a launch slot, in page-locked host memory the device writes to: the last wave of a traversal

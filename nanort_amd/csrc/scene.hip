@@ -439,6 +439,7 @@ struct nrt_scene {
   nrt::DevBuf d_nodes, d_insts, d_rays, d_list_t, d_list_node, d_count, d_best, d_mask, d_spill, d_spill_tmin, d_cursor;
   unsigned prune_min = 32768; // scenes of at least this many instances are listed by the pruning walk (k_scene_list_w4<true>)
   unsigned trav_min = 8;
+  unsigned cand_min = 1, cand_busy_max = 64; // batching of the per-instance steps of k_scene_trace (env NRT_SCENE_CAND / NRT_SCENE_CAND_BUSY; 1 / 64: none)
   unsigned trace_blocks_per_cu = 0, num_cus = 0, refill_min = 56; // persistent grid of k_scene_trace (env NRT_SCENE_REFILL; 16-48 measured slower on small scenes, 64 slower on 10 000 instances)
 };
 
@@ -662,6 +663,8 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     s->num_cus = (unsigned)prop.multiProcessorCount;
     if (const char *e = getenv("NRT_SCENE_REFILL")) s->refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_TRAV")) s->trav_min = (unsigned)std::min(64, std::max(1, atoi(e)));
+    if (const char *e = getenv("NRT_SCENE_CAND")) s->cand_min = (unsigned)std::min(64, std::max(1, atoi(e)));
+    if (const char *e = getenv("NRT_SCENE_CAND_BUSY")) s->cand_busy_max = (unsigned)std::min(65, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_PRUNE_MIN")) s->prune_min = (unsigned)std::max(0, atoi(e)); // (debugging / tests: the pruning walk on small scenes)
   }
   const unsigned trace_grid = std::min(grid, s->num_cus * s->trace_blocks_per_cu); // the trace kernel: every block resident
@@ -711,6 +714,8 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   a.num_parts = std::max(1u, std::min(8u, trace_grid));
   a.refill_min = s->refill_min;
   a.trav_min = s->trav_min;
+  a.cand_min = s->cand_min;
+  a.cand_busy_max = s->cand_busy_max;
   SCHK(s, nrt::launch_scene_trace(a, trace_grid, s->stream));
   if (!device) {
     SCHK(s, hipMemcpyAsync(hits_out, s->d_best.p, (size_t)n * sizeof(nrt_scene_hit_f32), hipMemcpyDeviceToHost, s->stream));

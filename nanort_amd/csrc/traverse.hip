@@ -2000,6 +2000,14 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
       }
     }
     // ---- candidates: finish a local walk, pick the next instance ---------------------------------------------------
+    // (Both steps are long and run under divergence — matrix products, a division-heavy lane set-up, the selection scan over the
+    // ray's list: the wave runs them for SEVERAL lanes at a time.  Lanes between two instances wait until `cand_min` of them have
+    // gathered, unless fewer than `cand_busy_max` lanes would be walking meanwhile.  Walking lanes always finish, so the waiting
+    // ones are served at the latest when nobody walks.)
+    const unsigned n_cand = (unsigned)__builtin_popcountll(__ballot(state == S_FIN || state == S_NEXT));
+    const unsigned n_busy = (unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP || state == W_LEAF));
+    const bool do_cand = n_cand != 0u && (n_cand >= a.cand_min || n_busy < a.cand_busy_max);
+    if (do_cand) {
     if (state == S_FIN) {
       if (L.hit_t < L.max_t) { // the local Traverse() hit (strict final predicate, nanort.h:2552)
         const SceneInst &nd = a.insts[inst];
@@ -2083,6 +2091,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
         }
       }
       if (state == S_DONE && a.mask) a.mask[i] = has_hit ? 1 : 0; // this ray is finished
+    }
     }
     if (__ballot(state != S_DONE) == 0ull) {
       if (exhausted) break;
