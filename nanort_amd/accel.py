@@ -406,6 +406,14 @@ class Scene:
         m = out.reshape(4, 4, 4)
         return {"xform": m[0], "inv_xform": m[1], "inv_xform33": m[2], "inv_transpose_xform33": m[3]}
 
+    def SetTunable(self, name, value):
+        """Scheduling knobs of the scene kernels (nrtSceneSetTunable): "single_pass", "trav_min", "refill_min", ..."""
+        self._check(self._L.nrtSceneSetTunable(self._h, name.encode(), int(value)))
+
+    def LastRedone(self):
+        """Rays of the last call that the single-pass walk handed to the listing path (nrtSceneLastRedone)."""
+        return int(self._L.nrtSceneLastRedone(self._h))
+
     def TraverseBatch(self, rays):
         from .wire import RAY_F32, SCENE_HIT_F32
 

@@ -29,7 +29,7 @@ SYMBOLS = [
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
     "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtGetWide8_f32", "nrtHostAlloc", "nrtHostFree",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
-    "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32",
+    "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32", "nrtSceneSetTunable", "nrtSceneLastRedone",
 ]
 
 
@@ -141,6 +141,10 @@ def lib():
     L.nrtSceneTraverseBatch_f32.restype = i32
     L.nrtSceneTraverseBatchDevice_f32.argtypes = [vp, vp, u64, vp, vp]
     L.nrtSceneTraverseBatchDevice_f32.restype = i32
+    L.nrtSceneSetTunable.argtypes = [vp, ctypes.c_char_p, i32]
+    L.nrtSceneSetTunable.restype = i32
+    L.nrtSceneLastRedone.argtypes = [vp]
+    L.nrtSceneLastRedone.restype = u64
     L.nrtHostAlloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
     L.nrtHostAlloc.restype = i32
     L.nrtHostFree.argtypes = [vp]

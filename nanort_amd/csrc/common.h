@@ -234,6 +234,30 @@ struct SceneTraceArgs {
   uint32_t cand_min;          // lanes waiting between two instances (a local walk ended / the next candidate is due) before the wave runs
                               // that — expensive, divergent — step for them; fewer wait while `cand_busy_max` or more lanes still walk
   uint32_t cand_busy_max;
+  const uint32_t *subset;     // non-null: the launch traces rays[subset[s]] for s < n (lists and counts are indexed by s, results by the ray)
+};
+
+// The single-pass scene walk (traverse.hip k_scene_walk): the top-level tree and the instances' trees walked by the same lane on
+// one stack, no per-ray list.  Rays it cannot certify (see the kernel) are appended to `redo` for the listing path.
+constexpr int kSceneWalkLdsStack = 16; // per-lane stack entries kept in LDS (top-level entries below, the open instance's above)
+struct SceneWalkArgs {
+  const nrt_ray_f32 *rays;
+  uint32_t n;
+  const SceneInst *insts;
+  const Wide4Node<float> *top_wide4; // the top-level tree over the instances' world boxes (root is a branch, nested, packed leaves)
+  const uint32_t *top_indices;       // its index array: position -> instance id
+  const float *inst_boxes;           // world box of instance k at inst_boxes + k * inst_box_stride: bmin[3], bmax[3]
+  uint32_t inst_box_stride;
+  nrt_scene_hit_f32 *hits;
+  uint8_t *mask;
+  uint32_t *spill;
+  float *spill_tmin;
+  uint32_t spill_stride;
+  uint32_t *cursor;
+  uint32_t num_parts;
+  uint32_t refill_min, trav_min, cand_min, cand_busy_max;
+  uint32_t *redo;       // [n]: rays left to the listing path
+  uint32_t *redo_count; // zero at launch
 };
 
 // Completion record of a launch slot, in page-locked host memory the device writes to: the last wave of a traversal

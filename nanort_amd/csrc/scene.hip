@@ -34,6 +34,8 @@ uint64_t nrt_internal_generation(const nrt_ctx *c);                      // api.
 namespace nrt {
 hipError_t launch_scene_trace(const SceneTraceArgs &args, unsigned grid, hipStream_t s); // traverse.hip
 int scene_trace_blocks_per_cu();
+hipError_t launch_scene_walk(const SceneWalkArgs &args, unsigned grid, hipStream_t s); // traverse.hip
+int scene_walk_blocks_per_cu();
 }
 
 namespace {
@@ -143,10 +145,10 @@ __device__ inline void list_add(ListTail &st, float t, uint32_t k, uint32_t cap,
 __global__ __launch_bounds__(256) void k_scene_list(const nrt_ray_f32 *__restrict__ rays, uint32_t n,
                                                     const NodeDev *__restrict__ nodes, uint32_t num_nodes, uint32_t cap,
                                                     float *__restrict__ list_t, uint32_t *__restrict__ list_node,
-                                                    uint32_t *__restrict__ count) {
+                                                    uint32_t *__restrict__ count, const uint32_t *__restrict__ subset) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  const nrt_ray_f32 r = rays[i];
+  const nrt_ray_f32 r = rays[subset ? subset[i] : i]; // (a subset launch lists rays[subset[i]] into slot i of n)
   ListTail st;
   for (uint32_t k = 0; k < num_nodes; k++) {
     float t;
@@ -178,10 +180,10 @@ __global__ __launch_bounds__(256) void k_scene_list_bvh(const nrt_ray_f32 *__res
                                                         const uint32_t *__restrict__ top_indices,
                                                         const NodeDev *__restrict__ nodes, uint32_t cap,
                                                         float *__restrict__ list_t, uint32_t *__restrict__ list_node,
-                                                        uint32_t *__restrict__ count) {
+                                                        uint32_t *__restrict__ count, const uint32_t *__restrict__ subset) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  const nrt_ray_f32 r = rays[i];
+  const nrt_ray_f32 r = rays[subset ? subset[i] : i];
   float inv[3];
   int sign[3];
 #pragma unroll
@@ -229,10 +231,10 @@ __global__ __launch_bounds__(256) void k_scene_list_w4(const nrt_ray_f32 *__rest
                                                        const uint32_t *__restrict__ top_indices,
                                                        const NodeDev *__restrict__ nodes, uint32_t cap,
                                                        float *__restrict__ list_t, uint32_t *__restrict__ list_node,
-                                                       uint32_t *__restrict__ count) {
+                                                       uint32_t *__restrict__ count, const uint32_t *__restrict__ subset) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  const nrt_ray_f32 r = rays[i];
+  const nrt_ray_f32 r = rays[subset ? subset[i] : i];
   float inv[3], pinv[3];
   int sign[3];
   bool tame = PRUNE; // every direction component is an ordinary non-zero number and the origin is finite: entry distances are monotone in the box
@@ -437,6 +439,11 @@ struct nrt_scene {
   bool use_top = false;
   uint32_t max_inst_depth = 0;   // deepest instance tree: sizes the overflow stack of k_scene_trace
   nrt::DevBuf d_nodes, d_insts, d_rays, d_list_t, d_list_node, d_count, d_best, d_mask, d_spill, d_spill_tmin, d_cursor;
+  nrt::DevBuf d_redo, d_redo_count;
+  uint32_t *h_redo_count = nullptr; // page-locked: how many rays the single-pass walk left to the listing path
+  uint64_t last_redone = 0;
+  unsigned single_pass = 1;   // scenes with a top-level tree are traced by k_scene_walk (no per-ray list); 0: always listing + k_scene_trace
+  unsigned walk_blocks_per_cu = 0;
   unsigned prune_min = 32768; // scenes of at least this many instances are listed by the pruning walk (k_scene_list_w4<true>)
   unsigned trav_min = 8;
   unsigned cand_min = 1, cand_busy_max = 64; // batching of the per-instance steps of k_scene_trace (env NRT_SCENE_CAND / NRT_SCENE_CAND_BUSY; 1 / 64: none)
@@ -487,9 +494,10 @@ void nrtSceneDestroy(nrt_scene *s) {
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
   nrt::DevBuf *bufs[] = {&s->d_nodes, &s->d_insts, &s->d_rays, &s->d_list_t, &s->d_list_node, &s->d_count,
-                         &s->d_best,  &s->d_mask,  &s->d_spill, &s->d_spill_tmin, &s->d_cursor};
+                         &s->d_best,  &s->d_mask,  &s->d_spill, &s->d_spill_tmin, &s->d_cursor, &s->d_redo, &s->d_redo_count};
   for (nrt::DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
+  if (s->h_redo_count) (void)hipHostFree(s->h_redo_count);
   if (s->top) nrtDestroy(s->top);
   (void)hipStreamDestroy(s->stream);
   delete s;
@@ -631,9 +639,70 @@ nrt_status nrtSceneNodeState_f32(nrt_scene *s, uint32_t node_id, float out[64]) 
 
 } // extern "C"
 
-// `device` = rays / hits_out / mask_out are device pointers (no PCIe traffic).  Two launches on the scene's stream — the
-// listing and k_scene_trace — and one synchronisation at the end (the scene owns the per-ray lists, so the call returns
-// with them free for the next one).
+// The listing path: one of the listing kernels + k_scene_trace, enqueued on the scene's stream, over the whole batch
+// (`subset` == nullptr) or over the rays named by `subset` (the ones the single-pass walk left over).
+static nrt_status scene_list_and_trace(nrt_scene *s, const nrt_ray_f32 *d_rays, uint32_t n, const uint32_t *subset,
+                                       nrt_scene_hit_f32 *d_hits, uint8_t *d_mask) {
+  const uint32_t num_nodes = (uint32_t)s->insts.size();
+  const uint32_t cap = std::min<uint32_t>(kMaxList, num_nodes);
+  SCHK(s, nrt::devbuf_ensure(&s->d_list_t, (size_t)cap * n * sizeof(float)));
+  SCHK(s, nrt::devbuf_ensure(&s->d_list_node, (size_t)cap * n * sizeof(uint32_t)));
+  SCHK(s, nrt::devbuf_ensure(&s->d_count, (size_t)n * sizeof(uint32_t)));
+  const unsigned grid = (n + 255u) / 256u; // the listing kernels: one ray per thread
+  const unsigned trace_grid = std::min(grid, s->num_cus * s->trace_blocks_per_cu); // the trace kernel: every block resident
+  const uint32_t levels = s->max_inst_depth + 2 > (uint32_t)nrt::kSceneLdsStack ? s->max_inst_depth + 2 - nrt::kSceneLdsStack : 0;
+  if (levels) {
+    SCHK(s, nrt::devbuf_ensure(&s->d_spill, (size_t)levels * trace_grid * 256u * sizeof(uint32_t)));
+    SCHK(s, nrt::devbuf_ensure(&s->d_spill_tmin, (size_t)levels * trace_grid * 256u * sizeof(float)));
+  }
+  SCHK(s, hipMemsetAsync(s->d_cursor.p, 0, (size_t)nrt::kMaxParts * nrt::kCursorStrideWords * sizeof(uint32_t), s->stream));
+  const NodeDev *d_nodes = (const NodeDev *)s->d_nodes.p;
+  if (s->use_top && s->top_view.wide4 && s->top_view.root_is_branch && s->top_view.tree_nested &&
+      3u * (s->top_view.tree_depth / 2u + 1u) + 2u < (uint32_t)kTopStack)
+  {
+    if (num_nodes >= s->prune_min) // (rays can enter more boxes than the list holds: the pruning walk)
+      hipLaunchKernelGGL(k_scene_list_w4<true>, dim3(grid), dim3(256), 0, s->stream, d_rays, n, (const nrt::Wide4Node<float> *)s->top_view.wide4,
+                         s->top_view.nodes, s->top_view.packed_leaves, s->top_view.indices, d_nodes, cap, (float *)s->d_list_t.p,
+                         (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p, subset);
+    else
+      hipLaunchKernelGGL(k_scene_list_w4<false>, dim3(grid), dim3(256), 0, s->stream, d_rays, n, (const nrt::Wide4Node<float> *)s->top_view.wide4,
+                         s->top_view.nodes, s->top_view.packed_leaves, s->top_view.indices, d_nodes, cap, (float *)s->d_list_t.p,
+                         (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p, subset);
+  }
+  else if (s->use_top)
+    hipLaunchKernelGGL(k_scene_list_bvh, dim3(grid), dim3(256), 0, s->stream, d_rays, n, s->top_view.nodes, s->top_view.indices,
+                       d_nodes, cap, (float *)s->d_list_t.p, (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p, subset);
+  else
+    hipLaunchKernelGGL(k_scene_list, dim3(grid), dim3(256), 0, s->stream, d_rays, n, d_nodes, num_nodes, cap,
+                       (float *)s->d_list_t.p, (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p, subset);
+  SCHK(s, hipGetLastError());
+  nrt::SceneTraceArgs a;
+  a.rays = d_rays;
+  a.n = n;
+  a.insts = (const nrt::SceneInst *)s->d_insts.p;
+  a.list_t = (const float *)s->d_list_t.p;
+  a.list_node = (const uint32_t *)s->d_list_node.p;
+  a.count = (const uint32_t *)s->d_count.p;
+  a.hits = d_hits;
+  a.mask = d_mask;
+  a.spill = (uint32_t *)s->d_spill.p;
+  a.spill_tmin = (float *)s->d_spill_tmin.p;
+  a.spill_stride = trace_grid * 256u;
+  a.cursor = (uint32_t *)s->d_cursor.p;
+  a.num_parts = std::max(1u, std::min(8u, trace_grid));
+  a.refill_min = s->refill_min;
+  a.trav_min = s->trav_min;
+  a.cand_min = s->cand_min;
+  a.cand_busy_max = s->cand_busy_max;
+  a.subset = subset;
+  SCHK(s, nrt::launch_scene_trace(a, trace_grid, s->stream));
+  return NRT_OK;
+}
+
+// `device` = rays / hits_out / mask_out are device pointers (no PCIe traffic).  Scenes with a top-level tree: ONE launch of the
+// single-pass walk (k_scene_walk), then — only if it left rays over — the listing path on those; other scenes (a handful of
+// nodes) and single_pass = 0: the listing path on the whole batch.  The call returns with everything finished (the scene owns
+// the per-ray scratch).
 static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t n64, nrt_scene_hit_f32 *hits_out,
                                  uint8_t *mask_out, bool device) {
   if (!s) return NRT_ERR_INVALID;
@@ -646,18 +715,14 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   for (size_t m = 0; m < s->mesh_gens.size(); m++)
     if (nrt_internal_generation(s->mesh_gens[m].first) != s->mesh_gens[m].second)
       return sfail(s, NRT_ERR_INVALID, "nrtSceneTraverseBatch: a mesh context was rebuilt or re-set since nrtSceneCommit (commit the scene again)");
-  const uint32_t n = (uint32_t)n64, num_nodes = (uint32_t)s->insts.size();
-  const uint32_t cap = std::min<uint32_t>(kMaxList, num_nodes);
+  const uint32_t n = (uint32_t)n64;
   SCHK(s, hipSetDevice(s->device));
   if (!device) SCHK(s, nrt::devbuf_ensure(&s->d_rays, (size_t)n * sizeof(nrt_ray_f32)));
-  SCHK(s, nrt::devbuf_ensure(&s->d_list_t, (size_t)cap * n * sizeof(float)));
-  SCHK(s, nrt::devbuf_ensure(&s->d_list_node, (size_t)cap * n * sizeof(uint32_t)));
-  SCHK(s, nrt::devbuf_ensure(&s->d_count, (size_t)n * sizeof(uint32_t)));
   if (!device) SCHK(s, nrt::devbuf_ensure(&s->d_best, (size_t)n * sizeof(nrt_scene_hit_f32)));
   if (!device && mask_out) SCHK(s, nrt::devbuf_ensure(&s->d_mask, (size_t)n));
-  const unsigned grid = (n + 255u) / 256u; // the listing kernels: one ray per thread
   if (s->trace_blocks_per_cu == 0) {
     s->trace_blocks_per_cu = (unsigned)nrt::scene_trace_blocks_per_cu();
+    s->walk_blocks_per_cu = (unsigned)nrt::scene_walk_blocks_per_cu();
     hipDeviceProp_t prop;
     SCHK(s, hipGetDeviceProperties(&prop, s->device));
     s->num_cus = (unsigned)prop.multiProcessorCount;
@@ -666,57 +731,64 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     if (const char *e = getenv("NRT_SCENE_CAND")) s->cand_min = (unsigned)std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_CAND_BUSY")) s->cand_busy_max = (unsigned)std::min(65, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_PRUNE_MIN")) s->prune_min = (unsigned)std::max(0, atoi(e)); // (debugging / tests: the pruning walk on small scenes)
-  }
-  const unsigned trace_grid = std::min(grid, s->num_cus * s->trace_blocks_per_cu); // the trace kernel: every block resident
-  const uint32_t levels = s->max_inst_depth + 2 > (uint32_t)nrt::kSceneLdsStack ? s->max_inst_depth + 2 - nrt::kSceneLdsStack : 0;
-  if (levels) {
-    SCHK(s, nrt::devbuf_ensure(&s->d_spill, (size_t)levels * trace_grid * 256u * sizeof(uint32_t)));
-    SCHK(s, nrt::devbuf_ensure(&s->d_spill_tmin, (size_t)levels * trace_grid * 256u * sizeof(float)));
+    if (const char *e = getenv("NRT_SCENE_WALK")) s->single_pass = atoi(e) != 0;
   }
   SCHK(s, nrt::devbuf_ensure(&s->d_cursor, (size_t)nrt::kMaxParts * nrt::kCursorStrideWords * sizeof(uint32_t)));
-  SCHK(s, hipMemsetAsync(s->d_cursor.p, 0, (size_t)nrt::kMaxParts * nrt::kCursorStrideWords * sizeof(uint32_t), s->stream));
-  const NodeDev *d_nodes = (const NodeDev *)s->d_nodes.p;
   const nrt_ray_f32 *d_rays = device ? rays : (const nrt_ray_f32 *)s->d_rays.p;
-
+  nrt_scene_hit_f32 *d_hits = device ? hits_out : (nrt_scene_hit_f32 *)s->d_best.p;
+  uint8_t *d_mask = device ? mask_out : (mask_out ? (uint8_t *)s->d_mask.p : nullptr);
   if (!device) SCHK(s, hipMemcpyAsync(s->d_rays.p, rays, (size_t)n * sizeof(nrt_ray_f32), hipMemcpyHostToDevice, s->stream));
-  if (s->use_top && s->top_view.wide4 && s->top_view.root_is_branch && s->top_view.tree_nested &&
-      3u * (s->top_view.tree_depth / 2u + 1u) + 2u < (uint32_t)kTopStack)
-  {
-    if (num_nodes >= s->prune_min) // (rays can enter more boxes than the list holds: the pruning walk)
-      hipLaunchKernelGGL(k_scene_list_w4<true>, dim3(grid), dim3(256), 0, s->stream, d_rays, n, (const nrt::Wide4Node<float> *)s->top_view.wide4,
-                         s->top_view.nodes, s->top_view.packed_leaves, s->top_view.indices, d_nodes, cap, (float *)s->d_list_t.p,
-                         (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p);
-    else
-      hipLaunchKernelGGL(k_scene_list_w4<false>, dim3(grid), dim3(256), 0, s->stream, d_rays, n, (const nrt::Wide4Node<float> *)s->top_view.wide4,
-                         s->top_view.nodes, s->top_view.packed_leaves, s->top_view.indices, d_nodes, cap, (float *)s->d_list_t.p,
-                         (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p);
+
+  s->last_redone = 0;
+  const bool walk = s->single_pass && s->use_top && s->top_view.wide4 && s->top_view.root_is_branch && s->top_view.tree_nested &&
+                    s->top_view.packed_leaves;
+  if (walk) {
+    if (!s->h_redo_count) SCHK(s, hipHostMalloc((void **)&s->h_redo_count, sizeof(uint32_t), hipHostMallocDefault));
+    SCHK(s, nrt::devbuf_ensure(&s->d_redo, (size_t)n * sizeof(uint32_t)));
+    SCHK(s, nrt::devbuf_ensure(&s->d_redo_count, sizeof(uint32_t)));
+    const unsigned grid = std::min((n + 255u) / 256u, s->num_cus * s->walk_blocks_per_cu);
+    // the lane's stack: top-level entries (three per two levels of the top-level tree, the instances of one leaf) below the open instance's
+    const uint32_t need = 3u * (s->top_view.tree_depth / 2u + 1u) + 2u + nrt::kPackedMaxCount + s->max_inst_depth + 2u;
+    const uint32_t levels = need > (uint32_t)nrt::kSceneWalkLdsStack ? need - nrt::kSceneWalkLdsStack : 0;
+    if (levels) {
+      SCHK(s, nrt::devbuf_ensure(&s->d_spill, (size_t)levels * grid * 256u * sizeof(uint32_t)));
+      SCHK(s, nrt::devbuf_ensure(&s->d_spill_tmin, (size_t)levels * grid * 256u * sizeof(float)));
+    }
+    SCHK(s, hipMemsetAsync(s->d_cursor.p, 0, (size_t)nrt::kMaxParts * nrt::kCursorStrideWords * sizeof(uint32_t), s->stream));
+    SCHK(s, hipMemsetAsync(s->d_redo_count.p, 0, sizeof(uint32_t), s->stream));
+    nrt::SceneWalkArgs w;
+    w.rays = d_rays;
+    w.n = n;
+    w.insts = (const nrt::SceneInst *)s->d_insts.p;
+    w.top_wide4 = (const nrt::Wide4Node<float> *)s->top_view.wide4;
+    w.top_indices = s->top_view.indices;
+    w.inst_boxes = (const float *)s->d_nodes.p; // NodeDev starts with xbmin[3], xbmax[3]
+    w.inst_box_stride = (uint32_t)(sizeof(NodeDev) / sizeof(float));
+    w.hits = d_hits;
+    w.mask = d_mask;
+    w.spill = (uint32_t *)s->d_spill.p;
+    w.spill_tmin = (float *)s->d_spill_tmin.p;
+    w.spill_stride = grid * 256u;
+    w.cursor = (uint32_t *)s->d_cursor.p;
+    w.num_parts = std::max(1u, std::min(8u, grid));
+    w.refill_min = s->refill_min;
+    w.trav_min = s->trav_min;
+    w.cand_min = s->cand_min;
+    w.cand_busy_max = s->cand_busy_max;
+    w.redo = (uint32_t *)s->d_redo.p;
+    w.redo_count = (uint32_t *)s->d_redo_count.p;
+    SCHK(s, nrt::launch_scene_walk(w, grid, s->stream));
+    SCHK(s, hipMemcpyAsync(s->h_redo_count, s->d_redo_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    SCHK(s, hipStreamSynchronize(s->stream));
+    s->last_redone = *s->h_redo_count;
+    if (*s->h_redo_count) {
+      const nrt_status st = scene_list_and_trace(s, d_rays, *s->h_redo_count, (const uint32_t *)s->d_redo.p, d_hits, d_mask);
+      if (st != NRT_OK) return st;
+    }
+  } else {
+    const nrt_status st = scene_list_and_trace(s, d_rays, n, nullptr, d_hits, d_mask);
+    if (st != NRT_OK) return st;
   }
-  else if (s->use_top)
-    hipLaunchKernelGGL(k_scene_list_bvh, dim3(grid), dim3(256), 0, s->stream, d_rays, n, s->top_view.nodes, s->top_view.indices,
-                       d_nodes, cap, (float *)s->d_list_t.p, (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p);
-  else
-    hipLaunchKernelGGL(k_scene_list, dim3(grid), dim3(256), 0, s->stream, d_rays, n, d_nodes, num_nodes, cap,
-                       (float *)s->d_list_t.p, (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p);
-  SCHK(s, hipGetLastError());
-  nrt::SceneTraceArgs a;
-  a.rays = d_rays;
-  a.n = n;
-  a.insts = (const nrt::SceneInst *)s->d_insts.p;
-  a.list_t = (const float *)s->d_list_t.p;
-  a.list_node = (const uint32_t *)s->d_list_node.p;
-  a.count = (const uint32_t *)s->d_count.p;
-  a.hits = device ? hits_out : (nrt_scene_hit_f32 *)s->d_best.p;
-  a.mask = device ? mask_out : (mask_out ? (uint8_t *)s->d_mask.p : nullptr);
-  a.spill = (uint32_t *)s->d_spill.p;
-  a.spill_tmin = (float *)s->d_spill_tmin.p;
-  a.spill_stride = trace_grid * 256u;
-  a.cursor = (uint32_t *)s->d_cursor.p;
-  a.num_parts = std::max(1u, std::min(8u, trace_grid));
-  a.refill_min = s->refill_min;
-  a.trav_min = s->trav_min;
-  a.cand_min = s->cand_min;
-  a.cand_busy_max = s->cand_busy_max;
-  SCHK(s, nrt::launch_scene_trace(a, trace_grid, s->stream));
   if (!device) {
     SCHK(s, hipMemcpyAsync(hits_out, s->d_best.p, (size_t)n * sizeof(nrt_scene_hit_f32), hipMemcpyDeviceToHost, s->stream));
     if (mask_out) SCHK(s, hipMemcpyAsync(mask_out, s->d_mask.p, (size_t)n, hipMemcpyDeviceToHost, s->stream));
@@ -736,5 +808,21 @@ nrt_status nrtSceneTraverseBatchDevice_f32(nrt_scene *s, const nrt_ray_f32 *d_ra
                                            uint8_t *d_mask_out) {
   return scene_traverse(s, d_rays, n, d_hits_out, d_mask_out, true);
 }
+
+nrt_status nrtSceneSetTunable(nrt_scene *s, const char *name, int value) {
+  if (!s || !name) return NRT_ERR_INVALID;
+  const std::string k(name);
+  const unsigned lanes = (unsigned)std::min(64, std::max(1, value));
+  if (k == "single_pass") s->single_pass = value != 0;
+  else if (k == "trav_min") s->trav_min = lanes;
+  else if (k == "refill_min") s->refill_min = lanes;
+  else if (k == "cand_min") s->cand_min = lanes;
+  else if (k == "cand_busy_max") s->cand_busy_max = (unsigned)std::min(65, std::max(1, value));
+  else if (k == "prune_min") s->prune_min = (unsigned)std::max(0, value);
+  else return sfail(s, NRT_ERR_INVALID, "nrtSceneSetTunable: unknown tunable '%s'", name);
+  return NRT_OK;
+}
+
+uint64_t nrtSceneLastRedone(const nrt_scene *s) { return s ? s->last_redone : 0; }
 
 } // extern "C"

@@ -1933,7 +1933,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
   // one atomic once `refill_min` lanes are free), so a wave keeps its lanes busy to the end of the batch instead of
   // waiting for the slowest of 64 fixed rays.
   Lane<float> L;
-  uint32_t i = 0; // this lane's ray
+  uint32_t i = 0, ri = 0; // this lane's slot in the launch (lists, counts) and its ray (== i unless the launch traces a subset)
   uint32_t cur = 0;
   int state = S_DONE, sp = 0;
   uint32_t cnt = 0, j = 0, inst = 0; // candidates of this ray; how many of them have been taken; the instance being walked
@@ -1976,7 +1976,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
         exhausted = tried >= a.num_parts;
         if (state == S_DONE && mine < a.n) {
           i = mine;
-          const nrt_ray_f32 r = a.rays[i];
+          ri = a.subset ? a.subset[i] : i;
+          const nrt_ray_f32 r = a.rays[ri];
 #pragma unroll
           for (int k = 0; k < 3; k++) {
             worg[k] = r.org[k];
@@ -1994,7 +1995,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
           h.v = 0.0f;
           h.prim_id = 0xFFFFFFFFu;
           h.node_id = 0xFFFFFFFFu;
-          a.hits[i] = h;
+          a.hits[ri] = h;
           state = S_NEXT;
         }
       }
@@ -2027,7 +2028,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
           h.v = L.v;
           h.prim_id = L.prim;
           h.node_id = inst;
-          a.hits[i] = h;
+          a.hits[ri] = h;
         }
       }
       state = S_NEXT;
@@ -2090,7 +2091,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
           }
         }
       }
-      if (state == S_DONE && a.mask) a.mask[i] = has_hit ? 1 : 0; // this ray is finished
+      if (state == S_DONE && a.mask) a.mask[ri] = has_hit ? 1 : 0; // this ray is finished
     }
     }
     if (__ballot(state != S_DONE) == 0ull) {
@@ -2155,6 +2156,352 @@ hipError_t launch_scene_trace(const SceneTraceArgs &args, unsigned grid, hipStre
 int scene_trace_blocks_per_cu() {
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scene_trace<kSceneLdsStack>, kTraverseBlock, 0) != hipSuccess || n < 1) n = 4;
+  return n > 8 ? 8 : n;
+}
+
+// ---------------------------------------------------------------------------
+// The single-pass scene walk: nanosg::Scene::Traverse (examples/nanosg/nanosg.h:778-870) WITHOUT the list.  The reference first
+// lists the (at most 64 nearest) instances whose world boxes the ray enters (BVHAccel::ListNodeIntersections,
+// nanort.h:2608-2692), sorted by (entry distance, id) =: rank, then walks the list: an instance is skipped once the nearest world
+// distance so far lies below its entry distance (:795), else traced with a fresh local ray, and a strictly nearer world
+// distance wins (:838).  The listing must follow the ray through the WHOLE scene before the first triangle is tested — on
+// 100 000 instances that was three quarters of the time.  This kernel walks the top-level tree (its Wide4Node records, near
+// slots first) and, whenever it reaches an entered instance, walks that instance's tree at once, in the same lane, on the same
+// stack (top-level entries below, the open instance's entries above `base`).  What makes that exact:
+//   * winner     = the traced hit with the smallest (t_world, rank) — the list order with strict '<' picks exactly that;
+//   * skipping   an instance or a top-level subtree entered at e is allowed when the current winner w has t_world_w < e and
+//                t_min_w < e: w ranks before everything in there, so the reference's cull has fired at or before it (entry
+//                distances only grow from a box to a box inside it — for rays whose direction components are ordinary non-zero
+//                numbers; other rays skip per instance only, never a subtree);
+//   * certificate at the end: at most 64 instances traced, and no OTHER traced hit lies in front of the winner's own box entry
+//                (t2 >= t_min_w).  Then the winner is inside the prefix of the list the reference processes, everything in
+//                that prefix was traced here, and nothing behind it can win.  A ray without the certificate (a hit that rounds
+//                to the near side of its own box while another hit lies in between; more than 64 boxes; direction vectors
+//                far shorter than 1, where the reference's cull compares a distance with a parameter and fires early) is
+//                appended to `redo` and traced by the listing path (k_scene_list* + k_scene_trace over the subset).
+// The argument is spelled out and tested on the CPU, with random visiting orders and random skipping, by the model
+// sgo_traverse_unordered_model (tests/test_scene_walk_model.py); tests/test_gpu_scene.py compares this kernel with the listing
+// path and the restatement record by record.
+// ---------------------------------------------------------------------------
+enum : int { T_ENTER = 7, S_END = 8 }; // a top-level leaf was reached: open its instance / the top-level stack ran empty: the ray is finished
+
+// The top-level tree is walked by the SAME step as the instances' trees: while a lane is in the top-level tree its Lane holds the
+// WORLD ray (hit_t pinned at ray.max_t: the box test is then ListNodeIntersections' own, nanort.h:2651), its record pointer is
+// the top-level tree's, and `cull_t` — max(winner's distance, winner's box entry, ray.min_t), +inf without a hit — takes the
+// place of the hit distance where the walk skips (a box entered beyond it ranks behind a nearer hit; the clipped entry
+// distance the step computes is the unclipped one whenever it exceeds ray.min_t).  A leaf reference of the top-level tree names
+// instances instead of triangles: the lane leaves the loop, opens the instance (its Lane becomes the local ray, `base` = the
+// stack height) and rejoins the same loop; when the stack is back at `base` the world ray returns.  Lanes in the top-level
+// tree and lanes inside instances therefore execute the same instructions.
+#define NRT_POP_ENTRY_SCENE()                                                                          \
+do {                                                                                                 \
+  const bool fin_ = (sp <= base);                     /* this level's part of the stack is empty */  \
+  const int s1_ = fin_ ? sp : sp - 1;                                                                \
+  const int sr_ = s1_ > 0 ? s1_ : 0;                                                                 \
+  typename SE::type e_ = s_stack[sr_ < STACK ? sr_ : STACK - 1][tid];                                \
+  if (!fin_ && s1_ >= STACK) {                                                                       \
+    const size_t o_ = (size_t)(s1_ - STACK) * a.spill_stride + gslot;                                \
+    e_ = SE::make(a.spill[o_], a.spill_tmin[o_]);                                                    \
+  }                                                                                                  \
+  const bool enter_ = !fin_ & (SE::tmin(e_) <= (in_top ? cull_t : L.hit_t));                         \
+  const uint32_t ref_ = SE::ref(e_);                                                                 \
+  sp = s1_;                                                                                          \
+  cur = enter_ ? (ref_ & ~kLeafBit) : cur;                                                           \
+  state = fin_ ? (in_top ? S_END : S_FIN) : (enter_ ? ((ref_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP); \
+} while (0)
+
+template <int STACK>
+__global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkArgs a) {
+  typedef float T;
+  typedef StackEntry<float> SE;
+  __shared__ SE::type s_stack[STACK][kTraverseBlock];
+
+  const unsigned tid = threadIdx.x;
+  const unsigned lane = lane_id();
+  const unsigned gslot = blockIdx.x * kTraverseBlock + tid;
+
+  Lane<float> L;
+  uint32_t i = 0;   // this lane's ray
+  uint32_t cur = 0; // record due (of the top-level tree or of the open instance's tree) / leaf reference reached
+  int state = S_DONE, sp = 0, base = 0;
+  bool in_top = true, tame = true;
+  float cur_tmin = 0.f; // box entry distance of the open instance
+  uint32_t inst = 0, traced = 0;
+  float best_t = 3.402823466e+38f, best_tmin = 0.f, t2 = __builtin_huge_valf(); // winner's distance and box entry; runner-up distance
+  float cull_t = __builtin_huge_valf();
+  uint32_t best_id = 0;
+  bool has_hit = false;
+  float worg[3] = {0.f, 0.f, 0.f}, wdir[3] = {0.f, 0.f, 0.f}, winv[3] = {0.f, 0.f, 0.f};
+  float wmin_t = 0.f, wmax_t = 0.f;
+  const WideNode<float> *wide = nullptr;
+  const Wide4Node<float> *wide4 = nullptr;
+  const LeafTri<float> *tris = nullptr;
+  const nrt_node_f32 *nodes = nullptr;
+  uint32_t packed = 1u;
+  bool exhausted = false;
+  uint32_t part = blockIdx.x % a.num_parts, tried = 0u;
+
+  auto world_ray = [&]() { // the lane (re-)enters the top-level tree
+    L.org0 = worg[0];
+    L.org1 = worg[1];
+    L.org2 = worg[2];
+    L.inv0 = winv[0];
+    L.inv1 = winv[1];
+    L.inv2 = winv[2];
+    L.min_t = wmin_t;
+    L.hit_t = wmax_t;
+    L.max_t = wmax_t;
+    L.pk = (wdir[0] < 0.0f ? 64u : 0u) | (wdir[1] < 0.0f ? 128u : 0u) | (wdir[2] < 0.0f ? 256u : 0u);
+    wide4 = a.top_wide4;
+    in_top = true;
+    base = 0;
+  };
+
+  for (;;) {
+    // ---- refill free lanes (as k_scene_trace) -------------------------------------------------------------------------
+    {
+      const unsigned long long free_lanes = __ballot(state == S_DONE);
+      const unsigned want = (unsigned)__builtin_popcountll(free_lanes);
+      if (!exhausted && want >= a.refill_min) {
+        const uint32_t per = a.n / a.num_parts;
+        uint32_t mine = a.n;
+        while (tried < a.num_parts) {
+          const uint32_t lo = part * per, len = (part + 1u == a.num_parts) ? a.n - lo : per;
+          uint32_t b0 = 0;
+          if (lane == (unsigned)__builtin_ctzll(free_lanes)) b0 = atomicAdd(a.cursor + kCursorStrideWords * part, want);
+          b0 = (uint32_t)__builtin_amdgcn_readlane((int)b0, __builtin_ctzll(free_lanes));
+          if (b0 < len) {
+            const uint32_t off = b0 + (uint32_t)__builtin_popcountll(free_lanes & ((1ull << lane) - 1ull));
+            mine = off < len ? lo + off : a.n;
+            break;
+          }
+          part = (part + 1u == a.num_parts) ? 0u : part + 1u;
+          tried++;
+        }
+        exhausted = tried >= a.num_parts;
+        if (state == S_DONE && mine < a.n) {
+          i = mine;
+          const nrt_ray_f32 r = a.rays[i];
+          // tame: ordinary non-zero direction components and a finite origin — entry distances then only grow from a box to a
+          // box inside it, which is what skipping top-level SUBTREES rests on.  Any other ray (axis-parallel, say) walks the whole
+          // top-level tree it enters (cull_t stays +inf) and skips per instance only, by the instance's own entry distance.
+          tame = true;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            worg[k] = r.org[k];
+            wdir[k] = r.dir[k];
+            winv[k] = safe_inverse<float>(r.dir[k]); // vsafe_inverse (nanort.h:2509 via :349-357): what the top-level boxes are tested with
+            tame = tame && (__builtin_fabsf(r.dir[k]) >= 1.1920928955078125e-07f) && (__builtin_fabsf(winv[k]) < __builtin_huge_valf()) &&
+                   (__builtin_fabsf(r.org[k]) < __builtin_huge_valf());
+          }
+          wmin_t = r.min_t;
+          wmax_t = r.max_t;
+          {
+            best_t = 3.402823466e+38f; // t_nearest = numeric_limits<T>::max(), nanosg.h:787
+            best_tmin = 0.f;
+            best_id = 0u;
+            t2 = __builtin_huge_valf();
+            cull_t = __builtin_huge_valf();
+            has_hit = false;
+            traced = 0u;
+            nrt_scene_hit_f32 h; // the miss record; overwritten by every better hit
+            h.t = r.max_t;
+            h.u = 0.0f;
+            h.v = 0.0f;
+            h.prim_id = 0xFFFFFFFFu;
+            h.node_id = 0xFFFFFFFFu;
+            a.hits[i] = h;
+            sp = 0;
+            world_ray();
+            cur = 0u; // record 0 == the root branch (its own box test is implied by its children's)
+            state = W_TRAV;
+          }
+        }
+      }
+    }
+    // ---- level changes: a local walk ended / an instance is opened / the ray is finished (long, divergent: for several lanes at a time) ----
+    {
+      const unsigned n_cand = (unsigned)__builtin_popcountll(__ballot(state == S_FIN || state == T_ENTER || state == S_END));
+      const unsigned n_busy = (unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP || state == W_LEAF));
+      if (n_cand != 0u && (n_cand >= a.cand_min || n_busy < a.cand_busy_max)) {
+        if (state == S_FIN) {
+          if (L.hit_t < L.max_t) { // the local Traverse() hit (strict final predicate, nanort.h:2552)
+            const SceneInst &nd = a.insts[inst];
+            float lp[3], wp[3];
+            lp[0] = L.org0 + L.hit_t * L.d0; // nanosg.h:823-825
+            lp[1] = L.org1 + L.hit_t * L.d1;
+            lp[2] = L.org2 + L.hit_t * L.d2;
+            scene_mult_v(wp, nd.xform, lp);
+            const float px = wp[0] - worg[0], py = wp[1] - worg[1], pz = wp[2] - worg[2];
+            const float t_world = __builtin_sqrtf(px * px + py * py + pz * pz); // vlength, nanort.h:383-385
+            // strict '<' in rank order (nanosg.h:838) == smallest (t_world, rank) in any order
+            const bool wins = t_world < best_t ||
+                              (has_hit && t_world == best_t && (cur_tmin < best_tmin || (cur_tmin == best_tmin && inst < best_id)));
+            if (wins) {
+              if (has_hit && best_t < t2) t2 = best_t; // the old winner becomes the runner-up
+              best_t = t_world;
+              best_tmin = cur_tmin;
+              best_id = inst;
+              has_hit = true;
+              const float c = best_t > best_tmin ? best_t : best_tmin;
+              cull_t = tame ? (c > wmin_t ? c : wmin_t) : __builtin_huge_valf();
+              nrt_scene_hit_f32 h;
+              h.t = t_world;
+              h.u = L.u;
+              h.v = L.v;
+              h.prim_id = L.prim;
+              h.node_id = inst;
+              a.hits[i] = h;
+            } else if (t_world < t2) {
+              t2 = t_world;
+            }
+          }
+          world_ray();
+          state = W_POP;
+        } else if (state == T_ENTER) {
+          // cur: a leaf reference of the top-level tree, (count - 1, first) into its index array.  One instance is opened now;
+          // the others of a leaf of several (boxes the builder could not separate) wait on the stack as a leaf of one fewer.
+          const uint32_t lcount = (cur >> kPackedFirstBits) + 1u, lfirst = cur & kPackedFirstMask;
+          if (lcount > 1u) NRT_PUSH_IF(true, kLeafBit | ((lcount - 2u) << kPackedFirstBits) | (lfirst + 1u), -__builtin_huge_valf());
+          const uint32_t k = a.top_indices[lfirst];
+          const float *bx = a.inst_boxes + (size_t)k * a.inst_box_stride;
+          const bool s0 = wdir[0] < 0.0f, s1 = wdir[1] < 0.0f, s2 = wdir[2] < 0.0f;
+          const float n0 = ((s0 ? bx[3] : bx[0]) - worg[0]) * winv[0], n1 = ((s1 ? bx[4] : bx[1]) - worg[1]) * winv[1],
+                      n2 = ((s2 ? bx[5] : bx[2]) - worg[2]) * winv[2];
+          const float f0 = ((s0 ? bx[0] : bx[3]) - worg[0]) * winv[0], f1 = ((s1 ? bx[1] : bx[4]) - worg[1]) * winv[1],
+                      f2 = ((s2 ? bx[2] : bx[5]) - worg[2]) * winv[2];
+          // the leaf's own box test of ListNodeIntersections (IntersectRayAABB, nanort.h:2285-2325, hit_t == ray.max_t) ...
+          float tmn = wmin_t, tmx = wmax_t;
+          tmn = (n0 > tmn) ? n0 : tmn;
+          tmn = (n1 > tmn) ? n1 : tmn;
+          tmn = (n2 > tmn) ? n2 : tmn;
+          const float g0 = f0 * 1.00000024f, g1 = f1 * 1.00000024f, g2 = f2 * 1.00000024f;
+          tmx = (g0 < tmx) ? g0 : tmx;
+          tmx = (g1 < tmx) ? g1 : tmx;
+          tmx = (g2 < tmx) ? g2 : tmx;
+          // ... then NodeBBoxIntersector::Intersect (nanosg.h:603-639): the unclipped interval by the PLAIN reciprocal (for a tame
+          // ray the same numbers as above), whose near end the list is sorted by
+          const float p0 = 1.0f / wdir[0], p1 = 1.0f / wdir[1], p2 = 1.0f / wdir[2];
+          const float a0 = ((s0 ? bx[3] : bx[0]) - worg[0]) * p0, a1 = ((s1 ? bx[4] : bx[1]) - worg[1]) * p1,
+                      a2 = ((s2 ? bx[5] : bx[2]) - worg[2]) * p2;
+          const float b0 = ((s0 ? bx[0] : bx[3]) - worg[0]) * p0, b1 = ((s1 ? bx[1] : bx[4]) - worg[1]) * p1,
+                      b2 = ((s2 ? bx[2] : bx[5]) - worg[2]) * p2;
+          float e = (a1 > a0) ? a1 : a0;
+          e = (a2 > e) ? a2 : e;
+          float f = (b1 < b0) ? b1 : b0;
+          f = (b2 < f) ? b2 : f;
+          const bool entered = tmn <= tmx && e <= f;
+          const bool behind = has_hit && best_t < e && (best_tmin < e || (best_tmin == e && best_id < k)); // ranks behind a nearer hit
+          if (!entered || behind) {
+            state = W_POP; // (still in the top-level tree)
+          } else {
+            inst = k;
+            cur_tmin = e;
+            traced++;
+            const SceneInst &nd = a.insts[inst];
+            nrt_ray_f32 lr;
+            scene_mult_v(lr.org, nd.inv_xform, worg);   // nanosg.h:807
+            scene_mult_v(lr.dir, nd.inv_xform33, wdir); // nanosg.h:808
+            lr.min_t = 0.0f;                            // Ray() defaults (nanort.h:477-487): the world interval is not propagated
+            lr.max_t = 3.402823466e+38f;
+            lr.type = 0;
+            lane_init<float>(L, lr);
+            wide = (const WideNode<float> *)nd.wide;
+            wide4 = (const Wide4Node<float> *)nd.wide4;
+            tris = (const LeafTri<float> *)nd.tris;
+            nodes = nd.nodes;
+            packed = nd.packed_leaves;
+            in_top = false;
+            base = sp;
+            cur = 0u;
+            if (nd.root_is_branch && nd.tree_nested) {
+              state = W_TRAV;
+            } else {
+              const nrt_node_f32 root = nodes[0];
+              const bool root_hit = slab_test<float>(L, root.bmin, root.bmax);
+              if (nd.root_is_branch) {
+                state = root_hit ? W_TRAV : S_FIN;
+              } else { // single-leaf tree
+                cur = packed ? (((root.data[0] - 1u) << kPackedFirstBits) | root.data[1]) : 0u;
+                state = root_hit ? W_LEAF : S_FIN;
+              }
+            }
+          }
+        } else if (state == S_END) {
+          const bool certified = traced <= 64u && (!has_hit || t2 >= best_tmin);
+          if (certified) {
+            if (a.mask) a.mask[i] = has_hit ? 1 : 0;
+          } else {
+            a.redo[atomicAdd(a.redo_count, 1u)] = i;
+          }
+          state = S_DONE;
+        }
+      }
+    }
+    if (__ballot(state != S_DONE) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+
+    // ---- phase 1: inner nodes / stack pops, of the top-level tree and of the open instances alike --------------------
+    unsigned n_wait = (unsigned)__builtin_popcountll(__ballot(state == W_LEAF || state == S_FIN || state == T_ENTER || state == S_END));
+    while (state == W_TRAV || state == W_POP) {
+#pragma unroll
+      for (int u_ = 0; u_ < NRT_SCENE_P1_UNROLL; u_++) {
+        if (state == W_POP) NRT_POP_ENTRY_SCENE();
+        if (state == W_TRAV) {
+          if (wide4 != nullptr) {
+            const Wide4Node<float> w = wide4[cur];
+            Slab4<float> sl4_ = slab4(L, w);
+            const float ct_ = in_top ? cull_t : __builtin_huge_valf(); // (in the top-level tree: nothing entered beyond a nearer hit that ranks before it)
+#pragma unroll
+            for (int j_ = 0; j_ < 4; j_++) sl4_.h[j_] = sl4_.h[j_] && (sl4_.tm[j_] <= ct_);
+            NRT_STEP_NODE4_SL(sl4_, w);
+          } else {
+            const WideNode<float> w = wide[cur];
+            NRT_STEP_NODE(w);
+          }
+        }
+        state = (in_top && state == W_LEAF) ? T_ENTER : state; // a top-level leaf: instances, not triangles
+      }
+      n_wait += (unsigned)__builtin_popcountll(__ballot(state == W_LEAF || state == S_FIN || state == T_ENTER || state == S_END));
+      if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < a.trav_min && n_wait != 0u) break;
+    }
+
+    // ---- phase 2: leaves ---------------------------------------------------------------------------------------------
+    if (__ballot(state == W_LEAF) != 0ull) {
+      uint32_t lcnt = 0, first = 0;
+      if (state == W_LEAF) {
+        if (packed) {
+          lcnt = (cur >> kPackedFirstBits) + 1u;
+          first = cur & kPackedFirstMask;
+        } else {
+          lcnt = nodes[cur].data[0];
+          first = nodes[cur].data[1];
+        }
+      }
+      for (uint32_t k = 0; __ballot(k < lcnt) != 0ull; k += 2u) {
+        if (k < lcnt) {
+          const bool two = k + 1u < lcnt;
+          const LeafTri<float> t0 = tris[first + k];
+          const LeafTri<float> t1 = tris[first + (two ? k + 1u : k)];
+          tri_test<float, true>(L, t0, true, 0u, 0u, 0u, false); // default trace options (nanosg.h:817)
+          tri_test<float, true>(L, t1, two, 0u, 0u, 0u, false);
+        }
+      }
+      state = (state == W_LEAF) ? W_POP : state;
+    }
+  }
+}
+
+hipError_t launch_scene_walk(const SceneWalkArgs &args, unsigned grid, hipStream_t s) {
+  if (args.n == 0) return hipSuccess;
+  hipLaunchKernelGGL((k_scene_walk<kSceneWalkLdsStack>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+  return hipGetLastError();
+}
+int scene_walk_blocks_per_cu() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scene_walk<kSceneWalkLdsStack>, kTraverseBlock, 0) != hipSuccess || n < 1) n = 3;
   return n > 8 ? 8 : n;
 }
 

@@ -421,6 +421,8 @@ class SceneOracle:
         L = self.o.L
         L.sgo_node_update.argtypes = [ctypes.c_void_p]
         L.sgo_traverse.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        L.sgo_traverse_unordered_model.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
+                                                   ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.sgo_sizeof_node.restype = ctypes.c_int
         assert L.sgo_sizeof_node() == ctypes.sizeof(_SgNode)
         self.L = L
@@ -466,6 +468,17 @@ class SceneOracle:
         mask = np.zeros((rays.shape[0],), dtype=np.uint8)
         self.L.sgo_traverse(ctypes.cast(self.arr, ctypes.c_void_p), len(self.nodes), _p(rays), rays.shape[0], _p(hits), _p(mask))
         return hits, mask
+
+
+    def traverse_unordered_model(self, rays, seed=1, roughly_front_to_back=False):
+        """The single-pass walk's model (any visiting order, no list): (hits, mask, certified) — see nanosg_oracle.c."""
+        rays = np.ascontiguousarray(rays, dtype=ray_dtype(np.float32))
+        hits = np.zeros((rays.shape[0],), dtype=SCENE_HIT)
+        mask = np.zeros((rays.shape[0],), dtype=np.uint8)
+        cert = np.zeros((rays.shape[0],), dtype=np.uint8)
+        self.L.sgo_traverse_unordered_model(ctypes.cast(self.arr, ctypes.c_void_p), len(self.nodes), _p(rays), rays.shape[0], seed,
+                                            1 if roughly_front_to_back else 0, _p(hits), _p(mask), _p(cert))
+        return hits, mask, cert
 
 
 REF_V3_PATH = os.path.join(_HERE, "_ref", "libnanort_ref_v3.so")

@@ -290,4 +290,114 @@ void sgo_traverse(const sg_node *nodes, uint32_t num_nodes, const sg_ray *rays, 
   free(list);
 }
 
+/* MODEL (not a restatement) of the single-pass scene walk of nanort_amd/csrc/traverse.hip (k_scene_walk): the instances whose
+ * boxes a ray enters are visited in ANY order — here a seeded shuffle, or the sorted order with local disorder — and no list is
+ * kept.  Rules:
+ *   rank(i)   = (t_min_i, i), the order Scene::Traverse visits its list in (nanosg.h:793-795 over nanort.h:2676-2687);
+ *   winner    = the visited hit with the smallest (t_world, rank)  [the reference: strict '<' in rank order, nanosg.h:838];
+ *   may skip i whenever the current winner w has t_world_w < t_min_i AND rank(w) < rank(i)  [then the reference's early
+ *             cull (:795) has already fired at or before i]; the model skips such an instance or not by a coin;
+ *   certificate: at most 64 instances traced, and every OTHER hit lies at or beyond the winner's own box entry
+ *             (t2 >= t_min_w, t2 = second smallest t_world) — then the winner sits in the prefix of the list the reference
+ *             processes and nothing outside that prefix can beat it (scenes).  A ray without the certificate
+ *             is re-done by the listing path.
+ * tests/test_scene_walk_model.py: every certified ray equals sgo_traverse bit for bit, whatever the order and the coins. */
+void sgo_traverse_unordered_model(const sg_node *nodes, uint32_t num_nodes, const sg_ray *rays, uint64_t n, uint32_t seed,
+                                  int roughly_front_to_back, sg_hit *hits, uint8_t *mask, uint8_t *certified) {
+  sg_nodehit *list = (sg_nodehit *)malloc(sizeof(sg_nodehit) * (num_nodes ? num_nodes : 1));
+  uint64_t r;
+  for (r = 0; r < n; r++) {
+    const sg_ray *ray = &rays[r];
+    uint32_t cnt = 0, i, traced = 0;
+    uint64_t rng = ((uint64_t)seed << 32) ^ (r * 0x9E3779B97F4A7C15ull) ^ 0xD1B54A32D192ED03ull;
+    float best_t = FLT_MAX, best_tmin = 0.0f, t2 = INFINITY;
+    uint32_t best_id = 0;
+    int has_hit = 0;
+    sg_hit best;
+    best.t = ray->max_t;
+    best.u = best.v = 0.0f;
+    best.prim_id = best.node_id = 0xFFFFFFFFu;
+    for (i = 0; i < num_nodes; i++) {
+      float a, b;
+      if (node_interval(ray, &nodes[i], &a, &b)) {
+        list[cnt].t_min = a;
+        list[cnt].t_max = b;
+        list[cnt].node = i;
+        cnt++;
+      }
+    }
+    if (roughly_front_to_back) { /* what a near-child-first walk of a tree produces: sorted up to local disorder */
+      qsort(list, cnt, sizeof(sg_nodehit), nodehit_cmp);
+      for (i = 0; i + 1 < cnt; i++) {
+        uint32_t k;
+        sg_nodehit tmp;
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        k = i + (uint32_t)((rng >> 33) % 4u);
+        if (k >= cnt) k = cnt - 1;
+        tmp = list[i];
+        list[i] = list[k];
+        list[k] = tmp;
+      }
+    } else {
+      for (i = cnt; i > 1; i--) { /* Fisher-Yates */
+        uint32_t k;
+        sg_nodehit tmp;
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        k = (uint32_t)((rng >> 33) % i);
+        tmp = list[i - 1];
+        list[i - 1] = list[k];
+        list[k] = tmp;
+      }
+    }
+    for (i = 0; i < cnt; i++) {
+      const sg_node *nd = &nodes[list[i].node];
+      const float tmin_i = list[i].t_min;
+      const uint32_t id_i = list[i].node;
+      sg_ray lr;
+      sg_local_hit lh;
+      uint8_t m = 0;
+      if (has_hit && best_t < tmin_i && (best_tmin < tmin_i || (best_tmin == tmin_i && best_id < id_i))) {
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        if (roughly_front_to_back || ((rng >> 40) & 1u)) continue; /* allowed to skip: the coin decides (the kernel's order: always) */
+      }
+      traced++;
+      mat_multv(lr.org, nd->inv_xform, ray->org);
+      mat_multv(lr.dir, nd->inv_xform33, ray->dir);
+      lr.min_t = 0.0f;
+      lr.max_t = FLT_MAX;
+      lr.type = 0;
+      orc_traverse_f32(nd->nodes, nd->indices, nd->verts, 12, nd->faces, &lr, 1, NULL, &lh, &m, NULL);
+      if (m) {
+        float lp[3], wp[3], po[3], t_world;
+        int k, wins;
+        for (k = 0; k < 3; k++) lp[k] = lr.org[k] + lh.t * lr.dir[k];
+        mat_multv(wp, nd->xform, lp);
+        for (k = 0; k < 3; k++) po[k] = wp[k] - ray->org[k];
+        t_world = sqrtf(po[0] * po[0] + po[1] * po[1] + po[2] * po[2]);
+        wins = t_world < best_t ||
+               (has_hit && t_world == best_t && (tmin_i < best_tmin || (tmin_i == best_tmin && id_i < best_id)));
+        if (wins) {
+          if (has_hit && best_t < t2) t2 = best_t; /* the old winner becomes the runner-up */
+          best_t = t_world;
+          best_tmin = tmin_i;
+          best_id = id_i;
+          has_hit = 1;
+          best.t = t_world;
+          best.u = lh.u;
+          best.v = lh.v;
+          best.prim_id = lh.prim_id;
+          best.node_id = id_i;
+        } else if (t_world < t2) {
+          t2 = t_world; /* (a NaN distance is neither a winner nor a runner-up: the reference ignores it too) */
+        }
+      }
+    }
+    hits[r] = best;
+    if (mask) mask[r] = (uint8_t)has_hit;
+    /* 1: certified; else why not — 2: more than 64 traced, 4: another hit in front of the winner's box entry */
+    certified[r] = (uint8_t)((traced <= 64u && (!has_hit || t2 >= best_tmin)) ? 1u : ((traced > 64u ? 2u : 0u) | ((has_hit && !(t2 >= best_tmin)) ? 4u : 0u)));
+  }
+  free(list);
+}
+
 int sgo_sizeof_node(void) { return (int)sizeof(sg_node); }

@@ -278,3 +278,77 @@ def test_rays_that_enter_more_than_64_boxes_keep_the_64_nearest(oracle, monkeypa
     assert int(mk.sum()) > 500
     assert np.array_equal(mk, om)
     assert fields_equal(h, oh, ("t", "u", "v", "prim_id", "node_id"))
+
+
+@pytest.mark.parametrize("dir_scale", [1.0, 0.25, 4.0])
+def test_single_pass_walk_equals_the_listing_path_and_the_restatement(oracle, dir_scale):
+    """The default scene path (k_scene_walk: no per-ray list, top-level tree and instance trees on one stack, rays it cannot
+    certify re-done by the listing path) against the listing path alone (tunable single_pass = 0) and the restatement, on
+    material chosen to break it: a crowd of overlapping instances (rays enter dozens of boxes, some more than 64), perfectly
+    flat planes (hits that round to the near side of their own box entry), coincident copies (equal distances: the lower id
+    wins), direction vectors far from unit length (the reference culls by comparing a distance with a parameter, nanosg.h:795),
+    axis-parallel rays (no subtree is ever skipped for them).  Every field must agree."""
+    from scene_fixture import xform
+    from nanort_amd.wire import RAY_F32
+
+    rng = np.random.default_rng(21)
+    sv, sf = scenes.sphere(12, 6)
+    sv = (sv - np.array([0, 5, 0], dtype=np.float32)).astype(np.float32)
+    pv, pf = scenes.plane(8, 8)
+    pv = pv.copy()
+    pv[:, 1] = 0.0
+    meshes = []
+    for v, f in ((sv, sf), (pv, pf)):
+        a = BVHAccel(np.float32)
+        assert a.Build(f.shape[0], TriangleMesh(v, f))
+        meshes.append((v, f, a, a.GetTree()))
+    sc = Scene()
+    O = ob.SceneOracle(oracle)
+
+    def add(which, x):
+        v, f, a, tree = meshes[which]
+        sc.AddNode(a, x)
+        O.add_node(v, f, x, tree=tree)
+
+    for k in range(300):
+        s = rng.uniform(0.05, 0.35, 3)
+        x = xform(tuple(s), rng.uniform(0, 6.28), rng.uniform(0, 6.28), tuple(rng.uniform(-4, 4, 3) + np.array([0, 5, 0])))
+        add(0, x)
+        if k % 10 == 0:
+            add(0, x)  # a coincident copy
+    for k in range(6):
+        x = xform((0.5, 1, 0.5), 0.3 * (k % 2), 0, (0, 1.0 + k, 0))
+        add(1, x)
+        add(1, x)
+    assert sc.Commit() and O.commit()
+    n = 6000
+    rays = np.zeros(n, dtype=RAY_F32)
+    org = rng.uniform(-7, 7, size=(n, 3)) + np.array([0, 5, 0])
+    tgt = rng.uniform(-4, 4, size=(n, 3)) + np.array([0, 5, 0])
+    d = tgt - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays["org"] = org.astype(np.float32)
+    rays["dir"] = (d * dir_scale).astype(np.float32)
+    rays["max_t"] = 3.0e38
+    rays["dir"][:50, 0] = 0.0  # axis-parallel: such rays never skip a top-level subtree, only instances
+    rays["dir"][50:80, 1] = -0.0
+    rays = np.concatenate([rays, scenes.camera_rays(96, 64)])
+    oh, om = O.traverse(rays)
+    h1, m1 = sc.TraverseBatch(rays)
+    redone = sc.LastRedone()
+    sc.SetTunable("single_pass", 0)
+    h0, m0 = sc.TraverseBatch(rays)
+    assert sc.LastRedone() == 0
+    assert np.array_equal(m0, om) and fields_equal(h0, oh, ("t", "u", "v", "prim_id", "node_id"))
+    assert np.array_equal(m1, om) and fields_equal(h1, oh, ("t", "u", "v", "prim_id", "node_id"))
+    assert redone < len(rays)  # the walk itself finished the bulk ...
+    if dir_scale == 1.0:
+        assert redone < 0.2 * len(rays)
+    if dir_scale == 4.0:
+        assert redone > 0  # ... and with the reference's cull firing late, rays that trace more than 64 instances are handed over
+    # thresholds of the phases never change a record
+    sc.SetTunable("single_pass", 1)
+    for name, value in (("trav_min", 1), ("trav_min", 32), ("refill_min", 8), ("cand_min", 16)):
+        sc.SetTunable(name, value)
+        h2, m2 = sc.TraverseBatch(rays)
+        assert np.array_equal(m2, om) and fields_equal(h2, oh, ("t", "u", "v", "prim_id", "node_id")), (name, value)
