@@ -274,7 +274,7 @@ def wavefront_row():
 # hardware counters of a row's dominant kernel (outside every timed region): bench_rows.py --pmc-row NAME is re-run under
 # rocprofv3 --pmc (kernel trace only; one pass per counter set, as MI355X_MICROARCH.md prescribes)
 # ---------------------------------------------------------------------------
-ROW_KERNELS = {"scene_10k": "k_scene_trace", "scene_fixture": "k_scene_trace", "spheres_1m": "k_traverse_wide", "cylinders": "k_traverse_wide"}
+ROW_KERNELS = {"scene_10k": "k_scene_walk", "scene_fixture": "k_scene_walk", "spheres_1m": "k_traverse_wide", "cylinders": "k_traverse_wide"}
 
 
 def pmc_row_child(name):

@@ -432,9 +432,9 @@ NRT_API nrt_status nrtSceneTraverseBatch_f32(nrt_scene *scene, const nrt_ray_f32
  * sure `d_rays` is complete before calling. */
 NRT_API nrt_status nrtSceneTraverseBatchDevice_f32(nrt_scene *scene, const nrt_ray_f32 *d_rays, uint64_t num_rays,
                                                    nrt_scene_hit_f32 *d_hits_out, uint8_t *d_mask_out);
-/* Scheduling knobs of the scene kernels by name (they never change a result): "single_pass" (1: scenes with a top-level tree
+/* Scheduling knobs of the scene kernels by name (they never change a result): "single_pass" (1: scenes of 2048 nodes or more
  * are traced by the single-pass walk — top-level tree and instance trees on one stack, no per-ray list; rays it cannot certify
- * are re-done by the listing path; 0: listing + trace for every ray), "trav_min", "refill_min", "cand_min",
+ * are re-done by the listing path; 2: every scene of two nodes or more; 0: listing + trace for every ray), "trav_min", "refill_min", "cand_min",
  * "cand_busy_max" (lane-count thresholds of the phases), "prune_min" (instance count from which the listing prunes beyond a
  * full list). */
 NRT_API nrt_status nrtSceneSetTunable(nrt_scene *scene, const char *name, int value);

@@ -24,6 +24,12 @@ NRT_API int nrtDebugCounters(nrt_ctx *ctx, unsigned long long *out, int capacity
  * finished (100 MHz realtime ticks, 3 x u64 per wave).  Copies up to `cap` records of the most recent launch; returns
  * the number of waves of that launch, or -1 (tools/drain_probe.py). */
 NRT_API long nrtDebugWaveClocks(nrt_ctx *ctx, unsigned long long *out, long cap);
+/* Profiling aid: loop counters of the last scene query made after nrtSceneSetTunable(scene, "count_loops", 1) (a separately
+ * instantiated, slower k_scene_walk).  out16[0] = outer trips of all waves, [1..2] level-change blocks run / lanes served,
+ * [3..4] inner-phase trips / lane steps, [5] of those in the top-level tree, [6..7] leaf-phase trips / lanes with a first
+ * record, [8] instances opened, [9] top-level leaves reached, [10..12] shader-clock ticks in level changes / the inner phase /
+ * the leaf phase.  Returns 0 on success (tools/scene_loop_stats.py). */
+NRT_API int nrtSceneDebugCounters(nrt_scene *scene, unsigned long long *out, int capacity /* >= 16 */);
 
 #ifdef __cplusplus
 }

@@ -213,7 +213,10 @@ struct SceneInst {
   float inv_xform[4][4];      // world -> local, points
   float inv_xform33[4][4];    // world -> local, directions
   float xform[4][4];          // local -> world
+  float xbmin[3], xbmax[3];   // world box (k_scene_walk: the copy of this table in top-level-tree order lets one fetch open an instance)
+  uint32_t id, pad2;          // instance id (== its index in the by-id table)
 };
+static_assert(sizeof(SceneInst) == 272, "SceneInst");
 constexpr int kSceneLdsStack = 12; // per-lane stack entries of k_scene_trace kept in LDS; deeper ones go to the overflow arrays
 struct SceneTraceArgs {
   const nrt_ray_f32 *rays;
@@ -239,15 +242,15 @@ struct SceneTraceArgs {
 
 // The single-pass scene walk (traverse.hip k_scene_walk): the top-level tree and the instances' trees walked by the same lane on
 // one stack, no per-ray list.  Rays it cannot certify (see the kernel) are appended to `redo` for the listing path.
-constexpr int kSceneWalkLdsStack = 16; // per-lane stack entries kept in LDS (top-level entries below, the open instance's above)
+#ifndef NRT_SCENE_WALK_STACK
+#define NRT_SCENE_WALK_STACK 16
+#endif
+constexpr int kSceneWalkLdsStack = NRT_SCENE_WALK_STACK; // per-lane stack entries kept in LDS (top-level entries below, the open instance's above)
 struct SceneWalkArgs {
   const nrt_ray_f32 *rays;
   uint32_t n;
-  const SceneInst *insts;
+  const SceneInst *insts_top;        // the instance table in the order of the top-level tree's index array (a leaf reference's `first` indexes it)
   const Wide4Node<float> *top_wide4; // the top-level tree over the instances' world boxes (root is a branch, nested, packed leaves)
-  const uint32_t *top_indices;       // its index array: position -> instance id
-  const float *inst_boxes;           // world box of instance k at inst_boxes + k * inst_box_stride: bmin[3], bmax[3]
-  uint32_t inst_box_stride;
   nrt_scene_hit_f32 *hits;
   uint8_t *mask;
   uint32_t *spill;
@@ -258,6 +261,7 @@ struct SceneWalkArgs {
   uint32_t refill_min, trav_min, cand_min, cand_busy_max;
   uint32_t *redo;       // [n]: rays left to the listing path
   uint32_t *redo_count; // zero at launch
+  unsigned long long *counters; // profiling build only (libnanort_hip_prof.so): 13 loop counters of the launch, or null
 };
 
 // Completion record of a launch slot, in page-locked host memory the device writes to: the last wave of a traversal

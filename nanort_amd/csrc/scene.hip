@@ -27,6 +27,9 @@
 #include <vector>
 
 #include "common.h"
+#ifdef NRT_PROF
+#include "../../include/nanort_hip_prof.h"
+#endif
 
 struct nrt_ctx;
 nrt_status nrt_internal_tree_view(nrt_ctx *c, nrt::TreeViewF32 *out); // api.hip
@@ -50,6 +53,8 @@ struct NodeDev { // per-instance table in HBM
 constexpr int kMaxList = 64; // kMaxIntersections, nanosg.h:782
 constexpr int kTopStack = 64; // per-ray stack of the top-level walk (a deeper top-level tree falls back to the scan)
 constexpr uint32_t kScanMaxNodes = 8; // scenes of at most this many nodes are listed by the scan
+constexpr uint32_t kWalkMinNodes = 2048; // scenes of at least this many nodes are traced by the single-pass walk (1 000 instances: on par with the
+                                        // listing path, 5: 6 % slower, 10 000: 1.5x, 100 000: 7.7x faster — profiles/r04n_scene_walk.txt)
 
 // Matrix::MultV — nanosg.h:232-240
 __host__ __device__ inline void mult_v(float dst[3], const float m[4][4], const float v[3]) {
@@ -434,15 +439,18 @@ struct nrt_scene {
   bool committed = false;
   std::vector<std::pair<nrt_ctx *, uint64_t> > mesh_gens; // the distinct mesh contexts and their generations at Commit (the
                                                           // per-instance table caches their device addresses and flags)
-  nrt_ctx *top = nullptr;        // top-level BVH over the nodes' world boxes (scenes of more than kScanMaxNodes nodes)
+  nrt_ctx *top = nullptr;        // top-level BVH over the nodes' world boxes (scenes of two nodes or more)
   nrt::TreeViewF32 top_view;
-  bool use_top = false;
+  bool use_top = false;          // the listing kernels walk the top-level tree (scenes of more than kScanMaxNodes nodes; else they scan the nodes)
+  bool have_top = false;         // a top-level tree exists (two nodes or more): the single-pass walk uses it
   uint32_t max_inst_depth = 0;   // deepest instance tree: sizes the overflow stack of k_scene_trace
   nrt::DevBuf d_nodes, d_insts, d_rays, d_list_t, d_list_node, d_count, d_best, d_mask, d_spill, d_spill_tmin, d_cursor;
-  nrt::DevBuf d_redo, d_redo_count;
+  nrt::DevBuf d_redo, d_redo_count, d_counters, d_insts_top;
+  unsigned count_loops = 0; // profiling build only (tunable "count_loops"): the next calls run the counting instantiation of k_scene_walk
   uint32_t *h_redo_count = nullptr; // page-locked: how many rays the single-pass walk left to the listing path
   uint64_t last_redone = 0;
-  unsigned single_pass = 1;   // scenes with a top-level tree are traced by k_scene_walk (no per-ray list); 0: always listing + k_scene_trace
+  unsigned single_pass = 1;   // scenes of kWalkMinNodes nodes or more are traced by k_scene_walk (no per-ray list); 0: always listing +
+                              // k_scene_trace; 2: k_scene_walk for every scene of two nodes or more
   unsigned walk_blocks_per_cu = 0;
   unsigned prune_min = 32768; // scenes of at least this many instances are listed by the pruning walk (k_scene_list_w4<true>)
   unsigned trav_min = 8;
@@ -494,7 +502,7 @@ void nrtSceneDestroy(nrt_scene *s) {
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
   nrt::DevBuf *bufs[] = {&s->d_nodes, &s->d_insts, &s->d_rays, &s->d_list_t, &s->d_list_node, &s->d_count,
-                         &s->d_best,  &s->d_mask,  &s->d_spill, &s->d_spill_tmin, &s->d_cursor, &s->d_redo, &s->d_redo_count};
+                         &s->d_best,  &s->d_mask,  &s->d_spill, &s->d_spill_tmin, &s->d_cursor, &s->d_redo, &s->d_redo_count, &s->d_counters, &s->d_insts_top};
   for (nrt::DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (s->h_redo_count) (void)hipHostFree(s->h_redo_count);
@@ -567,6 +575,10 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
     memcpy(e.inv_xform, s->host_nodes[i].inv_xform, sizeof(e.inv_xform));
     memcpy(e.inv_xform33, s->host_nodes[i].inv_xform33, sizeof(e.inv_xform33));
     memcpy(e.xform, s->host_nodes[i].xform, sizeof(e.xform));
+    memcpy(e.xbmin, s->host_nodes[i].xbmin, sizeof(e.xbmin));
+    memcpy(e.xbmax, s->host_nodes[i].xbmax, sizeof(e.xbmax));
+    e.id = (uint32_t)i;
+    e.pad2 = 0;
     // deepest stack a walk of this tree can need: one pending sibling per level, three per two levels when stepping two
     s->max_inst_depth = std::max(s->max_inst_depth, e.wide4 ? 3u * (tv.tree_depth / 2u + 1u) : tv.tree_depth);
   }
@@ -576,7 +588,8 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
   // by the ordinary GPU builder: a box is handed over as a zero-radius "cylinder" from its low to its high corner, whose
   // bounding box is exactly the box.  Which nodes a ray lists does not depend on this tree's shape.
   s->use_top = false;
-  if (s->insts.size() > kScanMaxNodes) {
+  s->have_top = false;
+  if (s->insts.size() >= 2) {
     if (!s->top && nrtCreate(s->device, &s->top) != NRT_OK)
       return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level context: %s", nrtLastError(nullptr));
     std::vector<float> ends(6 * s->insts.size()), radii(2 * s->insts.size(), 0.0f);
@@ -596,7 +609,21 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
     if (nrtSetCylinders_f32(s->top, ends.data(), radii.data(), (uint32_t)s->insts.size(), 0) != NRT_OK ||
         nrtBuild_f32(s->top, &o, nullptr, nullptr) != NRT_OK || nrt_internal_tree_view(s->top, &s->top_view) != NRT_OK)
       return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level build: %s", nrtLastError(s->top));
-    s->use_top = s->top_view.tree_depth + 2 < (uint32_t)kTopStack; // (else: the scan)
+    // the single-pass walk opens an instance with ONE fetch: the instance table once more, in the order of the tree's index array
+    {
+      uint64_t nn = 0, ni = 0;
+      if (nrtTreeSize(s->top, &nn, &ni) != NRT_OK || ni != s->insts.size())
+        return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level index array: %s", nrtLastError(s->top));
+      std::vector<uint32_t> order(ni);
+      if (nrtGetTree_f32(s->top, nullptr, order.data()) != NRT_OK)
+        return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level index array: %s", nrtLastError(s->top));
+      std::vector<nrt::SceneInst> sorted(ni);
+      for (size_t q = 0; q < ni; q++) sorted[q] = table[order[q]];
+      SCHK(s, nrt::devbuf_ensure(&s->d_insts_top, sorted.size() * sizeof(nrt::SceneInst)));
+      SCHK(s, hipMemcpy(s->d_insts_top.p, sorted.data(), sorted.size() * sizeof(nrt::SceneInst), hipMemcpyHostToDevice));
+    }
+    s->have_top = true;                                                                              // the single-pass walk's
+    s->use_top = s->insts.size() > kScanMaxNodes && s->top_view.tree_depth + 2 < (uint32_t)kTopStack; // the listing kernels' (else: the scan)
   }
   s->mesh_gens.clear();
   for (size_t m = 0; m < meshes.size(); m++) s->mesh_gens.push_back(std::make_pair(meshes[m].first, meshes[m].second.tv.generation));
@@ -731,7 +758,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     if (const char *e = getenv("NRT_SCENE_CAND")) s->cand_min = (unsigned)std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_CAND_BUSY")) s->cand_busy_max = (unsigned)std::min(65, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_PRUNE_MIN")) s->prune_min = (unsigned)std::max(0, atoi(e)); // (debugging / tests: the pruning walk on small scenes)
-    if (const char *e = getenv("NRT_SCENE_WALK")) s->single_pass = atoi(e) != 0;
+    if (const char *e = getenv("NRT_SCENE_WALK")) s->single_pass = (unsigned)std::min(2, std::max(0, atoi(e)));
   }
   SCHK(s, nrt::devbuf_ensure(&s->d_cursor, (size_t)nrt::kMaxParts * nrt::kCursorStrideWords * sizeof(uint32_t)));
   const nrt_ray_f32 *d_rays = device ? rays : (const nrt_ray_f32 *)s->d_rays.p;
@@ -740,7 +767,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   if (!device) SCHK(s, hipMemcpyAsync(s->d_rays.p, rays, (size_t)n * sizeof(nrt_ray_f32), hipMemcpyHostToDevice, s->stream));
 
   s->last_redone = 0;
-  const bool walk = s->single_pass && s->use_top && s->top_view.wide4 && s->top_view.root_is_branch && s->top_view.tree_nested &&
+  const bool walk = s->single_pass && s->have_top && (s->insts.size() >= kWalkMinNodes || s->single_pass > 1) && s->top_view.wide4 && s->top_view.root_is_branch && s->top_view.tree_nested &&
                     s->top_view.packed_leaves;
   if (walk) {
     if (!s->h_redo_count) SCHK(s, hipHostMalloc((void **)&s->h_redo_count, sizeof(uint32_t), hipHostMallocDefault));
@@ -759,11 +786,8 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     nrt::SceneWalkArgs w;
     w.rays = d_rays;
     w.n = n;
-    w.insts = (const nrt::SceneInst *)s->d_insts.p;
+    w.insts_top = (const nrt::SceneInst *)s->d_insts_top.p;
     w.top_wide4 = (const nrt::Wide4Node<float> *)s->top_view.wide4;
-    w.top_indices = s->top_view.indices;
-    w.inst_boxes = (const float *)s->d_nodes.p; // NodeDev starts with xbmin[3], xbmax[3]
-    w.inst_box_stride = (uint32_t)(sizeof(NodeDev) / sizeof(float));
     w.hits = d_hits;
     w.mask = d_mask;
     w.spill = (uint32_t *)s->d_spill.p;
@@ -777,6 +801,14 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     w.cand_busy_max = s->cand_busy_max;
     w.redo = (uint32_t *)s->d_redo.p;
     w.redo_count = (uint32_t *)s->d_redo_count.p;
+    w.counters = nullptr;
+#ifdef NRT_PROF
+    if (s->count_loops) {
+      SCHK(s, nrt::devbuf_ensure(&s->d_counters, 16 * sizeof(unsigned long long)));
+      SCHK(s, hipMemsetAsync(s->d_counters.p, 0, 16 * sizeof(unsigned long long), s->stream));
+      w.counters = (unsigned long long *)s->d_counters.p;
+    }
+#endif
     SCHK(s, nrt::launch_scene_walk(w, grid, s->stream));
     SCHK(s, hipMemcpyAsync(s->h_redo_count, s->d_redo_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     SCHK(s, hipStreamSynchronize(s->stream));
@@ -813,16 +845,27 @@ nrt_status nrtSceneSetTunable(nrt_scene *s, const char *name, int value) {
   if (!s || !name) return NRT_ERR_INVALID;
   const std::string k(name);
   const unsigned lanes = (unsigned)std::min(64, std::max(1, value));
-  if (k == "single_pass") s->single_pass = value != 0;
+  if (k == "single_pass") s->single_pass = (unsigned)std::min(2, std::max(0, value));
   else if (k == "trav_min") s->trav_min = lanes;
   else if (k == "refill_min") s->refill_min = lanes;
   else if (k == "cand_min") s->cand_min = lanes;
   else if (k == "cand_busy_max") s->cand_busy_max = (unsigned)std::min(65, std::max(1, value));
   else if (k == "prune_min") s->prune_min = (unsigned)std::max(0, value);
+#ifdef NRT_PROF
+  else if (k == "count_loops") s->count_loops = value != 0;
+#endif
   else return sfail(s, NRT_ERR_INVALID, "nrtSceneSetTunable: unknown tunable '%s'", name);
   return NRT_OK;
 }
 
 uint64_t nrtSceneLastRedone(const nrt_scene *s) { return s ? s->last_redone : 0; }
+
+#ifdef NRT_PROF // libnanort_hip_prof.so only (include/nanort_hip_prof.h)
+int nrtSceneDebugCounters(nrt_scene *s, unsigned long long *out, int cap) {
+  if (!s || !out || cap < 16 || !s->d_counters.p) return 1;
+  if (hipStreamSynchronize(s->stream) != hipSuccess) return 1;
+  return hipMemcpy(out, s->d_counters.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 
 } // extern "C"

@@ -1206,6 +1206,9 @@ do {                                                                            
 // register pressure and the extra checks, 13 % per step in all: profiles/r02c_split_*.txt, r03g_split_asis.txt) and were
 // removed in round 3.  What a launch waits for at its end is the dependent chain of its few longest rays
 // (tools/drain_probe.py, tools/tail_first_probe.py); DESIGN.md 3.1 and 10 keep the numbers.)
+#ifndef NRT_SCENE_WALK_WAVES
+#define NRT_SCENE_WALK_WAVES 4 // waves per SIMD k_scene_walk is compiled for (128 registers; 5 -> 96 registers spills 30 of them and measured slower)
+#endif
 #ifndef NRT_SCENE_P1_UNROLL
 #define NRT_SCENE_P1_UNROLL 2 // ... of the two-level scene kernel
 #endif
@@ -2210,11 +2213,15 @@ do {                                                                            
   state = fin_ ? (in_top ? S_END : S_FIN) : (enter_ ? ((ref_ & kLeafBit) ? W_LEAF : W_TRAV) : W_POP); \
 } while (0)
 
-template <int STACK>
-__global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkArgs a) {
+template <int STACK, bool STATS>
+__global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) void k_scene_walk(const SceneWalkArgs a) {
   typedef float T;
   typedef StackEntry<float> SE;
   __shared__ SE::type s_stack[STACK][kTraverseBlock];
+  // (profiling build only) per wave: [0] outer trips, [1..2] level-change blocks run / lanes served, [3..4] inner-phase trips / lane
+  // steps, [5] of those steps in the top-level tree, [6..7] leaf-phase trips / lanes with a first record, [8] instances opened,
+  // [9] top-level leaves reached, [10..12] shader-clock ticks in level changes / the inner phase / the leaf phase
+  unsigned long long st[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   const unsigned tid = threadIdx.x;
   const unsigned lane = lane_id();
@@ -2226,7 +2233,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkAr
   int state = S_DONE, sp = 0, base = 0;
   bool in_top = true, tame = true;
   float cur_tmin = 0.f; // box entry distance of the open instance
-  uint32_t inst = 0, traced = 0;
+  uint32_t inst = 0, itop = 0, traced = 0; // the open instance's id and its position in the top-level order; instances opened so far
   float best_t = 3.402823466e+38f, best_tmin = 0.f, t2 = __builtin_huge_valf(); // winner's distance and box entry; runner-up distance
   float cull_t = __builtin_huge_valf();
   uint32_t best_id = 0;
@@ -2258,6 +2265,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkAr
   };
 
   for (;;) {
+    if (STATS) st[0]++;
     // ---- refill free lanes (as k_scene_trace) -------------------------------------------------------------------------
     {
       const unsigned long long free_lanes = __ballot(state == S_DONE);
@@ -2324,9 +2332,15 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkAr
       const unsigned n_cand = (unsigned)__builtin_popcountll(__ballot(state == S_FIN || state == T_ENTER || state == S_END));
       const unsigned n_busy = (unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP || state == W_LEAF));
       if (n_cand != 0u && (n_cand >= a.cand_min || n_busy < a.cand_busy_max)) {
+        const unsigned long long c0_ = STATS ? clock64() : 0ull;
+        if (STATS) {
+          st[1]++;
+          st[2] += n_cand;
+          st[9] += (unsigned)__builtin_popcountll(__ballot(state == T_ENTER));
+        }
         if (state == S_FIN) {
           if (L.hit_t < L.max_t) { // the local Traverse() hit (strict final predicate, nanort.h:2552)
-            const SceneInst &nd = a.insts[inst];
+            const SceneInst &nd = a.insts_top[itop];
             float lp[3], wp[3];
             lp[0] = L.org0 + L.hit_t * L.d0; // nanosg.h:823-825
             lp[1] = L.org1 + L.hit_t * L.d1;
@@ -2363,8 +2377,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkAr
           // the others of a leaf of several (boxes the builder could not separate) wait on the stack as a leaf of one fewer.
           const uint32_t lcount = (cur >> kPackedFirstBits) + 1u, lfirst = cur & kPackedFirstMask;
           if (lcount > 1u) NRT_PUSH_IF(true, kLeafBit | ((lcount - 2u) << kPackedFirstBits) | (lfirst + 1u), -__builtin_huge_valf());
-          const uint32_t k = a.top_indices[lfirst];
-          const float *bx = a.inst_boxes + (size_t)k * a.inst_box_stride;
+          const SceneInst &nd = a.insts_top[lfirst]; // (everything the opening needs in one record: id, world box, tree, matrices)
+          const uint32_t k = nd.id;
+          const float bx[6] = {nd.xbmin[0], nd.xbmin[1], nd.xbmin[2], nd.xbmax[0], nd.xbmax[1], nd.xbmax[2]};
           const bool s0 = wdir[0] < 0.0f, s1 = wdir[1] < 0.0f, s2 = wdir[2] < 0.0f;
           const float n0 = ((s0 ? bx[3] : bx[0]) - worg[0]) * winv[0], n1 = ((s1 ? bx[4] : bx[1]) - worg[1]) * winv[1],
                       n2 = ((s2 ? bx[5] : bx[2]) - worg[2]) * winv[2];
@@ -2396,9 +2411,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkAr
             state = W_POP; // (still in the top-level tree)
           } else {
             inst = k;
+            itop = lfirst;
             cur_tmin = e;
             traced++;
-            const SceneInst &nd = a.insts[inst];
             nrt_ray_f32 lr;
             scene_mult_v(lr.org, nd.inv_xform, worg);   // nanosg.h:807
             scene_mult_v(lr.dir, nd.inv_xform33, wdir); // nanosg.h:808
@@ -2436,6 +2451,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkAr
           }
           state = S_DONE;
         }
+        if (STATS) {
+          st[8] += (unsigned)__builtin_popcountll(__ballot(!in_top && base == sp && (state == W_TRAV || state == W_LEAF || state == S_FIN) && cur == 0u));
+          st[10] += clock64() - c0_;
+        }
       }
     }
     if (__ballot(state != S_DONE) == 0ull) {
@@ -2444,11 +2463,23 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkAr
     }
 
     // ---- phase 1: inner nodes / stack pops, of the top-level tree and of the open instances alike --------------------
+    const unsigned long long c1_ = STATS ? clock64() : 0ull;
     unsigned n_wait = (unsigned)__builtin_popcountll(__ballot(state == W_LEAF || state == S_FIN || state == T_ENTER || state == S_END));
     while (state == W_TRAV || state == W_POP) {
+      if (STATS) st[3]++;
 #pragma unroll
       for (int u_ = 0; u_ < NRT_SCENE_P1_UNROLL; u_++) {
-        if (state == W_POP) NRT_POP_ENTRY_SCENE();
+        if (state == W_POP) {
+          NRT_POP_ENTRY_SCENE();
+          if (state == S_FIN && !(L.hit_t < L.max_t)) { // the instance was missed (most are): back into the top-level tree right here
+            world_ray();
+            state = W_POP;
+          }
+        }
+        if (STATS) {
+          st[4] += (unsigned)__builtin_popcountll(__ballot(state == W_TRAV));
+          st[5] += (unsigned)__builtin_popcountll(__ballot(state == W_TRAV && in_top));
+        }
         if (state == W_TRAV) {
           if (wide4 != nullptr) {
             const Wide4Node<float> w = wide4[cur];
@@ -2469,6 +2500,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkAr
     }
 
     // ---- phase 2: leaves ---------------------------------------------------------------------------------------------
+    const unsigned long long c2_ = STATS ? clock64() : 0ull;
+    if (STATS) st[11] += c2_ - c1_;
     if (__ballot(state == W_LEAF) != 0ull) {
       uint32_t lcnt = 0, first = 0;
       if (state == W_LEAF) {
@@ -2481,6 +2514,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkAr
         }
       }
       for (uint32_t k = 0; __ballot(k < lcnt) != 0ull; k += 2u) {
+        if (STATS) {
+          st[6]++;
+          st[7] += (unsigned)__builtin_popcountll(__ballot(k < lcnt));
+        }
         if (k < lcnt) {
           const bool two = k + 1u < lcnt;
           const LeafTri<float> t0 = tris[first + k];
@@ -2490,18 +2527,29 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_walk(const SceneWalkAr
         }
       }
       state = (state == W_LEAF) ? W_POP : state;
+      if (STATS) st[12] += clock64() - c2_;
     }
+  }
+  if (STATS && lane == 0 && a.counters) {
+#pragma unroll
+    for (int q = 0; q < 13; q++) atomicAdd(&a.counters[q], st[q]);
   }
 }
 
 hipError_t launch_scene_walk(const SceneWalkArgs &args, unsigned grid, hipStream_t s) {
   if (args.n == 0) return hipSuccess;
-  hipLaunchKernelGGL((k_scene_walk<kSceneWalkLdsStack>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+#ifdef NRT_PROF
+  if (args.counters) {
+    hipLaunchKernelGGL((k_scene_walk<kSceneWalkLdsStack, true>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+    return hipGetLastError();
+  }
+#endif
+  hipLaunchKernelGGL((k_scene_walk<kSceneWalkLdsStack, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
   return hipGetLastError();
 }
 int scene_walk_blocks_per_cu() {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scene_walk<kSceneWalkLdsStack>, kTraverseBlock, 0) != hipSuccess || n < 1) n = 3;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scene_walk<kSceneWalkLdsStack, false>, kTraverseBlock, 0) != hipSuccess || n < 1) n = 3;
   return n > 8 ? 8 : n;
 }
 

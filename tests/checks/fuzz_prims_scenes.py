@@ -154,7 +154,7 @@ def scene_round():
             a = BVHAccel(np.float32)
             assert a.Build(f.shape[0], TriangleMesh(v, f))
             MESHES.append((v, f, a, a.GetTree()))
-    count = int(rng.choice([1, 2, 7, 30, 90]))
+    count = int(rng.choice([1, 2, 7, 30, 90, 400]))
     sc, O = Scene(), ob.SceneOracle(orc)
     centres = []
     prev = None
@@ -166,6 +166,12 @@ def scene_round():
         O.add_node(v, f, x, tree=tree)
         centres.append(x[3, :3])
     assert sc.Commit() and O.commit()
+    # which path traces the scene (0: listing + trace, 2: the single-pass walk whatever the size, 1: the default rule) and the
+    # thresholds of its phases never change a record
+    sc.SetTunable("single_pass", int(rng.choice([0, 1, 2, 2])))
+    sc.SetTunable("trav_min", int(rng.choice([1, 8, 24, 64])))
+    sc.SetTunable("refill_min", int(rng.choice([1, 32, 56, 64])))
+    sc.SetTunable("cand_min", int(rng.choice([1, 1, 16])))
     spread = max(2.0, float(np.abs(np.array(centres)).max()))
     pts = np.array(centres, dtype=np.float32) + rng.normal(size=(count, 3)).astype(np.float32) * 0.3
     rays = random_rays(4000, pts, spread=spread * 1.5, bounded=0.4)

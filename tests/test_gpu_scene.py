@@ -34,6 +34,12 @@ def test_same_local_trees_bit_identical(oracle, golden_dir):
     h, m = sc.TraverseBatch(rays)
     assert np.array_equal(m, g["mask"])
     assert fields_equal(h, g["hits"], ("t", "u", "v", "prim_id", "node_id"))
+    # a handful of nodes is listed by a scan by default; the single-pass walk over a five-leaf top-level tree gives the same records
+    sc.SetTunable("single_pass", 2)
+    h2, m2 = sc.TraverseBatch(rays)
+    assert sc.LastRedone() < len(rays) // 2
+    assert np.array_equal(m2, g["mask"])
+    assert fields_equal(h2, g["hits"], ("t", "u", "v", "prim_id", "node_id"))
 
 
 def test_gpu_built_local_trees_match_up_to_ties(oracle):
@@ -278,6 +284,12 @@ def test_rays_that_enter_more_than_64_boxes_keep_the_64_nearest(oracle, monkeypa
     assert int(mk.sum()) > 500
     assert np.array_equal(mk, om)
     assert fields_equal(h, oh, ("t", "u", "v", "prim_id", "node_id"))
+    if not prune:  # the single-pass walk on the same material: rays that trace more than 64 instances go back to the listing path
+        sc.SetTunable("single_pass", 2)
+        h, mk = sc.TraverseBatch(rays)
+        assert 0 < sc.LastRedone() < len(rays)
+        assert np.array_equal(mk, om)
+        assert fields_equal(h, oh, ("t", "u", "v", "prim_id", "node_id"))
 
 
 @pytest.mark.parametrize("dir_scale", [1.0, 0.25, 4.0])
@@ -334,6 +346,7 @@ def test_single_pass_walk_equals_the_listing_path_and_the_restatement(oracle, di
     rays["dir"][50:80, 1] = -0.0
     rays = np.concatenate([rays, scenes.camera_rays(96, 64)])
     oh, om = O.traverse(rays)
+    sc.SetTunable("single_pass", 2)  # (the default rule sends scenes below 2048 nodes to the listing path)
     h1, m1 = sc.TraverseBatch(rays)
     redone = sc.LastRedone()
     sc.SetTunable("single_pass", 0)
@@ -347,7 +360,7 @@ def test_single_pass_walk_equals_the_listing_path_and_the_restatement(oracle, di
     if dir_scale == 4.0:
         assert redone > 0  # ... and with the reference's cull firing late, rays that trace more than 64 instances are handed over
     # thresholds of the phases never change a record
-    sc.SetTunable("single_pass", 1)
+    sc.SetTunable("single_pass", 2)
     for name, value in (("trav_min", 1), ("trav_min", 32), ("refill_min", 8), ("cand_min", 16)):
         sc.SetTunable(name, value)
         h2, m2 = sc.TraverseBatch(rays)
