@@ -1,7 +1,7 @@
 """bench_rows.py — the SURVEY §8(f) "next" rows as numbers in the driver's line (`next_rows` of bench.py): one figure
 and one same-run parity sample each, outside the timed region.
 
-  scene_fixture / scene_10k   two-level (instanced) traversal, nanosg::Scene::Traverse (reference examples/nanosg/nanosg.h:778-870)
+  scene_fixture / scene_10k / scene_100k   two-level (instanced) traversal, nanosg::Scene::Traverse (reference examples/nanosg/nanosg.h:778-870)
   spheres_1m                  the particle example's primitive (reference examples/particle_primitive/main.cc:161-291)
   cylinders                   the cylinder example's primitive (reference examples/cylinder_primitive/main.cc:237-343)
   embree_stream               rtcIntersect1M of the Embree-2 shim (reference examples/embree-api/nanort-embree.cc:454-693)
@@ -46,7 +46,7 @@ def _fields_equal(a, b, keys):
 
 
 def scene_rows():
-    """5-node fixture (2 meshes, 1.07 M triangles) and 10 000 instances of a small mesh, 1920x1080 camera rays resident in HBM."""
+    """5-node fixture (2 meshes, 1.07 M triangles), 10 000 and 100 000 instances of a small mesh, 1920x1080 camera rays resident in HBM."""
     import torch
 
     from nanort_amd import BVHAccel, Scene, TriangleMesh, scenes
@@ -79,32 +79,40 @@ def scene_rows():
         "parity": {"kind": "port (oracle/nanosg_oracle.c over the GPU-built local trees)", "rays": int(oh.shape[0]),
                    "bit_identical": bool(np.array_equal(om, gm[::step])) and _fields_equal(oh, gh[::step], ("t", "u", "v", "prim_id", "node_id"))}}
     del sc, O, keep
-    # --- 10 000 instances
-    rng = np.random.default_rng(5)
+    # --- 10 000 and 100 000 instances (the single-pass walk; the listing path alone timed beside it)
     sv, sf = scenes.sphere(48, 24)
     sv = sv - np.array([0, 5, 0], dtype=np.float32)
     a = BVHAccel(np.float32)
     assert a.Build(sf.shape[0], TriangleMesh(sv, sf))
     tree = a.GetTree()
-    sc, O, N = Scene(), ob.SceneOracle(), 10000
-    for _ in range(N):
-        x = xform(tuple(rng.uniform(0.01, 0.04, 3)), rng.uniform(0, 6.28), rng.uniform(0, 6.28), tuple(rng.uniform(-9, 9, 3) + np.array([0, 5, 0])))
-        sc.AddNode(a, x)
-        O.add_node(sv, sf, x, tree=tree)
-    t0 = time.perf_counter()
-    assert sc.Commit()
-    commit_ms = (time.perf_counter() - t0) * 1e3
-    ms = _timed(lambda: sc.TraverseBatchDevice(d, o, m), reps=3)
-    gh, gm = o.cpu().numpy().view(SCENE_HIT_F32), m.cpu().numpy()
-    step = 4001
-    assert O.commit()
-    oh, om = O.traverse(rays[::step])  # (the restatement scans all 10 000 boxes per ray: keep the sample small)
-    out["scene_10k"] = {
-        "workload": "%d instances of a %d-triangle mesh, %dx%d camera rays in HBM" % (N, sf.shape[0], W, H),
-        "value": round(len(rays) / ms / 1e3, 1), "unit": "Mrays/s", "ms": round(ms, 4), "commit_ms": round(commit_ms, 2),
-        "hit_fraction": round(float(gm.mean()), 4),
-        "parity": {"kind": "port (oracle/nanosg_oracle.c over the GPU-built local tree)", "rays": int(oh.shape[0]),
-                   "bit_identical": bool(np.array_equal(om, gm[::step])) and _fields_equal(oh, gh[::step], ("t", "u", "v", "prim_id", "node_id"))}}
+    for key, N, step in (("scene_10k", 10000, 4001), ("scene_100k", 100000, 16001)):
+        rng = np.random.default_rng(5)
+        sc, O = Scene(), ob.SceneOracle()
+        for _ in range(N):
+            x = xform(tuple(rng.uniform(0.01, 0.04, 3)), rng.uniform(0, 6.28), rng.uniform(0, 6.28), tuple(rng.uniform(-9, 9, 3) + np.array([0, 5, 0])))
+            sc.AddNode(a, x)
+            O.add_node(sv, sf, x, tree=tree)
+        t0 = time.perf_counter()
+        assert sc.Commit()
+        commit_ms = (time.perf_counter() - t0) * 1e3
+        ms = _timed(lambda: sc.TraverseBatchDevice(d, o, m), reps=3)
+        redone = sc.LastRedone()
+        gh, gm = o.cpu().numpy().view(SCENE_HIT_F32), m.cpu().numpy()
+        assert O.commit()
+        oh, om = O.traverse(rays[::step])  # (the restatement scans all the boxes per ray: keep the sample small)
+        sc.SetTunable("single_pass", 0)
+        ms_list = _timed(lambda: sc.TraverseBatchDevice(d, o, m), reps=2)
+        lh, lm = o.cpu().numpy().view(SCENE_HIT_F32), m.cpu().numpy()
+        out[key] = {
+            "workload": "%d instances of a %d-triangle mesh, %dx%d camera rays in HBM" % (N, sf.shape[0], W, H),
+            "value": round(len(rays) / ms / 1e3, 1), "unit": "Mrays/s", "ms": round(ms, 4), "commit_ms": round(commit_ms, 2),
+            "path": "single-pass walk (k_scene_walk); rays handed to the listing path: %d" % redone,
+            "listing_path_alone": {"value": round(len(rays) / ms_list / 1e3, 1), "ms": round(ms_list, 4),
+                                   "records_identical": bool(np.array_equal(lm, gm)) and _fields_equal(lh, gh, ("t", "u", "v", "prim_id", "node_id"))},
+            "hit_fraction": round(float(gm.mean()), 4),
+            "parity": {"kind": "port (oracle/nanosg_oracle.c over the GPU-built local tree)", "rays": int(oh.shape[0]),
+                       "bit_identical": bool(np.array_equal(om, gm[::step])) and _fields_equal(oh, gh[::step], ("t", "u", "v", "prim_id", "node_id"))}}
+        del sc, O
     return out
 
 
@@ -274,7 +282,7 @@ def wavefront_row():
 # hardware counters of a row's dominant kernel (outside every timed region): bench_rows.py --pmc-row NAME is re-run under
 # rocprofv3 --pmc (kernel trace only; one pass per counter set, as MI355X_MICROARCH.md prescribes)
 # ---------------------------------------------------------------------------
-ROW_KERNELS = {"scene_10k": "k_scene_walk", "scene_fixture": "k_scene_walk", "spheres_1m": "k_traverse_wide", "cylinders": "k_traverse_wide"}
+ROW_KERNELS = {"scene_10k": "k_scene_walk", "scene_fixture": "k_scene_trace", "spheres_1m": "k_traverse_wide", "cylinders": "k_traverse_wide"}
 
 
 def pmc_row_child(name):

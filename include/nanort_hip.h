@@ -368,7 +368,7 @@ NRT_API nrt_status nrtSetLaunchTiming(nrt_ctx *ctx, int on);
  *                     "f64_row_fetch"
  *   scheduling        "refill_min", "trav_min", "trav_min4", "trav_min8", "leaf_min", "chunk", "chunk_tail_pct", "parts",
  *                     "static_pct", "static_bands", "static_slice_groups", "blocks_per_cu", "lds_stack", "wide_stack"
- *   builder           "morton" (Morton pre-pass), "subtree_rows" (0: the one-node-per-step subtree kernel; same tree)
+ *   builder           "morton" (Morton pre-pass); libnanort_hip_prof.so only: "subtree_rows" (0: the one-node-per-step subtree kernel; same tree)
  *   launches / host   "launch_timing" (== nrtSetLaunchTiming), "host_pipeline"
  *   probes            "debug" (bit mask: 1 / 2 skip triangle tests / traversal, 4 plain ray loads; the profiling bits 32 / 64 / 8192
  *                     act in libnanort_hip_prof.so only), "wide_scramble" (layout probe; next build)

@@ -145,7 +145,7 @@ struct nrt_ctx {
   unsigned trav_min4 = 24; // the same threshold for the fp32 two-level walk, whose inner loop runs two pop + step rounds per trip (profiles/r03Z_threshold_resweep*.txt)
   unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
   unsigned debug_flags = 0;
-  int subtree_rows = 1; // builder: subtree phase in row form (up to four nodes per step); 0: one node per step — same tree, the cross-check (tests/test_gpu_build.py)
+  int subtree_rows = 1; // builder: subtree phase in row form (up to four nodes per step); 0 (profiling build only): one node per step — same tree, the cross-check (tests/test_gpu_build.py)
   int morton = 0; // Morton-order the primitive records before the build (env NRT_MORTON=1): measured +0.4 ms at 1M tris for an identical tree, so off by default
   unsigned static_pct = 75; // share of a batch handed out statically, percent (env NRT_STATIC_PCT)
   unsigned static_bands = 8; // ... as up to this many slices per wave, one in each band of the batch
@@ -290,7 +290,9 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("blocks_per_cu", 0, 8, max_blocks_per_cu, unsigned), // cap on the persistent grid (0: occupancy)
     NRT_TUNABLE("debug", 0, 0x7FFFFFFF, debug_flags, unsigned),   // profiling bit mask
     NRT_TUNABLE("morton", 0, 1, morton, int),                     // Morton pre-pass of the builder (next build)
-    NRT_TUNABLE("subtree_rows", 0, 1, subtree_rows, int),         // 0: the builder's one-node-per-step subtree kernel (next build; same tree)
+#ifdef NRT_PROF
+    NRT_TUNABLE("subtree_rows", 0, 1, subtree_rows, int),         // 0: the builder's one-node-per-step subtree kernel (next build; same tree) — libnanort_hip_prof.so only
+#endif
     NRT_TUNABLE("wide", 0, 1, wide, int),                         // 0: the literal BVHNode loop
     NRT_TUNABLE("wide4", 0, 1, wide4, int),                       // two tree levels per step (next build / set_tree)
     NRT_TUNABLE("wide8", 0, 1, wide8, int),                       // the 8-wide compressed walk (next build / set_tree; hit t bit-equal, prim_id / u / v may differ at exact-t ties)

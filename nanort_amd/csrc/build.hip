@@ -77,7 +77,7 @@ constexpr int kMaxBins = 64;    // top phase: lane == bin
 constexpr int kSmallBins = 16;  // subtree phase: 3 x 15 candidates == 45 lanes
 constexpr uint32_t kMedian = 0xFFFFFFFFu;
 constexpr int kSceneReplicas = 16; // k_prim_records spreads its per-block atomics on the scene bounds over this many copies
-constexpr int kSubStack = 48;     // pending high-side children per subtree wave (LDS)
+[[maybe_unused]] constexpr int kSubStack = 48; // pending high-side children per subtree wave of k_subtree (LDS; profiling build)
 constexpr int kSubStackSafe = 36; // above this many, splits are forced to the object median (depth <= log2 n more)
 
 enum : uint32_t { KIND_SPLIT = 0, KIND_SMALL = 1, KIND_LEAF = 2 };
@@ -1375,6 +1375,7 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
 // ---------------------------------------------------------------------------
 // subtree phase: one wave builds everything below a node of <= kSmall prims
 // ---------------------------------------------------------------------------
+#ifdef NRT_PROF // the one-node-per-step form lives in libnanort_hip_prof.so only: the cross-check of the row form (tests/test_gpu_build.py, tunable subtree_rows = 0)
 // Pending high-side child of the per-wave subtree builder.
 template <typename T>
 struct SubPending {
@@ -1809,6 +1810,7 @@ __global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t 
   }
 }
 #undef NRT_SUB_REC
+#endif // NRT_PROF
 
 // ---------------------------------------------------------------------------
 // subtree phase, row form: up to four nodes of a subtree per step, one per 16-lane row
@@ -2598,7 +2600,12 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
                      uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, unsigned build_flags, DevBuf *workspace, DevBuf *nodes_buf,
                      DevBuf *indices_buf, void *pinned, hipEvent_t ev, std::string *err) {
   typedef typename Wire<T>::Node Node;
-  const bool morton_order = (build_flags & kBuildMorton) != 0, subtree_rows = (build_flags & kBuildSubtreeDfs) == 0;
+#ifdef NRT_PROF
+  const bool subtree_rows = (build_flags & kBuildSubtreeDfs) == 0;
+#else
+  const bool subtree_rows = true; // (k_subtree is not in this library)
+#endif
+  const bool morton_order = (build_flags & kBuildMorton) != 0;
   static_assert(offsetof(LevelInfo, level_begin) <= kBuildPinnedBytes, "state block");
   const int K = (int)(bin_size < 2 ? 2 : (bin_size > (uint32_t)kMaxBins ? (uint32_t)kMaxBins : bin_size));
   const int Ks = K < kSmallBins ? K : kSmallBins;
@@ -2708,12 +2715,14 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
 
     // ---- subtree phase + relayout + emission ---------------------------------------------------------
     if (num_small) {
-      if (subtree_rows)
-        hipLaunchKernelGGL((k_subtree_rows<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
-                           min_leaf, max_depth, scratch, premap, indices, info);
-      else // (the one-node-per-step form: kept as the cross-check of the row form, tunable subtree_rows = 0)
+#ifdef NRT_PROF
+      if (!subtree_rows) // (the one-node-per-step form: the cross-check of the row form, tunable subtree_rows = 0 of the profiling build)
         hipLaunchKernelGGL((k_subtree<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
                            min_leaf, max_depth, scratch, indices, info);
+      else
+#endif
+        hipLaunchKernelGGL((k_subtree_rows<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
+                           min_leaf, max_depth, scratch, premap, indices, info);
     }
     BCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_layout<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)(2 * kLayoutLds * sizeof(uint32_t)))); // (per device: set on every build, it costs nothing)

@@ -369,20 +369,31 @@ def test_non_finite_vertices_build_a_walkable_tree(oracle, real, kind):
 
 
 def _two_subtree_kernels(real, v, f, **opt):
-    """The same mesh through the row form of the subtree phase (the default) and the one-node-per-step form."""
-    out = []
-    for rows in (1, 0):
-        a = BVHAccel(real)
-        a.SetTunable("subtree_rows", rows)
-        o = default_build_options(real)
-        for k, val in opt.items():
-            o[k] = val
-        assert a.Build(f.shape[0], TriangleMesh(v, f), o)
-        nodes, idx = a.GetTree()
-        out.append((nodes, idx, a.GetStatistics()))
-        a.close()
-    (n1, i1, s1), (n0, i0, s0) = out
-    assert n1.tobytes() == n0.tobytes(), "the two subtree kernels must emit the same node array"
+    """The same mesh through the row form of the subtree phase (this process, the product library) and the one-node-per-step
+    form — which only the profiling build of the library carries: a child process builds with it and dumps the tree."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+
+    a = BVHAccel(real)
+    o = default_build_options(real)
+    for k, val in opt.items():
+        o[k] = val
+    assert a.Build(f.shape[0], TriangleMesh(v, f), o)
+    n1, i1 = a.GetTree()
+    s1 = a.GetStatistics()
+    a.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.savez(os.path.join(tmp, "in.npz"), v=v, f=f, real=np.dtype(real).name, tunables=json.dumps({"subtree_rows": 0}),
+                 options=json.dumps({k: (int(x) if float(x).is_integer() else float(x)) for k, x in opt.items()}))
+        r = subprocess.run([sys.executable, os.path.join(here, "checks", "build_dump.py"), os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1500:]
+        d = np.load(os.path.join(tmp, "out.npz"))
+        n0b, i0, s0 = d["nodes"].tobytes(), d["idx"], json.loads(str(d["stats"]))
+    assert n1.tobytes() == n0b, "the two subtree kernels must emit the same node array"
     assert np.array_equal(i1, i0)
     for key in ("max_tree_depth", "num_leaf_nodes", "num_branch_nodes"):
         assert s1[key] == s0[key], key
