@@ -436,7 +436,9 @@ NRT_API nrt_status nrtSceneTraverseBatchDevice_f32(nrt_scene *scene, const nrt_r
  * are traced by the single-pass walk — top-level tree and instance trees on one stack, no per-ray list; rays it cannot certify
  * are re-done by the listing path; 2: every scene of two nodes or more; 0: listing + trace for every ray), "trav_min", "refill_min", "cand_min",
  * "cand_busy_max" (lane-count thresholds of the phases), "prune_min" (instance count from which the listing prunes beyond a
- * full list). */
+ * full list), "walk_min" (instance count from which single_pass = 1 uses the walk; 2048).  After a batch of which the walk had to
+ * hand more than a quarter ("walk_backoff_pct", 25) to the listing path (direction vectors far shorter than 1, where the reference's cull compares a
+ * distance with a parameter) the next 15 calls use the listing path directly. */
 NRT_API nrt_status nrtSceneSetTunable(nrt_scene *scene, const char *name, int value);
 /* How many rays of the last nrtSceneTraverseBatch* call the single-pass walk handed to the listing path. */
 NRT_API uint64_t nrtSceneLastRedone(const nrt_scene *scene);

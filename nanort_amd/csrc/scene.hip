@@ -53,6 +53,7 @@ struct NodeDev { // per-instance table in HBM
 constexpr int kMaxList = 64; // kMaxIntersections, nanosg.h:782
 constexpr int kTopStack = 64; // per-ray stack of the top-level walk (a deeper top-level tree falls back to the scan)
 constexpr uint32_t kScanMaxNodes = 8; // scenes of at most this many nodes are listed by the scan
+constexpr unsigned kWalkBackoff = 15;   // listing-path calls after a batch of which the walk handed over more than a quarter
 constexpr uint32_t kWalkMinNodes = 2048; // scenes of at least this many nodes are traced by the single-pass walk (1 000 instances: on par with the
                                         // listing path, 5: 6 % slower, 10 000: 1.5x, 100 000: 7.7x faster — profiles/r04n_scene_walk.txt)
 
@@ -452,6 +453,9 @@ struct nrt_scene {
   unsigned single_pass = 1;   // scenes of kWalkMinNodes nodes or more are traced by k_scene_walk (no per-ray list); 0: always listing +
                               // k_scene_trace; 2: k_scene_walk for every scene of two nodes or more
   unsigned walk_blocks_per_cu = 0;
+  unsigned walk_backoff = 0;  // calls left that skip the walk (see scene_traverse)
+  unsigned walk_backoff_pct = 25; // share of a batch handed to the listing path above which the next kWalkBackoff calls skip the walk (tunable)
+  unsigned walk_min = kWalkMinNodes; // scenes of at least this many nodes are traced by the walk (tunable "walk_min")
   unsigned prune_min = 32768; // scenes of at least this many instances are listed by the pruning walk (k_scene_list_w4<true>)
   unsigned trav_min = 8;
   unsigned cand_min = 1, cand_busy_max = 64; // batching of the per-instance steps of k_scene_trace (env NRT_SCENE_CAND / NRT_SCENE_CAND_BUSY; 1 / 64: none)
@@ -589,6 +593,7 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
   // bounding box is exactly the box.  Which nodes a ray lists does not depend on this tree's shape.
   s->use_top = false;
   s->have_top = false;
+  s->walk_backoff = 0;
   if (s->insts.size() >= 2) {
     if (!s->top && nrtCreate(s->device, &s->top) != NRT_OK)
       return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level context: %s", nrtLastError(nullptr));
@@ -767,8 +772,13 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   if (!device) SCHK(s, hipMemcpyAsync(s->d_rays.p, rays, (size_t)n * sizeof(nrt_ray_f32), hipMemcpyHostToDevice, s->stream));
 
   s->last_redone = 0;
-  const bool walk = s->single_pass && s->have_top && (s->insts.size() >= kWalkMinNodes || s->single_pass > 1) && s->top_view.wide4 && s->top_view.root_is_branch && s->top_view.tree_nested &&
-                    s->top_view.packed_leaves;
+  const bool eligible = s->single_pass && s->have_top && (s->insts.size() >= s->walk_min || s->single_pass > 1) && s->top_view.wide4 &&
+                        s->top_view.root_is_branch && s->top_view.tree_nested && s->top_view.packed_leaves;
+  // a batch the walk could not certify for the most part (direction vectors far shorter than 1: the reference's cull then compares
+  // a distance with a parameter and fires early, nanosg.h:795) costs more than the listing path alone: after one, the next
+  // kWalkBackoff calls go straight to the listing path, then the walk is tried again
+  const bool walk = eligible && (s->single_pass > 1 || s->walk_backoff == 0);
+  if (eligible && !walk) s->walk_backoff--;
   if (walk) {
     if (!s->h_redo_count) SCHK(s, hipHostMalloc((void **)&s->h_redo_count, sizeof(uint32_t), hipHostMallocDefault));
     SCHK(s, nrt::devbuf_ensure(&s->d_redo, (size_t)n * sizeof(uint32_t)));
@@ -813,6 +823,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     SCHK(s, hipMemcpyAsync(s->h_redo_count, s->d_redo_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     SCHK(s, hipStreamSynchronize(s->stream));
     s->last_redone = *s->h_redo_count;
+    if ((uint64_t)*s->h_redo_count * 100u > (uint64_t)n * s->walk_backoff_pct) s->walk_backoff = kWalkBackoff;
     if (*s->h_redo_count) {
       const nrt_status st = scene_list_and_trace(s, d_rays, *s->h_redo_count, (const uint32_t *)s->d_redo.p, d_hits, d_mask);
       if (st != NRT_OK) return st;
@@ -851,6 +862,8 @@ nrt_status nrtSceneSetTunable(nrt_scene *s, const char *name, int value) {
   else if (k == "cand_min") s->cand_min = lanes;
   else if (k == "cand_busy_max") s->cand_busy_max = (unsigned)std::min(65, std::max(1, value));
   else if (k == "prune_min") s->prune_min = (unsigned)std::max(0, value);
+  else if (k == "walk_min") s->walk_min = (unsigned)std::max(2, value);
+  else if (k == "walk_backoff_pct") s->walk_backoff_pct = (unsigned)std::min(100, std::max(0, value));
 #ifdef NRT_PROF
   else if (k == "count_loops") s->count_loops = value != 0;
 #endif

@@ -359,6 +359,17 @@ def test_single_pass_walk_equals_the_listing_path_and_the_restatement(oracle, di
         assert redone < 0.2 * len(rays)
     if dir_scale == 4.0:
         assert redone > 0  # ... and with the reference's cull firing late, rays that trace more than 64 instances are handed over
+    if dir_scale == 0.25:  # the default rule backs off: a batch handed over above a threshold makes the next calls skip the walk
+        assert redone * 100 > len(rays)
+        sc.SetTunable("single_pass", 1)
+        sc.SetTunable("walk_min", 2)
+        sc.SetTunable("walk_backoff_pct", 1)
+        seen = []
+        for _ in range(3):
+            h3, m3 = sc.TraverseBatch(rays)
+            seen.append(sc.LastRedone())
+            assert np.array_equal(m3, om) and fields_equal(h3, oh, ("t", "u", "v", "prim_id", "node_id"))
+        assert seen[0] == redone and seen[1] == 0 and seen[2] == 0
     # thresholds of the phases never change a record
     sc.SetTunable("single_pass", 2)
     for name, value in (("trav_min", 1), ("trav_min", 32), ("refill_min", 8), ("cand_min", 16)):
