@@ -246,10 +246,26 @@ struct SceneTraceArgs {
 #define NRT_SCENE_WALK_STACK 16
 #endif
 constexpr int kSceneWalkLdsStack = NRT_SCENE_WALK_STACK; // per-lane stack entries kept in LDS (top-level entries below, the open instance's above)
+// What opening an instance needs, one 128-byte line per instance, in the order of the top-level tree's index array (a leaf
+// reference's `first` indexes the table): the twelve entries of each matrix that Matrix::MultV touches (nanosg.h:232-240:
+// m[0..3][0..2]), the world box, the id, and which mesh (tree) it instantiates.
+struct alignas(128) SceneOpen {
+  float inv[4][3];   // inv_xform: world -> local, points
+  float inv33[4][3]; // inv_xform33: world -> local, directions
+  float xbmin[3], xbmax[3];
+  uint32_t id, mesh;
+};
+static_assert(sizeof(SceneOpen) == 128, "SceneOpen");
+struct SceneMesh { // per distinct mesh context: its private traversal arrays (two levels per step, packed leaf references)
+  const void *wide4;
+  const void *tris;
+};
 struct SceneWalkArgs {
   const nrt_ray_f32 *rays;
   uint32_t n;
-  const SceneInst *insts_top;        // the instance table in the order of the top-level tree's index array (a leaf reference's `first` indexes it)
+  const SceneOpen *open_top;         // see SceneOpen
+  const SceneMesh *meshes;
+  const SceneInst *insts_top;        // the full instance table in the same order (its xform is read when an instance was hit)
   const Wide4Node<float> *top_wide4; // the top-level tree over the instances' world boxes (root is a branch, nested, packed leaves)
   nrt_scene_hit_f32 *hits;
   uint8_t *mask;

@@ -1,16 +1,21 @@
 // nanort_amd/csrc/scene.hip — two-level (instanced) traversal on the GPU: SURVEY.md §8(f) row 3.
 //
 // Replaces nanosg::Scene<float, M>::Commit / Traverse (reference examples/nanosg/nanosg.h:700-870) and the
-// BVHAccel::ListNodeIntersections it rests on (reference nanort.h:2608-2692).  Structure:
+// BVHAccel::ListNodeIntersections it rests on (reference nanort.h:2608-2692).  Two paths give the same records:
 //
-//   k_scene_list_bvh  per ray: which node boxes does the ray enter, sorted by entry distance, at most 64 — a walk
+//   THE SINGLE-PASS WALK (scenes of kWalkMinNodes nodes or more): k_scene_walk (traverse.hip) walks the top-level tree and, on
+//   reaching an instance, the instance's own tree in the same lane on the same stack — no per-ray list; a per-ray certificate
+//   says when the record is provably the reference's, the other rays (few) are appended to a list and go through
+//   THE LISTING PATH (small scenes; the rays handed over; tunable single_pass = 0):
+//
+//   k_scene_list*     per ray: which node boxes does the ray enter, sorted by entry distance, at most 64 — a walk
 //                     over the TOP-LEVEL BVH of the instances' world boxes (built on the GPU by the ordinary builder
 //                     with min_leaf_primitives = 1, as nanosg.h:730-735 does on the host).  The set of listed nodes
 //                     does not depend on the shape of that tree (every ancestor box contains the leaf box and the slab
 //                     arithmetic is monotone); scenes of a handful of nodes skip the tree (k_scene_list: a scan);
 //   k_scene_trace     (traverse.hip) per ray: the reference's loop over that list — early cull, ray into the node's
 //                     space, the node's own tree walked in the same lane, world distance, strict-nearer update —
-//                     for the whole batch in one launch: no per-node launches, no host round trips.
+//                     for the whole batch (or the subset handed over) in one launch: no per-node launches, no host round trips.
 //
 // The per-node arithmetic (Matrix::Mult / Inverse / MultV, XformBoundingBox, the two slab tests) follows the
 // reference operation for operation; this file is compiled with the same no-contraction / IEEE flags.
@@ -446,7 +451,8 @@ struct nrt_scene {
   bool have_top = false;         // a top-level tree exists (two nodes or more): the single-pass walk uses it
   uint32_t max_inst_depth = 0;   // deepest instance tree: sizes the overflow stack of k_scene_trace
   nrt::DevBuf d_nodes, d_insts, d_rays, d_list_t, d_list_node, d_count, d_best, d_mask, d_spill, d_spill_tmin, d_cursor;
-  nrt::DevBuf d_redo, d_redo_count, d_counters, d_insts_top;
+  nrt::DevBuf d_redo, d_redo_count, d_counters, d_insts_top, d_open_top, d_meshes;
+  bool walk_meshes_ok = false; // every mesh of the scene has the private layout k_scene_walk steps through (else: the listing path)
   unsigned count_loops = 0; // profiling build only (tunable "count_loops"): the next calls run the counting instantiation of k_scene_walk
   uint32_t *h_redo_count = nullptr; // page-locked: how many rays the single-pass walk left to the listing path
   uint64_t last_redone = 0;
@@ -506,7 +512,7 @@ void nrtSceneDestroy(nrt_scene *s) {
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
   nrt::DevBuf *bufs[] = {&s->d_nodes, &s->d_insts, &s->d_rays, &s->d_list_t, &s->d_list_node, &s->d_count,
-                         &s->d_best,  &s->d_mask,  &s->d_spill, &s->d_spill_tmin, &s->d_cursor, &s->d_redo, &s->d_redo_count, &s->d_counters, &s->d_insts_top};
+                         &s->d_best,  &s->d_mask,  &s->d_spill, &s->d_spill_tmin, &s->d_cursor, &s->d_redo, &s->d_redo_count, &s->d_counters, &s->d_insts_top, &s->d_open_top, &s->d_meshes};
   for (nrt::DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (s->h_redo_count) (void)hipHostFree(s->h_redo_count);
@@ -623,9 +629,35 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
       if (nrtGetTree_f32(s->top, nullptr, order.data()) != NRT_OK)
         return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level index array: %s", nrtLastError(s->top));
       std::vector<nrt::SceneInst> sorted(ni);
-      for (size_t q = 0; q < ni; q++) sorted[q] = table[order[q]];
+      std::vector<nrt::SceneOpen> open(ni); // (the 128-byte line an opening reads; the full record only when the instance was hit)
+      for (size_t q = 0; q < ni; q++) {
+        const nrt::SceneInst &e = table[order[q]];
+        sorted[q] = e;
+        nrt::SceneOpen &o = open[q];
+        for (int r = 0; r < 4; r++)
+          for (int c = 0; c < 3; c++) {
+            o.inv[r][c] = e.inv_xform[r][c];
+            o.inv33[r][c] = e.inv_xform33[r][c];
+          }
+        memcpy(o.xbmin, e.xbmin, sizeof(o.xbmin));
+        memcpy(o.xbmax, e.xbmax, sizeof(o.xbmax));
+        o.id = e.id;
+        o.mesh = mesh_of[order[q]];
+      }
       SCHK(s, nrt::devbuf_ensure(&s->d_insts_top, sorted.size() * sizeof(nrt::SceneInst)));
       SCHK(s, hipMemcpy(s->d_insts_top.p, sorted.data(), sorted.size() * sizeof(nrt::SceneInst), hipMemcpyHostToDevice));
+      SCHK(s, nrt::devbuf_ensure(&s->d_open_top, open.size() * sizeof(nrt::SceneOpen)));
+      SCHK(s, hipMemcpy(s->d_open_top.p, open.data(), open.size() * sizeof(nrt::SceneOpen), hipMemcpyHostToDevice));
+      std::vector<nrt::SceneMesh> mt(meshes.size());
+      s->walk_meshes_ok = true; // the walk steps two levels at a time through packed leaf references, from a branch root whose children lie inside it
+      for (size_t m = 0; m < meshes.size(); m++) {
+        const nrt::TreeViewF32 &tv = meshes[m].second.tv;
+        mt[m].wide4 = tv.wide4;
+        mt[m].tris = tv.prims;
+        s->walk_meshes_ok = s->walk_meshes_ok && tv.wide4 && tv.tree_nested && tv.root_is_branch && tv.packed_leaves;
+      }
+      SCHK(s, nrt::devbuf_ensure(&s->d_meshes, mt.size() * sizeof(nrt::SceneMesh)));
+      SCHK(s, hipMemcpy(s->d_meshes.p, mt.data(), mt.size() * sizeof(nrt::SceneMesh), hipMemcpyHostToDevice));
     }
     s->have_top = true;                                                                              // the single-pass walk's
     s->use_top = s->insts.size() > kScanMaxNodes && s->top_view.tree_depth + 2 < (uint32_t)kTopStack; // the listing kernels' (else: the scan)
@@ -772,7 +804,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   if (!device) SCHK(s, hipMemcpyAsync(s->d_rays.p, rays, (size_t)n * sizeof(nrt_ray_f32), hipMemcpyHostToDevice, s->stream));
 
   s->last_redone = 0;
-  const bool eligible = s->single_pass && s->have_top && (s->insts.size() >= s->walk_min || s->single_pass > 1) && s->top_view.wide4 &&
+  const bool eligible = s->single_pass && s->have_top && (s->insts.size() >= s->walk_min || s->single_pass > 1) && s->walk_meshes_ok && s->top_view.wide4 &&
                         s->top_view.root_is_branch && s->top_view.tree_nested && s->top_view.packed_leaves;
   // a batch the walk could not certify for the most part (direction vectors far shorter than 1: the reference's cull then compares
   // a distance with a parameter and fires early, nanosg.h:795) costs more than the listing path alone: after one, the next
@@ -796,6 +828,8 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     nrt::SceneWalkArgs w;
     w.rays = d_rays;
     w.n = n;
+    w.open_top = (const nrt::SceneOpen *)s->d_open_top.p;
+    w.meshes = (const nrt::SceneMesh *)s->d_meshes.p;
     w.insts_top = (const nrt::SceneInst *)s->d_insts_top.p;
     w.top_wide4 = (const nrt::Wide4Node<float> *)s->top_view.wide4;
     w.hits = d_hits;

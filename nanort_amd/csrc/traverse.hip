@@ -1908,8 +1908,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_w8(const TraverseAr
 // (:823-836) and keep it if strictly nearer (:838).  Lanes of a wave are at different candidates of different instances
 // at the same time — every lane carries its instance's array bases — so there is no per-instance launch, no compaction
 // and no host round trip; the wave alternates between the inner-node phase and the leaf phase like k_traverse_wide.
-// (No refill: a wave keeps its 64 rays to the end.  Instanced scenes are traced through this kernel at 1-2 Grays/s,
-// DESIGN.md §8; the refill machinery of k_traverse_wide is what the single-level path buys its last factor of two with.)
+// A lane whose ray is finished takes the next one from a per-partition work cursor (a wave refills once `refill_min` lanes are
+// free).  Since round 4 this kernel traces small scenes and the rays the single-pass walk (k_scene_walk, below) hands over;
+// scenes of thousands of instances go through that walk, which keeps no list at all.
 // ---------------------------------------------------------------------------
 enum : int { S_NEXT = 4, S_FIN = 5, S_DONE = 6 }; // besides W_TRAV / W_LEAF / W_POP: pick the next candidate / a local walk ended / ray finished
 
@@ -2240,11 +2241,8 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
   bool has_hit = false;
   float worg[3] = {0.f, 0.f, 0.f}, wdir[3] = {0.f, 0.f, 0.f}, winv[3] = {0.f, 0.f, 0.f};
   float wmin_t = 0.f, wmax_t = 0.f;
-  const WideNode<float> *wide = nullptr;
-  const Wide4Node<float> *wide4 = nullptr;
+  const Wide4Node<float> *wide4 = nullptr; // the tree being walked: the top-level tree's records or the open instance's
   const LeafTri<float> *tris = nullptr;
-  const nrt_node_f32 *nodes = nullptr;
-  uint32_t packed = 1u;
   bool exhausted = false;
   uint32_t part = blockIdx.x % a.num_parts, tried = 0u;
 
@@ -2377,7 +2375,7 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
           // the others of a leaf of several (boxes the builder could not separate) wait on the stack as a leaf of one fewer.
           const uint32_t lcount = (cur >> kPackedFirstBits) + 1u, lfirst = cur & kPackedFirstMask;
           if (lcount > 1u) NRT_PUSH_IF(true, kLeafBit | ((lcount - 2u) << kPackedFirstBits) | (lfirst + 1u), -__builtin_huge_valf());
-          const SceneInst &nd = a.insts_top[lfirst]; // (everything the opening needs in one record: id, world box, tree, matrices)
+          const SceneOpen &nd = a.open_top[lfirst]; // (everything the opening needs in one 128-byte line: id, world box, matrices, mesh)
           const uint32_t k = nd.id;
           const float bx[6] = {nd.xbmin[0], nd.xbmin[1], nd.xbmin[2], nd.xbmax[0], nd.xbmax[1], nd.xbmax[2]};
           const bool s0 = wdir[0] < 0.0f, s1 = wdir[1] < 0.0f, s2 = wdir[2] < 0.0f;
@@ -2415,32 +2413,24 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
             cur_tmin = e;
             traced++;
             nrt_ray_f32 lr;
-            scene_mult_v(lr.org, nd.inv_xform, worg);   // nanosg.h:807
-            scene_mult_v(lr.dir, nd.inv_xform33, wdir); // nanosg.h:808
-            lr.min_t = 0.0f;                            // Ray() defaults (nanort.h:477-487): the world interval is not propagated
+            // Matrix::MultV (nanosg.h:232-240) with inv_xform / inv_xform33 (:807-808), the twelve entries it reads
+            lr.org[0] = nd.inv[0][0] * worg[0] + nd.inv[1][0] * worg[1] + nd.inv[2][0] * worg[2] + nd.inv[3][0];
+            lr.org[1] = nd.inv[0][1] * worg[0] + nd.inv[1][1] * worg[1] + nd.inv[2][1] * worg[2] + nd.inv[3][1];
+            lr.org[2] = nd.inv[0][2] * worg[0] + nd.inv[1][2] * worg[1] + nd.inv[2][2] * worg[2] + nd.inv[3][2];
+            lr.dir[0] = nd.inv33[0][0] * wdir[0] + nd.inv33[1][0] * wdir[1] + nd.inv33[2][0] * wdir[2] + nd.inv33[3][0];
+            lr.dir[1] = nd.inv33[0][1] * wdir[0] + nd.inv33[1][1] * wdir[1] + nd.inv33[2][1] * wdir[2] + nd.inv33[3][1];
+            lr.dir[2] = nd.inv33[0][2] * wdir[0] + nd.inv33[1][2] * wdir[1] + nd.inv33[2][2] * wdir[2] + nd.inv33[3][2];
+            lr.min_t = 0.0f; // Ray() defaults (nanort.h:477-487): the world interval is not propagated
             lr.max_t = 3.402823466e+38f;
             lr.type = 0;
             lane_init<float>(L, lr);
-            wide = (const WideNode<float> *)nd.wide;
-            wide4 = (const Wide4Node<float> *)nd.wide4;
-            tris = (const LeafTri<float> *)nd.tris;
-            nodes = nd.nodes;
-            packed = nd.packed_leaves;
+            const SceneMesh &mesh = a.meshes[nd.mesh];
+            wide4 = (const Wide4Node<float> *)mesh.wide4;
+            tris = (const LeafTri<float> *)mesh.tris;
             in_top = false;
             base = sp;
             cur = 0u;
-            if (nd.root_is_branch && nd.tree_nested) {
-              state = W_TRAV;
-            } else {
-              const nrt_node_f32 root = nodes[0];
-              const bool root_hit = slab_test<float>(L, root.bmin, root.bmax);
-              if (nd.root_is_branch) {
-                state = root_hit ? W_TRAV : S_FIN;
-              } else { // single-leaf tree
-                cur = packed ? (((root.data[0] - 1u) << kPackedFirstBits) | root.data[1]) : 0u;
-                state = root_hit ? W_LEAF : S_FIN;
-              }
-            }
+            state = W_TRAV; // (every tree this kernel walks has a branch root whose children's boxes lie inside it: scene.hip checks)
           }
         } else if (state == S_END) {
           const bool certified = traced <= 64u && (!has_hit || t2 >= best_tmin);
@@ -2481,17 +2471,12 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
           st[5] += (unsigned)__builtin_popcountll(__ballot(state == W_TRAV && in_top));
         }
         if (state == W_TRAV) {
-          if (wide4 != nullptr) {
-            const Wide4Node<float> w = wide4[cur];
-            Slab4<float> sl4_ = slab4(L, w);
-            const float ct_ = in_top ? cull_t : __builtin_huge_valf(); // (in the top-level tree: nothing entered beyond a nearer hit that ranks before it)
+          const Wide4Node<float> w = wide4[cur];
+          Slab4<float> sl4_ = slab4(L, w);
+          const float ct_ = in_top ? cull_t : __builtin_huge_valf(); // (in the top-level tree: nothing entered beyond a nearer hit that ranks before it)
 #pragma unroll
-            for (int j_ = 0; j_ < 4; j_++) sl4_.h[j_] = sl4_.h[j_] && (sl4_.tm[j_] <= ct_);
-            NRT_STEP_NODE4_SL(sl4_, w);
-          } else {
-            const WideNode<float> w = wide[cur];
-            NRT_STEP_NODE(w);
-          }
+          for (int j_ = 0; j_ < 4; j_++) sl4_.h[j_] = sl4_.h[j_] && (sl4_.tm[j_] <= ct_);
+          NRT_STEP_NODE4_SL(sl4_, w);
         }
         state = (in_top && state == W_LEAF) ? T_ENTER : state; // a top-level leaf: instances, not triangles
       }
@@ -2504,14 +2489,9 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
     if (STATS) st[11] += c2_ - c1_;
     if (__ballot(state == W_LEAF) != 0ull) {
       uint32_t lcnt = 0, first = 0;
-      if (state == W_LEAF) {
-        if (packed) {
-          lcnt = (cur >> kPackedFirstBits) + 1u;
-          first = cur & kPackedFirstMask;
-        } else {
-          lcnt = nodes[cur].data[0];
-          first = nodes[cur].data[1];
-        }
+      if (state == W_LEAF) { // (packed leaf references: scene.hip checks)
+        lcnt = (cur >> kPackedFirstBits) + 1u;
+        first = cur & kPackedFirstMask;
       }
       for (uint32_t k = 0; __ballot(k < lcnt) != 0ull; k += 2u) {
         if (STATS) {
