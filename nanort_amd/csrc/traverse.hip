@@ -1912,6 +1912,27 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse_w8(const TraverseAr
 // free).  Since round 4 this kernel traces small scenes and the rays the single-pass walk (k_scene_walk, below) hands over;
 // scenes of thousands of instances go through that walk, which keeps no list at all.
 // ---------------------------------------------------------------------------
+// A record fetched through a per-lane pointer that came out of memory (an instance's array bases in the scene kernels) is a FLAT
+// access as far as the compiler can tell — flat loads also take a slot of the LDS queue and wait on both counters.  These
+// pointers are device-memory addresses: say so (address space 1) and the loads become global_load.
+template <typename R>
+__device__ __forceinline__ R load_global_record(const R *p) {
+  R r;
+  if constexpr (sizeof(R) % 16 == 0 && alignof(R) >= 16) {
+    typedef uint32_t u4g __attribute__((ext_vector_type(4)));
+    const u4g __attribute__((address_space(1))) *g = (const u4g __attribute__((address_space(1))) *)p;
+    u4g *d = reinterpret_cast<u4g *>(&r);
+#pragma unroll
+    for (unsigned q = 0; q < sizeof(R) / 16; q++) d[q] = g[q];
+  } else {
+    static_assert(sizeof(R) % 4 == 0, "whole words");
+    const uint32_t __attribute__((address_space(1))) *g = (const uint32_t __attribute__((address_space(1))) *)p;
+    uint32_t *d = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+    for (unsigned q = 0; q < sizeof(R) / 4; q++) d[q] = g[q]; // (neighbouring words: the compiler merges them into the widest loads the alignment allows)
+  }
+  return r;
+}
 enum : int { S_NEXT = 4, S_FIN = 5, S_DONE = 6 }; // besides W_TRAV / W_LEAF / W_POP: pick the next candidate / a local walk ended / ray finished
 
 __device__ __forceinline__ void scene_mult_v(float dst[3], const float m[4][4], const float v[3]) { // Matrix::MultV, nanosg.h:232-240
@@ -2114,10 +2135,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
       }
       if (state == W_TRAV) {
         if (wide4 != nullptr) { // (trees whose child boxes lie inside their parents': two levels per step, NRT_STEP_NODE4)
-          const Wide4Node<float> w = wide4[cur];
+          const Wide4Node<float> w = load_global_record(wide4 + cur);
           NRT_STEP_NODE4(w);
         } else {
-          const WideNode<float> w = wide[cur];
+          const WideNode<float> w = load_global_record(wide + cur);
           NRT_STEP_NODE(w);
         }
       }
@@ -2141,8 +2162,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
       for (uint32_t k = 0; __ballot(k < lcnt) != 0ull; k += 2u) { // two records per trip, as in k_traverse_wide
         if (k < lcnt) { // (divergent on purpose: the lanes' record arrays differ)
           const bool two = k + 1u < lcnt;
-          const LeafTri<float> t0 = tris[first + k];
-          const LeafTri<float> t1 = tris[first + (two ? k + 1u : k)];
+          const LeafTri<float> t0 = load_global_record(tris + first + k);
+          const LeafTri<float> t1 = load_global_record(tris + first + (two ? k + 1u : k));
           tri_test<float, true>(L, t0, true, 0u, 0u, 0u, false); // default trace options (nanosg.h:817)
           tri_test<float, true>(L, t1, two, 0u, 0u, 0u, false);
         }
@@ -2471,7 +2492,7 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
           st[5] += (unsigned)__builtin_popcountll(__ballot(state == W_TRAV && in_top));
         }
         if (state == W_TRAV) {
-          const Wide4Node<float> w = wide4[cur];
+          const Wide4Node<float> w = load_global_record(wide4 + cur);
           Slab4<float> sl4_ = slab4(L, w);
           const float ct_ = in_top ? cull_t : __builtin_huge_valf(); // (in the top-level tree: nothing entered beyond a nearer hit that ranks before it)
 #pragma unroll
@@ -2500,8 +2521,8 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
         }
         if (k < lcnt) {
           const bool two = k + 1u < lcnt;
-          const LeafTri<float> t0 = tris[first + k];
-          const LeafTri<float> t1 = tris[first + (two ? k + 1u : k)];
+          const LeafTri<float> t0 = load_global_record(tris + first + k);
+          const LeafTri<float> t1 = load_global_record(tris + first + (two ? k + 1u : k));
           tri_test<float, true>(L, t0, true, 0u, 0u, 0u, false); // default trace options (nanosg.h:817)
           tri_test<float, true>(L, t1, two, 0u, 0u, 0u, false);
         }
