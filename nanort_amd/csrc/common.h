@@ -213,7 +213,7 @@ struct SceneInst {
   float inv_xform[4][4];      // world -> local, points
   float inv_xform33[4][4];    // world -> local, directions
   float xform[4][4];          // local -> world
-  float xbmin[3], xbmax[3];   // world box (k_scene_walk: the copy of this table in top-level-tree order lets one fetch open an instance)
+  float xbmin[3], xbmax[3];   // world box
   uint32_t id, pad2;          // instance id (== its index in the by-id table)
 };
 static_assert(sizeof(SceneInst) == 272, "SceneInst");
@@ -265,7 +265,7 @@ struct SceneWalkArgs {
   uint32_t n;
   const SceneOpen *open_top;         // see SceneOpen
   const SceneMesh *meshes;
-  const SceneInst *insts_top;        // the full instance table in the same order (its xform is read when an instance was hit)
+  const SceneInst *insts;            // the full instance table, by id (its xform is read when an instance was hit)
   const Wide4Node<float> *top_wide4; // the top-level tree over the instances' world boxes (root is a branch, nested, packed leaves)
   nrt_scene_hit_f32 *hits;
   uint8_t *mask;

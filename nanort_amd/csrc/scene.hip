@@ -451,7 +451,7 @@ struct nrt_scene {
   bool have_top = false;         // a top-level tree exists (two nodes or more): the single-pass walk uses it
   uint32_t max_inst_depth = 0;   // deepest instance tree: sizes the overflow stack of k_scene_trace
   nrt::DevBuf d_nodes, d_insts, d_rays, d_list_t, d_list_node, d_count, d_best, d_mask, d_spill, d_spill_tmin, d_cursor;
-  nrt::DevBuf d_redo, d_redo_count, d_counters, d_insts_top, d_open_top, d_meshes;
+  nrt::DevBuf d_redo, d_redo_count, d_counters, d_open_top, d_meshes;
   bool walk_meshes_ok = false; // every mesh of the scene has the private layout k_scene_walk steps through (else: the listing path)
   unsigned count_loops = 0; // profiling build only (tunable "count_loops"): the next calls run the counting instantiation of k_scene_walk
   uint32_t *h_redo_count = nullptr; // page-locked: how many rays the single-pass walk left to the listing path
@@ -512,7 +512,7 @@ void nrtSceneDestroy(nrt_scene *s) {
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
   nrt::DevBuf *bufs[] = {&s->d_nodes, &s->d_insts, &s->d_rays, &s->d_list_t, &s->d_list_node, &s->d_count,
-                         &s->d_best,  &s->d_mask,  &s->d_spill, &s->d_spill_tmin, &s->d_cursor, &s->d_redo, &s->d_redo_count, &s->d_counters, &s->d_insts_top, &s->d_open_top, &s->d_meshes};
+                         &s->d_best,  &s->d_mask,  &s->d_spill, &s->d_spill_tmin, &s->d_cursor, &s->d_redo, &s->d_redo_count, &s->d_counters, &s->d_open_top, &s->d_meshes};
   for (nrt::DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (s->h_redo_count) (void)hipHostFree(s->h_redo_count);
@@ -620,7 +620,7 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
     if (nrtSetCylinders_f32(s->top, ends.data(), radii.data(), (uint32_t)s->insts.size(), 0) != NRT_OK ||
         nrtBuild_f32(s->top, &o, nullptr, nullptr) != NRT_OK || nrt_internal_tree_view(s->top, &s->top_view) != NRT_OK)
       return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level build: %s", nrtLastError(s->top));
-    // the single-pass walk opens an instance with ONE fetch: the instance table once more, in the order of the tree's index array
+    // the single-pass walk opens an instance with ONE fetch: a 128-byte line per instance, in the order of the tree's index array
     {
       uint64_t nn = 0, ni = 0;
       if (nrtTreeSize(s->top, &nn, &ni) != NRT_OK || ni != s->insts.size())
@@ -628,11 +628,9 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
       std::vector<uint32_t> order(ni);
       if (nrtGetTree_f32(s->top, nullptr, order.data()) != NRT_OK)
         return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level index array: %s", nrtLastError(s->top));
-      std::vector<nrt::SceneInst> sorted(ni);
-      std::vector<nrt::SceneOpen> open(ni); // (the 128-byte line an opening reads; the full record only when the instance was hit)
+      std::vector<nrt::SceneOpen> open(ni); // (the 128-byte line an opening reads; the full record, by id, only when the instance was hit)
       for (size_t q = 0; q < ni; q++) {
         const nrt::SceneInst &e = table[order[q]];
-        sorted[q] = e;
         nrt::SceneOpen &o = open[q];
         for (int r = 0; r < 4; r++)
           for (int c = 0; c < 3; c++) {
@@ -644,8 +642,6 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
         o.id = e.id;
         o.mesh = mesh_of[order[q]];
       }
-      SCHK(s, nrt::devbuf_ensure(&s->d_insts_top, sorted.size() * sizeof(nrt::SceneInst)));
-      SCHK(s, hipMemcpy(s->d_insts_top.p, sorted.data(), sorted.size() * sizeof(nrt::SceneInst), hipMemcpyHostToDevice));
       SCHK(s, nrt::devbuf_ensure(&s->d_open_top, open.size() * sizeof(nrt::SceneOpen)));
       SCHK(s, hipMemcpy(s->d_open_top.p, open.data(), open.size() * sizeof(nrt::SceneOpen), hipMemcpyHostToDevice));
       std::vector<nrt::SceneMesh> mt(meshes.size());
@@ -830,7 +826,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     w.n = n;
     w.open_top = (const nrt::SceneOpen *)s->d_open_top.p;
     w.meshes = (const nrt::SceneMesh *)s->d_meshes.p;
-    w.insts_top = (const nrt::SceneInst *)s->d_insts_top.p;
+    w.insts = (const nrt::SceneInst *)s->d_insts.p;
     w.top_wide4 = (const nrt::Wide4Node<float> *)s->top_view.wide4;
     w.hits = d_hits;
     w.mask = d_mask;

@@ -2255,7 +2255,7 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
   int state = S_DONE, sp = 0, base = 0;
   bool in_top = true, tame = true;
   float cur_tmin = 0.f; // box entry distance of the open instance
-  uint32_t inst = 0, itop = 0, traced = 0; // the open instance's id and its position in the top-level order; instances opened so far
+  uint32_t inst = 0, traced = 0; // the open instance's id; instances opened so far
   float best_t = 3.402823466e+38f, best_tmin = 0.f, t2 = __builtin_huge_valf(); // winner's distance and box entry; runner-up distance
   float cull_t = __builtin_huge_valf();
   uint32_t best_id = 0;
@@ -2359,7 +2359,7 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
         }
         if (state == S_FIN) {
           if (L.hit_t < L.max_t) { // the local Traverse() hit (strict final predicate, nanort.h:2552)
-            const SceneInst &nd = a.insts_top[itop];
+            const SceneInst &nd = a.insts[inst]; // (the full record, by id: only an instance that was hit needs its xform)
             float lp[3], wp[3];
             lp[0] = L.org0 + L.hit_t * L.d0; // nanosg.h:823-825
             lp[1] = L.org1 + L.hit_t * L.d1;
@@ -2415,7 +2415,12 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
           tmx = (g2 < tmx) ? g2 : tmx;
           // ... then NodeBBoxIntersector::Intersect (nanosg.h:603-639): the unclipped interval by the PLAIN reciprocal (for a tame
           // ray the same numbers as above), whose near end the list is sorted by
-          const float p0 = 1.0f / wdir[0], p1 = 1.0f / wdir[1], p2 = 1.0f / wdir[2];
+          float p0 = winv[0], p1 = winv[1], p2 = winv[2]; // (a tame ray's safe reciprocal IS the plain one: the same division)
+          if (!tame) {
+            p0 = 1.0f / wdir[0];
+            p1 = 1.0f / wdir[1];
+            p2 = 1.0f / wdir[2];
+          }
           const float a0 = ((s0 ? bx[3] : bx[0]) - worg[0]) * p0, a1 = ((s1 ? bx[4] : bx[1]) - worg[1]) * p1,
                       a2 = ((s2 ? bx[5] : bx[2]) - worg[2]) * p2;
           const float b0 = ((s0 ? bx[0] : bx[3]) - worg[0]) * p0, b1 = ((s1 ? bx[1] : bx[4]) - worg[1]) * p1,
@@ -2430,7 +2435,6 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
             state = W_POP; // (still in the top-level tree)
           } else {
             inst = k;
-            itop = lfirst;
             cur_tmin = e;
             traced++;
             nrt_ray_f32 lr;
