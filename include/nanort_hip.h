@@ -432,11 +432,12 @@ NRT_API nrt_status nrtSceneTraverseBatch_f32(nrt_scene *scene, const nrt_ray_f32
  * sure `d_rays` is complete before calling. */
 NRT_API nrt_status nrtSceneTraverseBatchDevice_f32(nrt_scene *scene, const nrt_ray_f32 *d_rays, uint64_t num_rays,
                                                    nrt_scene_hit_f32 *d_hits_out, uint8_t *d_mask_out);
-/* Scheduling knobs of the scene kernels by name (they never change a result): "single_pass" (1: scenes of 2048 nodes or more
+/* Scheduling knobs of the scene kernels by name (they never change a result): "single_pass" (1: scenes of 64 nodes or more
  * are traced by the single-pass walk — top-level tree and instance trees on one stack, no per-ray list; rays it cannot certify
- * are re-done by the listing path; 2: every scene of two nodes or more; 0: listing + trace for every ray), "trav_min", "refill_min", "cand_min",
+ * are re-done by the listing path; 2: every scene of two nodes or more; 0: listing + trace for every ray), "trav_min", "refill_min"
+ * (listing path), "walk_trav_min", "walk_refill_min" (the walk's), "cand_min",
  * "cand_busy_max" (lane-count thresholds of the phases), "prune_min" (instance count from which the listing prunes beyond a
- * full list), "walk_min" (instance count from which single_pass = 1 uses the walk; 2048).  After a batch of which the walk had to
+ * full list), "walk_min" (instance count from which single_pass = 1 uses the walk; 64).  After a batch of which the walk had to
  * hand more than a quarter ("walk_backoff_pct", 25) to the listing path (direction vectors far shorter than 1, where the reference's cull compares a
  * distance with a parameter) the next 15 calls use the listing path directly. */
 NRT_API nrt_status nrtSceneSetTunable(nrt_scene *scene, const char *name, int value);

@@ -59,8 +59,8 @@ constexpr int kMaxList = 64; // kMaxIntersections, nanosg.h:782
 constexpr int kTopStack = 64; // per-ray stack of the top-level walk (a deeper top-level tree falls back to the scan)
 constexpr uint32_t kScanMaxNodes = 8; // scenes of at most this many nodes are listed by the scan
 constexpr unsigned kWalkBackoff = 15;   // listing-path calls after a batch of which the walk handed over more than a quarter
-constexpr uint32_t kWalkMinNodes = 2048; // scenes of at least this many nodes are traced by the single-pass walk (1 000 instances: on par with the
-                                        // listing path, 5: 6 % slower, 10 000: 1.5x, 100 000: 7.7x faster — profiles/r04n_scene_walk.txt)
+constexpr uint32_t kWalkMinNodes = 64; // scenes of at least this many nodes are traced by the single-pass walk (100 - 1 000 instances: 5-8 % faster than the
+                                      // listing path, 10 000: 1.7x, 100 000: 9x; the 5-node fixture: 6-20 % slower — profiles/r04n_scene_walk.txt, r04t_*)
 
 // Matrix::MultV — nanosg.h:232-240
 __host__ __device__ inline void mult_v(float dst[3], const float m[4][4], const float v[3]) {
@@ -459,6 +459,7 @@ struct nrt_scene {
   unsigned single_pass = 1;   // scenes of kWalkMinNodes nodes or more are traced by k_scene_walk (no per-ray list); 0: always listing +
                               // k_scene_trace; 2: k_scene_walk for every scene of two nodes or more
   unsigned walk_blocks_per_cu = 0;
+  unsigned walk_trav_min = 24, walk_refill_min = 24; // the walk's own phase thresholds (profiles/r04t_scene_walk_thresholds.txt: 8 / 56, the listing path's, cost it 10-13 %)
   unsigned walk_backoff = 0;  // calls left that skip the walk (see scene_traverse)
   unsigned walk_backoff_pct = 25; // share of a batch handed to the listing path above which the next kWalkBackoff calls skip the walk (tunable)
   unsigned walk_min = kWalkMinNodes; // scenes of at least this many nodes are traced by the walk (tunable "walk_min")
@@ -791,6 +792,8 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     if (const char *e = getenv("NRT_SCENE_CAND")) s->cand_min = (unsigned)std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_CAND_BUSY")) s->cand_busy_max = (unsigned)std::min(65, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_PRUNE_MIN")) s->prune_min = (unsigned)std::max(0, atoi(e)); // (debugging / tests: the pruning walk on small scenes)
+    if (const char *e = getenv("NRT_SCENE_WALK_TRAV")) s->walk_trav_min = (unsigned)std::min(64, std::max(1, atoi(e)));
+    if (const char *e = getenv("NRT_SCENE_WALK_REFILL")) s->walk_refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_WALK")) s->single_pass = (unsigned)std::min(2, std::max(0, atoi(e)));
   }
   SCHK(s, nrt::devbuf_ensure(&s->d_cursor, (size_t)nrt::kMaxParts * nrt::kCursorStrideWords * sizeof(uint32_t)));
@@ -835,8 +838,8 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     w.spill_stride = grid * 256u;
     w.cursor = (uint32_t *)s->d_cursor.p;
     w.num_parts = std::max(1u, std::min(8u, grid));
-    w.refill_min = s->refill_min;
-    w.trav_min = s->trav_min;
+    w.refill_min = s->walk_refill_min;
+    w.trav_min = s->walk_trav_min;
     w.cand_min = s->cand_min;
     w.cand_busy_max = s->cand_busy_max;
     w.redo = (uint32_t *)s->d_redo.p;
@@ -889,6 +892,8 @@ nrt_status nrtSceneSetTunable(nrt_scene *s, const char *name, int value) {
   if (k == "single_pass") s->single_pass = (unsigned)std::min(2, std::max(0, value));
   else if (k == "trav_min") s->trav_min = lanes;
   else if (k == "refill_min") s->refill_min = lanes;
+  else if (k == "walk_trav_min") s->walk_trav_min = lanes;
+  else if (k == "walk_refill_min") s->walk_refill_min = lanes;
   else if (k == "cand_min") s->cand_min = lanes;
   else if (k == "cand_busy_max") s->cand_busy_max = (unsigned)std::min(65, std::max(1, value));
   else if (k == "prune_min") s->prune_min = (unsigned)std::max(0, value);

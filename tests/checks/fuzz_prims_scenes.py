@@ -169,8 +169,10 @@ def scene_round():
     # which path traces the scene (0: listing + trace, 2: the single-pass walk whatever the size, 1: the default rule) and the
     # thresholds of its phases never change a record
     sc.SetTunable("single_pass", int(rng.choice([0, 1, 2, 2])))
-    sc.SetTunable("trav_min", int(rng.choice([1, 8, 24, 64])))
-    sc.SetTunable("refill_min", int(rng.choice([1, 32, 56, 64])))
+    for name in ("trav_min", "walk_trav_min"):
+        sc.SetTunable(name, int(rng.choice([1, 8, 24, 64])))
+    for name in ("refill_min", "walk_refill_min"):
+        sc.SetTunable(name, int(rng.choice([1, 24, 56, 64])))
     sc.SetTunable("cand_min", int(rng.choice([1, 1, 16])))
     spread = max(2.0, float(np.abs(np.array(centres)).max()))
     pts = np.array(centres, dtype=np.float32) + rng.normal(size=(count, 3)).astype(np.float32) * 0.3

@@ -346,7 +346,7 @@ def test_single_pass_walk_equals_the_listing_path_and_the_restatement(oracle, di
     rays["dir"][50:80, 1] = -0.0
     rays = np.concatenate([rays, scenes.camera_rays(96, 64)])
     oh, om = O.traverse(rays)
-    sc.SetTunable("single_pass", 2)  # (the default rule sends scenes below 2048 nodes to the listing path)
+    sc.SetTunable("single_pass", 2)  # (whatever the default size rule says)
     h1, m1 = sc.TraverseBatch(rays)
     redone = sc.LastRedone()
     sc.SetTunable("single_pass", 0)
@@ -372,7 +372,7 @@ def test_single_pass_walk_equals_the_listing_path_and_the_restatement(oracle, di
         assert seen[0] == redone and seen[1] == 0 and seen[2] == 0
     # thresholds of the phases never change a record
     sc.SetTunable("single_pass", 2)
-    for name, value in (("trav_min", 1), ("trav_min", 32), ("refill_min", 8), ("cand_min", 16)):
+    for name, value in (("walk_trav_min", 1), ("walk_trav_min", 48), ("walk_refill_min", 1), ("walk_refill_min", 64), ("cand_min", 16)):
         sc.SetTunable(name, value)
         h2, m2 = sc.TraverseBatch(rays)
         assert np.array_equal(m2, om) and fields_equal(h2, oh, ("t", "u", "v", "prim_id", "node_id")), (name, value)
