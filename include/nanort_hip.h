@@ -443,6 +443,9 @@ NRT_API nrt_status nrtSceneTraverseBatchDevice_f32(nrt_scene *scene, const nrt_r
 NRT_API nrt_status nrtSceneSetTunable(nrt_scene *scene, const char *name, int value);
 /* How many rays of the last nrtSceneTraverseBatch* call the single-pass walk handed to the listing path. */
 NRT_API uint64_t nrtSceneLastRedone(const nrt_scene *scene);
+/* Which path the last nrtSceneTraverseBatch* call took: 1 = the single-pass walk (plus the listing path for the rays it handed
+ * over), 0 = the listing path alone (small scenes, single_pass = 0, a mesh whose tree the walk cannot step through, back-off). */
+NRT_API int nrtSceneLastPath(const nrt_scene *scene);
 
 #ifdef __cplusplus
 }

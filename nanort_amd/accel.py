@@ -414,6 +414,10 @@ class Scene:
         """Rays of the last call that the single-pass walk handed to the listing path (nrtSceneLastRedone)."""
         return int(self._L.nrtSceneLastRedone(self._h))
 
+    def LastPath(self):
+        """1: the last call went through the single-pass walk, 0: the listing path alone (nrtSceneLastPath)."""
+        return int(self._L.nrtSceneLastPath(self._h))
+
     def TraverseBatch(self, rays):
         from .wire import RAY_F32, SCENE_HIT_F32
 

@@ -29,7 +29,7 @@ SYMBOLS = [
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
     "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtGetWide8_f32", "nrtHostAlloc", "nrtHostFree",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
-    "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32", "nrtSceneSetTunable", "nrtSceneLastRedone",
+    "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32", "nrtSceneSetTunable", "nrtSceneLastRedone", "nrtSceneLastPath",
 ]
 
 
@@ -145,6 +145,8 @@ def lib():
     L.nrtSceneSetTunable.restype = i32
     L.nrtSceneLastRedone.argtypes = [vp]
     L.nrtSceneLastRedone.restype = u64
+    L.nrtSceneLastPath.argtypes = [vp]
+    L.nrtSceneLastPath.restype = i32
     L.nrtHostAlloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
     L.nrtHostAlloc.restype = i32
     L.nrtHostFree.argtypes = [vp]

@@ -259,7 +259,11 @@ static_assert(sizeof(SceneOpen) == 128, "SceneOpen");
 struct SceneMesh { // per distinct mesh context: its private traversal arrays (two levels per step, packed leaf references)
   const void *wide4;
   const void *tris;
+  uint32_t root_leaf;  // the tree is ONE leaf (a quad, a billboard): no records to step through — its box is tested, then its triangles
+  uint32_t leaf_ref;   // ... that leaf's packed reference (count - 1, first)
+  float bmin[3], bmax[3]; // ... and node 0's box
 };
+static_assert(sizeof(SceneMesh) == 48, "SceneMesh");
 struct SceneWalkArgs {
   const nrt_ray_f32 *rays;
   uint32_t n;

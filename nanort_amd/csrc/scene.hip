@@ -456,6 +456,7 @@ struct nrt_scene {
   unsigned count_loops = 0; // profiling build only (tunable "count_loops"): the next calls run the counting instantiation of k_scene_walk
   uint32_t *h_redo_count = nullptr; // page-locked: how many rays the single-pass walk left to the listing path
   uint64_t last_redone = 0;
+  int last_path = 0; // 1: the last call went through the single-pass walk (0: the listing path alone)
   unsigned single_pass = 1;   // scenes of kWalkMinNodes nodes or more are traced by k_scene_walk (no per-ray list); 0: always listing +
                               // k_scene_trace; 2: k_scene_walk for every scene of two nodes or more
   unsigned walk_blocks_per_cu = 0;
@@ -649,9 +650,19 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
       s->walk_meshes_ok = true; // the walk steps two levels at a time through packed leaf references, from a branch root whose children lie inside it
       for (size_t m = 0; m < meshes.size(); m++) {
         const nrt::TreeViewF32 &tv = meshes[m].second.tv;
+        const nrt_node_f32 &root = meshes[m].second.root;
+        memset(&mt[m], 0, sizeof(mt[m]));
         mt[m].wide4 = tv.wide4;
         mt[m].tris = tv.prims;
-        s->walk_meshes_ok = s->walk_meshes_ok && tv.wide4 && tv.tree_nested && tv.root_is_branch && tv.packed_leaves;
+        const bool one_leaf = !tv.root_is_branch && root.flag != 0 && root.data[0] >= 1 && root.data[0] <= nrt::kPackedMaxCount &&
+                              root.data[1] <= nrt::kPackedFirstMask;
+        if (one_leaf) {
+          mt[m].root_leaf = 1;
+          mt[m].leaf_ref = ((root.data[0] - 1u) << nrt::kPackedFirstBits) | root.data[1];
+          memcpy(mt[m].bmin, root.bmin, sizeof(mt[m].bmin));
+          memcpy(mt[m].bmax, root.bmax, sizeof(mt[m].bmax));
+        }
+        s->walk_meshes_ok = s->walk_meshes_ok && tv.prims && (one_leaf || (tv.wide4 && tv.tree_nested && tv.root_is_branch && tv.packed_leaves));
       }
       SCHK(s, nrt::devbuf_ensure(&s->d_meshes, mt.size() * sizeof(nrt::SceneMesh)));
       SCHK(s, hipMemcpy(s->d_meshes.p, mt.data(), mt.size() * sizeof(nrt::SceneMesh), hipMemcpyHostToDevice));
@@ -803,6 +814,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   if (!device) SCHK(s, hipMemcpyAsync(s->d_rays.p, rays, (size_t)n * sizeof(nrt_ray_f32), hipMemcpyHostToDevice, s->stream));
 
   s->last_redone = 0;
+  s->last_path = 0;
   const bool eligible = s->single_pass && s->have_top && (s->insts.size() >= s->walk_min || s->single_pass > 1) && s->walk_meshes_ok && s->top_view.wide4 &&
                         s->top_view.root_is_branch && s->top_view.tree_nested && s->top_view.packed_leaves;
   // a batch the walk could not certify for the most part (direction vectors far shorter than 1: the reference's cull then compares
@@ -811,6 +823,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
   const bool walk = eligible && (s->single_pass > 1 || s->walk_backoff == 0);
   if (eligible && !walk) s->walk_backoff--;
   if (walk) {
+    s->last_path = 1;
     if (!s->h_redo_count) SCHK(s, hipHostMalloc((void **)&s->h_redo_count, sizeof(uint32_t), hipHostMallocDefault));
     SCHK(s, nrt::devbuf_ensure(&s->d_redo, (size_t)n * sizeof(uint32_t)));
     SCHK(s, nrt::devbuf_ensure(&s->d_redo_count, sizeof(uint32_t)));
@@ -907,6 +920,7 @@ nrt_status nrtSceneSetTunable(nrt_scene *s, const char *name, int value) {
 }
 
 uint64_t nrtSceneLastRedone(const nrt_scene *s) { return s ? s->last_redone : 0; }
+int nrtSceneLastPath(const nrt_scene *s) { return s ? s->last_path : 0; }
 
 #ifdef NRT_PROF // libnanort_hip_prof.so only (include/nanort_hip_prof.h)
 int nrtSceneDebugCounters(nrt_scene *s, unsigned long long *out, int cap) {

@@ -2455,7 +2455,11 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
             in_top = false;
             base = sp;
             cur = 0u;
-            state = W_TRAV; // (every tree this kernel walks has a branch root whose children's boxes lie inside it: scene.hip checks)
+            state = W_TRAV; // (a branch root whose children's boxes lie inside it: scene.hip checks ...)
+            if (mesh.root_leaf) { // (... or a tree of one leaf: node 0's own box test, nanort.h:2526-2531, then its triangles)
+              cur = mesh.leaf_ref;
+              state = slab_test<float>(L, mesh.bmin, mesh.bmax) ? W_LEAF : S_FIN;
+            }
           }
         } else if (state == S_END) {
           const bool certified = traced <= 64u && (!has_hit || t2 >= best_tmin);

@@ -349,9 +349,10 @@ def test_single_pass_walk_equals_the_listing_path_and_the_restatement(oracle, di
     sc.SetTunable("single_pass", 2)  # (whatever the default size rule says)
     h1, m1 = sc.TraverseBatch(rays)
     redone = sc.LastRedone()
+    assert sc.LastPath() == 1
     sc.SetTunable("single_pass", 0)
     h0, m0 = sc.TraverseBatch(rays)
-    assert sc.LastRedone() == 0
+    assert sc.LastRedone() == 0 and sc.LastPath() == 0
     assert np.array_equal(m0, om) and fields_equal(h0, oh, ("t", "u", "v", "prim_id", "node_id"))
     assert np.array_equal(m1, om) and fields_equal(h1, oh, ("t", "u", "v", "prim_id", "node_id"))
     assert redone < len(rays)  # the walk itself finished the bulk ...
@@ -369,10 +370,49 @@ def test_single_pass_walk_equals_the_listing_path_and_the_restatement(oracle, di
             h3, m3 = sc.TraverseBatch(rays)
             seen.append(sc.LastRedone())
             assert np.array_equal(m3, om) and fields_equal(h3, oh, ("t", "u", "v", "prim_id", "node_id"))
-        assert seen[0] == redone and seen[1] == 0 and seen[2] == 0
+        assert seen[0] == redone and seen[1] == 0 and seen[2] == 0 and sc.LastPath() == 0
     # thresholds of the phases never change a record
     sc.SetTunable("single_pass", 2)
     for name, value in (("walk_trav_min", 1), ("walk_trav_min", 48), ("walk_refill_min", 1), ("walk_refill_min", 64), ("cand_min", 16)):
         sc.SetTunable(name, value)
         h2, m2 = sc.TraverseBatch(rays)
         assert np.array_equal(m2, om) and fields_equal(h2, oh, ("t", "u", "v", "prim_id", "node_id")), (name, value)
+
+
+def test_walk_opens_one_leaf_meshes_too(oracle):
+    """Instances of a mesh whose tree is ONE leaf (a quad: two triangles) next to instances of a sphere: the single-pass walk
+    tests node 0's box and goes straight to the triangles.  Every field equals the restatement; the walk (not the listing path)
+    did the work."""
+    from scene_fixture import xform
+
+    rng = np.random.default_rng(33)
+    qv = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], dtype=np.float32)
+    qf = np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32)
+    sv, sf = scenes.sphere(12, 6)
+    sv = (sv - np.array([0, 5, 0], dtype=np.float32)).astype(np.float32)
+    meshes = []
+    for v, f in ((qv, qf), (sv, sf)):
+        a = BVHAccel(np.float32)
+        assert a.Build(f.shape[0], TriangleMesh(v, f))
+        meshes.append((v, f, a, a.GetTree()))
+    assert meshes[0][3][0].shape[0] == 1  # the quad's tree: one node, a leaf
+    sc = Scene()
+    O = ob.SceneOracle(oracle)
+    for k in range(400):
+        v, f, a, tree = meshes[0 if k % 3 else 1]
+        s = rng.uniform(0.1, 0.6, 3) if k % 3 else rng.uniform(0.03, 0.1, 3)
+        x = xform(tuple(s), rng.uniform(0, 6.28), rng.uniform(0, 6.28), tuple(rng.uniform(-5, 5, 3) + np.array([0, 5, 0])))
+        sc.AddNode(a, x)
+        O.add_node(v, f, x, tree=tree)
+    assert sc.Commit() and O.commit()
+    rays = scenes.camera_rays(200, 120)
+    rays["org"] += rng.uniform(-0.5, 0.5, size=(rays.shape[0], 3)).astype(np.float32)
+    oh, om = O.traverse(rays)
+    h, m = sc.TraverseBatch(rays)
+    assert sc.LastPath() == 1 and sc.LastRedone() < len(rays) // 4  # 400 nodes: the walk's, and it certified the bulk
+    assert 0.05 < om.mean() < 0.99
+    assert np.array_equal(m, om) and fields_equal(h, oh, ("t", "u", "v", "prim_id", "node_id"))
+    sc.SetTunable("single_pass", 0)
+    h0, m0 = sc.TraverseBatch(rays)
+    assert sc.LastPath() == 0
+    assert np.array_equal(m0, om) and fields_equal(h0, oh, ("t", "u", "v", "prim_id", "node_id"))
