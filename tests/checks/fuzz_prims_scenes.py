@@ -150,7 +150,9 @@ def scene_round():
         cube_f = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4],
                            [1, 5, 7], [1, 7, 3]], dtype=np.uint32)
         MESHES = []
-        for v, f in ((sv.astype(np.float32), sf), (pv.astype(np.float32) * 0.2, pf), (g, cube_f)):
+        quad_v = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], dtype=np.float32)  # a one-leaf tree
+        quad_f = np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32)
+        for v, f in ((sv.astype(np.float32), sf), (pv.astype(np.float32) * 0.2, pf), (g, cube_f), (quad_v, quad_f)):
             a = BVHAccel(np.float32)
             assert a.Build(f.shape[0], TriangleMesh(v, f))
             MESHES.append((v, f, a, a.GetTree()))
