@@ -427,9 +427,10 @@ NRT_API nrt_status nrtSceneTraverseBatch_f32(nrt_scene *scene, const nrt_ray_f32
                                              nrt_scene_hit_f32 *hits_out, uint8_t *hit_mask_out);
 
 /* The same traversal with rays and results resident in HBM (device pointers; d_mask_out may be NULL): no PCIe traffic.
- * Two launches on the scene's own stream (the listing over the top-level BVH, then one trace kernel for the whole batch)
- * and one synchronisation at the end: the call is SYNCHRONOUS (the scene owns the per-ray lists), and the caller makes
- * sure `d_rays` is complete before calling. */
+ * On the scene's own stream: scenes of 64 nodes or more — ONE launch of the single-pass walk (top-level tree and instance trees on
+ * one per-lane stack, no per-ray list), a 4-byte read-back, and only if the walk handed rays over, the two launches below on
+ * those; smaller scenes — two launches (the listing over the top-level BVH, then one trace kernel for the whole batch).  The call
+ * is SYNCHRONOUS (the scene owns the per-ray scratch), and the caller makes sure `d_rays` is complete before calling. */
 NRT_API nrt_status nrtSceneTraverseBatchDevice_f32(nrt_scene *scene, const nrt_ray_f32 *d_rays, uint64_t num_rays,
                                                    nrt_scene_hit_f32 *d_hits_out, uint8_t *d_mask_out);
 /* Scheduling knobs of the scene kernels by name (they never change a result): "single_pass" (1: scenes of 64 nodes or more
