@@ -105,3 +105,26 @@ def test_more_than_64_boxes_entered_loses_the_certificate_not_the_result(oracle)
     rays["dir"] = np.array([0, 0, 1], dtype=np.float32)
     rays["max_t"] = 3.0e38
     check(O, rays, min_certified=0.0)
+
+
+def test_bounded_world_intervals_and_axis_parallel_rays(oracle):
+    """min_t > 0 and finite max_t on the WORLD ray clip only the box tests of the listing (the local rays ignore them,
+    nanosg.h:806 TODO) — and rays with zero direction components take the reference's vsafe_inverse / plain-reciprocal pair."""
+    rng = np.random.default_rng(14)
+    sv, sf = scenes.sphere(10, 5)
+    sv = sv - np.array([0, 5, 0], dtype=np.float32)
+    tree = oracle.build(sv, sf)[:2]
+    O = ob.SceneOracle(oracle)
+    for k in range(120):
+        O.add_node(sv, sf, xform(tuple(rng.uniform(0.05, 0.3, 3)), rng.uniform(0, 6.28), rng.uniform(0, 6.28),
+                                 tuple(np.round(rng.uniform(-3, 3, 3)) + np.array([0, 5, 0]))), tree=tree)
+    O.commit()
+    rays = ray_batch(rng, 3000, 1.0, spread=5.0)
+    rays["min_t"] = rng.choice([0.0, 0.5, 3.0], size=len(rays)).astype(np.float32)
+    rays["max_t"] = rng.choice([2.0, 6.0, 3.0e38], size=len(rays)).astype(np.float32)
+    axis = ray_batch(rng, 600, 1.0, spread=5.0)
+    axis["org"] = np.round(axis["org"])
+    axis["dir"][:] = 0.0
+    axis["dir"][np.arange(600), rng.integers(0, 3, 600)] = rng.choice([-1.0, 1.0], 600)
+    axis["dir"][:200] = np.where(axis["dir"][:200] == 0.0, -0.0, axis["dir"][:200])
+    check(O, np.concatenate([rays, axis]), min_certified=0.8)
