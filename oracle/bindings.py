@@ -168,6 +168,25 @@ class Oracle:
             return hits, mask, counters
         return hits, mask
 
+    def traverse_fused_slab_model(self, nodes, indices, verts, faces, rays, slack_ulps=2):
+        """MODEL (oracle/fused_slab_model.inc): inner boxes by the fused, conservative test, leaves re-tested exactly.
+        Returns (hits, mask, counters(nodes popped, leaves tested, triangles tested, inner nodes entered only by the fused test))."""
+        assert verts.dtype == np.float32 and nodes.dtype == node_dtype(np.float32) and rays.dtype == ray_dtype(np.float32)
+        faces = np.ascontiguousarray(faces, dtype=np.uint32)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        nodes = np.ascontiguousarray(nodes)
+        rays = np.ascontiguousarray(rays)
+        n = rays.shape[0]
+        hits = np.zeros((n,), dtype=hit_dtype(np.float32))
+        mask = np.zeros((n,), dtype=np.uint8)
+        counters = np.zeros((4,), dtype=np.uint64)
+        fn = self.L.orc_traverse_fused_slab_model_f32
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                       ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        fn.restype = None
+        fn(_p(nodes), _p(indices), _p(verts), 12, _p(faces), _p(rays), n, int(slack_ulps), _p(hits), _p(mask), _p(counters))
+        return hits, mask, counters
+
     def wide8_build(self, nodes, indices, verts, faces, collapse_mode=0):
         """The 8-wide compressed layout of a reference-format fp32 tree, built by the CPU MODEL (oracle/wide8_model.inc).
         Returns a Wide8Model (arrays + walk)."""
