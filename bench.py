@@ -158,7 +158,8 @@ def reference_order_results(wl):
         a.SetTunable("order4", was)
 
 
-def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, width, gpu_results=None, budget_s=12.0, gpu_results_ref_order=None):
+def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, width, gpu_results=None, budget_s=12.0, gpu_results_ref_order=None,
+                 timed_walk="default (the reference's slot order, tunable order4 = 0)"):
     """Reference (or port) timed on the host cores over a bounded sample of the same buffers; with `gpu_results` =
     (hits1, mask1, hits2, mask2) of the GPU's timed walk also the parity check of the same run (SURVEY 8d);
     `gpu_results_ref_order`: the same waves through the reference-order walk (reference_order_results)."""
@@ -220,9 +221,9 @@ def cpu_baseline(verts, faces, rays1, rays2, gpu_nodes, gpu_indices, width, gpu_
             th2, tm2, t2 = R.traverse(rays2, threads=best_t, chunk=width)
             out["value_on_gpu_built_tree"] = round(total / (t1 + t2) / 1e6, 4)
             if gpu_results is not None:
-                # same node array, the timed (default) walk: hit flags and t bit-equal, prim_id / u / v may differ at exact-t ties only
+                # same node array, the TIMED walk (the default walk: the reference's leaf sequence, so every count below is 0)
                 gh1, gm1, gh2, gm2 = gpu_results
-                out["parity_same_tree"] = {"walk": "default (slots entered by entry distance)",
+                out["parity_same_tree"] = {"walk": timed_walk,
                                            "primary": parity(th1, tm1, gh1, gm1), "bounce": parity(th2, tm2, gh2, gm2),
                                            "t_and_hit_flags_bit_identical": bool(np.array_equal(tm1, gm1) and np.array_equal(tm2, gm2) and
                                                                                  th1["t"].tobytes() == gh1["t"].tobytes() and th2["t"].tobytes() == gh2["t"].tobytes())}
@@ -372,6 +373,38 @@ def pipelined(accel, torch, wave1, wave2, steps, rays_per_step, frames_in_flight
     dt = time.perf_counter() - t0
     return {"frames_in_flight": frames_in_flight, "value": round(rays_per_step * steps / dt / 1e6, 1), "unit": "Mrays/s",
             "ms_per_step": round(dt / steps * 1e3, 4)}
+
+
+def opt_in_distance_order(wl, steps):
+    """The same K steps through the OPT-IN walk (tunable order4 = 1: a record's four slots entered by entry distance), into
+    scratch buffers, with its records compared with the timed default walk's on the same tree over BOTH whole waves.  Never
+    `value`: its parity class is the contract's, not bit identity."""
+    torch, a = wl.torch, wl.accel
+    h1, m1 = torch.empty_like(wl.d_hits1), torch.empty_like(wl.d_mask1)
+    h2, m2 = torch.empty_like(wl.d_hits2), torch.empty_like(wl.d_mask2)
+    ref = wl.results()
+    a.SetTunable("order4", 1)
+    try:
+        for _ in range(2):
+            a.TraverseBatchDevice(wl.d_rays1, h1, m1)
+            a.TraverseBatchDevice(wl.d_rays2, h2, m2)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(steps):
+            a.TraverseBatchDevice(wl.d_rays1, h1, m1)
+            a.TraverseBatchDevice(wl.d_rays2, h2, m2)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = float(ev[0].elapsed_time(ev[1])) / steps
+        kernel = a.LastKernelName()
+    finally:
+        a.SetTunable("order4", 0)
+    got = (h1.cpu().numpy().view(wl.HIT), m1.cpu().numpy(), h2.cpu().numpy().view(wl.HIT)[:wl.n2], m2.cpu().numpy()[:wl.n2])
+    return {"tunable": "order4 = 1", "kernel": kernel, "value": round((wl.n1 + wl.n2) / ms / 1e3, 1), "unit": "Mrays/s", "ms_per_step": round(ms, 4),
+            "vs_default_walk_same_tree": {"primary": parity(ref[0], ref[1], got[0], got[1]), "bounce": parity(ref[2], ref[3], got[2], got[3])},
+            "note": "opt-in: another leaf sequence than the reference's — among primitives at exactly the same t another one may be named "
+                    "(prim_id_mismatches, all of them at exact-t ties when within_tolerance is true)"}
 
 
 def multi_batch(accel, torch, wave1, wave2, steps, rays_per_step):
@@ -776,6 +809,81 @@ def measure_config(name, mesh_path=None, reps=5, parity_rays=200_000):
 
 
 # ---------------------------------------------------------------------------
+def dry_run(args):
+    """`bench.py --gpus N --dry-run`: everything a multi-GPU run can trip over BEFORE anything is launched — device count, the
+    environment the ranks need, the RCCL backend, the library and its symbols, the rendezvous port, tile divisibility and the
+    per-rank / root buffer sizes against the device's memory.  Prints one JSON object; exit code 0 when every check passes."""
+    import socket
+
+    checks = []
+
+    def check(name, ok, detail):
+        checks.append({"check": name, "ok": bool(ok), "detail": detail})
+
+    n = args.gpus
+    cfg = CONFIGS[args.config]
+    try:
+        import torch
+        import torch.distributed as td
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        check("devices", have >= n, "%d GPU(s) visible, %d requested" % (have, n))
+        check("rccl_backend", td.is_available() and td.is_nccl_available(), "torch.distributed nccl (== RCCL on ROCm) available: %s" % (td.is_available() and td.is_nccl_available()))
+        mem = [torch.cuda.get_device_properties(i).total_memory for i in range(min(have, n))]
+    except Exception as e:  # pragma: no cover
+        check("torch", False, repr(e))
+        have, mem = 0, []
+    ipc = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    check("hsa_ipc_mode", n == 1 or ipc in (None, "0"), "HSA_ENABLE_IPC_MODE_LEGACY=%r (bench.py exports 0 for the ranks it spawns; anything else breaks RCCL's "
+          "dmabuf IPC on this driver)" % ipc)
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    try:
+        socket.getaddrinfo(addr, None)
+        check("master_addr", True, "%s resolves" % addr)
+    except Exception as e:
+        check("master_addr", False, "%s does not resolve: %r (use 127.0.0.1)" % (addr, e))
+    port = int(os.environ.get("MASTER_PORT", 29500 + (os.getpid() % 2000)))
+    try:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", port))
+        sk.close()
+        check("master_port", True, "port %d is free" % port)
+    except Exception as e:
+        check("master_port", "MASTER_PORT" in os.environ and "WORLD_SIZE" in os.environ, "port %d: %r" % (port, e))
+    try:
+        from nanort_amd import capi
+
+        L = capi.lib()
+        missing = [f for f in ("nrtCreate", "nrtBuild_f32", "nrtTraverseBatchDevice_f32", "nrtTraverseBatchesDevice_f32") if not hasattr(L, f)]
+        check("library", not missing, "%s loads%s" % (capi.LIB_PATH, (", missing " + ",".join(missing)) if missing else ""))
+    except Exception as e:
+        check("library", False, repr(e))
+    W, H = cfg["w"], cfg["h"]
+    strong = cfg["scaling"] == "strong" and "tile_of" not in cfg
+    if strong:
+        check("tiles", H % n == 0, "%d rows over %d ranks: %s" % (H, n, "equal row-interleaved tiles of %d rows" % (H // max(1, n)) if H % n == 0 else "do not split equally"))
+    rows = H // (cfg.get("tile_of", 1) * n) if "tile_of" in cfg else (H // n if strong else H)
+    rb = 4 if cfg["real"] == "f32" else 8
+    ray_b, hit_b = (36, 16) if rb == 4 else (72, 32)
+    n1 = W * rows
+    if cfg["mesh"] == "sphere":
+        tris = 69696
+    else:
+        tris = 2 * cfg["mesh"][1] * cfg["mesh"][2]
+    # per rank: two waves of rays, two double-buffered record + flag sets, the tree and its private layouts, the build workspace
+    tree_b = tris * (12 + 9 * rb // 3 + 4) + 2 * tris * (40 if rb == 4 else 64) + tris * (40 if rb == 4 else 80) + 2 * tris * (64 + 128 if rb == 4 else 112) + tris * 170
+    per_rank = 2 * n1 * ray_b + 4 * n1 * (hit_b + 1) + tree_b
+    root_extra = 4 * n * n1 * hit_b  # the root's two double-buffered gather targets per wave
+    need = per_rank + root_extra
+    cap = min(mem) if mem else 288 * 10**9
+    check("memory", need < 0.8 * cap, "rank 0 needs about %.2f GB (%.2f GB per rank + %.2f GB of gather buffers at the root) of %.0f GB%s" % (
+        need / 1e9, per_rank / 1e9, root_extra / 1e9, cap / 1e9, "" if mem else " (nominal: no device visible)"))
+    check("gather", True, "%d x %d B = %.1f MB of hit records per wave reach the root over its direct xGMI links" % (n * n1, hit_b, n * n1 * hit_b / 1e6))
+    ok = all(c["ok"] for c in checks)
+    print(json.dumps({"dry_run": True, "ok": ok, "n_gpus": n, "config": args.config, "rays_per_rank_per_wave": n1, "checks": checks}), flush=True)
+    return 0 if ok else 2
+
+
 def self_spawn(args, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) and relay their output."""
     import torch
@@ -799,18 +907,20 @@ class Timed:
     max over ranks.  One step = wave 1 + wave 2 (+ for N > 1 the asynchronous, double-buffered gather of both waves' hit
     records to rank 0, every gather completing inside the region)."""
 
-    def __init__(self, wl, steps, warmup, world, rank, dist, shared):
+    def __init__(self, wl, steps, warmup, world, rank, dist, shared, check_gather=False):
         import torch
 
         from nanort_amd import dist as nd
 
         accel, n1, HIT = wl.accel, wl.n1, wl.HIT
         comm_dev = "cpu" if shared else "cuda"
-        nbuf = 2 if world > 1 else 1
+        # the exchange runs whenever a process group exists: N > 1, or N = 1 under --force-dist (the RCCL path on a one-GPU box)
+        use_dist = dist is not None
+        nbuf = 2 if use_dist else 1
         hit_bufs1 = [wl.d_hits1] + [torch.empty_like(wl.d_hits1) for _ in range(nbuf - 1)]
         hit_bufs2 = [wl.d_hits2] + [torch.empty_like(wl.d_hits2) for _ in range(nbuf - 1)]
         gathered1 = gathered2 = [None, None]
-        if world > 1 and rank == 0:
+        if use_dist and rank == 0:
             gathered1 = [torch.empty(world * n1 * HIT.itemsize, dtype=torch.uint8, device=comm_dev) for _ in range(2)]
             gathered2 = [torch.empty(world * n1 * HIT.itemsize, dtype=torch.uint8, device=comm_dev) for _ in range(2)]
         pending = [[None, None], [None, None]]  # [wave][buffer]
@@ -819,7 +929,7 @@ class Timed:
         def step(ev=None):
             b = step_no[0] % nbuf
             step_no[0] += 1
-            if world > 1:
+            if use_dist:
                 for w in (0, 1):
                     if pending[w][b] is not None:
                         pending[w][b].wait()  # the gathers that last used this buffer pair (two steps ago)
@@ -829,7 +939,7 @@ class Timed:
             accel.TraverseBatchDevice(wl.d_rays1, hit_bufs1[b], wl.d_mask1)
             if ev is not None:
                 ev[1].record()
-            if world > 1:
+            if use_dist:
                 src = hit_bufs1[b].cpu() if shared else hit_bufs1[b]  # (test hook: staged through the host for gloo)
                 _, pending[0][b] = nd.gather_hit_records(src, world, rank, dist, out=gathered1[b], async_op=True)
             if ev is not None:
@@ -837,7 +947,7 @@ class Timed:
             accel.TraverseBatchDevice(wl.d_rays2, hit_bufs2[b], wl.d_mask2)
             if ev is not None:
                 ev[3].record()
-            if world > 1:
+            if use_dist:
                 src = hit_bufs2[b].cpu() if shared else hit_bufs2[b]
                 _, pending[1][b] = nd.gather_hit_records(src, world, rank, dist, out=gathered2[b], async_op=True)
 
@@ -863,7 +973,7 @@ class Timed:
         self.k_ms1 = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
         self.k_ms2 = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
         region = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -873,7 +983,7 @@ class Timed:
         region[1].record()
         drain()  # every gather issued inside the timed region completes inside it
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         self.dt = time.perf_counter() - t0
         self.kernel_name = accel.LastKernelName()
@@ -882,7 +992,8 @@ class Timed:
         self.rays_per_step = wl.n1 + wl.n2
         self.per_rank = None
         self.total_rays = float(self.rays_per_step)
-        if world > 1:
+        self.gather_check = None
+        if use_dist:
             # a blocking gather of one wave's records, timed on its own (outside the timed region)
             g0 = time.perf_counter()
             src = hit_bufs1[0].cpu() if shared else hit_bufs1[0]
@@ -904,6 +1015,24 @@ class Timed:
                              "launch_ms": [round(float(x) / (2 * steps), 4) for x in allt[:, 5]],
                              "gather_ms_one_wave_blocking": [round(float(x), 4) for x in allt[:, 4]]}
             self.gathered_bytes_per_step = int(2 * world * n1 * HIT.itemsize)
+            if check_gather:
+                # The frame the root assembled from the LAST step's gathers against each rank's own records of that step (the
+                # ranks' records travel once more, through an independent all_gather): de-interleaving included.
+                last = (step_no[0] - 1) % nbuf  # the gather above reused buffer 0 for wave 1: compare wave 2 of the last step
+                mine = (hit_bufs2[last].cpu() if shared else hit_bufs2[last]).contiguous()
+                every = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine)
+                if rank == 0:
+                    rows = n1 // wl.width
+                    got = nd.assemble_image(gathered2[last].cpu().numpy(), wl.width, rows * world, world, HIT)
+                    want = np.empty((rows * world, wl.width), dtype=HIT)
+                    for r in range(world):
+                        want[r::world] = every[r].cpu().numpy().view(HIT).reshape(rows, wl.width)
+                    local_ok = bool(gathered2[last][: n1 * HIT.itemsize].cpu().numpy().tobytes() == hit_bufs2[last].cpu().numpy().tobytes())
+                    self.gather_check = {"wave": "bounce, last timed step", "records": int(got.shape[0]),
+                                         "assembled_frame_identical_to_the_ranks_records": bool(got.tobytes() == want.reshape(-1).tobytes()),
+                                         "root_slice_identical_to_its_own_buffer": local_ok,
+                                         "device_tensors": not shared, "backend": dist.get_backend()}
         self.value = self.total_rays * steps / self.dt / 1e6
         self.ms_per_step = self.dt / steps * 1e3
 
@@ -925,6 +1054,11 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the untimed measurements of the other single-GPU configs")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the untimed figures of the SURVEY 8(f) rows")
     ap.add_argument("--no-strong", action="store_true", help="N > 1, default config: skip the strong-scaling C4 sub-object")
+    ap.add_argument("--dry-run", action="store_true", help="validate device count / environment / RCCL / buffer sizes for --gpus N without launching anything")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1: run the N > 1 code path anyway — torch.distributed over RCCL (backend nccl, world size 1), the asynchronous "
+                         "double-buffered gather of both waves' records on device tensors — so that the exchange executes on a one-GPU box")
+    ap.add_argument("--check-gather", action="store_true", help="with a process group: compare the frame the root assembled from the gathers with the ranks' own records")
     ap.add_argument("--pmc-dir", default=None, help="keep the raw rocprofv3 counter CSVs here")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-configs", default="C3", help=argparse.SUPPRESS)
@@ -939,6 +1073,8 @@ def main():
 
     if args.pmc_child:
         return pmc_child(args)
+    if args.dry_run:
+        sys.exit(dry_run(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args, sys.argv[1:]))
 
@@ -961,10 +1097,14 @@ def main():
         raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # --force-dist without a launcher: a one-rank group of our own
+            os.environ.setdefault("MASTER_PORT", str(29500 + (os.getpid() % 2000)))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if shared:
             dist.init_process_group(backend="gloo")
         else:
@@ -981,7 +1121,7 @@ def main():
     c1, c2 = wl.counters()
     bytes1, bytes2 = algorithmic_bytes(c1, wl.rb), algorithmic_bytes(c2, wl.rb)
 
-    T = Timed(wl, args.steps, args.warmup, world, rank, dist, shared)
+    T = Timed(wl, args.steps, args.warmup, world, rank, dist, shared, check_gather=args.check_gather)
     k_ms1, k_ms2, kernel_name, region_ms = T.k_ms1, T.k_ms2, T.kernel_name, T.region_ms
     launch_ms = region_ms / (2 * args.steps)
     if world > 1:
@@ -1067,9 +1207,31 @@ def main():
         if pmc_err:
             roof["pmc_error"] = pmc_err
         hb = roof.get("hbm")
+        # Compulsory bytes of an average launch: every ray record read and every hit record + flag written once, plus the part of
+        # the private tree a launch can touch read ONCE (an upper bound: the whole Wide4Node / WideNode array and every leaf record,
+        # capped by what the walk fetched at all) — the denominator-free counterpart of `traffic`: traffic / compulsory is the
+        # re-read factor, compulsory_frac the HBM fraction the launch would reach if every byte moved once.
+        branches = int(wl.stats["num_branch_nodes"])
+        rec_b = 128 if wl.rb == 4 else 112
+        tri_b = 40 if wl.rb == 4 else 80
+        tree_once = branches * rec_b + wl.faces.shape[0] * tri_b
+        io_b = {w: n * (wl.RAY.itemsize + wl.HIT.itemsize + 1) for w, n in (("primary", n1), ("bounce", n2))}
+        alg_tree = {"primary": bytes1 - 52 * n1 if wl.rb == 4 else bytes1 - 104 * n1, "bounce": bytes2 - 52 * n2 if wl.rb == 4 else bytes2 - 104 * n2}
+        comp = sum(io_b[w] + min(tree_once, max(0, alg_tree[w])) for w in ("primary", "bounce")) / 2.0
+        comp_gbs = comp / (launch_ms * 1e-3) / 1e9
         roof.update({"bound": "hbm", "achieved": hb["achieved_GBs"] if hb else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": hb["frac"] if hb else None, "traffic": hb["bytes_per_launch"] if hb else None,
-                     "traffic_source": source or "UNMEASURED (no counter pass in this run)"})
+                     "traffic_source": source or "UNMEASURED (no counter pass in this run)",
+                     "achieved_definition": "HBM-side bytes per launch from this run's FETCH_SIZE / WRITE_SIZE counters over the average launch of the "
+                                            "timed region (a fraction of a real peak); SURVEY 8(d)'s algorithmic bytes are `algorithmic_*` below — they "
+                                            "count re-reads that L2 and the Infinity Cache serve and exceed the HBM peak",
+                     "algorithmic_bytes": int((bytes1 + bytes2) // 2), "algorithmic_GBs": round(alg_gbs, 1),
+                     "algorithmic_x_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
+                     "compulsory_bytes": int(comp), "compulsory_GBs": round(comp_gbs, 1), "compulsory_frac": round(comp_gbs / HBM_PEAK_GBS, 4),
+                     "compulsory_definition": "per launch: rays in + hit records and flags out, once, + the private tree (%d branch records x %d B + %d leaf "
+                                              "records x %d B = %.1f MB) read once — an upper bound on what a launch must move" % (
+                                                  branches, rec_b, wl.faces.shape[0], tri_b, tree_once / 1e6),
+                     "traffic_over_compulsory": round(hb["bytes_per_launch"] / comp, 3) if hb else None})
         if hb and world > 1:
             # per-rank fractions: this rank's measured bytes per launch (the ranks' shares are equally many interleaved rows of the
             # same frame) over every rank's own average launch of the timed region
@@ -1100,9 +1262,11 @@ def main():
             "bvh": {"nodes": wl.num_nodes, "max_depth": int(wl.stats["max_tree_depth"])},
             "roofline": roof,
         }
-        if world > 1:
+        if dist is not None:
             out["multi_gpu"] = dict(T.per_rank, rccl_ranks=world, backend="gloo (test hook)" if shared else "nccl (RCCL)",
                                     gathered_bytes_per_step=T.gathered_bytes_per_step)
+            if T.gather_check is not None:
+                out["multi_gpu"]["gather_check"] = T.gather_check
             if strong is not None:
                 out["strong_c4"] = strong
         if world == 1 and not args.no_extras:
@@ -1113,6 +1277,8 @@ def main():
             if n2:
                 out["multi_batch"] = multi_batch(accel, torch, (wl.d_rays1, wl.d_hits1, wl.d_mask1), (wl.d_rays2, wl.d_hits2[: n2 * HIT.itemsize], wl.d_mask2[:n2]),
                                                  args.steps, n1 + n2)
+            if wl.real == np.float32 and not accel.GetTunable("order4"):
+                out["opt_in_distance_order"] = opt_in_distance_order(wl, args.steps)
             rays_s = scenes.secondary_rays("shadow", wl.verts32, wl.faces, wl.rays1_f32, wl.hits1_f32, wl.mask1)
             if wl.real != np.float32:
                 from nanort_amd.wire import widen_rays
@@ -1195,7 +1361,7 @@ def main():
             except Exception as e:  # pragma: no cover
                 out["next_rows"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

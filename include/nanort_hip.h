@@ -362,30 +362,28 @@ NRT_API float nrtLastBuildMs(nrt_ctx *ctx);
 NRT_API nrt_status nrtSetLaunchTiming(nrt_ctx *ctx, int on);
 /* Traversal / build tunables by name (no reference counterpart; the library's defaults are the measured optimum on MI355X):
  *   which walk        "wide" (0: the literal BVHNode loop), "wide4" (two tree levels per step; next build / set_tree),
- *                     "order4" (1, the default: a record's four slots entered by entry distance — t and hit flags bit-equal to
- *                     the reference on the same node array, prim_id / u / v may differ at exact-t ties; 0: the reference's own
- *                     order, every field bit-identical), "wide8" (the 8-wide compressed walk, opt-in; next build / set_tree),
- *                     "f64_row_fetch"
- *   scheduling        "refill_min", "trav_min", "trav_min4", "trav_min8", "leaf_min", "chunk", "chunk_tail_pct", "parts",
+ *                     "order4" (0, the default: a record's four slots in the binary loop's order, nanort.h:2538-2543 — the same
+ *                     leaves in the same order as the reference, every field of every record bit-identical to it on the same
+ *                     node array; 1, opt-in, 2...5 % faster: slots entered by entry distance — another leaf sequence, so among
+ *                     primitives at EXACTLY the same t another one may be named (prim_id / u / v), and where a leaf box's entry
+ *                     distance rounds above the distance of a hit inside it the box may be culled under another hit and t itself
+ *                     differ by its last bits: contract-level parity, SURVEY.md §8d, not the bit-exact class), "f64_row_fetch"
+ *   scheduling        "refill_min", "trav_min", "trav_min4", "leaf_min", "chunk", "chunk_tail_pct", "parts",
  *                     "static_pct", "static_bands", "static_slice_groups", "blocks_per_cu", "lds_stack", "wide_stack"
  *   builder           "morton" (Morton pre-pass); libnanort_hip_prof.so only: "subtree_rows" (0: the one-node-per-step subtree kernel; same tree)
  *   launches / host   "launch_timing" (== nrtSetLaunchTiming), "host_pipeline"
  *   probes            "debug" (bit mask: 1 / 2 skip triangle tests / traversal, 4 plain ray loads; the profiling bits 32 / 64 / 8192
  *                     act in libnanort_hip_prof.so only), "wide_scramble" (layout probe; next build)
  * Values are clamped to the tunable's range; an unknown name is NRT_ERR_INVALID.  Tunables that shape the private tree layout
- * ("wide4", "wide8", "wide_scramble", "morton") take effect with the next nrtBuild / nrtSetTree.  The environment variable
- * NRT_<NAME> (upper case) overrides a default at nrtCreate — a debugging aid; programs use these calls. */
+ * ("wide4", "wide_scramble", "morton") take effect with the next nrtBuild / nrtSetTree.  The environment variable
+ * NRT_<NAME> (upper case) overrides a default at nrtCreate ONLY when the process also sets NRT_ALLOW_ENV=1 (libnanort_hip_prof.so:
+ * always) — a debugging aid; a stray variable cannot move a product context to another walk.  Programs use these calls. */
 NRT_API nrt_status nrtSetTunable(nrt_ctx *ctx, const char *name, long long value);
 NRT_API nrt_status nrtGetTunable(nrt_ctx *ctx, const char *name, long long *value_out);
 /* Name of the traversal kernel variant the most recent traversal launch of this context used, spelled as
  * rocprofv3 prints it without the argument list (static storage; "" before the first launch).  bench.py
  * reports it in `roofline.kernel` and matches the counter rows of its PMC passes against it. */
 NRT_API const char *nrtLastKernelName(const nrt_ctx *ctx);
-/* Test aid: copy out the private 8-wide compressed layout of the current fp32 tree (built when the tunable "wide8" is set
- * before nrtBuild / nrtSetTree): 80-byte node records and 40-byte leaf records (nanort_amd/csrc/common.h: Wide8Node, W8Rec).
- * Either output may be NULL; the counts are always returned.  tests/test_gpu_wide8.py compares the arrays with the CPU
- * model's (the wide8 model under the test infrastructure).  (No reference counterpart.) */
-NRT_API nrt_status nrtGetWide8_f32(nrt_ctx *ctx, void *nodes_out, void *recs_out, uint64_t *num_nodes, uint64_t *num_recs);
 /* (The profiling entry points — loop-occupancy counters, per-wave time stamps — are not part of this library: they live in
  * libnanort_hip_prof.so, declared in nanort_hip_prof.h, together with the counting / clocked kernel instantiations.) */
 

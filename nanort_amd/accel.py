@@ -204,16 +204,6 @@ class BVHAccel:
             self._check(getattr(self._L, "nrtGetTree_" + self._s)(self._h, _p(nodes), _p(indices)))
         return nodes, indices
 
-    def GetWide8(self):
-        """Test aid (nrtGetWide8_f32): the private 8-wide compressed layout of the current tree as raw bytes —
-        (node records [n, 80] uint8, leaf records [m, 10] uint32).  Needs the tunable wide8 set before Build / SetTree."""
-        nn, nr = ctypes.c_uint64(0), ctypes.c_uint64(0)
-        self._check(self._L.nrtGetWide8_f32(self._h, None, None, ctypes.byref(nn), ctypes.byref(nr)))
-        nodes = np.zeros((int(nn.value), 80), dtype=np.uint8)
-        recs = np.zeros((int(nr.value), 10), dtype=np.uint32)
-        self._check(self._L.nrtGetWide8_f32(self._h, _p(nodes), _p(recs), ctypes.byref(nn), ctypes.byref(nr)))
-        return nodes, recs
-
     def GetNodes(self):
         return self.GetTree()[0]
 

@@ -27,7 +27,7 @@ SYMBOLS = [
     "nrtTraverseBatchMulti_f32", "nrtTraverseBatchMulti_f64", "nrtDeviceCount",
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
-    "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtGetWide8_f32", "nrtHostAlloc", "nrtHostFree",
+    "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtHostAlloc", "nrtHostFree",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
     "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32", "nrtSceneSetTunable", "nrtSceneLastRedone", "nrtSceneLastPath",
 ]
@@ -161,8 +161,6 @@ def lib():
     L.nrtLastTraverseMs.restype = ctypes.c_float
     L.nrtLastBuildMs.argtypes = [vp]
     L.nrtLastBuildMs.restype = ctypes.c_float
-    L.nrtGetWide8_f32.argtypes = [vp, vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
-    L.nrtGetWide8_f32.restype = i32
     L.nrtDeviceCount.argtypes = []
     L.nrtDeviceCount.restype = i32
     L.nrtLastKernelName.argtypes = [vp]

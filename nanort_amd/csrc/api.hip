@@ -45,10 +45,6 @@ hipError_t launch_make_wide(const typename Wire<T>::Node *, uint32_t, uint32_t p
 template <typename T>
 hipError_t launch_gather_leaf_tris(const uint32_t *, const uint32_t *, const T *, LeafTri<T> *,
                                    uint32_t, hipStream_t);
-hipError_t launch_traverse_w8(const TraverseArgs<float> &args, unsigned grid, hipStream_t s, const char **name_out);
-int traverse_w8_blocks_per_cu();
-hipError_t launch_w8_build(const nrt_node_f32 *nodes, const LeafTri<float> *tris, Wide8Node *out, W8Rec *recs, uint32_t *queue,
-                           W8BuildState *st, uint32_t cap_nodes, uint32_t cap_recs, int num_cus, hipStream_t s);
 struct BuildResult {
   uint64_t num_nodes;
   uint32_t max_depth, num_leaves, num_branches, max_leaf_count;
@@ -88,12 +84,6 @@ struct nrt_ctx {
   void *d_tris = nullptr;        // LeafTri<T>[num_indices] == b_tris.p
   void *d_wide = nullptr;        // WideNode<T>[branches]   == b_wide.p
   void *d_wide4 = nullptr;       // Wide4Node<T>[branches]  == b_wide4.p (triangle trees only, and only when wide4 is on)
-  // the 8-wide compressed layout (opt-in, tunable wide8: wide8.hip; fp32 triangle trees with nested boxes and a branch root)
-  DevBuf b_w8nodes, b_w8recs, b_w8queue;
-  void *d_w8nodes = nullptr, *d_w8recs = nullptr; // set once the construction has been seen to succeed (finish_wide8_result)
-  W8BuildState *h_w8state = nullptr;              // page-locked copy of the construction's state
-  bool w8_result_pending = false;
-  uint32_t num_w8_nodes = 0, num_w8_recs = 0;
   uint32_t num_branch_records = 0; // nodes with flag == 0 in the node array (reachable or not)
   uint64_t num_nodes = 0, num_indices = 0;
   uint32_t tree_depth = 0;
@@ -155,9 +145,11 @@ struct nrt_ctx {
   // Two tree levels per step (Wide4Node records, traverse.hip NRT_STEP_NODE4): the production walk of fp32 triangle trees
   // whose child boxes lie inside their parents'.  env NRT_WIDE4=0 goes back to one level per step.
   int wide4 = 1;
-  int wide8 = 0; // the 8-wide compressed walk (next build / set_tree builds its layout; contract-level parity as order4)
-  unsigned trav_min8 = 24, w8_blocks_per_cu = 0;
-  int order4 = 1; // two-level walk: slots of a record entered by entry distance — the default since round 4 (+2...5 % on every config; t / hit flags bit-equal to the reference on the same node array, prim_id / u / v may differ at exact-t ties); 0: the binary loop's order, every field bit-identical to the reference on the same node array
+  // two-level walk, order of a record's four slots.  0 (default since round 5): the binary loop's order — the same leaves in the
+  // same order as nanort.h:2526-2548, every field of every record bit-identical to the reference on the same node array.
+  // 1 (opt-in): by entry distance, +2...5 % — the closest t is the reference's except where a leaf box's entry distance rounds
+  // above a hit inside it, and among primitives at exactly the same t another one may be named (contract-level parity)
+  int order4 = 0;
   int wide_scramble = 0; // probe (tunable wide_scramble): the private node records in a pseudo-random order instead of pre-order
   unsigned wide4_blocks_per_cu = 0;
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
@@ -248,8 +240,6 @@ static void free_tree(nrt_ctx *c) {
   c->generation++; // whoever cached device addresses / flags of the old tree (a committed nrt_scene) can tell
   c->d_wide = nullptr;
   c->d_wide4 = nullptr;
-  c->d_w8nodes = c->d_w8recs = nullptr;
-  c->w8_result_pending = false;
   c->d_nodes = nullptr;
   c->d_indices = nullptr;
   c->d_tris = nullptr;
@@ -295,9 +285,7 @@ static const TunableDesc kTunables[] = {
 #endif
     NRT_TUNABLE("wide", 0, 1, wide, int),                         // 0: the literal BVHNode loop
     NRT_TUNABLE("wide4", 0, 1, wide4, int),                       // two tree levels per step (next build / set_tree)
-    NRT_TUNABLE("wide8", 0, 1, wide8, int),                       // the 8-wide compressed walk (next build / set_tree; hit t bit-equal, prim_id / u / v may differ at exact-t ties)
-    NRT_TUNABLE("trav_min8", 1, 64, trav_min8, unsigned),         // ... its inner-loop exit threshold
-    NRT_TUNABLE("order4", 0, 1, order4, int),                     // two-level walk: 1 = slots by entry distance (hit t bit-equal; prim_id / u / v may differ at exact-t ties), 0 = the reference's order
+    NRT_TUNABLE("order4", 0, 1, order4, int),                     // two-level walk: 0 (default) = the reference's order, every field bit-identical; 1 = slots by entry distance (faster; contract-level parity at ties)
     NRT_TUNABLE("launch_timing", 0, 1, launch_timing, int),       // == nrtSetLaunchTiming
     NRT_TUNABLE("host_pipeline", 0, 1, host_pipeline, int),       // pipelined host entry point
     NRT_TUNABLE("wide_scramble", 0, 1, wide_scramble, int),       // probe: WideNode / Wide4Node records in a pseudo-random order (next build)
@@ -321,7 +309,7 @@ static bool tunable_set(nrt_ctx *c, const char *name, long long v) {
   if (!d) return false;
   d->set(c, std::min(d->hi, std::max(d->lo, v)));
   // the occupancy figures depend on the variant the tunables select: recompute on the next launch
-  c->blocks_per_cu = c->wide_blocks_per_cu = c->wide4_blocks_per_cu = c->sphere_blocks_per_cu = c->w8_blocks_per_cu = 0;
+  c->blocks_per_cu = c->wide_blocks_per_cu = c->wide4_blocks_per_cu = c->sphere_blocks_per_cu = 0;
   return true;
 }
 
@@ -387,8 +375,12 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     c->num_cus = prop.multiProcessorCount;
-  // Environment overrides (debugging aid): NRT_<NAME> for every tunable of nrtSetTunable, applied once at creation.
+  // Environment overrides (debugging aid): NRT_<NAME> for every tunable of nrtSetTunable, applied once at creation — in the
+  // profiling library always, in the product library only when the process opts in with NRT_ALLOW_ENV=1: a stray variable in
+  // a user's environment must not move the product between parity classes (order4) or walks.
+  const bool allow_env = env_overrides_allowed();
   for (const TunableDesc &d : kTunables) {
+    if (!allow_env) break;
     char env[64] = "NRT_";
     size_t k = 4;
     for (const char *p = d.name; *p && k + 1 < sizeof(env); p++) env[k++] = (char)toupper((unsigned char)*p);
@@ -418,12 +410,11 @@ void nrtDestroy(nrt_ctx *c) {
   }
   free_tree(c);
   free_mesh(c);
-  DevBuf *bufs[] = {&c->b_verts, &c->b_radii, &c->b_faces, &c->st_rays, &c->st_hits, &c->st_mask, &c->b_nodes, &c->b_indices, &c->b_tris, &c->b_wide, &c->b_wide4, &c->b_wide_scratch, &c->b_build_ws, &c->b_wave_clock, &c->b_w8nodes, &c->b_w8recs, &c->b_w8queue};
+  DevBuf *bufs[] = {&c->b_verts, &c->b_radii, &c->b_faces, &c->st_rays, &c->st_hits, &c->st_mask, &c->b_nodes, &c->b_indices, &c->b_tris, &c->b_wide, &c->b_wide4, &c->b_wide_scratch, &c->b_build_ws, &c->b_wave_clock};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->build_state) (void)hipHostFree(c->build_state);
-  if (c->h_w8state) (void)hipHostFree(c->h_w8state);
   hipEvent_t evs[] = {c->ev_b0, c->ev_b1, c->ev_build_state};
   for (hipEvent_t ev : evs)
     if (ev) (void)hipEventDestroy(ev);
@@ -586,41 +577,7 @@ static nrt_status finish_wide(nrt_ctx *c) {
   HIPCHK(c, launch_make_wide<T>((const typename Wire<T>::Node *)c->d_nodes, (uint32_t)c->num_nodes, c->packed_leaves,
                                 (uint32_t *)c->b_wide_scratch.p, (WideNode<T> *)c->d_wide, (Wide4Node<T> *)c->d_wide4,
                                 c->wide_scramble ? c->num_branch_records : 0u, c->stream));
-  // the 8-wide compressed layout (opt-in): fp32 triangle trees whose child boxes lie inside their parents', branch root
-  c->d_w8nodes = c->d_w8recs = nullptr;
-  c->w8_result_pending = false;
-  if constexpr (sizeof(T) == 4) {
-    const uint64_t leaves = c->num_nodes - c->num_branch_records;
-    const uint64_t cap_recs = leaves * ((uint64_t)c->max_leaf_count + 1u) + 2u;
-    if (c->wide8 && c->prim_kind == kPrimTriangles && c->root_is_branch && c->tree_nested && c->min_leaf_count >= 1 &&
-        c->max_leaf_count <= 30 && c->num_branch_records < (1u << kW8BaseBits) && cap_recs < (1ull << kW8BaseBits)) {
-      if (!c->h_w8state) HIPCHK(c, hipHostMalloc((void **)&c->h_w8state, sizeof(W8BuildState), hipHostMallocDefault));
-      if ((st = ensure(c, c->b_w8nodes, (size_t)c->num_branch_records * sizeof(Wide8Node)))) return st;
-      if ((st = ensure(c, c->b_w8recs, (size_t)cap_recs * sizeof(W8Rec)))) return st;
-      if ((st = ensure(c, c->b_w8queue, 64 + (size_t)c->num_branch_records * sizeof(uint32_t)))) return st;
-      W8BuildState *d_state = (W8BuildState *)c->b_w8queue.p;
-      HIPCHK(c, launch_w8_build((const nrt_node_f32 *)c->d_nodes, (const LeafTri<float> *)c->d_tris, (Wide8Node *)c->b_w8nodes.p,
-                                (W8Rec *)c->b_w8recs.p, (uint32_t *)((char *)c->b_w8queue.p + 64), d_state, c->num_branch_records,
-                                (uint32_t)cap_recs, c->num_cus, c->stream));
-      memset(c->h_w8state, 0xFF, sizeof(W8BuildState));
-      HIPCHK(c, hipMemcpyAsync(c->h_w8state, d_state, sizeof(W8BuildState), hipMemcpyDeviceToHost, c->stream));
-      c->w8_result_pending = true;
-    }
-  }
   return NRT_OK;
-}
-
-// After the context's stream has drained behind finish_wide: did the 8-wide construction succeed?  (A failed one leaves
-// the context on its other walks; it cannot fail with the capacities computed above.)
-static void finish_wide8_result(nrt_ctx *c) {
-  if (!c->w8_result_pending) return;
-  c->w8_result_pending = false;
-  const W8BuildState &h = *c->h_w8state;
-  if (h.failed != 0u || h.pending != 0u || h.tail == 0u || h.tail > c->num_branch_records) return;
-  c->num_w8_nodes = h.tail;
-  c->num_w8_recs = h.rec_tail + 2u;
-  c->d_w8nodes = c->b_w8nodes.p;
-  c->d_w8recs = c->b_w8recs.p;
 }
 
 template <typename T>
@@ -695,7 +652,6 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
   HIPCHK(c, hipMemcpy(c->d_indices, indices, num_indices * sizeof(uint32_t), hipMemcpyHostToDevice));
   if ((st = finish_tree<T>(c))) return st;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  finish_wide8_result(c);
   return NRT_OK;
 }
 
@@ -766,7 +722,6 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   }
   HIPCHK(c, hipEventRecord(c->ev_b1, c->stream));
   HIPCHK(c, hipEventSynchronize(c->ev_b1));
-  finish_wide8_result(c);
   c->have_build_time = true;
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev_b0, c->ev_b1));
@@ -885,15 +840,12 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   // reject a primitive a profiled launch walks one level per step, whose profiling variant honours them)
   const bool prof_needs_w2 = (dbg & (32u | 8192u)) && !plain_options && !spheres;
   const bool use_wide4 = use_wide && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch && !prof_needs_w2;
-  // the 8-wide compressed walk: closest-hit and occlusion walks of fp32 triangle trees that had the layout built
-  const bool use_w8 = use_wide && sizeof(T) == 4 && c->wide8 && c->d_w8nodes && !spheres && !(dbg & 8192u);
-  if (use_w8 && c->w8_blocks_per_cu == 0) c->w8_blocks_per_cu = (unsigned)traverse_w8_blocks_per_cu();
   if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, false);
   if (use_wide4 && !spheres && c->wide4_blocks_per_cu == 0) c->wide4_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(kWide4LdsStack, kPrimTriangles, true);
   if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, use_wide4); // (one kind and one walk per context)
-  unsigned blocks_per_cu = spheres ? c->sphere_blocks_per_cu : (use_w8 ? c->w8_blocks_per_cu : (use_wide4 ? c->wide4_blocks_per_cu : (use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu)));
+  unsigned blocks_per_cu = spheres ? c->sphere_blocks_per_cu : (use_wide4 ? c->wide4_blocks_per_cu : (use_wide ? c->wide_blocks_per_cu : c->blocks_per_cu));
   if (c->max_blocks_per_cu && blocks_per_cu > c->max_blocks_per_cu) blocks_per_cu = c->max_blocks_per_cu;
-  const int stack_entries = use_w8 ? kW8LdsStack : (use_wide4 ? kWide4LdsStack : (spheres ? 10 : (use_wide ? c->wide_stack : c->lds_stack)));
+  const int stack_entries = use_wide4 ? kWide4LdsStack : (spheres ? 10 : (use_wide ? c->wide_stack : c->lds_stack));
   uint64_t need_blocks = (n + kTraverseBlock - 1) / kTraverseBlock;
   unsigned grid = (unsigned)std::min<uint64_t>(need_blocks, (uint64_t)c->num_cus * blocks_per_cu);
   const unsigned parts = std::max(1u, std::min(c->num_parts, grid));
@@ -913,8 +865,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   const uint32_t dyn_per_band = static_per_wave ? (uint32_t)(((uint64_t)n / bands - band_static) / c->chunk) * c->chunk : 0u;
   const uint32_t band_len = band_static + dyn_per_band;
   // deepest possible stack: one pending sibling per level of the path — three per TWO levels when a step covers two
-  // (8-wide walk: at most an inner group and a leaf group per level of the wide tree, which is no deeper than the binary one)
-  const uint32_t max_entries = use_w8 ? 2u * (c->tree_depth + 1u) + 2u : (use_wide4 ? 3u * (c->tree_depth / 2u + 1u) + 2u : c->tree_depth + 2u);
+  const uint32_t max_entries = use_wide4 ? 3u * (c->tree_depth / 2u + 1u) + 2u : c->tree_depth + 2u;
   const uint32_t levels = max_entries > (uint32_t)stack_entries ? max_entries - stack_entries : 0;
   if (levels) { // (growing a buffer frees the old one, which waits for every launch in flight)
     nrt_status st = ensure(c, slot->spill, (size_t)levels * total_threads * sizeof(uint32_t));
@@ -934,8 +885,6 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.cyl_test_cap = c->cyl_test_cap;
   a.wide = (const WideNode<T> *)c->d_wide;
   a.wide4 = use_wide4 ? (const Wide4Node<T> *)c->d_wide4 : nullptr;
-  a.wide8 = use_w8 ? (const Wide8Node *)c->d_w8nodes : nullptr;
-  a.w8recs = use_w8 ? (const W8Rec *)c->d_w8recs : nullptr;
   a.packed_leaves = c->packed_leaves;
   a.wide_below_4g = (c->f64_row_fetch && (uint64_t)c->num_branch_records * sizeof(WideNode<T>) < (1ull << 32)) ? 1u : 0u;
   a.root_is_branch = c->root_is_branch;
@@ -1009,7 +958,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.chunk = c->chunk;
   a.chunk_tail_pct = c->chunk_tail_pct;
   a.refill_min = c->refill_min;
-  a.trav_min = use_w8 ? c->trav_min8 : (use_wide4 ? c->trav_min4 : c->trav_min);
+  a.trav_min = use_wide4 ? c->trav_min4 : c->trav_min;
   a.leaf_min = c->leaf_min;
 
   if (count || (dbg & 32u)) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), s));
@@ -1023,9 +972,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.done_publish = post_pass ? 0u : 1u;
   timed = timed && !use_rec;
   if (timed) HIPCHK(c, hipEventRecord(slot->t0, s));
-  if (use_w8) {
-    if constexpr (sizeof(T) == 4) HIPCHK(c, launch_traverse_w8(a, grid, s, &c->last_kernel));
-  } else if (use_wide) {
+  if (use_wide) {
     HIPCHK(c, launch_traverse_wide<T>(a, grid, c->wide_stack, c->prim_kind, s, &c->last_kernel));
   } else {
     HIPCHK(c, launch_traverse<T>(a, grid, count, c->lds_stack, s));
@@ -1244,6 +1191,9 @@ static nrt_status traverse_batches_device(nrt_ctx *c, uint32_t nb, const typenam
   for (uint32_t k = 0; k < nb; k++)
     if (flags && (flags[k] & NRT_BATCH_OCCLUSION) && counts[k] && !(d_masks && d_masks[k]))
       return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchesDevice: occlusion batch %u has no flag array", k);
+  for (uint32_t k = 0; k < nb; k++) // as nrtTraverseBatchDevice: a closest-hit batch needs its record array
+    if (counts[k] && !(flags && (flags[k] & NRT_BATCH_OCCLUSION)) && !d_hits[k])
+      return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchesDevice: batch %u has no hit array", k);
   TraverseBatches<T> mb;
   mb.nb = 0;
   uint64_t total = 0;
@@ -1535,25 +1485,6 @@ long nrtDebugWaveClocks(nrt_ctx *c, unsigned long long *out, long cap) {
 }
 
 #endif
-
-// Test aid: the 8-wide compressed layout of the current tree (tunable wide8), for the comparison with the CPU model.
-// Either output may be NULL; the counts are always returned.  NRT_ERR_INVALID when the context holds no such layout.
-nrt_status nrtGetWide8_f32(nrt_ctx *c, void *nodes_out, void *recs_out, uint64_t *num_nodes, uint64_t *num_recs) {
-  if (!c) return NRT_ERR_INVALID;
-  if (!c->d_w8nodes) {
-    if (c->h_w8state)
-      return fail(c, NRT_ERR_INVALID, "nrtGetWide8: no 8-wide layout (last construction: failed=%u pending=%u head=%u tail=%u rec_tail=%u of %u branch records)",
-                  c->h_w8state->failed, c->h_w8state->pending, c->h_w8state->head, c->h_w8state->tail, c->h_w8state->rec_tail, c->num_branch_records);
-    return fail(c, NRT_ERR_INVALID, "nrtGetWide8: no 8-wide layout (set the tunable wide8 before nrtBuild / nrtSetTree)");
-  }
-  HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (num_nodes) *num_nodes = c->num_w8_nodes;
-  if (num_recs) *num_recs = c->num_w8_recs;
-  if (nodes_out) HIPCHK(c, hipMemcpy(nodes_out, c->d_w8nodes, (size_t)c->num_w8_nodes * sizeof(Wide8Node), hipMemcpyDeviceToHost));
-  if (recs_out) HIPCHK(c, hipMemcpy(recs_out, c->d_w8recs, (size_t)c->num_w8_recs * sizeof(W8Rec), hipMemcpyDeviceToHost));
-  return NRT_OK;
-}
 
 float nrtLastBuildMs(nrt_ctx *c) {
   if (!c || !c->have_build_time) return -1.f;

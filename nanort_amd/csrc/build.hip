@@ -2614,7 +2614,7 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
 
   // (test hook, NRT_BUILD_TINY_TOP=1: the first attempt gets a 16-node top array, so every build of more than a few
   // thousand primitives overflows once and is retried — the path lopsided splits take)
-  const char *tiny_env = getenv("NRT_BUILD_TINY_TOP");
+  const char *tiny_env = env_overrides_allowed() ? getenv("NRT_BUILD_TINY_TOP") : nullptr;
   const bool tiny_top = tiny_env && atoi(tiny_env) != 0;
   for (size_t top_scale = 1;; top_scale *= 8) {
     const BuildPlan<T> plan(n, top_scale, tiny_top && top_scale == 1);

@@ -9,10 +9,23 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/nanort_hip.h"
 
 namespace nrt {
+
+// NRT_<NAME> environment overrides are a debugging aid: the profiling library always honours them, the product library only
+// when the process opts in with NRT_ALLOW_ENV=1 — a stray variable must not move a product context to another walk or
+// parity class behind its caller's back.
+inline bool env_overrides_allowed() {
+#ifdef NRT_PROF
+  return true;
+#else
+  const char *e = getenv("NRT_ALLOW_ENV");
+  return e && e[0] == '1' && e[1] == 0;
+#endif
+}
 
 constexpr int kWave = 64;           // gfx950 wavefront
 constexpr int kTraverseBlock = 256; // 4 waves, one per SIMD
@@ -154,41 +167,6 @@ constexpr uint32_t kPackedFirstBits = 27;
 constexpr uint32_t kPackedFirstMask = (1u << kPackedFirstBits) - 1u;
 constexpr uint32_t kPackedMaxCount = 16;
 
-// Eight children per record with conservatively QUANTISED boxes (the opt-in 8-wide walk, wide8.hip / traverse.hip
-// k_traverse_w8; tunable "wide8").  Built from the reference-format BVHNode array: a wide node is a binary branch whose
-// subtree is opened greedily (largest surface area first) until it has 8 children or only leaves.
-//   p, e          child plane = p[k] + q * 2^(e[k] - 127), q = 0..255; lower planes rounded down, upper planes up
-//   imask / lmask slots holding an inner / a leaf child (a slot's position encodes the traversal order: slots are visited in
-//                 ascending (slot ^ octant of the ray's direction signs) when no distance decides)
-//   child_base    record index of the first inner child; inner children are consecutive, in slot order
-//   leaf_base     first 40-byte record of this node's leaf blocks (W8Rec array); every leaf child owns `stride` records:
-//                 one box record {exact bmin, bmax, count} followed by its `count` triangle records (LeafTri layout)
-// Inner nodes are only ever tested conservatively; a leaf's triangles are tested after its EXACT box has passed the
-// reference's slab test, so t / u / v stay the reference's bits (prim_id may differ at exact-t ties: DESIGN.md §3.1).
-struct alignas(16) Wide8Node {
-  float p[3];
-  uint8_t e[3];
-  uint8_t imask;
-  uint32_t child_base;
-  uint32_t leaf_base;
-  uint8_t lmask;
-  uint8_t stride;
-  uint8_t pad[2];
-  uint32_t root; // the binary branch node this record was made from
-  uint8_t qlo[3][8];
-  uint8_t qhi[3][8];
-};
-static_assert(sizeof(Wide8Node) == 80, "Wide8Node");
-struct alignas(8) W8Rec { // a box record {bmin[3], bmax[3], count, 0, 0, 0} or a triangle record (LeafTri<float>)
-  uint32_t w[10];
-};
-static_assert(sizeof(W8Rec) == 40, "W8Rec");
-struct W8BuildState { // device-resident state of the breadth-first construction (wide8.hip)
-  uint32_t head, tail, pending, rec_tail, failed, pad[3];
-};
-constexpr uint32_t kW8BaseBits = 27; // stack entries carry a record base in 27 bits (+ 5 bits of leaf stride)
-constexpr int kW8LdsStack = 12;
-
 // Device-side view of a context's fp32 tree for the code inside this library that walks it in its own kernels (the
 // two-level scene kernel, scene.hip).  Not part of the C ABI.
 struct TreeViewF32 {
@@ -322,8 +300,6 @@ struct TraverseArgs {
   uint32_t cyl_test_cap;         // primitive kind 2: the intersector's test_cap flag
   const WideNode<T> *wide; // may be null (binary kernel only)
   const Wide4Node<T> *wide4; // may be null: two tree levels per record (the WIDTH = 4 variants)
-  const Wide8Node *wide8;    // may be null: the 8-wide compressed walk (k_traverse_w8)
-  const W8Rec *w8recs;       // its leaf blocks
   uint32_t packed_leaves;  // leaf references of `wide` are PACKED (see WideNode)
   uint32_t wide_below_4g;  // the WideNode array is smaller than 4 GiB: the fp64 walk may address it with 32-bit byte offsets (slab_pair_presel)
   uint32_t root_is_branch; // node 0 is a branch (every tree of more than one node)

@@ -602,7 +602,11 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
   s->use_top = false;
   s->have_top = false;
   s->walk_backoff = 0;
-  if (s->insts.size() >= 2) {
+  // ... only where something reads it: the listing kernels of scenes of more than kScanMaxNodes nodes, the single-pass walk from
+  // walk_min nodes (or forced, single_pass = 2).  A handful of nodes is scanned: no context, no build, no read-back for them
+  // (a tunable that makes the walk eligible later commits the scene again: scene_traverse).
+  const bool want_top = s->insts.size() > kScanMaxNodes || (s->single_pass && (s->insts.size() >= s->walk_min || s->single_pass > 1));
+  if (s->insts.size() >= 2 && want_top) {
     if (!s->top && nrtCreate(s->device, &s->top) != NRT_OK)
       return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level context: %s", nrtLastError(nullptr));
     std::vector<float> ends(6 * s->insts.size()), radii(2 * s->insts.size(), 0.0f);
@@ -798,6 +802,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     hipDeviceProp_t prop;
     SCHK(s, hipGetDeviceProperties(&prop, s->device));
     s->num_cus = (unsigned)prop.multiProcessorCount;
+    if (nrt::env_overrides_allowed()) {
     if (const char *e = getenv("NRT_SCENE_REFILL")) s->refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_TRAV")) s->trav_min = (unsigned)std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_CAND")) s->cand_min = (unsigned)std::min(64, std::max(1, atoi(e)));
@@ -806,6 +811,13 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     if (const char *e = getenv("NRT_SCENE_WALK_TRAV")) s->walk_trav_min = (unsigned)std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_WALK_REFILL")) s->walk_refill_min = (unsigned)std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NRT_SCENE_WALK")) s->single_pass = (unsigned)std::min(2, std::max(0, atoi(e)));
+    }
+  }
+  // the walk became eligible after Commit (nrtSceneSetTunable / the variables above) on a scene committed without its top-level tree
+  if (s->single_pass && !s->have_top && s->insts.size() >= 2 && s->insts.size() <= kScanMaxNodes &&
+      (s->insts.size() >= s->walk_min || s->single_pass > 1)) {
+    const nrt_status st = nrtSceneCommit(s);
+    if (st) return st;
   }
   SCHK(s, nrt::devbuf_ensure(&s->d_cursor, (size_t)nrt::kMaxParts * nrt::kCursorStrideWords * sizeof(uint32_t)));
   const nrt_ray_f32 *d_rays = device ? rays : (const nrt_ray_f32 *)s->d_rays.p;

@@ -1236,9 +1236,6 @@ do {                                                                            
 #ifndef NRT_W2_TRI_UNROLL
 #define NRT_W2_TRI_UNROLL 2 // ... and in the one-level variants (fp32 and fp64)
 #endif
-#ifndef NRT_W8_P1_UNROLL
-#define NRT_W8_P1_UNROLL 1 // 8-wide walk: pop + step rounds per trip of the inner loop
-#endif
 #ifndef NRT_W4_WAVES
 #define NRT_W4_WAVES 1 // minimum waves per SIMD asked of the WIDTH = 4 variants (1: whatever the register allocation gives)
 #endif
@@ -1571,328 +1568,6 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
     atomicAdd(&a.counters[9], st_t_p1);
     atomicAdd(&a.counters[10], st_t_p2);
     atomicAdd(&a.counters[11], st_act2b);   // leaf loop, two records per trip: lanes with a second record
-  }
-}
-
-// ---------------------------------------------------------------------------
-// The 8-wide compressed walk (opt-in: tunable "wide8"; layout and construction: common.h Wide8Node, wide8.hip).
-//
-// A step fetches ONE 80-byte record (five 16-byte loads) and tests EIGHT child boxes whose planes are stored as bytes
-// relative to the node's origin and per-axis power-of-two scale.  The slab arithmetic is folded: with A = scale * inv and
-// B = (p - org) * inv a plane's distance is fma(q, A, B) — one conversion and one fma per plane.  It is CONSERVATIVE, not
-// exact: the quantised box contains the child's box, and B carries an error margin (2^-21 / 2^-20 of the largest distance
-// the node can produce, on the low / high side) that covers every rounding of this form and of the reference's own
-// (nanort.h:2285-2325, MaxMult included), so a child the reference's slab test accepts is always accepted here.  An infinite
-// reciprocal (|dir| < eps, nanort.h:442-461) is replaced by +-2^100 inside this arithmetic only; NaNs drop out of the
-// v_max / v_min chains as they do in the reference's safemax / safemin.
-// Exactness comes back at the leaves: a leaf child's block starts with a record holding its EXACT box, which must pass
-// the reference's own slab test against the current hit distance before any of its triangles is tested (on a tree whose
-// child boxes lie inside their parents' that implies the test of every ancestor).  So the triangles tested are a subset of
-// those the reference loop can reach and a superset of those that can change the result: t (and the u, v, prim_id that go
-// with it) are the reference's, except that among primitives at EXACTLY the same t the survivor may be another one — the
-// contract's parity bar, checked ray by ray in tests/test_gpu_wide8.py; the default walk stays bit-identical.
-//
-// Order and stack: of the inner children hit, the NEAREST (entry distance; ties and sub-8-ulp differences by slot) is
-// entered at once; the others wait as ONE stack entry — {child_base, pending slots, a 16-bit lower bound of their entry
-// distances}: popped children come in ascending (slot ^ ray octant), the slot assignment of the builder making that
-// roughly front to back; a group whose bound exceeds the hit distance is dropped without a fetch.  Leaf children hit form
-// one leaf group: tested at once when no inner child was hit, else parked on the stack above the inner group.  At most two
-// pushes per step, and the stack is as deep as the wide tree is (<= 2 entries per level).
-// ---------------------------------------------------------------------------
-#define NRT_W8_BIG 1.2676506002282294e30f    // 2^100
-#define NRT_W8_EPS_LO 4.76837158203125e-07f  // 2^-21
-#define NRT_W8_EPS_HI 9.5367431640625e-07f   // 2^-20
-
-template <bool PLAIN, bool STATS>
-__global__ __launch_bounds__(kTraverseBlock) void k_traverse_w8(const TraverseArgs<float> a) {
-  typedef float T;
-  constexpr int STACK = kW8LdsStack;
-  __shared__ uint2 s_stack[STACK][kTraverseBlock];
-  typedef Wire<float>::Ray Ray;
-  typedef Wire<float>::Hit Hit;
-
-  const unsigned tid = threadIdx.x;
-  const unsigned lane = lane_id();
-  const unsigned gslot = blockIdx.x * kTraverseBlock + tid;
-  const bool cull = a.cull_back_face != 0;
-  uint32_t *const spill_y = reinterpret_cast<uint32_t *>(a.spill_tmin);
-
-  NRT_BATCH_TABLE_SETUP();
-  Lane<float> L; // (so0..2 hold the bits of the ray's reciprocal direction with infinities replaced by +-2^100)
-  uint32_t rid = kInvalid;
-  uint32_t cur = 0;  // W_TRAV: record index; W_LEAF: leaf_base | stride << 27
-  uint32_t lgrp = 0; // W_LEAF: lmask << 8 | leaf children still to test (priority space)
-  uint32_t oct = 0;  // direction-sign octant of the lane's ray
-  int state = W_IDLE;
-  int sp = 0;
-  Claim ck;
-  claim_init<T>(a, ck);
-  if (blockIdx.x == 0 && threadIdx.x < kMaxParts)
-    __hip_atomic_store(a.next_cursor + kCursorStrideWords * threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  done_begin<T>(a);
-  uint32_t st_steps = 0, st_empty = 0, st_leaves = 0, st_reject = 0, st_tris = 0, st_drop = 0; // STATS only
-
-#define W8_WRITE_RESULT()                               \
-  do {                                                  \
-    const bool hit_ = L.hit_t < L.max_t;                \
-    Hit h_;                                             \
-    h_.u = hit_ ? L.u : T(0);                           \
-    h_.v = hit_ ? L.v : T(0);                           \
-    h_.t = hit_ ? L.hit_t : L.max_t;                    \
-    h_.prim_id = hit_ ? L.prim : kInvalid;              \
-    Hit *hp_ = a.hits;                                  \
-    uint8_t *mp_ = a.mask;                              \
-    if (multi) {                                        \
-      const BatchPtrs bp_ = s_tbl[batch_of<T>(a, rid)]; \
-      hp_ = (Hit *)bp_.hits_v;                          \
-      mp_ = bp_.mask_v;                                 \
-    }                                                   \
-    if (hp_) store_hit_nt<T>(hp_ + rid, h_);            \
-    if (mp_) mp_[rid] = hit_ ? (uint8_t)1 : (uint8_t)0; \
-  } while (0)
-#define W8_STORE_ENTRY(at_, ex_, ey_)                                                                  \
-  do {                                                                                                 \
-    if ((at_) < STACK) {                                                                               \
-      s_stack[(at_)][tid] = make_uint2((ex_), (ey_));                                                  \
-    } else {                                                                                           \
-      const size_t o_ = (size_t)((at_) - STACK) * a.spill_stride + gslot;                              \
-      a.spill[o_] = (ex_);                                                                             \
-      spill_y[o_] = (ey_);                                                                             \
-    }                                                                                                  \
-  } while (0)
-
-  for (;;) {
-    // ---- refill idle lanes (as k_traverse_wide) ------------------------------------------
-    unsigned long long idle = __ballot(state == W_IDLE);
-    if (!ck.exhausted && (unsigned)__builtin_popcountll(idle) >= a.refill_min) {
-      unsigned long long fresh = idle;
-      while (fresh != 0ull && !ck.exhausted) {
-        if (ck.next == ck.end && !claim_chunk<T>(a, ck, lane, __builtin_ctzll(fresh))) break;
-        const unsigned want = (unsigned)__builtin_popcountll(fresh);
-        const unsigned avail = ck.end - ck.next;
-        const unsigned take = want < avail ? want : avail;
-        const unsigned rank = (unsigned)__builtin_popcountll(fresh & ((1ull << lane) - 1ull));
-        if (state == W_IDLE && rank < take) {
-          if (rid != kInvalid) W8_WRITE_RESULT();
-          rid = ck.next + rank;
-          const Ray *rp_ = a.rays;
-          uint32_t bq_ = 0u;
-          if (multi) {
-            const uint32_t b_ = batch_of<T>(a, rid);
-            rp_ = (const Ray *)s_tbl[b_].rays_v;
-            bq_ = (a.batch_anyhit >> b_) & 1u;
-          }
-          const Ray r = load_ray_nt<T>(rp_ + rid);
-          lane_init<T>(L, r);
-          L.pk |= bq_ << 9;
-          oct = (L.pk >> 6) & 7u;
-          {
-            const float big0 = __builtin_copysignf(NRT_W8_BIG, L.inv0), big1 = __builtin_copysignf(NRT_W8_BIG, L.inv1),
-                        big2 = __builtin_copysignf(NRT_W8_BIG, L.inv2);
-            L.so0 = __float_as_uint(__builtin_fabsf(L.inv0) == Const<T>::inf() ? big0 : L.inv0);
-            L.so1 = __float_as_uint(__builtin_fabsf(L.inv1) == Const<T>::inf() ? big1 : L.inv1);
-            L.so2 = __float_as_uint(__builtin_fabsf(L.inv2) == Const<T>::inf() ? big2 : L.inv2);
-          }
-          sp = 0;
-          cur = 0u; // record 0: the root (a branch; its own box test is implied by its children's)
-          state = W_TRAV;
-          if (a.debug_flags & 2u) state = W_POP;
-        }
-        ck.next += take;
-        fresh = __ballot(state == W_IDLE);
-      }
-      idle = __ballot(state == W_IDLE);
-    }
-    if (idle == ~0ull) {
-      if (ck.exhausted) break;
-      continue;
-    }
-
-    // ---- phase 1: records / stack pops ---------------------------------------------------
-    unsigned n_wait_leaf = (unsigned)__builtin_popcountll(__ballot(state == W_LEAF));
-    while (state == W_TRAV || state == W_POP) {
-#pragma unroll
-      for (int u_ = 0; u_ < NRT_W8_P1_UNROLL; u_++) {
-      if (state == W_POP) {
-        const int s1_ = sp > 0 ? sp - 1 : 0;
-        uint2 e_ = s_stack[s1_ < STACK ? s1_ : STACK - 1][tid];
-        if (s1_ >= STACK) {
-          const size_t o_ = (size_t)(s1_ - STACK) * a.spill_stride + gslot;
-          e_ = make_uint2(a.spill[o_], spill_y[o_]);
-        }
-        const bool fin_ = (sp == 0);
-        const bool alive_ = !fin_ & (__uint_as_float(e_.y & 0xFFFF0000u) <= L.hit_t);
-        const bool leafg_ = (e_.x >> kW8BaseBits) != 0u;
-        const uint32_t pend_ = e_.y & 0xFFu, tm_ = (e_.y >> 8) & 0xFFu;
-        const uint32_t slot_ = ((uint32_t)__builtin_ctz(pend_ | 0x100u) ^ oct) & 7u; // the pending child first in priority order
-        const uint32_t rest_ = pend_ & (pend_ - 1u);
-        const bool inner_ = alive_ & !leafg_, leaves_ = alive_ & leafg_;
-        const bool again_ = inner_ & (rest_ != 0u); // the group stays on the stack, one child fewer
-        if (again_) W8_STORE_ENTRY(s1_, e_.x, (e_.y & 0xFFFFFF00u) | rest_);
-        if (STATS) st_drop += (!fin_ & !alive_) ? 1u : 0u;
-        sp = again_ ? sp : s1_;
-        cur = inner_ ? e_.x + (uint32_t)__builtin_popcount(tm_ & ((1u << slot_) - 1u)) : (leaves_ ? e_.x : cur);
-        lgrp = leaves_ ? (e_.y & 0xFFFFu) : lgrp;
-        state = fin_ ? W_IDLE : (inner_ ? W_TRAV : (leaves_ ? W_LEAF : W_POP));
-      }
-      if (state == W_TRAV) {
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        const char *nb_ = reinterpret_cast<const char *>(a.wide8) + (size_t)cur * sizeof(Wide8Node);
-        const u4 h0 = *reinterpret_cast<const u4 *>(nb_), h1 = *reinterpret_cast<const u4 *>(nb_ + 16);
-        const u4 q0 = *reinterpret_cast<const u4 *>(nb_ + 32), q1 = *reinterpret_cast<const u4 *>(nb_ + 48),
-                 q2 = *reinterpret_cast<const u4 *>(nb_ + 64);
-        if (STATS) st_steps++;
-        float tmin[8], tmax[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          tmin[j] = L.min_t;
-          tmax[j] = L.hit_t;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const uint32_t lo_a = k == 0 ? q0.x : (k == 1 ? q0.z : q1.x), lo_b = k == 0 ? q0.y : (k == 1 ? q0.w : q1.y);
-          const uint32_t hi_a = k == 0 ? q1.z : (k == 1 ? q2.x : q2.z), hi_b = k == 0 ? q1.w : (k == 1 ? q2.y : q2.w);
-          const bool sg = ((L.pk >> (6 + k)) & 1u) != 0u;
-          const uint32_t na = sg ? hi_a : lo_a, nb = sg ? hi_b : lo_b, fa = sg ? lo_a : hi_a, fb = sg ? lo_b : hi_b;
-          const float sc = __uint_as_float(((h0.w >> (8 * k)) & 0xFFu) << 23);
-          const float iq = __uint_as_float(k == 0 ? L.so0 : (k == 1 ? L.so1 : L.so2));
-          const float pk_ = __uint_as_float(k == 0 ? h0.x : (k == 1 ? h0.y : h0.z));
-          const float A = sc * iq;
-          const float B = (pk_ - L.org(k)) * iq;
-          const float M = __builtin_fmaf(__builtin_fabsf(A), 255.0f, __builtin_fabsf(B));
-          const float Blo = __builtin_fmaf(M, -NRT_W8_EPS_LO, B), Bhi = __builtin_fmaf(M, NRT_W8_EPS_HI, B);
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const float n0 = (float)((na >> (8 * j)) & 0xFFu), n1 = (float)((nb >> (8 * j)) & 0xFFu);
-            const float f0 = (float)((fa >> (8 * j)) & 0xFFu), f1 = (float)((fb >> (8 * j)) & 0xFFu);
-            tmin[j] = Const<T>::fmax(__builtin_fmaf(n0, A, Blo), tmin[j]);
-            tmin[4 + j] = Const<T>::fmax(__builtin_fmaf(n1, A, Blo), tmin[4 + j]);
-            tmax[j] = Const<T>::fmin(__builtin_fmaf(f0, A, Bhi), tmax[j]);
-            tmax[4 + j] = Const<T>::fmin(__builtin_fmaf(f1, A, Bhi), tmax[4 + j]);
-          }
-        }
-        const uint32_t imask = h0.w >> 24, lmask = h1.z & 0xFFu, stride = (h1.z >> 8) & 0xFFu;
-        uint32_t hm = 0u;
-        uint32_t key[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          hm |= (tmin[j] <= tmax[j]) ? (1u << j) : 0u;
-          const float kf = tmin[j] > 0.0f ? tmin[j] : 0.0f; // (non-positive and NaN distances sort first and bound nothing)
-          key[j] = (__float_as_uint(kf) & ~7u) | (uint32_t)j;
-        }
-        const uint32_t ih = hm & imask, lh = hm & lmask;
-        uint32_t best = 0xFFFFFFFFu;
-#pragma unroll
-        for (int j = 0; j < 8; j++) best = min(best, ((ih >> j) & 1u) ? key[j] : 0xFFFFFFFFu);
-        const bool has_in = ih != 0u;
-        const uint32_t slot_in = best & 7u;
-        const uint32_t ih_rest = has_in ? (ih & ~(1u << slot_in)) : 0u;
-        uint32_t second = 0xFFFFFFFFu, lmin = 0xFFFFFFFFu;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          second = min(second, ((ih_rest >> j) & 1u) ? key[j] : 0xFFFFFFFFu);
-          lmin = min(lmin, ((lh >> j) & 1u) ? key[j] : 0xFFFFFFFFu);
-        }
-        // 16-bit lower bounds of the groups' entry distances (a distance that is not positive bounds nothing: -inf)
-        const uint32_t g_in = (second >> 16) ? (second & 0xFFFF0000u) : 0xFF800000u;
-        const uint32_t g_lf = (lmin >> 16) ? (lmin & 0xFFFF0000u) : 0xFF800000u;
-        // both masks into priority space (bit = slot ^ octant): the three conditional swaps of an XOR permutation
-        uint32_t pm = ih_rest | (lh << 8);
-        {
-          const uint32_t s4 = ((pm & 0x0F0Fu) << 4) | ((pm >> 4) & 0x0F0Fu);
-          pm = (oct & 4u) ? s4 : pm;
-          const uint32_t s2 = ((pm & 0x3333u) << 2) | ((pm >> 2) & 0x3333u);
-          pm = (oct & 2u) ? s2 : pm;
-          const uint32_t s1 = ((pm & 0x5555u) << 1) | ((pm >> 1) & 0x5555u);
-          pm = (oct & 1u) ? s1 : pm;
-        }
-        const uint32_t ihp_rest = pm & 0xFFu, lhp = pm >> 8;
-        const bool push_in = ih_rest != 0u, push_lf = (lh != 0u) & has_in;
-        const uint32_t ex_in = h1.x, ey_in = g_in | (imask << 8) | ihp_rest;
-        const uint32_t ex_lf = h1.y | (stride << kW8BaseBits), ey_lf = g_lf | (lmask << 8) | lhp;
-        if (__ballot(sp > STACK - 2) == 0ull) { // every stepping lane has room for both entries in LDS: unconditional stores
-          s_stack[sp][tid] = make_uint2(ex_in, ey_in);
-          sp += push_in ? 1 : 0;
-          s_stack[sp][tid] = make_uint2(ex_lf, ey_lf);
-          sp += push_lf ? 1 : 0;
-        } else {
-          if (push_in) {
-            W8_STORE_ENTRY(sp, ex_in, ey_in);
-            sp++;
-          }
-          if (push_lf) {
-            W8_STORE_ENTRY(sp, ex_lf, ey_lf);
-            sp++;
-          }
-        }
-        if (STATS) st_empty += hm == 0u ? 1u : 0u;
-        cur = has_in ? h1.x + (uint32_t)__builtin_popcount(imask & ((1u << slot_in) - 1u)) : (lh != 0u ? ex_lf : cur);
-        lgrp = (!has_in & (lh != 0u)) ? ((lmask << 8) | lhp) : lgrp;
-        state = has_in ? W_TRAV : (lh != 0u ? W_LEAF : W_POP);
-      }
-      }
-      n_wait_leaf += (unsigned)__builtin_popcountll(__ballot(state == W_LEAF));
-      if ((unsigned)__builtin_popcountll(__ballot(state == W_TRAV || state == W_POP)) < a.trav_min &&
-          (n_wait_leaf != 0u || !ck.exhausted))
-        break;
-    }
-
-    // ---- phase 2: leaf groups -------------------------------------------------------------
-    const unsigned n_leaf = (unsigned)__builtin_popcountll(__ballot(state == W_LEAF));
-    const bool refill_due = !ck.exhausted && (unsigned)__builtin_popcountll(__ballot(state == W_IDLE)) >= a.refill_min;
-    if (n_leaf != 0u && !(n_leaf < a.leaf_min && refill_due)) {
-      const bool mine = state == W_LEAF;
-      const uint32_t lbase = cur & ((1u << kW8BaseBits) - 1u), lstride = cur >> kW8BaseBits, lmask_ = lgrp >> 8;
-      uint32_t pend = mine ? (lgrp & 0xFFu) : 0u;
-      if (a.debug_flags & 1u) pend = 0u;
-      uint32_t lrec = 0u, li = 0u, lcnt = 0u; // the open leaf: its box record, the next triangle, its count
-      for (;;) {
-        const bool open = li < lcnt;
-        const bool start = !open & (pend != 0u);
-        if (__ballot(open | start) == 0ull) break;
-        if (start) { // the next leaf of the group, in priority order
-          const uint32_t slot = ((uint32_t)__builtin_ctz(pend) ^ oct) & 7u;
-          pend &= pend - 1u;
-          lrec = lbase + (uint32_t)__builtin_popcount(lmask_ & ((1u << slot) - 1u)) * lstride;
-          li = 0u;
-          lcnt = 0u;
-        }
-        const LeafTri<float> *rp = reinterpret_cast<const LeafTri<float> *>(a.w8recs) + lrec;
-        const LeafTri<float> t0 = rp[1u + li], t1 = rp[2u + li]; // (requested before the box record is looked at: one round trip per leaf)
-        if (start) {
-          const LeafTri<float> bx = rp[0];
-          const bool ok = slab_test<float>(L, bx.p0, bx.p1); // the reference's own test of the leaf's EXACT box (nanort.h:2285-2325)
-          lcnt = ok ? min(__float_as_uint(bx.p2[0]), lstride - 1u) : 0u; // (a block holds at most stride - 1 triangles)
-          if (STATS) {
-            st_leaves++;
-            st_reject += ok ? 0u : 1u;
-          }
-        }
-        if (STATS) st_tris += (li < lcnt ? 1u : 0u) + (li + 1u < lcnt ? 1u : 0u);
-        if (PLAIN) {
-          tri_test<T, true>(L, t0, li < lcnt, 0u, 0u, 0u, false);
-          tri_test<T, true>(L, t1, li + 1u < lcnt, 0u, 0u, 0u, false);
-        } else {
-          tri_test<T>(L, t0, li < lcnt, a.range0, a.range1, a.skip_prim, cull);
-          tri_test<T>(L, t1, li + 1u < lcnt, a.range0, a.range1, a.skip_prim, cull);
-        }
-        li += 2u;
-      }
-      if (a.any_hit | a.batch_anyhit) sp = (mine && L.hit_t < L.max_t && (a.any_hit != 0u || (L.pk & 512u) != 0u)) ? 0 : sp;
-      state = mine ? W_POP : state;
-    }
-  }
-  if (rid != kInvalid) W8_WRITE_RESULT();
-#undef W8_WRITE_RESULT
-#undef W8_STORE_ENTRY
-  done_end<T>(a, lane);
-  if (STATS) { // counters[0..5]: records fetched, of those with no child hit, leaf boxes fetched, of those rejected, triangle tests, groups dropped
-    unsigned long long v[6] = {st_steps, st_empty, st_leaves, st_reject, st_tris, st_drop};
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
-      if (lane == 0) atomicAdd(&a.counters[i], v[i]);
-    }
   }
 }
 
@@ -2888,30 +2563,6 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
 }
 #undef NRT_LAUNCH_WIDE
 #undef NRT_LAUNCH_WIDE_O
-
-// The 8-wide compressed walk (fp32 triangle trees; the caller checked what it needs).
-hipError_t launch_traverse_w8(const TraverseArgs<float> &args, unsigned grid, hipStream_t s, const char **name_out) {
-#ifdef NRT_PROF
-  if (args.debug_flags & 32u) {
-    hipLaunchKernelGGL((k_traverse_w8<true, true>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
-    if (name_out) *name_out = "nrt::k_traverse_w8<true, true>";
-  } else
-#endif
-  if (args.plain_options) {
-    hipLaunchKernelGGL((k_traverse_w8<true, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
-    if (name_out) *name_out = "nrt::k_traverse_w8<true, false>";
-  } else {
-    hipLaunchKernelGGL((k_traverse_w8<false, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
-    if (name_out) *name_out = "nrt::k_traverse_w8<false, false>";
-  }
-  return hipGetLastError();
-}
-int traverse_w8_blocks_per_cu() {
-  int n = 0;
-  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_w8<true, false>, kTraverseBlock, 0);
-  if (e != hipSuccess || n < 1) n = 4;
-  return n > 8 ? 8 : n;
-}
 
 template <typename T>
 int traverse_wide_blocks_per_cu(int lds_stack, int prim_kind, bool wide4) {

@@ -34,57 +34,6 @@ def _trace_opt_words(opts):
     return np.frombuffer(np.asarray(opts, dtype=TRACE_OPTIONS).tobytes(), dtype=np.uint32).copy()
 
 
-W8_NODE = np.dtype([("p", "<f4", (3,)), ("e", "u1", (3,)), ("imask", "u1"), ("child_base", "<u4"), ("leaf_base", "<u4"),
-                    ("lmask", "u1"), ("stride", "u1"), ("pad", "u1", (2,)), ("root", "<u4"), ("qlo", "u1", (3, 8)),
-                    ("qhi", "u1", (3, 8))])
-assert W8_NODE.itemsize == 80
-W8_REC = np.dtype([("w", "<u4", (10,))])
-
-
-class Wide8Model:
-    """CPU model of the 8-wide compressed walk (test infrastructure)."""
-
-    def __init__(self, L, nodes, indices, verts, faces, collapse_mode):
-        self.L = L
-        self.verts = np.ascontiguousarray(verts)
-        self.faces = np.ascontiguousarray(faces, dtype=np.uint32)
-        nodes = np.ascontiguousarray(nodes)
-        indices = np.ascontiguousarray(indices, dtype=np.uint32)
-        self.h = L.orc_wide8_build_f32(_p(nodes), nodes.shape[0], _p(indices), _p(self.verts), 12, _p(self.faces), int(collapse_mode))
-        if not self.h:
-            raise ValueError("wide8 model: node 0 must be a branch and every leaf must hold 1..30 primitives")
-        self.num_nodes = int(L.orc_wide8_num_nodes(self.h))
-        self.num_recs = int(L.orc_wide8_num_recs(self.h))
-
-    def arrays(self):
-        n = np.zeros(self.num_nodes, dtype=W8_NODE)
-        r = np.zeros(self.num_recs, dtype=W8_REC)
-        self.L.orc_wide8_copy(self.h, _p(n), _p(r))
-        return n, r
-
-    def traverse(self, rays, opts=None, order_mode=0, cull_mode=1):
-        """Returns (hits, mask, counters[8]): steps, empty steps, leaves fetched, leaves rejected by the exact box test,
-        triangle tests, max stack, groups dropped by their distance bound, rays."""
-        rays = np.ascontiguousarray(rays)
-        assert rays.dtype == ray_dtype(np.float32)
-        n = rays.shape[0]
-        hits = np.zeros((n,), dtype=hit_dtype(np.float32))
-        mask = np.zeros((n,), dtype=np.uint8)
-        counters = np.zeros((8,), dtype=np.uint64)
-        w = _trace_opt_words(opts)
-        self.L.orc_wide8_traverse_f32(self.h, _p(self.verts), 12, _p(self.faces), _p(rays), n, _p(w), _p(hits), _p(mask),
-                                      _p(counters), int(order_mode), int(cull_mode))
-        return hits, mask, counters
-
-    def __del__(self):
-        try:
-            if self.h:
-                self.L.orc_wide8_free(self.h)
-                self.h = None
-        except Exception:
-            pass
-
-
 class Oracle:
     """The plain-C restatement."""
 
@@ -103,15 +52,6 @@ class Oracle:
             w4 = getattr(L, "orc_traverse_wide4_model_" + s)
             w4.argtypes = [vp, vp, vp, sz, vp, vp, u64, vp, vp, vp, vp, vp, vp, u64, vp]
             w4.restype = None
-        L.orc_wide8_build_f32.argtypes = [vp, u64, vp, vp, sz, vp, ctypes.c_int]
-        L.orc_wide8_build_f32.restype = vp
-        L.orc_wide8_free.argtypes = [vp]
-        L.orc_wide8_num_nodes.argtypes = [vp]
-        L.orc_wide8_num_nodes.restype = u32
-        L.orc_wide8_num_recs.argtypes = [vp]
-        L.orc_wide8_num_recs.restype = u32
-        L.orc_wide8_copy.argtypes = [vp, vp, vp]
-        L.orc_wide8_traverse_f32.argtypes = [vp, vp, sz, vp, vp, u64, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int]
         L.orc_free.argtypes = [vp]
         L.orc_sizeof.argtypes = [ctypes.c_int]
         L.orc_sizeof.restype = ctypes.c_int
@@ -167,31 +107,6 @@ class Oracle:
         if count:
             return hits, mask, counters
         return hits, mask
-
-    def traverse_fused_slab_model(self, nodes, indices, verts, faces, rays, slack_ulps=2):
-        """MODEL (oracle/fused_slab_model.inc): inner boxes by the fused, conservative test, leaves re-tested exactly.
-        Returns (hits, mask, counters(nodes popped, leaves tested, triangles tested, inner nodes entered only by the fused test))."""
-        assert verts.dtype == np.float32 and nodes.dtype == node_dtype(np.float32) and rays.dtype == ray_dtype(np.float32)
-        faces = np.ascontiguousarray(faces, dtype=np.uint32)
-        indices = np.ascontiguousarray(indices, dtype=np.uint32)
-        nodes = np.ascontiguousarray(nodes)
-        rays = np.ascontiguousarray(rays)
-        n = rays.shape[0]
-        hits = np.zeros((n,), dtype=hit_dtype(np.float32))
-        mask = np.zeros((n,), dtype=np.uint8)
-        counters = np.zeros((4,), dtype=np.uint64)
-        fn = self.L.orc_traverse_fused_slab_model_f32
-        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
-                       ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-        fn.restype = None
-        fn(_p(nodes), _p(indices), _p(verts), 12, _p(faces), _p(rays), n, int(slack_ulps), _p(hits), _p(mask), _p(counters))
-        return hits, mask, counters
-
-    def wide8_build(self, nodes, indices, verts, faces, collapse_mode=0):
-        """The 8-wide compressed layout of a reference-format fp32 tree, built by the CPU MODEL (oracle/wide8_model.inc).
-        Returns a Wide8Model (arrays + walk)."""
-        assert verts.dtype == np.float32 and nodes.dtype == node_dtype(np.float32)
-        return Wide8Model(self.L, nodes, indices, verts, faces, collapse_mode)
 
     def traverse_wide4_model(self, nodes, indices, verts, faces, rays, opts=None, trail_cap=0):
         """The sequential MODEL of the kernel's two-levels-per-step walk (oracle/wide4_model_body.inc).

@@ -49,3 +49,25 @@ def test_missing_counters_leave_their_part_out():
     pmc = {"primary": {"FETCH_SIZE": 1.0, "WRITE_SIZE": 1.0}, "bounce": {"FETCH_SIZE": 1.0, "WRITE_SIZE": 1.0}}
     r = b.roofline_from_counters(pmc, {"primary": 0.1, "bounce": 0.1}, 256)
     assert r["hbm"] is not None and r["valu"] is None and r["l1"] is None
+
+
+def test_dry_run_preflight_reports_what_a_multi_gpu_run_would_trip_over():
+    """`bench.py --gpus 8 --dry-run` launches nothing: on a box without 8 GPUs it names the device count as the failing check
+    and still validates the library, the rendezvous, the tile split and the buffer sizes."""
+    import json
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "C4", "--dry-run"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=ROOT)
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["dry_run"] is True and out["n_gpus"] == 8 and out["rays_per_rank_per_wave"] == 4096 * 512
+    checks = {c["check"]: c for c in out["checks"]}
+    for name in ("devices", "rccl_backend", "hsa_ipc_mode", "master_addr", "master_port", "library", "tiles", "memory", "gather"):
+        assert name in checks, name
+    assert checks["library"]["ok"] and checks["tiles"]["ok"] and checks["memory"]["ok"]
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    assert checks["devices"]["ok"] == (have >= 8)
+    assert (r.returncode == 0) == out["ok"]

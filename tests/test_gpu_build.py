@@ -33,6 +33,19 @@ def build(real, v, f, **opt):
     return a, nodes, idx
 
 
+def check_opt_in_distance_order(a, rays, h0, m0, oracle, nodes, idx, v, f, max_ties=None):
+    """The opt-in walk (tunable order4 = 1) against the default walk's records on the SAME tree, whole batch: flags and t
+    bit-equal, u / v / prim_id equal except at exact-t ties, each of which is re-verified against the restatement restricted to
+    the reported primitive (helpers.assert_hits_match).  Leaves the context on the default walk."""
+    a.SetTunable("order4", 1)
+    try:
+        h1, m1 = a.TraverseBatch(rays)
+        assert ", 4, 1>" in a.LastKernelName(), a.LastKernelName()
+    finally:
+        a.SetTunable("order4", 0)
+    return assert_hits_match(h0, m0, h1, m1, oracle, nodes, idx, v, f, rays, max_ties=max_ties)
+
+
 def test_c1_build_valid_and_parity(oracle, c1_mesh, golden_dir):
     v, f = c1_mesh
     a, nodes, idx = build(np.float32, v, f)
@@ -118,6 +131,7 @@ def test_top_array_overflow_is_retried_with_the_same_result(monkeypatch):
     for real in (np.float32, np.float64):
         vv = v.astype(real)
         _, n1, i1 = build(real, vv, f)
+        monkeypatch.setenv("NRT_ALLOW_ENV", "1")
         monkeypatch.setenv("NRT_BUILD_TINY_TOP", "1")
         a, n2, i2 = build(real, vv, f)
         monkeypatch.delenv("NRT_BUILD_TINY_TOP")
@@ -159,6 +173,13 @@ def test_c2_sphere_full_frame_vs_reference_sample(oracle, golden_dir):
     st = int(s["stride"])
     onodes, oidx, _ = oracle.build(v, f)
     assert_hits_match(s["hits"], s["mask"], h[::st], mk[::st], oracle, onodes, oidx, v, f, rays[::st], max_ties=200)
+    # the default walk is the reference's leaf sequence: every field identical to the restatement on the GPU-built tree
+    assert ", 4, 0>" in a.LastKernelName(), a.LastKernelName()
+    sub = slice(None, None, 5)
+    oh, om = oracle.traverse(nodes, idx, v, f, rays[sub])
+    assert_hits_identical(oh, om, h[sub], mk[sub])
+    ties = check_opt_in_distance_order(a, rays, h, mk, oracle, nodes, idx, v, f)
+    print("C2: %d exact-t ties renamed by the opt-in distance order on the full frame" % ties)
 
 
 def test_c3_plane_1m_full_frame(oracle, golden_dir):
@@ -179,9 +200,12 @@ def test_c3_plane_1m_full_frame(oracle, golden_dir):
     onodes, oidx, _ = oracle.build(v, f)
     ties = assert_hits_match(s["hits"], s["mask"], h[::st], mk[::st], oracle, onodes, oidx, v, f, rays[::st], max_ties=2000)
     # the GPU traversal and the CPU restatement agree bit-for-bit on the GPU-built tree (subsample)
-    sub = rays[::97]
+    assert ", 4, 0>" in a.LastKernelName(), a.LastKernelName()  # the shipped default: the reference's slot order
+    sub = rays[::7]
     oh, om = oracle.traverse(nodes, idx, v, f, sub)
-    assert_hits_identical(oh, om, h[::97], mk[::97])
+    assert_hits_identical(oh, om, h[::7], mk[::7])
+    ties4 = check_opt_in_distance_order(a, rays, h, mk, oracle, nodes, idx, v, f)
+    print("C3: %d exact-t ties renamed by the opt-in distance order on the full frame" % ties4)
     # properties: permuting the rays permutes the hits; tracing twice is idempotent
     perm = np.random.default_rng(0).permutation(rays.shape[0])
     hp, mp = a.TraverseBatch(rays[perm])
@@ -223,6 +247,7 @@ def test_morton_prepass_gives_a_valid_equal_quality_tree(oracle, monkeypatch):
     records do not depend on it."""
     v, f = scenes.sphere(160, 80)
     a0, n0, i0 = build(np.float32, v, f)
+    monkeypatch.setenv("NRT_ALLOW_ENV", "1")  # (environment overrides are a debugging aid the process must opt into)
     monkeypatch.setenv("NRT_MORTON", "1")
     a1, n1, i1 = build(np.float32, v, f)
     m0 = validate_bvh(n0, i0, v, f, stats=a0.GetStatistics())
@@ -267,9 +292,12 @@ def test_c4_10m_triangles_4k_tile(oracle):
     rays = scenes.camera_rays(4096, 4096, 1792, 2304)  # the central tile
     h, mk = a.TraverseBatch(rays)
     assert int(mk.sum()) > rays.shape[0] // 2
-    sub = slice(None, None, 1009)
+    assert ", 4, 0>" in a.LastKernelName(), a.LastKernelName()
+    sub = slice(None, None, 53)
     oh, om = oracle.traverse(nodes, idx, v, f, rays[sub])
     assert_hits_identical(oh, om, h[sub], mk[sub])
+    ties4 = check_opt_in_distance_order(a, rays, h, mk, oracle, nodes, idx, v, f)
+    print("C4 tile: %d exact-t ties renamed by the opt-in distance order" % ties4)
     perm = np.random.default_rng(1).permutation(rays.shape[0])[:500000]
     hp, mp = a.TraverseBatch(rays[perm])
     assert hp.tobytes() == h[perm].tobytes() and np.array_equal(mp, mk[perm])

@@ -246,6 +246,7 @@ def test_rays_that_enter_more_than_64_boxes_keep_the_64_nearest(oracle, monkeypa
     from scene_fixture import xform
 
     if prune:  # the front-to-back walk that skips what lies beyond a full list (by default only on scenes of >= 32768 instances)
+        monkeypatch.setenv("NRT_ALLOW_ENV", "1")  # (environment overrides are a debugging aid the process must opt into)
         monkeypatch.setenv("NRT_SCENE_PRUNE_MIN", "1")
     sv, sf = scenes.sphere(16, 8)
     sv = (sv - np.array([0, 5, 0], dtype=np.float32)).astype(np.float32)

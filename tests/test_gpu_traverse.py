@@ -428,7 +428,7 @@ def test_host_entry_point_from_several_threads(c1):
     assert not errors, errors
 
 
-@pytest.mark.parametrize("real,mode", [(np.float32, "default"), (np.float32, "order4"), (np.float32, "wide8"), (np.float32, "one_level"), (np.float64, "default")])
+@pytest.mark.parametrize("real,mode", [(np.float32, "default"), (np.float32, "order4"), (np.float32, "one_level"), (np.float64, "default")])
 def test_several_batches_in_one_launch_equal_separate_launches(real, mode):
     """nrtTraverseBatchesDevice: independent batches of unequal sizes (one empty, one without a mask) walked by ONE persistent
     launch — the records of each batch are exactly those of its own nrtTraverseBatchDevice call (fp64 contexts launch the
@@ -439,8 +439,6 @@ def test_several_batches_in_one_launch_equal_separate_launches(real, mode):
 
     v, f = scenes.plane(200, 100)
     a = BVHAccel(real)
-    if mode == "wide8":
-        a.SetTunable("wide8", 1)
     if mode == "one_level":
         a.SetTunable("wide4", 0)
     assert a.Build(f.shape[0], TriangleMesh(v.astype(real), f))
@@ -472,8 +470,6 @@ def test_several_batches_in_one_launch_equal_separate_launches(real, mode):
     counts = a.TraverseBatchesDevice(dev)
     torch.cuda.synchronize()
     assert counts == [r.shape[0] for r in sets]
-    if real == np.float32:
-        assert ("k_traverse_w8" in a.LastKernelName()) == (mode == "wide8"), a.LastKernelName()
     for k, ((d_r, d_h, d_m, n), (h, m)) in enumerate(zip(dev, want)):
         got = d_h.cpu().numpy()[: n * HIT.itemsize].view(HIT)
         assert all(got[f_].tobytes() == h[f_].tobytes() for f_ in ("t", "u", "v", "prim_id")), "batch %d" % k  # (fp64 records carry 4 padding bytes)

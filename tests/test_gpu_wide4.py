@@ -50,6 +50,7 @@ def hostile_rays(v, n, seed):
 def both_widths(monkeypatch, make_accel, rays, opts=None):
     out = {}
     for w4 in ("0", "1"):
+        monkeypatch.setenv("NRT_ALLOW_ENV", "1")  # (environment overrides are a debugging aid the process must opt into)
         monkeypatch.setenv("NRT_WIDE4", w4)  # read by nrtCreate
         a = make_accel()
         h, m = a.TraverseBatch(rays, opts) if opts is not None else a.TraverseBatch(rays)
