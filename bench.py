@@ -1293,6 +1293,27 @@ def main():
             ms_s = float(np.median(ts))
             out["primary_plus_shadow"] = {"value": round((n1 + rays_s.shape[0]) / (k_ms1 + ms_s) / 1e3, 1), "unit": "Mrays/s",
                                           "shadow_ms": round(ms_s, 4), "shadow_rays": int(rays_s.shape[0])}
+            if wl.real == np.float32 and rays_s.shape[0]:
+                # ... and as ONE launch over both waves, the shadow wave as an occlusion query (nrtTraverseBatchesDevice): one launch tail
+                d_ms = torch.empty(rays_s.shape[0], dtype=torch.uint8, device="cuda")
+                pair = [(wl.d_rays1, wl.d_hits1, wl.d_mask1), (d_rs, None, d_ms, None, "occlusion")]
+                for _ in range(2):
+                    accel.TraverseBatchesDevice(pair)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                torch.cuda.synchronize()
+                ev[0].record()
+                for _ in range(5):
+                    accel.TraverseBatchesDevice(pair)
+                ev[1].record()
+                torch.cuda.synchronize()
+                ms_pair = float(ev[0].elapsed_time(ev[1])) / 5
+                accel.TraverseBatchDevice(d_rs, d_hs, d_ms.new_empty(d_ms.shape))
+                flags_sep = torch.empty_like(d_ms)
+                accel.TraverseBatchDevice(d_rs, d_hs, flags_sep)
+                torch.cuda.synchronize()
+                out["primary_plus_shadow"]["one_launch"] = {"value": round((n1 + rays_s.shape[0]) / ms_pair / 1e3, 1), "ms": round(ms_pair, 4),
+                                                            "occlusion_flags_equal_closest_hit_flags": bool(torch.equal(d_ms, flags_sep))}
+                del d_ms, flags_sep
             del d_rs, d_hs
             # a SECOND bounce: rays generated from the bounce-1 hits by the same host generator, traced in the order the
             # renderer produces them (how far does coherence decay with depth? — profiles/r03a_reorder_probe_*: a random

@@ -124,14 +124,49 @@ static void TraceWave(const nanort::BVHAccel<float> &accel, const Scene &sc, con
   *count += n;
 }
 
+static bool g_separate_waves = false;  // --separate-waves: one TraverseBatch() call per wave (the round-4 behaviour), for comparison
+
+// Two independent waves that are ready at the same time — the shadow query of one depth and the path wave of the next:
+// with the GPU backend ONE TraverseBatches() call (one upload, one persistent launch over both waves — one launch tail
+// instead of two —, one download; the shadow wave as an occlusion query, whose flags equal the closest-hit flags);
+// otherwise the two per-ray host loops.  Records, flags and therefore the image are the same either way.
+static void TraceShadowAndNext(const nanort::BVHAccel<float> &accel, const Scene &sc, const std::vector<Ray> &shadow_rays,
+                               const std::vector<Ray> &next_rays, bool use_batch, std::vector<Hit> *shadow_hits,
+                               std::vector<unsigned char> *shadow_mask, std::vector<Hit> *next_hits, std::vector<unsigned char> *next_mask,
+                               double *secs, uint64_t *count) {
+#ifdef NANORT_USE_HIP_BACKEND
+  if (use_batch && !g_separate_waves) {
+    shadow_mask->assign(shadow_rays.size(), 0);
+    next_hits->resize(next_rays.size());
+    next_mask->assign(next_rays.size(), 0);
+    if (shadow_rays.empty() && next_rays.empty()) return;
+    auto t0 = std::chrono::steady_clock::now();
+    const Ray *r[2] = {shadow_rays.data(), next_rays.data()};
+    const size_t n[2] = {shadow_rays.size(), next_rays.size()};
+    Hit *h[2] = {NULL, next_hits->data()};
+    unsigned char *m[2] = {shadow_mask->data(), next_mask->data()};
+    const unsigned char occ[2] = {1, 0};
+    if (!accel.TraverseBatches(2, r, n, h, m, occ)) {
+      fprintf(stderr, "TraverseBatches failed: %s\n", accel.LastBackendError().c_str());
+      exit(1);
+    }
+    *secs += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *count += shadow_rays.size() + next_rays.size();
+    return;
+  }
+#endif
+  TraceWave(accel, sc, shadow_rays, use_batch, shadow_hits, shadow_mask, secs, count);
+  TraceWave(accel, sc, next_rays, use_batch, next_hits, next_mask, secs, count);
+}
+
 static void Render(const nanort::BVHAccel<float> &accel, const Scene &sc, int W, int H, int spp, int max_depth, bool use_batch,
                    std::vector<float> *image, double *trace_secs, uint64_t *rays_traced) {
   const float3 light(8.0f, 12.0f, 15.0f), light_power(600.0f), albedo(0.75f, 0.7f, 0.6f), sky(0.4f, 0.5f, 0.7f);
   image->assign(3 * (size_t)W * H, 0.0f);
   std::vector<Path> paths, next_paths;
   std::vector<Ray> rays, shadow_rays, next_rays;
-  std::vector<Hit> hits, shadow_hits;
-  std::vector<unsigned char> mask, shadow_mask;
+  std::vector<Hit> hits, shadow_hits, next_hits;
+  std::vector<unsigned char> mask, shadow_mask, next_mask;
   std::vector<float3> shadow_contrib;
   std::vector<uint32_t> shadow_pixel;
 
@@ -158,8 +193,8 @@ static void Render(const nanort::BVHAccel<float> &accel, const Scene &sc, int W,
         r.min_t = 0.001f;
         r.max_t = 1.0e30f;
       }
+    TraceWave(accel, sc, rays, use_batch, &hits, &mask, trace_secs, rays_traced);  // the camera wave; deeper waves ride with the shadow queries below
     for (int depth = 0; depth <= max_depth && !paths.empty(); depth++) {
-      TraceWave(accel, sc, rays, use_batch, &hits, &mask, trace_secs, rays_traced);
       // shade: misses pick up the sky; hits queue a shadow ray (NEE) and, below max depth, a bounce
       shadow_rays.clear();
       shadow_contrib.clear();
@@ -214,7 +249,7 @@ static void Render(const nanort::BVHAccel<float> &accel, const Scene &sc, int W,
           next_rays.push_back(br);
         }
       }
-      TraceWave(accel, sc, shadow_rays, use_batch, &shadow_hits, &shadow_mask, trace_secs, rays_traced);
+      TraceShadowAndNext(accel, sc, shadow_rays, next_rays, use_batch, &shadow_hits, &shadow_mask, &next_hits, &next_mask, trace_secs, rays_traced);
       for (size_t i = 0; i < shadow_rays.size(); i++) {
         if (shadow_mask[i]) continue;  // occluded
         float *px = &(*image)[3 * (size_t)shadow_pixel[i]];
@@ -222,6 +257,8 @@ static void Render(const nanort::BVHAccel<float> &accel, const Scene &sc, int W,
       }
       paths.swap(next_paths);
       rays.swap(next_rays);
+      hits.swap(next_hits);
+      mask.swap(next_mask);
     }
   }
 }
@@ -260,6 +297,8 @@ int main(int argc, char **argv) {
       raw = argv[++i];  // the accumulated float RGB image, row-major, for comparisons
     } else if (!strcmp(argv[i], "--verify")) {
       verify = true;
+    } else if (!strcmp(argv[i], "--separate-waves")) {
+      g_separate_waves = true;
     }
   }
   Scene sc;
@@ -288,7 +327,8 @@ int main(int argc, char **argv) {
   double secs = 0.0;
   uint64_t rays = 0;
   Render(accel, sc, W, H, spp, depth, batch, &image, &secs, &rays);
-  printf("%s: %llu rays in %.3f s of tracing = %.2f Mrays/s (host-visible, PCIe included)\n", batch ? "TraverseBatch" : "per-ray Traverse",
+  printf("%s: %llu rays in %.3f s of tracing = %.2f Mrays/s (host-visible, PCIe included)\n",
+         batch ? (g_separate_waves ? "TraverseBatch (one call per wave)" : "TraverseBatch + TraverseBatches (shadow and next wave in one launch)") : "per-ray Traverse",
          (unsigned long long)rays, secs, (double)rays / secs / 1e6);
   SavePPM(out.c_str(), image, W, H);
   if (!raw.empty()) {

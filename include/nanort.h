@@ -971,6 +971,10 @@ struct HipApi<float> {
                                     uint8_t *const *m, const uint32_t *fl, void *s) {
     return nrtTraverseBatchesDevice_f32(c, nb, r, n, o, h, m, fl, s);
   }
+  static nrt_status TraverseBatchesHost(nrt_ctx *c, uint32_t nb, const RayPod *const *r, const uint64_t *n, const nrt_trace_options *o, HitPod *const *h,
+                                        uint8_t *const *m, const uint32_t *fl) {
+    return nrtTraverseBatches_f32(c, nb, r, n, o, h, m, fl);
+  }
   static nrt_status TraverseMulti(nrt_ctx *const *cs, uint32_t nc, const RayPod *r, uint64_t n, uint64_t row, const nrt_trace_options *o, HitPod *h, uint8_t *m) {
     return nrtTraverseBatchMulti_f32(cs, nc, r, n, row, o, h, m);
   }
@@ -998,6 +1002,10 @@ struct HipApi<double> {
   static nrt_status TraverseBatches(nrt_ctx *c, uint32_t nb, const RayPod *const *r, const uint64_t *n, const nrt_trace_options *o, HitPod *const *h,
                                     uint8_t *const *m, const uint32_t *fl, void *s) {
     return nrtTraverseBatchesDevice_f64(c, nb, r, n, o, h, m, fl, s);
+  }
+  static nrt_status TraverseBatchesHost(nrt_ctx *c, uint32_t nb, const RayPod *const *r, const uint64_t *n, const nrt_trace_options *o, HitPod *const *h,
+                                        uint8_t *const *m, const uint32_t *fl) {
+    return nrtTraverseBatches_f64(c, nb, r, n, o, h, m, fl);
   }
   static nrt_status TraverseMulti(nrt_ctx *const *cs, uint32_t nc, const RayPod *r, uint64_t n, uint64_t row, const nrt_trace_options *o, HitPod *h, uint8_t *m) {
     return nrtTraverseBatchMulti_f64(cs, nc, r, n, row, o, h, m);
@@ -1237,6 +1245,61 @@ class BVHAccel {
     }
     return true;
   }
+  // Several independent HOST waves in ONE launch (nrtTraverseBatches): what a host-shaded wavefront renderer has ready at the
+  // same time — the shadow query of one depth and the path wave of the next — uploaded together, walked by one persistent
+  // launch (one launch tail instead of one per wave), downloaded together.  `occlusion[k]` != 0 makes wave k an occlusion
+  // query: only hit_out[k] (required) is written.  For the other waves isects[k][i] is written only on a hit, like
+  // TraverseBatch(); hit_out[k] may be NULL.  Records and flags are exactly those of separate TraverseBatch() /
+  // OccludedBatch() calls.  `occlusion` may be NULL.
+  bool TraverseBatches(size_t num_waves, const Ray<T> *const *rays, const size_t *num_rays, TriangleIntersection<T> *const *isects,
+                       unsigned char *const *hit_out, const unsigned char *occlusion, const BVHTraceOptions &options = BVHTraceOptions()) const {
+    typedef detail::HipApi<T> Api;
+    typedef typename Api::HitPod HitPod;
+    if (!TraverseBatchImpl(static_cast<const Ray<T> *>(NULL), 0, static_cast<TriangleIntersection<T> *>(NULL), NULL, options)) return false;  // (context, primitive kind, a tree adopted by Load())
+    size_t total = 0;
+    for (size_t k = 0; k < num_waves; k++) total += num_rays[k];
+    if (total == 0) return true;
+    HitPod *tmp = static_cast<HitPod *>(StageEnsure(&stage_hits_, &stage_hits_cap_, total * sizeof(HitPod)));
+    unsigned char *tmask = static_cast<unsigned char *>(StageEnsure(&stage_mask_, &stage_mask_cap_, total));
+    if (!tmp || !tmask) {
+      backend_error_ = "TraverseBatches: out of host memory for the staging buffers";
+      return false;
+    }
+    std::vector<const typename Api::RayPod *> r(num_waves);
+    std::vector<HitPod *> h(num_waves);
+    std::vector<uint8_t *> m(num_waves);
+    std::vector<uint64_t> n(num_waves);
+    std::vector<uint32_t> fl(num_waves);
+    size_t off = 0;
+    for (size_t k = 0; k < num_waves; k++) {
+      const bool occ = occlusion && occlusion[k];
+      if (num_rays[k] && occ && !(hit_out && hit_out[k])) {
+        backend_error_ = "TraverseBatches: an occlusion wave needs its hit_out array";
+        return false;
+      }
+      r[k] = reinterpret_cast<const typename Api::RayPod *>(rays[k]);
+      h[k] = occ ? NULL : tmp + off;
+      m[k] = (hit_out && hit_out[k]) ? hit_out[k] : tmask + off;
+      n[k] = num_rays[k];
+      fl[k] = occ ? NRT_BATCH_OCCLUSION : 0u;
+      off += num_rays[k];
+    }
+    nrt_trace_options o;
+    std::memcpy(&o, &options, sizeof(o));
+    if (Api::TraverseBatchesHost(ctx_.get(), static_cast<uint32_t>(num_waves), r.data(), n.data(), &o, h.data(), m.data(), fl.data()) != NRT_OK) {
+      backend_error_ = nrtLastError(ctx_.get());
+      return false;
+    }
+    for (size_t k = 0; k < num_waves; k++) {
+      if (fl[k] || !isects || !isects[k]) continue;
+      const HitPod *src = h[k];
+      const uint8_t *mk = m[k];
+      TriangleIntersection<T> *dst = isects[k];
+      for (size_t i = 0; i < num_rays[k]; i++)
+        if (mk[i]) std::memcpy(static_cast<void *>(&dst[i]), &src[i], sizeof(HitPod));
+    }
+    return true;
+  }
   // Opt-in extension without a reference counterpart: occlusion queries.  occluded_out[i] is exactly what
   // TraverseBatch() would report in hit_out[i], but a ray stops at the first primitive it accepts (shadow rays).
   bool OccludedBatch(const Ray<T> *rays, size_t num_rays, unsigned char *occluded_out, const BVHTraceOptions &options = BVHTraceOptions()) const {
@@ -1286,7 +1349,7 @@ class BVHAccel {
       return false;
     }
     if (test_cap != cyl_test_cap_ || device_tree_stale_) {  // the flag lives with the primitives on the device
-      if (nodes_.empty() || nrtSetCylinders_f32(ctx_.get(), cyl_endpoints_, cyl_radii_, static_cast<unsigned int>(indices_.size()), test_cap ? 1 : 0) != NRT_OK ||
+      if (nodes_.empty() || nrtSetCylinders_f32(ctx_.get(), cyl_endpoints_, cyl_radii_, cyl_count_, test_cap ? 1 : 0) != NRT_OK ||
           nrtSetTree_f32(ctx_.get(), reinterpret_cast<const nrt_node_f32 *>(&nodes_[0]), nodes_.size(), &indices_[0], indices_.size()) != NRT_OK) {
         backend_error_ = nodes_.empty() ? "TraverseBatch: empty tree" : nrtLastError(ctx_.get());
         return false;
@@ -1738,6 +1801,7 @@ class BVHAccel {
     (void)pred;
     cyl_endpoints_ = geom.GetEndpoints();
     cyl_radii_ = geom.GetRadii();
+    cyl_count_ = n;
     cyl_test_cap_ = true;
     return HipBuild(n, options, 2, [&](nrt_ctx *c) { return nrtSetCylinders_f32(c, geom.GetEndpoints(), geom.GetRadii(), n, 1); });
   }
@@ -1801,8 +1865,12 @@ class BVHAccel {
       fprintf(stderr, "[nanort] HIP build failed: %s\n", backend_error_.c_str());
       return false;
     }
+    // (the index array names a primitive once per leaf slot: n entries, except for cylinders the library cut into segments for
+    // its builder, which are named once per segment — the reference's Traverse takes such a tree as it is)
+    uint64_t tree_nodes = num_nodes, tree_indices = n;
+    if (nrtTreeSize(c, &tree_nodes, &tree_indices) != NRT_OK) tree_indices = n;
     nodes_.resize(static_cast<size_t>(num_nodes));
-    indices_.resize(n);
+    indices_.resize(static_cast<size_t>(tree_indices));
     if (Api::GetTree(c, reinterpret_cast<typename Api::NodePod *>(&nodes_[0]), &indices_[0]) != NRT_OK) {
       backend_error_ = nrtLastError(c);
       nodes_.clear();
@@ -1843,6 +1911,7 @@ class BVHAccel {
   int device_prim_kind_ = -1;  // what the device context was built over: 0 triangles, 1 spheres, 2 cylinders, -1 nothing usable
   const float *cyl_endpoints_ = NULL;  // cylinder primitive: what Build() was given
   const float *cyl_radii_ = NULL;
+  unsigned int cyl_count_ = 0;
   mutable bool cyl_test_cap_ = true;
   // TraverseBatch staging (grow-only): pinned through nrtHostAlloc, plain malloc if that fails
   mutable std::shared_ptr<void> stage_hits_, stage_mask_;

@@ -314,6 +314,19 @@ NRT_API nrt_status nrtTraverseBatchesDevice_f64(nrt_ctx *ctx, uint32_t num_batch
                                                 nrt_hit_f64 *const *d_hits_out, uint8_t *const *d_masks_out,
                                                 const uint32_t *batch_flags, void *hip_stream);
 
+/* The same for HOST batches: every batch is uploaded next to the others, ONE launch walks them all, the records come back batch
+ * by batch — what a host-shaded wavefront renderer submits together (the shadow query of one depth and the path wave of the
+ * next), with one launch tail instead of `num_batches`.  Host pointers in and out, synchronous; at most 2^26 rays per call.
+ * An occlusion batch needs its masks_out entry; a closest-hit batch its hits_out entry (masks_out[k] may be NULL).  Unlike the
+ * reference's Traverse (nanort.h:1205-1211) — and like nrtTraverseBatch — every record of a closest-hit batch is written: a
+ * miss stores {0, 0, ray.max_t, 0xFFFFFFFF}.  Records are exactly those of separate nrtTraverseBatch / nrtOccludedBatch calls. */
+NRT_API nrt_status nrtTraverseBatches_f32(nrt_ctx *ctx, uint32_t num_batches, const nrt_ray_f32 *const *rays, const uint64_t *num_rays,
+                                          const nrt_trace_options *options, nrt_hit_f32 *const *hits_out, uint8_t *const *masks_out,
+                                          const uint32_t *batch_flags);
+NRT_API nrt_status nrtTraverseBatches_f64(nrt_ctx *ctx, uint32_t num_batches, const nrt_ray_f64 *const *rays, const uint64_t *num_rays,
+                                          const nrt_trace_options *options, nrt_hit_f64 *const *hits_out, uint8_t *const *masks_out,
+                                          const uint32_t *batch_flags);
+
 /* One HOST batch spread over several contexts — typically one per GPU of the node (nrtDeviceCount), each holding the same
  * tree: nrtBuild is deterministic, so building the same mesh on every context gives bit-identical replicas (or nrtSetTree the
  * same arrays).  The batch is cut into rows of `row_len` rays (an image row; 0 = 4096) and row r is traced by context

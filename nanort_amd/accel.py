@@ -299,6 +299,33 @@ class BVHAccel:
         self._check(getattr(self._L, "nrtTraverseBatchesDevice_" + self._s)(self._h, nb, rays, counts, _p(options), hits, masks, flags, stream))
         return [int(c) for c in counts]
 
+    def TraverseBatches(self, batches, options=None):
+        """nrtTraverseBatches: several independent HOST batches — a list of ray arrays or (rays, "occlusion") pairs — uploaded
+        together, walked by ONE persistent launch, downloaded together.  Returns a list of (hits, mask) per closest-hit batch
+        and (None, mask) per occlusion batch: exactly what TraverseBatch / OccludedBatch return for each of them."""
+        RAY, HIT = ray_dtype(self.real), hit_dtype(self.real)
+        nb = len(batches)
+        rays = (ctypes.c_void_p * nb)()
+        hits = (ctypes.c_void_p * nb)()
+        masks = (ctypes.c_void_p * nb)()
+        counts = (ctypes.c_uint64 * nb)()
+        flags = (ctypes.c_uint32 * nb)()
+        keep, out = [], []
+        for k, b in enumerate(batches):
+            occ = isinstance(b, tuple) and len(b) > 1 and b[1] == "occlusion"
+            r = np.ascontiguousarray(b[0] if isinstance(b, tuple) else b, dtype=RAY)
+            h = None if occ else np.zeros((r.shape[0],), dtype=HIT)
+            m = np.zeros((r.shape[0],), dtype=np.uint8)
+            keep.append(r)
+            out.append((h, m))
+            rays[k], counts[k], flags[k] = (r.ctypes.data if r.shape[0] else None), r.shape[0], (1 if occ else 0)
+            hits[k] = None if (occ or not r.shape[0]) else h.ctypes.data
+            masks[k] = m.ctypes.data if r.shape[0] else None
+        if options is not None:
+            options = np.asarray(options, dtype=TRACE_OPTIONS).reshape(1)
+        self._check(getattr(self._L, "nrtTraverseBatches_" + self._s)(self._h, nb, rays, counts, _p(options), hits, masks, flags))
+        return out
+
     def OccludedBatch(self, rays, options=None):
         """Opt-in extension: only the hit flags of TraverseBatch(), each ray stopping at the first primitive it accepts."""
         rays = np.ascontiguousarray(rays, dtype=ray_dtype(self.real))

@@ -23,7 +23,7 @@ SYMBOLS = [
     "nrtGetTree_f32", "nrtGetTree_f64", "nrtTreeSize",
     "nrtSetTree_f32", "nrtSetTree_f64",
     "nrtTraverseBatch_f32", "nrtTraverseBatch_f64",
-    "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64", "nrtTraverseBatchesDevice_f32", "nrtTraverseBatchesDevice_f64",
+    "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64", "nrtTraverseBatchesDevice_f32", "nrtTraverseBatchesDevice_f64", "nrtTraverseBatches_f32", "nrtTraverseBatches_f64",
     "nrtTraverseBatchMulti_f32", "nrtTraverseBatchMulti_f64", "nrtDeviceCount",
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
@@ -104,6 +104,9 @@ def lib():
         f.restype = i32
         f = getattr(L, "nrtTraverseBatchesDevice_" + s)
         f.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp, vp]
+        f.restype = i32
+        f = getattr(L, "nrtTraverseBatches_" + s)
+        f.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
         f.restype = i32
         f = getattr(L, "nrtTraverseCountDevice_" + s)
         f.argtypes = [vp, vp, u64, vp, ctypes.POINTER(TraceCounters)]

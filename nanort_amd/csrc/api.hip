@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ctype.h>
+#include <math.h>
+#include <cmath>
 
 #include <algorithm>
 #include <atomic>
@@ -51,10 +53,12 @@ struct BuildResult {
 };
 // (build.hip) enqueues a whole build; its size and statistics arrive in `pinned` behind `ev`: gpu_build_result waits for them
 template <typename T>
-hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, bool cylinders, uint32_t num_faces,
+hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, bool cylinders, const uint32_t *d_prim_map, uint32_t num_faces,
                      uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, unsigned build_flags, // (bit 0: Morton pre-pass, bit 1: one-node-per-step subtree kernel)
                      DevBuf *workspace, DevBuf *nodes_buf, DevBuf *indices_buf, void *pinned, hipEvent_t ev, std::string *err);
 hipError_t gpu_build_result(const void *pinned, hipEvent_t ev, BuildResult *res);
+hipError_t launch_cylinder_segments(const float *verts, const float *radii, const uint32_t *seg_off, uint32_t n, float *seg_verts,
+                                    float *seg_radii, uint32_t *seg_prim, hipStream_t s);
 } // namespace nrt
 
 using namespace nrt;
@@ -71,6 +75,11 @@ struct nrt_ctx {
   // mesh (tight xyz in HBM)
   int prim_kind = kPrimTriangles; // kPrimSpheres: d_verts = centres, d_radii = radii, no faces; kPrimCylinders: d_verts = 2 end points, d_radii = 2 radii per primitive
   uint32_t cyl_test_cap = 1;
+  // cylinders cut into segments for the builder (build.hip k_cylinder_segments): what the tree is built over when num_segs != 0
+  DevBuf b_seg_verts, b_seg_radii, b_seg_prim, b_seg_off;
+  uint32_t num_segs = 0;
+  int cyl_split = 32;     // most segments a cylinder is cut into (tunable "cyl_split"; 1: never; read by nrtSetCylinders)
+  int cyl_seg_radii = 8;  // ... one per this many tube radii of its length (tunable "cyl_seg_radii")
   DevBuf b_verts, b_radii, b_faces; // grow-only: a per-frame SetMesh allocates nothing in the steady state
   void *d_verts = nullptr;          // == b_verts.p while primitives are set
   void *d_radii = nullptr;
@@ -252,6 +261,7 @@ static void free_mesh(nrt_ctx *c) {
   c->d_faces = nullptr;
   c->d_radii = nullptr;
   c->num_faces = c->num_verts = 0;
+  c->num_segs = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -280,6 +290,8 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("blocks_per_cu", 0, 8, max_blocks_per_cu, unsigned), // cap on the persistent grid (0: occupancy)
     NRT_TUNABLE("debug", 0, 0x7FFFFFFF, debug_flags, unsigned),   // profiling bit mask
     NRT_TUNABLE("morton", 0, 1, morton, int),                     // Morton pre-pass of the builder (next build)
+    NRT_TUNABLE("cyl_split", 1, 64, cyl_split, int),              // cylinders: most segments one is cut into for the builder (1: never; next nrtSetCylinders)
+    NRT_TUNABLE("cyl_seg_radii", 1, 1024, cyl_seg_radii, int),    // ... one segment per this many tube radii of length (next nrtSetCylinders)
 #ifdef NRT_PROF
     NRT_TUNABLE("subtree_rows", 0, 1, subtree_rows, int),         // 0: the builder's one-node-per-step subtree kernel (next build; same tree) — libnanort_hip_prof.so only
 #endif
@@ -410,7 +422,7 @@ void nrtDestroy(nrt_ctx *c) {
   }
   free_tree(c);
   free_mesh(c);
-  DevBuf *bufs[] = {&c->b_verts, &c->b_radii, &c->b_faces, &c->st_rays, &c->st_hits, &c->st_mask, &c->b_nodes, &c->b_indices, &c->b_tris, &c->b_wide, &c->b_wide4, &c->b_wide_scratch, &c->b_build_ws, &c->b_wave_clock};
+  DevBuf *bufs[] = {&c->b_verts, &c->b_radii, &c->b_faces, &c->st_rays, &c->st_hits, &c->st_mask, &c->b_nodes, &c->b_indices, &c->b_tris, &c->b_wide, &c->b_wide4, &c->b_wide_scratch, &c->b_build_ws, &c->b_wave_clock, &c->b_seg_verts, &c->b_seg_radii, &c->b_seg_prim, &c->b_seg_off};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->d_counters) (void)hipFree(c->d_counters);
@@ -528,6 +540,44 @@ static nrt_status set_cylinders(nrt_ctx *c, const float *endpoints, const float 
   c->d_radii = c->b_radii.p;
   HIPCHK(c, hipMemcpy(c->d_verts, endpoints, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_radii, radii, 2 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  // Segments for the builder (build.hip, k_cylinder_segments): a cylinder many radii long is handed over as several pieces
+  // with their own tight boxes and the cylinder's id.  Counts on the host (the arrays are here anyway), pieces on the device.
+  c->num_segs = 0;
+  if (c->cyl_split > 1) {
+    std::vector<uint32_t> off((size_t)n + 1);
+    uint64_t total = 0;
+    for (int pass = 0; pass < 2 && total == 0; pass++) {
+      // (second pass: the segment array would not fit the packed leaf references — fall back to half as many pieces at most)
+      const uint32_t kmax = (uint32_t)c->cyl_split >> pass;
+      uint64_t t = 0;
+      for (uint32_t i = 0; i < n; i++) {
+        const float *p0 = endpoints + 6 * (size_t)i, *p1 = p0 + 3;
+        const float r0 = radii[2 * (size_t)i], r1 = radii[2 * (size_t)i + 1];
+        const float rr = r0 > r1 ? r0 : r1;
+        const double dx = (double)p1[0] - p0[0], dy = (double)p1[1] - p0[1], dz = (double)p1[2] - p0[2];
+        const double len = sqrt(dx * dx + dy * dy + dz * dz);
+        uint32_t k = 1;
+        if (kmax > 1 && rr > 0.0f && std::isfinite(len) && std::isfinite(rr) && len > 0.0) { // (zero-radius "cylinders" are boxes: the top-level tree of a scene)
+          const double want = ceil(len / ((double)c->cyl_seg_radii * (double)rr));
+          k = want >= (double)kmax ? kmax : (want < 1.0 ? 1u : (uint32_t)want);
+        }
+        off[i] = (uint32_t)t;
+        t += k;
+      }
+      off[n] = (uint32_t)t;
+      if (t < (uint64_t)kPackedFirstMask) total = t;
+    }
+    if (total > (uint64_t)n) {
+      if ((st = ensure(c, c->b_seg_off, ((size_t)n + 1) * sizeof(uint32_t))) || (st = ensure(c, c->b_seg_verts, 6 * (size_t)total * sizeof(float))) ||
+          (st = ensure(c, c->b_seg_radii, 2 * (size_t)total * sizeof(float))) || (st = ensure(c, c->b_seg_prim, (size_t)total * sizeof(uint32_t))))
+        return st;
+      HIPCHK(c, hipMemcpyAsync(c->b_seg_off.p, off.data(), ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, launch_cylinder_segments((const float *)c->d_verts, (const float *)c->d_radii, (const uint32_t *)c->b_seg_off.p, n,
+                                         (float *)c->b_seg_verts.p, (float *)c->b_seg_radii.p, (uint32_t *)c->b_seg_prim.p, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream)); // (`off` is pageable host memory)
+      c->num_segs = (uint32_t)total;
+    }
+  }
   return NRT_OK;
 }
 
@@ -691,14 +741,18 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   BuildResult res;
   std::string err;
   HIPCHK(c, hipEventRecord(c->ev_b0, c->stream));
-  hipError_t e = gpu_build<T>(c->stream, (const T *)c->d_verts, c->d_faces, (const T *)c->d_radii, c->prim_kind == kPrimCylinders, c->num_faces, min_leaf, max_depth,
+  // (cylinder contexts whose cylinders were cut into segments: the tree is built over the segments, each carrying its cylinder's id)
+  const bool segs = c->prim_kind == kPrimCylinders && c->num_segs != 0 && sizeof(T) == 4;
+  const uint32_t build_n = segs ? c->num_segs : c->num_faces;
+  hipError_t e = gpu_build<T>(c->stream, segs ? (const T *)c->b_seg_verts.p : (const T *)c->d_verts, c->d_faces, segs ? (const T *)c->b_seg_radii.p : (const T *)c->d_radii,
+                              c->prim_kind == kPrimCylinders, segs ? (const uint32_t *)c->b_seg_prim.p : nullptr, build_n, min_leaf, max_depth,
                               bin_size, (c->morton ? 1u : 0u) | (c->subtree_rows ? 0u : 2u), &c->b_build_ws, &c->b_nodes, &c->b_indices, c->build_state, c->ev_build_state, &err);
   if (e != hipSuccess) return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s (%s)", err.c_str(), hipGetErrorString(e));
   // everything is enqueued; the leaf-ordered primitive records need the index array only, so they are enqueued too before
   // the host waits for the tree's size (the GPU stays busy meanwhile)
   c->d_nodes = c->b_nodes.p;
   c->d_indices = (uint32_t *)c->b_indices.p;
-  c->num_indices = c->num_faces;
+  c->num_indices = build_n;
   nrt_status fst = finish_leaf_records<T>(c);
   if (fst) {
     free_tree(c); // (no half-built tree is left behind: a later traversal call then reports "no tree")
@@ -1236,6 +1290,61 @@ static nrt_status traverse_batches_device(nrt_ctx *c, uint32_t nb, const typenam
   return NRT_OK;
 }
 
+// The same for HOST batches (nrtTraverseBatches): every batch is staged next to the others, ONE launch walks them all (one
+// launch tail: a host renderer's shadow query of one depth and its path wave of the next), the records come back batch by
+// batch.  Like nrtTraverseBatch the staging buffers are the context's: one host call at a time.
+template <typename T>
+static nrt_status traverse_batches_host(nrt_ctx *c, uint32_t nb, const typename Wire<T>::Ray *const *rays, const uint64_t *counts,
+                                        const nrt_trace_options *opt, typename Wire<T>::Hit *const *hits, uint8_t *const *masks,
+                                        const uint32_t *flags) {
+  typedef typename Wire<T>::Ray Ray;
+  typedef typename Wire<T>::Hit Hit;
+  if (!c) return NRT_ERR_INVALID;
+  if (nb == 0) return NRT_OK;
+  if (!rays || !counts || !hits) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: NULL argument");
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < nb; k++) {
+    if (!counts[k]) continue;
+    const bool occ = flags && (flags[k] & NRT_BATCH_OCCLUSION);
+    if (!rays[k]) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: batch %u has no rays", k);
+    if (occ && !(masks && masks[k])) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: occlusion batch %u has no flag array", k);
+    if (!occ && !hits[k]) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: batch %u has no hit array", k);
+    total += counts[k];
+  }
+  if (total == 0) return NRT_OK;
+  if (total > (1ull << 26)) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: more than 2^26 rays in one call");
+  std::lock_guard<std::mutex> host_lock(c->host_mutex);
+  HIPCHK(c, hipSetDevice(c->device));
+  nrt_status st;
+  if ((st = ensure(c, c->st_rays, total * sizeof(Ray))) || (st = ensure(c, c->st_hits, total * sizeof(Hit))) || (st = ensure(c, c->st_mask, total)))
+    return st;
+  std::vector<const Ray *> d_r(nb, nullptr);
+  std::vector<Hit *> d_h(nb, nullptr);
+  std::vector<uint8_t *> d_m(nb, nullptr);
+  uint64_t off = 0;
+  for (uint32_t k = 0; k < nb; k++) {
+    if (!counts[k]) continue;
+    d_r[k] = (const Ray *)c->st_rays.p + off;
+    d_h[k] = (Hit *)c->st_hits.p + off;
+    d_m[k] = (uint8_t *)c->st_mask.p + off;
+    HIPCHK(c, hipMemcpyAsync((void *)d_r[k], rays[k], counts[k] * sizeof(Ray), hipMemcpyHostToDevice, c->stream));
+    off += counts[k];
+  }
+  st = traverse_batches_device<T>(c, nb, d_r.data(), counts, opt, d_h.data(), d_m.data(), flags, c->stream);
+  if (st) {
+    (void)hipStreamSynchronize(c->stream);
+    return st;
+  }
+  for (uint32_t k = 0; k < nb; k++) {
+    if (!counts[k]) continue;
+    const bool occ = flags && (flags[k] & NRT_BATCH_OCCLUSION);
+    if (!occ) HIPCHK(c, hipMemcpyAsync(hits[k], d_h[k], counts[k] * sizeof(Hit), hipMemcpyDeviceToHost, c->stream));
+    if (masks && masks[k]) HIPCHK(c, hipMemcpyAsync(masks[k], d_m[k], counts[k], hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return NRT_OK;
+}
+
 template <typename T>
 static nrt_status occluded_host(nrt_ctx *c, const typename Wire<T>::Ray *rays, uint64_t n, const nrt_trace_options *opt, uint8_t *mask) {
   if (!c) return NRT_ERR_INVALID;
@@ -1394,6 +1503,14 @@ nrt_status nrtTraverseBatchesDevice_f32(nrt_ctx *c, uint32_t nb, const nrt_ray_f
 nrt_status nrtTraverseBatchesDevice_f64(nrt_ctx *c, uint32_t nb, const nrt_ray_f64 *const *r, const uint64_t *n, const nrt_trace_options *o,
                                         nrt_hit_f64 *const *h, uint8_t *const *m, const uint32_t *fl, void *s) {
   return traverse_batches_device<double>(c, nb, r, n, o, h, m, fl, (hipStream_t)s);
+}
+nrt_status nrtTraverseBatches_f32(nrt_ctx *c, uint32_t nb, const nrt_ray_f32 *const *r, const uint64_t *n, const nrt_trace_options *o,
+                                  nrt_hit_f32 *const *h, uint8_t *const *m, const uint32_t *fl) {
+  return traverse_batches_host<float>(c, nb, r, n, o, h, m, fl);
+}
+nrt_status nrtTraverseBatches_f64(nrt_ctx *c, uint32_t nb, const nrt_ray_f64 *const *r, const uint64_t *n, const nrt_trace_options *o,
+                                  nrt_hit_f64 *const *h, uint8_t *const *m, const uint32_t *fl) {
+  return traverse_batches_host<double>(c, nb, r, n, o, h, m, fl);
 }
 nrt_status nrtTraverseCountDevice_f32(nrt_ctx *c, const nrt_ray_f32 *r, uint64_t n, const nrt_trace_options *o,
                                       nrt_trace_counters *out) {

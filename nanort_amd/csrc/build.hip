@@ -433,6 +433,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_prim_records(const T *__restrict__ verts,
                                                       const uint32_t *__restrict__ faces,
                                                       const T *__restrict__ radii, bool cylinders, uint32_t n,
+                                                      const uint32_t *__restrict__ prim_map,
                                                       PrimRec<T> *__restrict__ recs,
                                                       BoundsAcc<T> *__restrict__ scene) {
   typedef typename Ord<T>::U U;
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(256) void k_prim_records(const T *__restrict__ vert
       clo[k] = tmin(clo[k], r.c[k]);
       chi[k] = tmax(chi[k], r.c[k]);
     }
-    r.prim = i;
+    r.prim = prim_map ? prim_map[i] : i; // (cylinder SEGMENTS carry their cylinder's id: k_cylinder_segments)
     recs[i] = r;
   }
 #pragma unroll
@@ -2588,6 +2589,74 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
     }                                                                   \
   } while (0)
 
+// ---------------------------------------------------------------------------
+// Long cylinders, cut into SEGMENTS for the builder (round 5).  The cylinder example's scene is box-spanning needles (random
+// end points in the scene box, examples/cylinder_primitive/main.cc:428-462): a tree over their whole boxes prunes nothing —
+// every box covers a fair part of the scene (4 200 L1 look-ups per ray, 44 Mrays/s in round 4).  So the builder is handed
+// one primitive per SEGMENT of a cylinder's axis, each with the tight box of its piece of the tube — the box of the two
+// end points of the piece, each grown by the radius the intersector uses for the whole tube, max(r0, r1)
+// (main.cc:256), plus a few ulps for the rounding of the interior end points — and the CYLINDER's id: the index array then
+// names a cylinder once per segment, a leaf tests the whole cylinder (CylinderIntersector::Intersect is a pure function of
+// (ray, cylinder, current t): testing a cylinder twice returns the same record or rejects it), and the closest hit of a
+// cylinder lies in the box of the segment it falls on.  The segment count is fixed on the host (nrtSetCylinders: length over
+// `cyl_seg_radii` tube radii, at most `cyl_split`); a cylinder of one segment keeps the reference's own box
+// (CylinderGeometry::BoundingBox, main.cc:132-165: p0 -/+ r0, p1 -/+ r1).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cylinder_segments(const float *__restrict__ verts, const float *__restrict__ radii,
+                                                           const uint32_t *__restrict__ seg_off, uint32_t n,
+                                                           float *__restrict__ seg_verts, float *__restrict__ seg_radii,
+                                                           uint32_t *__restrict__ seg_prim) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t first = seg_off[i], K = seg_off[i + 1] - first;
+  float p0[3], p1[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    p0[k] = verts[6 * (size_t)i + k];
+    p1[k] = verts[6 * (size_t)i + 3 + k];
+  }
+  const float r0 = radii[2 * (size_t)i], r1 = radii[2 * (size_t)i + 1];
+  if (K <= 1u) { // unsplit: the reference's own box
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      seg_verts[6 * (size_t)first + k] = p0[k];
+      seg_verts[6 * (size_t)first + 3 + k] = p1[k];
+    }
+    seg_radii[2 * (size_t)first] = r0;
+    seg_radii[2 * (size_t)first + 1] = r1;
+    seg_prim[first] = i;
+    return;
+  }
+  const float rr = r0 > r1 ? r0 : r1; // std::max<float>(r0, r1), main.cc:256
+  const float invK = 1.0f / (float)K;
+  float a[3] = {p0[0], p0[1], p0[2]};
+  for (uint32_t j = 0; j < K; j++) {
+    float b[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) b[k] = (j + 1u == K) ? p1[k] : p0[k] + (p1[k] - p0[k]) * ((float)(j + 1u) * invK);
+    // the interior end points are rounded (a few ulps of their coordinates): the radius carries that slack
+    const float mag = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fabsf(a[2])) + fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fabsf(b[2])) + rr;
+    const float rs = rr + 1.0e-6f * mag;
+    const size_t o = (size_t)first + j;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      seg_verts[6 * o + k] = a[k];
+      seg_verts[6 * o + 3 + k] = b[k];
+      a[k] = b[k];
+    }
+    seg_radii[2 * o] = rs;
+    seg_radii[2 * o + 1] = rs;
+    seg_prim[o] = i;
+  }
+}
+
+hipError_t launch_cylinder_segments(const float *verts, const float *radii, const uint32_t *seg_off, uint32_t n, float *seg_verts,
+                                    float *seg_radii, uint32_t *seg_prim, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cylinder_segments, dim3((n + 255u) / 256u), dim3(256), 0, s, verts, radii, seg_off, n, seg_verts, seg_radii, seg_prim);
+  return hipGetLastError();
+}
+
 // Builds into caller-owned grow-only buffers (no allocation in the steady state of a per-frame rebuild).
 // The host has to learn two things from the device: that the top phase has run out of large nodes, and the tree's size
 // and statistics.  Neither read-back leaves the GPU idle: the state block is copied into page-locked memory (`pinned`,
@@ -2596,7 +2665,7 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
 // (their grids are upper bounds; the node array is sized for the 2n - 1 nodes a tree over n primitives can have).
 // gpu_build returns once everything is enqueued; gpu_build_result() waits for the final state block.
 template <typename T>
-hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, bool cylinders, uint32_t n,
+hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, const T *d_radii, bool cylinders, const uint32_t *d_prim_map, uint32_t n,
                      uint32_t min_leaf, uint32_t max_depth, uint32_t bin_size, unsigned build_flags, DevBuf *workspace, DevBuf *nodes_buf,
                      DevBuf *indices_buf, void *pinned, hipEvent_t ev, std::string *err) {
   typedef typename Wire<T>::Node Node;
@@ -2640,7 +2709,7 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     hipLaunchKernelGGL((k_init_scene<T>), dim3(1), dim3(64), 0, s, scene, info, (uint32_t)plan.max_top, gbins, child_acc);
     {
       unsigned grid = (unsigned)std::min<size_t>(((size_t)n + 255) / 256, 2048);
-      hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, d_radii, cylinders, n, recs[0], scene);
+      hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, d_radii, cylinders, n, d_prim_map, recs[0], scene);
     }
     int cur = 0; // buffer holding the ranges of the nodes being split
     if (morton_order && n > 1) {
@@ -2760,9 +2829,9 @@ hipError_t gpu_build_result(const void *pinned, hipEvent_t ev, BuildResult *res)
   return hipSuccess;
 }
 
-template hipError_t gpu_build<float>(hipStream_t, const float *, const uint32_t *, const float *, bool, uint32_t, uint32_t,
+template hipError_t gpu_build<float>(hipStream_t, const float *, const uint32_t *, const float *, bool, const uint32_t *, uint32_t, uint32_t,
                                      uint32_t, uint32_t, unsigned, DevBuf *, DevBuf *, DevBuf *, void *, hipEvent_t, std::string *);
-template hipError_t gpu_build<double>(hipStream_t, const double *, const uint32_t *, const double *, bool, uint32_t, uint32_t,
+template hipError_t gpu_build<double>(hipStream_t, const double *, const uint32_t *, const double *, bool, const uint32_t *, uint32_t, uint32_t,
                                       uint32_t, uint32_t, unsigned, DevBuf *, DevBuf *, DevBuf *, void *, hipEvent_t, std::string *);
 
 } // namespace nrt

@@ -36,32 +36,74 @@ def test_reference_tree_matches_golden_fixture(golden_dir):
         check(h, m, g["hits" + key], g["mask" + key])
 
 
+def leaf_segments_cover(nodes, idx, v, r, n_check=2000):
+    """Every leaf entry names a cylinder whose AXIS crosses the leaf's box grown by the tube radius (a segment's box is the box
+    of a piece of the axis grown by the radius), and every cylinder is named at least once."""
+    rr = np.maximum(r[:, 0], r[:, 1])
+    for i in range(min(nodes.shape[0], n_check)):
+        nd = nodes[i]
+        if nd["flag"] == 1:
+            cnt, first = int(nd["data"][0]), int(nd["data"][1])
+            for p in idx[first:first + cnt]:
+                lo, hi = nd["bmin"] - 1e-5, nd["bmax"] + 1e-5
+                # clip the axis segment p0 + s (p1 - p0), s in [0, 1], against the box (the box holds a piece of the tube)
+                p0, d = v[p, 0].astype(np.float64), (v[p, 1] - v[p, 0]).astype(np.float64)
+                s0, s1 = 0.0, 1.0
+                for k in range(3):
+                    if d[k] == 0:
+                        assert lo[k] <= p0[k] <= hi[k] or rr[p] > 0
+                        continue
+                    a, b = (lo[k] - rr[p] - p0[k]) / d[k], (hi[k] + rr[p] - p0[k]) / d[k]
+                    s0, s1 = max(s0, min(a, b)), min(s1, max(a, b))
+                assert s0 <= s1 + 1e-6, (i, int(p))
+        else:
+            for ch in nd["data"]:
+                assert np.all(nodes[ch]["bmin"] >= nd["bmin"]) and np.all(nodes[ch]["bmax"] <= nd["bmax"])
+
+
+@pytest.mark.parametrize("split", [1, 32], ids=["whole_boxes", "segments"])
 @pytest.mark.parametrize("n", [1, 3, 4, 5, 257, 4000, 100000])
-def test_gpu_built_tree(n):
+def test_gpu_built_tree(n, split, golden_dir):
+    """The GPU-built tree — over the reference's whole-cylinder boxes (cyl_split = 1) or over SEGMENTS of the cylinders (the
+    default: long needles cut into pieces with tight boxes, each piece naming its cylinder) — walked by the GPU and by the
+    restated example (oracle/cylinder_oracle.c) over the same arrays: every field of every record identical.  On the fixture
+    scene also against the UNMODIFIED example's own records (its own tree): same flags, t, ids and parameters."""
     v, r = scenes.random_cylinders(n)
     a = BVHAccel(np.float32)
+    a.SetTunable("cyl_split", split)
     assert a.Build(n, CylinderGeometry(v, r))
     nodes, idx = a.GetTree()
     st = a.GetStatistics()
     assert int(st["num_leaf_nodes"]) + int(st["num_branch_nodes"]) == nodes.shape[0]
-    assert sorted(idx.tolist()) == list(range(n))
-    lo = np.minimum(v[:, 0] - r[:, 0, None], v[:, 1] - r[:, 1, None])
-    hi = np.maximum(v[:, 0] + r[:, 0, None], v[:, 1] + r[:, 1, None])
-    for i in range(min(nodes.shape[0], 2000)):
-        nd = nodes[i]
-        if nd["flag"] == 1:
-            cnt, first = int(nd["data"][0]), int(nd["data"][1])
-            assert 1 <= cnt <= 4
-            p = idx[first:first + cnt]
-            assert np.all(lo[p] >= nd["bmin"]) and np.all(hi[p] <= nd["bmax"])
-        else:
-            for ch in nd["data"]:
-                assert np.all(nodes[ch]["bmin"] >= nd["bmin"]) and np.all(nodes[ch]["bmax"] <= nd["bmax"])
+    assert sorted(set(idx.tolist())) == list(range(n))
+    if split == 1:
+        assert sorted(idx.tolist()) == list(range(n))
+        lo = np.minimum(v[:, 0] - r[:, 0, None], v[:, 1] - r[:, 1, None])
+        hi = np.maximum(v[:, 0] + r[:, 0, None], v[:, 1] + r[:, 1, None])
+        for i in range(min(nodes.shape[0], 2000)):
+            nd = nodes[i]
+            if nd["flag"] == 1:
+                cnt, first = int(nd["data"][0]), int(nd["data"][1])
+                assert 1 <= cnt <= 4
+                p = idx[first:first + cnt]
+                assert np.all(lo[p] >= nd["bmin"]) and np.all(hi[p] <= nd["bmax"])
+    else:
+        if n >= 4:
+            assert idx.shape[0] > n  # the example's needles are hundreds of radii long: every one is cut
+        leaf_segments_cover(nodes, idx, v, r)
     rays = sphere_fixture.rays() if n >= 4000 else sphere_fixture.rays()[::7]
     h, m = a.TraverseBatch(rays)
     oh, om = ob.CylinderOracle().traverse(nodes, idx, v, r, rays)
     check(h, m, oh, om)
     assert int(m.sum()) > 0
+    if n == sphere_fixture.N_CYLINDERS:  # the unmodified example's records on ITS tree (tests/golden, oracle/gen_golden_cylinders.py)
+        g = np.load(os.path.join(golden_dir, "cylinders_ref.npz"))
+        assert np.array_equal(m, g["mask"])
+        same = h["prim_id"] == g["hits"]["prim_id"]
+        assert np.array_equal(h["t"], g["hits"]["t"])
+        assert same.mean() > 0.999  # (two tubes crossing at exactly the same t may be named either way)
+        for f in ("u", "v", "normal"):
+            assert np.array_equal(h[f][same], g["hits"][f][same]), f
 
 
 def test_device_entry_point_and_errors():
@@ -92,7 +134,7 @@ def test_degenerate_cylinders_and_hostile_rays():
         a = BVHAccel(np.float32)
         assert a.Build(v.shape[0], CylinderGeometry(v, r, test_cap=cap))
         nodes, idx = a.GetTree()
-        assert sorted(idx.tolist()) == list(range(v.shape[0]))
+        assert sorted(set(idx.tolist())) == list(range(v.shape[0]))
         h, m = a.TraverseBatch(rays)
         oh, om = ob.CylinderOracle().traverse(nodes, idx, v, r, rays, test_cap=cap)
         assert np.array_equal(m, om)

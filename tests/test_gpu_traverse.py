@@ -482,3 +482,50 @@ def test_several_batches_in_one_launch_equal_separate_launches(real, mode):
     got = dev[0][1].cpu().numpy().view(HIT)
     assert all(got[f_].tobytes() == want[0][0][f_].tobytes() for f_ in ("t", "u", "v", "prim_id"))
     assert a.LastTraverseMs() > 0
+
+
+@pytest.mark.parametrize("real", [np.float32, np.float64])
+def test_host_batches_in_one_launch_equal_separate_host_calls(real):
+    """nrtTraverseBatches: host batches of unequal sizes (one empty, one an occlusion query) uploaded together and walked by
+    ONE launch return exactly the records / flags of separate nrtTraverseBatch / nrtOccludedBatch calls (fp64: the batches are
+    launched one after the other behind the same entry point)."""
+    from nanort_amd import NrtError
+
+    v, f = scenes.plane(160, 90)
+    a = BVHAccel(real)
+    assert a.Build(f.shape[0], TriangleMesh(v.astype(real), f))
+    rays1 = scenes.camera_rays(320, 180)
+    h1, m1 = a.TraverseBatch(rays1 if real == np.float32 else widen_rays(rays1))
+    h32 = h1
+    if real != np.float32:
+        from nanort_amd.wire import HIT_F32
+
+        h32 = np.zeros(h1.shape[0], dtype=HIT_F32)
+        for k in ("t", "u", "v"):
+            h32[k] = h1[k].astype(np.float32)
+        h32["prim_id"] = h1["prim_id"]
+    bounce = scenes.secondary_rays("bounce", v, f, rays1, h32, m1)
+    shadow = scenes.secondary_rays("shadow", v, f, rays1, h32, m1)
+    sets = [shadow, bounce, bounce[:0], rays1[:777]]
+    if real != np.float32:
+        sets = [widen_rays(r) for r in sets]
+    got = a.TraverseBatches([(sets[0], "occlusion"), sets[1], sets[2], sets[3]])
+    assert got[0][0] is None and np.array_equal(got[0][1], a.OccludedBatch(sets[0]))
+    for k in (1, 2, 3):
+        if sets[k].shape[0] == 0:
+            assert got[k][0].shape[0] == 0
+            continue
+        h, m = a.TraverseBatch(sets[k])
+        assert all(got[k][0][f_].tobytes() == h[f_].tobytes() for f_ in ("t", "u", "v", "prim_id")), k
+        assert np.array_equal(got[k][1], m)
+    if real == np.float32:
+        assert ", 4, 0>" in a.LastKernelName()
+    with pytest.raises(NrtError):  # an occlusion batch needs its flag array (checked by the C entry point, not the binding)
+        import ctypes
+
+        nb = 1
+        r = (ctypes.c_void_p * nb)(sets[0].ctypes.data)
+        n = (ctypes.c_uint64 * nb)(sets[0].shape[0])
+        fl = (ctypes.c_uint32 * nb)(1)
+        hh = (ctypes.c_void_p * nb)(None)
+        a._check(getattr(a._L, "nrtTraverseBatches_" + a._s)(a._h, nb, r, n, None, hh, None, fl))

@@ -400,7 +400,18 @@ def test_wavefront_path_tracer_example_gpu_equals_host(tmp_path):
                         "--out", str(tmp_path / "img.ppm")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     assert "verify: 0 differing float components" in r.stdout
+    assert "shadow and next wave in one launch" in r.stdout  # (the default: BVHAccel::TraverseBatches, one launch per depth)
     print(r.stdout)
+    # one TraverseBatch() call per wave instead: the same image in every bit (the records do not depend on how waves share launches)
+    outs = {}
+    for mode in ([], ["--separate-waves"]):
+        raw = tmp_path / ("img%d.f32" % len(mode))
+        q = subprocess.run([str(exe), "--size", "480", "270", "--spp", "2", "--depth", "3", "--grid", "400", "200", "--raw", str(raw),
+                            "--out", str(tmp_path / "x.ppm")] + mode, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert q.returncode == 0, q.stdout
+        outs[len(mode)] = open(raw, "rb").read()
+        print(q.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0]) == 480 * 270 * 3 * 4
 
 
 @pytest.mark.gpu
