@@ -72,18 +72,6 @@ static_assert(kHandoff <= kSmall && kHandoff >= 64, "hand-off size");
 #ifndef NRT_BUILD_TILE
 #define NRT_BUILD_TILE 2048
 #endif
-#ifndef NRT_BIN_FUSE_PARTITION
-#define NRT_BIN_FUSE_PARTITION 1 // round 5: a node that fits ONE chunk is binned, split AND partitioned by its k_bin block (k_partition skips it): one sweep and one dependent kernel less per deep level, same tree
-#endif
-#ifndef NRT_CHUNK_DESC
-#define NRT_CHUNK_DESC 1 // round 5: k_level_setup leaves {active slot, top index} per chunk; k_bin / k_partition blocks read that instead of searching chunk_base (two dependent round trips less at the head of every block)
-#endif
-#ifndef NRT_BIN_COOP_FLUSH
-#define NRT_BIN_COOP_FLUSH 1 // round 5: k_bin's lanes flush their last run of a bin together where 8 or more of a wave end in the same bin (same bins, same tree)
-#endif
-#ifndef NRT_CHILDREN_GRID_MIN
-#define NRT_CHILDREN_GRID_MIN 1024 // levels that can hold more active nodes than this create their children with a grid of their own (k_children) instead of inside k_level_setup's single block
-#endif
 constexpr int kTile = NRT_BUILD_TILE; // primitives per top-phase chunk (256 threads x kTile / 256 rounds); any value gives the same tree
 constexpr int kMaxBins = 64;    // top phase: lane == bin
 constexpr int kSmallBins = 16;  // subtree phase: 3 x 15 candidates == 45 lanes
@@ -836,7 +824,7 @@ template <typename T>
 __global__ __launch_bounds__(1024) void k_level_setup(TopNode<T> *top, uint32_t *active, uint32_t *chunk_base,
                                                        LevelInfo *info, BoundsAcc<T> *child_acc, uint32_t max_active,
                                                        LeafRule rule, uint32_t dst_buf, uint32_t *small_list,
-                                                       int with_children, uint2 *chunk_desc) {
+                                                       int with_children) {
   // phase A: finish the previous level — its active list is still in `active` — by creating its children
   if (with_children) {
     const uint32_t prev_active = info->num_active;
@@ -882,9 +870,6 @@ __global__ __launch_bounds__(1024) void k_level_setup(TopNode<T> *top, uint32_t 
       chunk_base[slot] = pc + c - nch;
       top[i].chunk_base = pc + c - nch;
       top[i].nchunks = nch;
-#if NRT_CHUNK_DESC
-      for (uint32_t j = 0; j < nch; j++) chunk_desc[pc + c - nch + j] = make_uint2(slot, i); // (a few hundred stores by one lane at the very top, one or two per lane where chunks are many)
-#endif
     }
     __syncthreads();
     if (tid == 1023) {
@@ -1005,25 +990,19 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__restrict__ active,
                                              const uint32_t *__restrict__ chunk_base, const LevelInfo *info,
                                              const PrimRec<T> *__restrict__ recs, int kpack, GBins<T> *gbins,
-                                             uint32_t *__restrict__ chunk_hist, uint32_t *chunk_left_base, uint32_t max_active,
-                                             PrimRec<T> *__restrict__ dst, BoundsAcc<T> *child_acc,
-                                             const uint2 *__restrict__ chunk_desc) {
+                                             uint32_t *__restrict__ chunk_hist, uint32_t *chunk_left_base, uint32_t max_active) {
   if (blockIdx.x >= info->num_chunks) return; // grids are upper bounds
   const uint32_t num_active = info->num_active;
   typedef typename Ord<T>::U U;
   __shared__ uint32_t s_cnt[3][kMaxBins];
   __shared__ U s_min[3][kMaxBins][3];
   __shared__ U s_max[3][kMaxBins][3];
-  const uint32_t chunk = blockIdx.x;
-#if NRT_CHUNK_DESC
-  const uint2 cd = chunk_desc[chunk];
-#else
   __shared__ uint32_t s_task;
+  const uint32_t chunk = blockIdx.x;
   if (threadIdx.x < 64u) {
     const uint32_t t = find_task_wave(chunk_base, num_active, chunk, threadIdx.x);
     if (threadIdx.x == 0) s_task = t;
   }
-#endif
   for (int i = threadIdx.x; i < 3 * kMaxBins; i += 256) {
     const int k = i / kMaxBins, b = i % kMaxBins;
     s_cnt[k][b] = 0;
@@ -1033,15 +1012,9 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
     }
   }
   __syncthreads();
-#if NRT_CHUNK_DESC
-  const uint32_t a = cd.x;
-  TopNode<T> &nd = top[cd.y];
-  const uint32_t begin = nd.l + (chunk - nd.chunk_base) * kTile;
-#else
   const uint32_t a = s_task;
   TopNode<T> &nd = top[active[a]];
   const uint32_t begin = nd.l + (chunk - chunk_base[a]) * kTile;
-#endif
   const uint32_t end = (nd.r - begin < (uint32_t)kTile) ? nd.r : begin + kTile;
   const int K = node_bins(kpack, nd.r - nd.l);
   const bool whole_node = nd.nchunks == 1u;
@@ -1124,54 +1097,12 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
       bin_rec(recs[p]);
     }
 #endif
-#if NRT_BIN_COOP_FLUSH
-    // The last run of every lane is flushed by the wave together (round 5).  Where the input is coherent — the top levels:
-    // few nodes, wide bins, a mesh stored in spatial order — nearly all 64 lanes end in the SAME bin of an axis, and their 7
-    // LDS atomics each serialise 64 ways on one address (SQ_LDS_BANK_CONFLICT: 8.9 cycles per LDS instruction over a build,
-    // profiles/r05a_build_pmc.txt).  Groups of 8 lanes or more that end in the same bin are reduced with DPP and flushed by
-    // one lane — up to three groups per axis; whatever is left flushes lane by lane as before.  Sums, minima and maxima do
-    // not depend on who adds them: same bins, same tree.
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      unsigned long long rem = __ballot(pb[k] >= 0);
-      const unsigned lane_c = threadIdx.x & 63u;
-      for (int it = 0; it < 3 && rem != 0ull; it++) {
-        const int leader = (int)__builtin_ctzll(rem);
-        const int b0 = __builtin_amdgcn_readlane(pb[k], leader);
-        const bool mine = ((rem >> lane_c) & 1ull) != 0ull && pb[k] == b0;
-        const unsigned long long grp = __ballot(mine);
-        if (__builtin_popcountll(grp) < 8) break;
-        uint32_t c = mine ? pc[k] : 0u;
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-        U rmin[3], rmax[3];
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          rmin[d] = wave_umin<U>(mine ? pmin[k][d] : (U)Ord<T>::highest());
-          rmax[d] = wave_umax<U>(mine ? pmax[k][d] : (U)Ord<T>::lowest());
-        }
-        if ((int)lane_c == leader) {
-          atomicAdd(&s_cnt[k][b0], c);
-#pragma unroll
-          for (int d = 0; d < 3; d++) {
-            atomicMin(&s_min[k][b0][d], rmin[d]);
-            atomicMax(&s_max[k][b0][d], rmax[d]);
-          }
-        }
-        rem &= ~grp;
-      }
-      if (((rem >> lane_c) & 1ull) != 0ull) flush(k);
-    }
-#else
 #pragma unroll
     for (int k = 0; k < 3; k++)
       if (pb[k] >= 0) flush(k);
-#endif
   }
   __syncthreads();
   if (whole_node) { // the node's complete bins are in LDS: split it here (k_split skips it)
-#if NRT_BIN_FUSE_PARTITION
-    __shared__ uint32_t s_split[3]; // axis, split bin, low-side count
-#endif
     if (threadIdx.x < 64u) {
       const unsigned lane = threadIdx.x;
       uint32_t cnt3[3] = {0, 0, 0};
@@ -1195,132 +1126,11 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
         nd.nleft = best_nl;
         nd.child0 = info->child_base + 2 * a;
         chunk_left_base[chunk] = 0; // the chunk's low side starts at the node's
-#if NRT_BIN_FUSE_PARTITION
-        s_split[0] = (uint32_t)best_axis;
-        s_split[1] = best_bin;
-        s_split[2] = best_nl;
-#endif
       }
       // this node's global slot was never touched; the slot the next level may hand out is reset as k_split would
       if (a + num_active < max_active)
         for (int k = 0; k < 3; k++) clean_bins<T>(&gbins[a + num_active], k, lane);
     }
-#if NRT_BIN_FUSE_PARTITION
-    // ... and partition it here as well (round 5): the block holds the node's whole range, so the stable scatter into the other
-    // record buffer and the children's bounds need nobody else — k_partition skips the node, and a deep level (every node from
-    // the ninth level on) is one sweep over the records instead of two.  Same result as k_partition: records keep their order
-    // on either side (a lane's `per` consecutive records, lanes in order: a block-wide exclusive scan of the per-lane low-side
-    // counts gives every record the rank k_partition's ballots give it), min / max do not depend on the order they are taken in.
-    __shared__ uint32_t s_scan[4];
-    __shared__ U s_cacc[2][12];
-    if (threadIdx.x < 24) s_cacc[threadIdx.x / 12][threadIdx.x % 12] = ((threadIdx.x % 12) % 6 < 3) ? (U)Ord<T>::highest() : (U)Ord<T>::lowest();
-    __syncthreads();
-    {
-      const int axis = (int)s_split[0];
-      const uint32_t split_bin = s_split[1], nleft = s_split[2];
-      const T plo = axis == 0 ? lo[0] : (axis == 1 ? lo[1] : lo[2]);
-      const T psc = axis == 0 ? sc[0] : (axis == 1 ? sc[1] : sc[2]);
-      const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-      const uint32_t per = (end - begin + 255u) >> 8;
-      const uint32_t p0 = begin + threadIdx.x * per;
-      constexpr uint32_t kHoldP = sizeof(T) == 4 ? (kPerLane < 8u ? kPerLane : 8u) : (kPerLane < 4u ? kPerLane : 4u);
-      // pass 1: this lane's low-side count (the records come from L1 / L2: the binning pass just read them)
-      uint32_t lmask = 0, nl = 0;
-      for (uint32_t h0 = 0; h0 < per; h0 += kHoldP) {
-        T cc[kHoldP];
-#pragma unroll
-        for (uint32_t q = 0; q < kHoldP; q++)
-          if (h0 + q < per && p0 + h0 + q < end) {
-            const PrimRec<T> &r = recs[p0 + h0 + q];
-            cc[q] = axis == 0 ? r.c[0] : (axis == 1 ? r.c[1] : r.c[2]);
-          }
-#pragma unroll
-        for (uint32_t q = 0; q < kHoldP; q++)
-          if (h0 + q < per && p0 + h0 + q < end) {
-            const bool left = split_bin == kMedian ? (p0 + h0 + q - begin) < nleft : (uint32_t)bin_of<T>(cc[q], plo, psc, K) < split_bin;
-            lmask |= left ? (1u << (h0 + q)) : 0u;
-            nl += left ? 1u : 0u;
-          }
-      }
-      // block-wide exclusive scan of the low-side counts (lanes, then the four waves)
-      uint32_t inc = nl;
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off);
-        if (lane >= (unsigned)off) inc += t;
-      }
-      if (lane == 63u) s_scan[w] = inc;
-      __syncthreads();
-      uint32_t base_l = inc - nl;
-      for (unsigned j = 0; j < w; j++) base_l += s_scan[j];
-      // records before this lane's first: threadIdx.x * per of them are valid unless the range ended earlier
-      const uint32_t before = (p0 < end ? p0 : end) - begin;
-      const uint32_t base_r = before - base_l;
-      // pass 2: scatter + the children's bounds
-      T acc_lo[2][3], acc_hi[2][3], acc_clo[2][3], acc_chi[2][3];
-#pragma unroll
-      for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          acc_lo[s][d] = acc_clo[s][d] = Lim<T>::max();
-          acc_hi[s][d] = acc_chi[s][d] = -Lim<T>::max();
-        }
-      uint32_t rl = 0, rr_ = 0;
-      for (uint32_t h0 = 0; h0 < per; h0 += kHoldP) {
-        PrimRec<T> rr[kHoldP];
-#pragma unroll
-        for (uint32_t q = 0; q < kHoldP; q++)
-          if (h0 + q < per && p0 + h0 + q < end) rr[q] = recs[p0 + h0 + q];
-#pragma unroll
-        for (uint32_t q = 0; q < kHoldP; q++)
-          if (h0 + q < per && p0 + h0 + q < end) {
-            const bool left = ((lmask >> (h0 + q)) & 1u) != 0u;
-            const uint32_t d = left ? begin + base_l + rl : begin + nleft + base_r + rr_;
-            rl += left ? 1u : 0u;
-            rr_ += left ? 0u : 1u;
-            dst[d] = rr[q];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-              if (left) {
-                acc_lo[0][k] = tmin(acc_lo[0][k], rr[q].bmin[k]);
-                acc_hi[0][k] = tmax(acc_hi[0][k], rr[q].bmax[k]);
-                acc_clo[0][k] = tmin(acc_clo[0][k], rr[q].c[k]);
-                acc_chi[0][k] = tmax(acc_chi[0][k], rr[q].c[k]);
-              } else {
-                acc_lo[1][k] = tmin(acc_lo[1][k], rr[q].bmin[k]);
-                acc_hi[1][k] = tmax(acc_hi[1][k], rr[q].bmax[k]);
-                acc_clo[1][k] = tmin(acc_clo[1][k], rr[q].c[k]);
-                acc_chi[1][k] = tmax(acc_chi[1][k], rr[q].c[k]);
-              }
-            }
-          }
-      }
-#pragma unroll
-      for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          for (int off = 32; off > 0; off >>= 1) {
-            acc_lo[s][k] = tmin(acc_lo[s][k], __shfl_xor(acc_lo[s][k], off));
-            acc_hi[s][k] = tmax(acc_hi[s][k], __shfl_xor(acc_hi[s][k], off));
-            acc_clo[s][k] = tmin(acc_clo[s][k], __shfl_xor(acc_clo[s][k], off));
-            acc_chi[s][k] = tmax(acc_chi[s][k], __shfl_xor(acc_chi[s][k], off));
-          }
-          if (lane == 0) {
-            atomicMin(&s_cacc[s][k], Ord<T>::enc(acc_lo[s][k]));
-            atomicMax(&s_cacc[s][3 + k], Ord<T>::enc(acc_hi[s][k]));
-            atomicMin(&s_cacc[s][6 + k], Ord<T>::enc(acc_clo[s][k]));
-            atomicMax(&s_cacc[s][9 + k], Ord<T>::enc(acc_chi[s][k]));
-          }
-        }
-      __syncthreads();
-      if (threadIdx.x < 24) {
-        const int s = threadIdx.x / 12, j = threadIdx.x % 12;
-        if (j % 6 < 3)
-          atomicMin(&child_acc[2 * a + s].v[j], s_cacc[s][j]);
-        else
-          atomicMax(&child_acc[2 * a + s].v[j], s_cacc[s][j]);
-      }
-    }
-#endif
     return;
   }
   GBins<T> *g = &gbins[a];
@@ -1432,40 +1242,24 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
                                                    const uint32_t *__restrict__ chunk_base, const LevelInfo *info,
                                                    const uint32_t *__restrict__ chunk_left_base,
                                                    const PrimRec<T> *__restrict__ src, PrimRec<T> *__restrict__ dst,
-                                                   int kpack, BoundsAcc<T> *child_acc, const uint2 *__restrict__ chunk_desc) {
+                                                   int kpack, BoundsAcc<T> *child_acc) {
   typedef typename Ord<T>::U U;
+  __shared__ uint32_t s_task;
   __shared__ uint32_t s_w[2][4];
   __shared__ U s_acc[2][12];
   const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const uint32_t chunk = blockIdx.x;
   if (chunk >= info->num_chunks) return; // grids are upper bounds
-#if NRT_CHUNK_DESC
-  const uint2 cd = chunk_desc[chunk];
-#else
-  __shared__ uint32_t s_task;
   const uint32_t num_active = info->num_active;
   if (tid < 64u) {
     const uint32_t t = find_task_wave(chunk_base, num_active, chunk, tid);
     if (tid == 0) s_task = t;
   }
-#endif
   if (tid < 24) s_acc[tid / 12][tid % 12] = ((tid % 12) % 6 < 3) ? (U)Ord<T>::highest() : (U)Ord<T>::lowest();
   __syncthreads();
-#if NRT_CHUNK_DESC
-  const uint32_t a = cd.x;
-  const TopNode<T> &nd = top[cd.y];
-#else
   const uint32_t a = s_task;
   const TopNode<T> &nd = top[active[a]];
-#endif
-#if NRT_BIN_FUSE_PARTITION
-  if (nd.nchunks == 1u) return; // (partitioned by its k_bin block, which held the whole node)
-#endif
-#if NRT_CHUNK_DESC
-  const uint32_t off_in_node = (chunk - nd.chunk_base) * kTile;
-#else
   const uint32_t off_in_node = (chunk - chunk_base[a]) * kTile;
-#endif
   const uint32_t begin = nd.l + off_in_node;
   const uint32_t end = (nd.r - begin < (uint32_t)kTile) ? nd.r : begin + kTile;
   const uint32_t left_base = chunk_left_base[chunk];
@@ -2752,7 +2546,7 @@ template <typename T>
 struct BuildPlan { // carve-up of the build workspace for n primitives
   size_t max_top, max_active, max_chunks;
   size_t off_recs0, off_recs1, off_scratch, off_top, off_child_acc, off_active, off_chunk_base, off_gbins,
-      off_chunk_hist, off_chunk_left, off_chunk_desc, off_small, off_scene, off_info, off_sort, off_premap, sort_blocks, total;
+      off_chunk_hist, off_chunk_left, off_small, off_scene, off_info, off_sort, off_premap, sort_blocks, total;
   BuildPlan(uint32_t n, size_t top_scale, bool tiny_top = false) {
     typedef typename Wire<T>::Node Node;
     max_active = (size_t)n / kHandoff + 2;
@@ -2776,7 +2570,6 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
     off_gbins = take(max_active * sizeof(GBins<T>));
     off_chunk_hist = take(max_chunks * 3 * kMaxBins * sizeof(uint32_t));
     off_chunk_left = take(max_chunks * sizeof(uint32_t));
-    off_chunk_desc = take(max_chunks * sizeof(uint2));
     off_small = take((max_top + 1) * sizeof(uint32_t));
     off_scene = take((1 + kSceneReplicas) * sizeof(BoundsAcc<T>));
     off_info = take(sizeof(LevelInfo));
@@ -2908,7 +2701,6 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     GBins<T> *gbins = (GBins<T> *)(base + plan.off_gbins);
     uint32_t *chunk_hist = (uint32_t *)(base + plan.off_chunk_hist);
     uint32_t *chunk_left = (uint32_t *)(base + plan.off_chunk_left);
-    uint2 *chunk_desc = (uint2 *)(base + plan.off_chunk_desc);
     uint32_t *small_list = (uint32_t *)(base + plan.off_small);
     BoundsAcc<T> *scene = (BoundsAcc<T> *)(base + plan.off_scene);
     LevelInfo *info = (LevelInfo *)(base + plan.off_info);
@@ -2955,12 +2747,12 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
       // children of the level partitioned last (their records are in recs[cur]): inside k_level_setup while a level
       // cannot have more than 1024 active nodes, by a grid of their own below that
       const size_t prev_max = level == 0 ? 0 : (level - 1 < 31 ? std::min<size_t>((size_t)1 << (level - 1), plan.max_active) : plan.max_active);
-      const bool wide = prev_max > (size_t)NRT_CHILDREN_GRID_MIN;
+      const bool wide = prev_max > 1024;
       if (wide)
         hipLaunchKernelGGL((k_children<T>), dim3((unsigned)((prev_max + 255) / 256)), dim3(256), 0, s, top, active, child_acc,
                            (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, info);
       hipLaunchKernelGGL((k_level_setup<T>), dim3(1), dim3(1024), 0, s, top, active, chunk_base, info, child_acc,
-                         (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, wide ? 0 : 1, chunk_desc);
+                         (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, wide ? 0 : 1);
       const bool check = level >= first_check;
       if (check) {
         BCHK(hipMemcpyAsync(pinned, info, state_bytes, hipMemcpyDeviceToHost, s));
@@ -2969,11 +2761,11 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
       const size_t a_max = level < 31 ? std::min<size_t>((size_t)1 << level, plan.max_active) : plan.max_active;
       const size_t c_max = std::min<size_t>((size_t)n / kTile + a_max + 1, plan.max_chunks);
       hipLaunchKernelGGL((k_bin<T>), dim3((unsigned)c_max), dim3(256), 0, s, top, active, chunk_base, info, recs[cur],
-                         K | (Ks << 8), gbins, chunk_hist, chunk_left, (uint32_t)plan.max_active, recs[1 - cur], child_acc, chunk_desc);
+                         K | (Ks << 8), gbins, chunk_hist, chunk_left, (uint32_t)plan.max_active);
       hipLaunchKernelGGL((k_split<T>), dim3((unsigned)a_max), dim3(64), 0, s, top, active, gbins, K | (Ks << 8), chunk_hist,
                          chunk_left, info, (uint32_t)plan.max_active);
       hipLaunchKernelGGL((k_partition<T>), dim3((unsigned)c_max), dim3(256), 0, s, top, active, chunk_base, info,
-                         chunk_left, recs[cur], recs[1 - cur], K | (Ks << 8), child_acc, chunk_desc);
+                         chunk_left, recs[cur], recs[1 - cur], K | (Ks << 8), child_acc);
       BCHK(hipGetLastError());
       cur = 1 - cur;
       if (check) {
