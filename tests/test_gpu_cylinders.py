@@ -96,14 +96,19 @@ def test_gpu_built_tree(n, split, golden_dir):
     oh, om = ob.CylinderOracle().traverse(nodes, idx, v, r, rays)
     check(h, m, oh, om)
     assert int(m.sum()) > 0
-    if n == sphere_fixture.N_CYLINDERS:  # the unmodified example's records on ITS tree (tests/golden, oracle/gen_golden_cylinders.py)
+    if n == sphere_fixture.N_CYLINDERS:
+        # the unmodified example's records on ITS OWN tree (tests/golden, oracle/gen_golden_cylinders.py), camera rays: unit
+        # directions — the example's cap test measures in distance and its side test in ray parameter (main.cc:272-343), so for
+        # other rays its own answer depends on the tree.  Across trees a hit may be named differently only where two tubes
+        # cross at the same t or a box test rounds the other way at a grazing hit: a handful of rays at most.
         g = np.load(os.path.join(golden_dir, "cylinders_ref.npz"))
-        assert np.array_equal(m, g["mask"])
-        same = h["prim_id"] == g["hits"]["prim_id"]
-        assert np.array_equal(h["t"], g["hits"]["t"])
-        assert same.mean() > 0.999  # (two tubes crossing at exactly the same t may be named either way)
+        cam = sphere_fixture.CAM_W * sphere_fixture.CAM_H
+        gh, gm = g["hits"][:cam], g["mask"][:cam]
+        differ = (m[:cam] != gm) | (h["t"][:cam] != gh["t"]) | (h["prim_id"][:cam] != gh["prim_id"])
+        assert int(differ.sum()) <= 3, int(differ.sum())
+        same = ~differ
         for f in ("u", "v", "normal"):
-            assert np.array_equal(h[f][same], g["hits"][f][same]), f
+            assert np.array_equal(h[f][:cam][same], gh[f][same]), f
 
 
 def test_device_entry_point_and_errors():
