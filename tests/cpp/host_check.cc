@@ -316,7 +316,10 @@ static int cylinders(const char *scene_path, int W, int H, const char *out_path)
   uint64_t nn = accel.GetNodes().size();
   fwrite(&nn, 8, 1, fp);
   fwrite(accel.GetNodes().data(), sizeof(nanort::BVHNode<float>), nn, fp);
-  fwrite(accel.GetIndices().data(), 4, n, fp);
+  // (the index array names a cylinder once per SEGMENT when the GPU builder cut the cylinders: its length is written too)
+  uint64_t ni = accel.GetIndices().size();
+  fwrite(&ni, 8, 1, fp);
+  fwrite(accel.GetIndices().data(), 4, ni, fp);
   fclose(fp);
   return 0;
 }

@@ -100,7 +100,11 @@ def read_cyl_output(path, n, nprims):
     o += 8
     nodes = np.frombuffer(raw, dtype=NODE_F32, count=nn, offset=o)
     o += nn * NODE_F32.itemsize
-    idx = np.frombuffer(raw, dtype=np.uint32, count=nprims, offset=o)
+    ni = int(np.frombuffer(raw, dtype=np.uint64, count=1, offset=o)[0])  # (>= nprims: one entry per cylinder SEGMENT on the GPU backend)
+    o += 8
+    assert ni >= nprims
+    idx = np.frombuffer(raw, dtype=np.uint32, count=ni, offset=o)
+    assert sorted(set(idx.tolist())) == list(range(nprims))
     return hits, mask, nodes, idx
 
 
