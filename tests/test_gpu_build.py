@@ -304,6 +304,39 @@ def test_c4_10m_triangles_4k_tile(oracle):
     print("C4: build %.2f ms, %d nodes, depth %d" % (a.LastBuildMs(), m["num_nodes"], m["max_depth"]))
 
 
+def test_c4_full_frame_from_eight_row_interleaved_tiles(oracle):
+    """Config C4 end to end on ONE GPU: the 4096x4096 frame over the 10 M-triangle plane traced as the eight row-interleaved
+    tiles eight ranks would own (bench.py / nanort_amd.dist: rank r traces rows r, r + 8, ...), the 16-byte records
+    reassembled by dist.assemble_image exactly as the root does with its gathered buffer — and that frame equals the frame
+    traced as ONE 16.8 M-ray batch in every byte; a strided sample of it equals the restated reference on the GPU-built tree."""
+    from nanort_amd import dist as nd
+    from nanort_amd.wire import HIT_F32
+
+    W = H = 4096
+    world = 8
+    v, f = scenes.plane(2500, 2000)
+    a, nodes, idx = build(np.float32, v, f)
+    tiles_h, tiles_m = [], []
+    for r in range(world):
+        rays = scenes.camera_rays_rows(W, H, r, world, nd.rows_per_rank(H, r, world))
+        h, m = a.TraverseBatch(rays)
+        tiles_h.append(h)
+        tiles_m.append(m)
+    gathered = np.concatenate(tiles_h)  # rank-major, as dist.gather_hit_records delivers it
+    img = nd.assemble_image(gathered.view(np.uint8), W, H, world, HIT_F32)
+    mask = np.empty((H, W), dtype=np.uint8)
+    for r in range(world):
+        mask[r::world] = tiles_m[r].reshape(-1, W)
+    del tiles_h, gathered
+    full = scenes.camera_rays(W, H)
+    hf, mf = a.TraverseBatch(full)
+    assert img.tobytes() == hf.tobytes() and np.array_equal(mask.reshape(-1), mf)
+    sub = slice(None, None, 4099)
+    oh, om = oracle.traverse(nodes, idx, v, f, full[sub])
+    assert_hits_identical(oh, om, hf[sub], mf[sub])
+    assert int(mf.sum()) > W * H // 2
+
+
 def test_context_reuse_across_mesh_sizes(oracle):
     """One context, rebuilt over meshes of different sizes (grow-only workspace, no stale state): each tree is valid
     and traces like a fresh context's."""
