@@ -1575,6 +1575,7 @@ __global__ __launch_bounds__(256, NRT_MID_WAVES) void k_mid(TopNode<T> *top, con
     if (tid == 0) { // the level's children: one pair per node, consecutive
       const uint32_t c0 = atomicAdd(&info->top_count, 2u * nq);
       if ((unsigned long long)c0 + 2ull * nq > info->top_cap) { // the caller rebuilds without this phase
+        atomicSub(&info->top_count, 2u * nq); // (the count stays a bound on the records that exist: k_layout and the emission sweep [0, top_count))
         info->error = 1;
         s_abort = 1;
       }
