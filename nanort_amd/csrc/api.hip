@@ -50,7 +50,6 @@ hipError_t launch_gather_leaf_tris(const uint32_t *, const uint32_t *, const T *
 struct BuildResult {
   uint64_t num_nodes;
   uint32_t max_depth, num_leaves, num_branches, max_leaf_count;
-  uint32_t error; // the middle phase ran out of top-array slots (lopsided splits): the caller rebuilds without it
 };
 // (build.hip) enqueues a whole build; its size and statistics arrive in `pinned` behind `ev`: gpu_build_result waits for them
 template <typename T>
@@ -145,7 +144,6 @@ struct nrt_ctx {
   unsigned trav_min4 = 24; // the same threshold for the fp32 two-level walk, whose inner loop runs two pop + step rounds per trip (profiles/r03Z_threshold_resweep*.txt)
   unsigned num_parts = 8; // ray partitions == XCDs (env NRT_PARTS)
   unsigned debug_flags = 0;
-  unsigned build_mid = 0; // builder: nodes of at most this many primitives leave the level-synchronous phase for the block-resident middle phase (k_mid; 0: none; same tree at any value)
   int subtree_rows = 1; // builder: subtree phase in row form (up to four nodes per step); 0 (profiling build only): one node per step — same tree, the cross-check (tests/test_gpu_build.py)
   int morton = 0; // Morton-order the primitive records before the build (env NRT_MORTON=1): measured +0.4 ms at 1M tris for an identical tree, so off by default
   unsigned static_pct = 75; // share of a batch handed out statically, percent (env NRT_STATIC_PCT)
@@ -294,7 +292,6 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("morton", 0, 1, morton, int),                     // Morton pre-pass of the builder (next build)
     NRT_TUNABLE("cyl_split", 1, 64, cyl_split, int),              // cylinders: most segments one is cut into for the builder (1: never; next nrtSetCylinders)
     NRT_TUNABLE("cyl_seg_radii", 1, 1024, cyl_seg_radii, int),    // ... one segment per this many tube radii of length (next nrtSetCylinders)
-    NRT_TUNABLE("build_mid", 0, 1 << 20, build_mid, unsigned),     // builder: node size handed to the block-resident middle phase (next build; 0: off; same tree)
 #ifdef NRT_PROF
     NRT_TUNABLE("subtree_rows", 0, 1, subtree_rows, int),         // 0: the builder's one-node-per-step subtree kernel (next build; same tree) — libnanort_hip_prof.so only
 #endif
@@ -747,22 +744,16 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   // (cylinder contexts whose cylinders were cut into segments: the tree is built over the segments, each carrying its cylinder's id)
   const bool segs = c->prim_kind == kPrimCylinders && c->num_segs != 0 && sizeof(T) == 4;
   const uint32_t build_n = segs ? c->num_segs : c->num_faces;
-  hipError_t e = hipSuccess;
-  nrt_status fst = NRT_OK;
-  for (int attempt = 0; attempt < 2; attempt++) {
-  // (second attempt: without the middle phase, whose top-array allocation cannot be retried from the host — the
-  // level-synchronous phase grows the array itself; only chains of very lopsided splits get here)
-  const unsigned mid = attempt == 0 ? c->build_mid : 0u;
-  e = gpu_build<T>(c->stream, segs ? (const T *)c->b_seg_verts.p : (const T *)c->d_verts, c->d_faces, segs ? (const T *)c->b_seg_radii.p : (const T *)c->d_radii,
-                   c->prim_kind == kPrimCylinders, segs ? (const uint32_t *)c->b_seg_prim.p : nullptr, build_n, min_leaf, max_depth,
-                   bin_size, (c->morton ? 1u : 0u) | (c->subtree_rows ? 0u : 2u) | (mid << 8), &c->b_build_ws, &c->b_nodes, &c->b_indices, c->build_state, c->ev_build_state, &err);
+  hipError_t e = gpu_build<T>(c->stream, segs ? (const T *)c->b_seg_verts.p : (const T *)c->d_verts, c->d_faces, segs ? (const T *)c->b_seg_radii.p : (const T *)c->d_radii,
+                              c->prim_kind == kPrimCylinders, segs ? (const uint32_t *)c->b_seg_prim.p : nullptr, build_n, min_leaf, max_depth,
+                              bin_size, (c->morton ? 1u : 0u) | (c->subtree_rows ? 0u : 2u), &c->b_build_ws, &c->b_nodes, &c->b_indices, c->build_state, c->ev_build_state, &err);
   if (e != hipSuccess) return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s (%s)", err.c_str(), hipGetErrorString(e));
   // everything is enqueued; the leaf-ordered primitive records need the index array only, so they are enqueued too before
   // the host waits for the tree's size (the GPU stays busy meanwhile)
   c->d_nodes = c->b_nodes.p;
   c->d_indices = (uint32_t *)c->b_indices.p;
   c->num_indices = build_n;
-  fst = finish_leaf_records<T>(c);
+  nrt_status fst = finish_leaf_records<T>(c);
   if (fst) {
     free_tree(c); // (no half-built tree is left behind: a later traversal call then reports "no tree")
     return fst;
@@ -770,12 +761,6 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   if ((e = gpu_build_result(c->build_state, c->ev_build_state, &res)) != hipSuccess) {
     free_tree(c);
     return fail(c, NRT_ERR_DEVICE, "nrtBuild: %s", hipGetErrorString(e));
-  }
-  if (!res.error) break;
-  if (attempt == 1) {
-    free_tree(c);
-    return fail(c, NRT_ERR_DEVICE, "nrtBuild: the top array overflowed");
-  }
   }
   c->num_nodes = res.num_nodes;
   c->tree_depth = res.max_depth;

@@ -52,7 +52,6 @@ enum : unsigned { kBuildMorton = 1u, kBuildSubtreeDfs = 2u }; // gpu_build's bui
 struct BuildResult {
   uint64_t num_nodes;
   uint32_t max_depth, num_leaves, num_branches, max_leaf_count;
-  uint32_t error;
 };
 
 constexpr int kSmall = 256;     // nodes at or below this many primitives are binned with kSmallBins bins (part of the tree's definition)
@@ -81,7 +80,7 @@ constexpr int kSceneReplicas = 16; // k_prim_records spreads its per-block atomi
 [[maybe_unused]] constexpr int kSubStack = 48; // pending high-side children per subtree wave of k_subtree (LDS; profiling build)
 constexpr int kSubStackSafe = 36; // above this many, splits are forced to the object median (depth <= log2 n more)
 
-enum : uint32_t { KIND_SPLIT = 0, KIND_SMALL = 1, KIND_LEAF = 2, KIND_MID = 3 }; // (KIND_MID: transient — a node waiting for k_mid, which makes it a KIND_SPLIT)
+enum : uint32_t { KIND_SPLIT = 0, KIND_SMALL = 1, KIND_LEAF = 2 };
 
 // ---- order-preserving integer images of floating-point values ---------------
 template <typename T>
@@ -197,7 +196,6 @@ struct LevelInfo {
   uint32_t top_cap;
   uint32_t num_levels;  // levels recorded in level_begin
   uint32_t num_nodes;   // nodes of the finished tree (k_layout)
-  uint32_t num_mid;     // nodes handed to k_mid (running count, all levels)
   uint32_t level_begin[kMaxTopLevels + 2];
 };
 
@@ -555,7 +553,6 @@ __global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info, uint32_t top_
     info->num_active = 0;
     info->num_chunks = 0;
     info->num_small = 0;
-    info->num_mid = 0;
     info->max_depth = 0;
     info->num_leaves = 0;
     info->num_branches = 0;
@@ -575,13 +572,12 @@ __global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info, uint32_t top_
 // The reference's leaf rule (nanort.h:1781-1783): a range of at most min_leaf_primitives, or one at the depth cap, is a leaf.
 struct LeafRule {
   uint32_t max_depth, leaf_max; // leaf_max = max(min_leaf_primitives, 1)
-  uint32_t mid;                 // nodes of at most this many primitives leave the level-synchronous phase for k_mid (0: none do)
 };
 template <typename T>
 __device__ __forceinline__ uint32_t classify(uint32_t n, uint32_t depth, LeafRule rule) {
   if (n <= (uint32_t)kHandoff) return KIND_SMALL;
   if (depth >= rule.max_depth || n <= rule.leaf_max) return KIND_LEAF; // the rule applied to a node too large for one wave
-  return n <= rule.mid ? KIND_MID : KIND_SPLIT;
+  return KIND_SPLIT;
 }
 
 // scene[0] <- min / max over the replicas k_prim_records reduced into (idempotent); called by threads 0..11 of one block
@@ -601,7 +597,7 @@ __global__ void k_combine_scene(BoundsAcc<T> *scene) {
 
 template <typename T>
 __global__ void k_make_root(BoundsAcc<T> *scene, uint32_t n, LeafRule rule, uint32_t buf, TopNode<T> *top,
-                            uint32_t *small_list, uint32_t *mid_list, LevelInfo *info) {
+                            uint32_t *small_list, LevelInfo *info) {
   if (threadIdx.x < 12) combine_scene<T>(scene, threadIdx.x);
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -629,7 +625,6 @@ __global__ void k_make_root(BoundsAcc<T> *scene, uint32_t n, LeafRule rule, uint
   t.parent = kNoParent;
   top[0] = t;
   if (t.kind == KIND_SMALL) small_list[atomicAdd(&info->num_small, 1u)] = 0;
-  if (t.kind == KIND_MID) mid_list[atomicAdd(&info->num_mid, 1u)] = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -779,7 +774,7 @@ __global__ __launch_bounds__(256) void k_gather_records(const PrimRec<T> *__rest
 template <typename T>
 __device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *active, BoundsAcc<T> *child_acc, uint32_t a,
                                               uint32_t num_active, uint32_t max_active, LeafRule rule, uint32_t dst_buf,
-                                              uint32_t *small_list, uint32_t *mid_list, LevelInfo *info) {
+                                              uint32_t *small_list, LevelInfo *info) {
   const TopNode<T> p = top[active[a]];
   for (uint32_t c = 0; c < 2; c++) {
     TopNode<T> t;
@@ -810,7 +805,6 @@ __device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *a
     const uint32_t ci = p.child0 + c;
     top[ci] = t;
     if (t.kind == KIND_SMALL) small_list[atomicAdd(&info->num_small, 1u)] = ci;
-    if (t.kind == KIND_MID) mid_list[atomicAdd(&info->num_mid, 1u)] = ci;
   }
 }
 
@@ -819,23 +813,23 @@ __device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *a
 template <typename T>
 __global__ __launch_bounds__(256) void k_children(TopNode<T> *top, const uint32_t *__restrict__ active, BoundsAcc<T> *child_acc,
                                                   uint32_t max_active, LeafRule rule, uint32_t dst_buf,
-                                                  uint32_t *small_list, uint32_t *mid_list, LevelInfo *info) {
+                                                  uint32_t *small_list, LevelInfo *info) {
   const uint32_t a = blockIdx.x * 256u + threadIdx.x;
   const uint32_t num_active = info->num_active;
   if (a >= num_active) return;
-  make_children<T>(top, active, child_acc, a, num_active, max_active, rule, dst_buf, small_list, mid_list, info);
+  make_children<T>(top, active, child_acc, a, num_active, max_active, rule, dst_buf, small_list, info);
 }
 
 template <typename T>
 __global__ __launch_bounds__(1024) void k_level_setup(TopNode<T> *top, uint32_t *active, uint32_t *chunk_base,
                                                        LevelInfo *info, BoundsAcc<T> *child_acc, uint32_t max_active,
                                                        LeafRule rule, uint32_t dst_buf, uint32_t *small_list,
-                                                       uint32_t *mid_list, int with_children) {
+                                                       int with_children) {
   // phase A: finish the previous level — its active list is still in `active` — by creating its children
   if (with_children) {
     const uint32_t prev_active = info->num_active;
     for (uint32_t a = threadIdx.x; a < prev_active; a += 1024u)
-      make_children<T>(top, active, child_acc, a, prev_active, max_active, rule, dst_buf, small_list, mid_list, info);
+      make_children<T>(top, active, child_acc, a, prev_active, max_active, rule, dst_buf, small_list, info);
     __syncthreads(); // (block-wide: the children are visible to the scan below, and `active` may be rewritten)
   }
   // phase B: the new level's active list and chunk ranges
@@ -1380,368 +1374,6 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
 }
 
 // ---------------------------------------------------------------------------
-// middle phase: one BLOCK builds the upper levels below a node of at most `rule.mid` primitives
-// ---------------------------------------------------------------------------
-// MIDDLE PHASE (round 5; round 4's node-by-node form: profiles/r04l_build_mid_phase_negative.txt).  The last levels of the
-// level-synchronous phase each cost four dependent launches whose duration is one block's latency chain (~70 us per level
-// whatever its size: profiles/r05a_build_pmc.txt, r05b_build_experiments_negative.txt).  A node of at most kMidPer * 256
-// primitives leaves that phase (KIND_MID) and is finished — down to the subtree tasks of <= kHandoff primitives — by ONE block,
-// LEVEL BY LEVEL: all the nodes of the block's current level (disjoint sub-ranges of the block's range, at most kMidNodes of
-// them: each holds more than kHandoff primitives) are binned in ONE pass over the block's records (every lane owns `per`
-// consecutive record positions; per-node bins in LDS), cut by the block's waves (one node per wave at a time), and partitioned
-// in ONE more pass (a block-wide scan of the low-side flags, re-based per node, gives every record its stable destination in
-// the other record buffer; the children's bounds are reduced on the way).  A level is two passes and a handful of barriers
-// however many nodes it holds — round 4's form paid that per NODE.  Every decision is the level-synchronous phase's, taken by
-// the same device functions on the same values (node_bins, bin_scale / bin_of on the centroid bounds, eval_split with its tie
-// rules, the object-median fallback, the stable order of the partition; counts, minima and maxima do not depend on the order
-// they are combined in): THE TREE IS THE SAME.  Children are allocated in pairs from the top array (k_layout works from the
-// parent links and depths, not from levels), subtree tasks are appended to small_list, every node records the buffer its
-// range ends up in (TopNode::buf).
-#ifndef NRT_MID_WAVES
-#define NRT_MID_WAVES 3 // waves per SIMD k_mid is compiled for (== blocks per CU: its 44 KB of LDS allow three)
-#endif
-#ifndef NRT_MID_HOLD
-#define NRT_MID_HOLD 2 // records a lane of k_mid requests together
-#endif
-constexpr int kMidPer = 8;    // record positions per lane: k_mid takes nodes of at most 256 * kMidPer primitives
-// nodes of one level of one block are disjoint and hold more than kHandoff primitives each: at most max_prims / (kHandoff + 1)
-template <typename T>
-struct MidLimit { // fp32: blocks of up to 2048 primitives, 7 nodes per level; fp64 (twice the LDS per bin): 1024, 3
-  static constexpr uint32_t max_prims = sizeof(T) == 4 ? 256u * kMidPer : 128u * kMidPer;
-  static constexpr int nodes = sizeof(T) == 4 ? 8 : 4;
-};
-static_assert(MidLimit<float>::max_prims / (kHandoff + 1) < (uint32_t)MidLimit<float>::nodes, "k_mid: node table (fp32)");
-static_assert(MidLimit<double>::max_prims / (kHandoff + 1) < (uint32_t)MidLimit<double>::nodes, "k_mid: node table (fp64)");
-template <typename T>
-__global__ __launch_bounds__(256, NRT_MID_WAVES) void k_mid(TopNode<T> *top, const uint32_t *__restrict__ mid_list, PrimRec<T> *recs0, PrimRec<T> *recs1,
-                                             int kpack, LeafRule rule, uint32_t *small_list, LevelInfo *info) {
-  typedef typename Ord<T>::U U;
-  constexpr int NQ = MidLimit<T>::nodes; // nodes of one level (fp64 blocks take half the primitives: half the table, the same LDS)
-  __shared__ uint32_t s_cnt[NQ][3][kMaxBins];
-  __shared__ U s_min[NQ][3][kMaxBins][3];
-  __shared__ U s_max[NQ][3][kMaxBins][3];
-  __shared__ U s_acc[NQ][2][12];
-  __shared__ uint32_t s_bins[kMidPer][256]; // b0 | b1 << 8 | b2 << 16 | node << 24 of the record at p0 + i ([i][tid]: conflict-free); 0xFFFFFFFF: not in a node of this level
-  // the level's nodes, in range order (two tables: this level's and the next one's)
-  __shared__ uint32_t s_idx[2][NQ], s_l[2][NQ], s_r[2][NQ];
-  __shared__ T s_lo[2][NQ][3], s_sc[2][NQ][3];
-  __shared__ uint32_t s_axis[NQ], s_bin[NQ], s_nleft[NQ], s_base[NQ];
-  __shared__ uint32_t s_w[4];
-  __shared__ uint32_t s_nq[2], s_child_base, s_abort;
-  const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (blockIdx.x >= info->num_mid) return;
-  const uint32_t root = mid_list[blockIdx.x];
-  const uint32_t L = top[root].l, R = top[root].r;
-  uint32_t cur_buf = top[root].buf;
-  if (tid == 0) {
-    const TopNode<T> nd = top[root];
-    const int K = node_bins(kpack, nd.r - nd.l);
-    s_idx[0][0] = root;
-    s_l[0][0] = nd.l;
-    s_r[0][0] = nd.r;
-    for (int k = 0; k < 3; k++) {
-      s_lo[0][0][k] = nd.cmin[k];
-      s_sc[0][0][k] = bin_scale<T>(nd.cmin[k], nd.cmax[k], K);
-    }
-    s_nq[0] = 1;
-    s_abort = 0;
-  }
-  const uint32_t per = (R - L + 255u) >> 8;  // <= kMidPer
-  const uint32_t p0 = L + tid * per;          // this lane's record positions: [p0, p0 + mine), fixed for the whole block
-  const uint32_t mine = p0 >= R ? 0u : (R - p0 < per ? R - p0 : per);
-  constexpr uint32_t kHold = sizeof(T) == 4 ? (uint32_t)NRT_MID_HOLD : (NRT_MID_HOLD > 2 ? (uint32_t)NRT_MID_HOLD / 2u : 1u); // records requested together
-  static_assert(kMidPer % kHold == 0, "k_mid: whole batches");
-  __syncthreads();
-  for (int tab = 0;; tab ^= 1) {
-    const uint32_t nq = s_nq[tab];
-    if (nq == 0u || s_abort) break; // (uniform: written before the last barrier)
-    const PrimRec<T> *src = cur_buf ? recs1 : recs0;
-    PrimRec<T> *dst = cur_buf ? recs0 : recs1;
-    // ---- clear this level's bins and child accumulators ----
-    for (uint32_t i = tid; i < nq * 3u * (uint32_t)kMaxBins; i += 256u) {
-      const uint32_t q = i / (3u * kMaxBins), k = (i / kMaxBins) % 3u, b = i % kMaxBins;
-      s_cnt[q][k][b] = 0;
-      for (int d = 0; d < 3; d++) {
-        s_min[q][k][b][d] = Ord<T>::highest();
-        s_max[q][k][b][d] = Ord<T>::lowest();
-      }
-    }
-    if (tid < nq * 24u) s_acc[tid / 24u][(tid / 12u) & 1u][tid % 12u] = ((tid % 12u) % 6u < 3u) ? (U)Ord<T>::highest() : (U)Ord<T>::lowest();
-    if (tid == 0) s_nq[tab ^ 1] = 0;
-    __syncthreads();
-    // ---- pass 1: bins of every node of the level (k_bin's LDS reduction, run-merged per lane) ----
-    {
-      uint32_t q = 0;
-      while (q < nq && s_r[tab][q] <= p0) q++; // the first node that can hold one of this lane's positions
-      int pb[3] = {-1, -1, -1};
-      uint32_t pq = 0xFFFFFFFFu; // node of the pending runs
-      uint32_t pc[3] = {0, 0, 0};
-      U pmin[3][3], pmax[3][3];
-      auto flush = [&](int k) {
-        atomicAdd(&s_cnt[pq][k][pb[k]], pc[k]);
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          atomicMin(&s_min[pq][k][pb[k]][d], pmin[k][d]);
-          atomicMax(&s_max[pq][k][pb[k]][d], pmax[k][d]);
-        }
-      };
-#pragma unroll 1
-      for (uint32_t h0 = 0; h0 < mine; h0 += kHold) {
-        PrimRec<T> rr[kHold];
-#pragma unroll
-        for (uint32_t j = 0; j < kHold; j++)
-          if (h0 + j < mine) rr[j] = src[p0 + h0 + j];
-#pragma unroll
-        for (uint32_t j = 0; j < kHold; j++) {
-          if (h0 + j < mine) s_bins[h0 + j][tid] = 0xFFFFFFFFu;
-          if (h0 + j < mine) {
-            const uint32_t p = p0 + h0 + j;
-            while (q < nq && s_r[tab][q] <= p) q++;
-            if (q < nq && s_l[tab][q] <= p) {
-              if (q != pq) { // another node: the pending runs belong to the previous one
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                  if (pb[k] >= 0) flush(k);
-                  pb[k] = -1;
-                }
-                pq = q;
-              }
-              const PrimRec<T> &r = rr[j];
-              const int K = node_bins(kpack, s_r[tab][q] - s_l[tab][q]);
-              U emin[3], emax[3];
-#pragma unroll
-              for (int d = 0; d < 3; d++) {
-                emin[d] = Ord<T>::enc(r.bmin[d]);
-                emax[d] = Ord<T>::enc(r.bmax[d]);
-              }
-              uint32_t packed = q << 24;
-#pragma unroll
-              for (int k = 0; k < 3; k++) {
-                const int b = bin_of<T>(r.c[k], s_lo[tab][q][k], s_sc[tab][q][k], K);
-                packed |= (uint32_t)b << (8 * k);
-                if (b == pb[k]) {
-                  pc[k]++;
-#pragma unroll
-                  for (int d = 0; d < 3; d++) {
-                    pmin[k][d] = emin[d] < pmin[k][d] ? emin[d] : pmin[k][d];
-                    pmax[k][d] = emax[d] > pmax[k][d] ? emax[d] : pmax[k][d];
-                  }
-                } else {
-                  if (pb[k] >= 0) flush(k);
-                  pb[k] = b;
-                  pc[k] = 1;
-#pragma unroll
-                  for (int d = 0; d < 3; d++) {
-                    pmin[k][d] = emin[d];
-                    pmax[k][d] = emax[d];
-                  }
-                }
-              }
-              s_bins[h0 + j][tid] = packed;
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 3; k++)
-        if (pb[k] >= 0) flush(k);
-    }
-    __syncthreads();
-    // ---- the cuts: wave w takes nodes w, w + 4 (lane == bin) ----
-    for (uint32_t q = w; q < nq; q += 4u) {
-      const uint32_t n = s_r[tab][q] - s_l[tab][q];
-      const int K = node_bins(kpack, n);
-      uint32_t cnt3[3] = {0, 0, 0};
-      U mn3[3][3], mx3[3][3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        if ((int)lane < K) cnt3[k] = s_cnt[q][k][lane];
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-          mn3[k][d] = s_min[q][k][lane][d];
-          mx3[k][d] = s_max[q][k][lane][d];
-        }
-      }
-      int best_axis;
-      uint32_t best_bin, best_nl;
-      eval_split<T>(K, lane, cnt3, mn3, mx3, best_axis, best_bin, best_nl);
-      if (best_bin == kMedian) best_nl = n >> 1; // no separable centroids: object median (nanort.h:1849)
-      if (lane == 0) {
-        s_axis[q] = (uint32_t)best_axis;
-        s_bin[q] = best_bin;
-        s_nleft[q] = best_nl;
-      }
-    }
-    if (tid == 0) { // the level's children: one pair per node, consecutive
-      const uint32_t c0 = atomicAdd(&info->top_count, 2u * nq);
-      if ((unsigned long long)c0 + 2ull * nq > info->top_cap) { // the caller rebuilds without this phase
-        atomicSub(&info->top_count, 2u * nq); // (the count stays a bound on the records that exist: k_layout and the emission sweep [0, top_count))
-        info->error = 1;
-        s_abort = 1;
-      }
-      s_child_base = c0;
-    }
-    __syncthreads();
-    if (s_abort) break;
-    // ---- sides from the stored bins; a block-wide scan of the low-side flags, re-based per node ----
-    uint32_t side = 0u, my_left = 0u; // bit i: the record at p0 + i goes to the low side of its node
-    uint32_t active = 0u; // bit i: the record at p0 + i belongs to a node of this level
-#pragma unroll 1
-    for (uint32_t i = 0; i < mine; i++) {
-      const uint32_t bi = s_bins[i][tid];
-      if (bi != 0xFFFFFFFFu) {
-        const uint32_t q = bi >> 24;
-        const uint32_t sb = s_bin[q];
-        const bool left = sb == kMedian ? (p0 + i - s_l[tab][q]) < s_nleft[q] : ((bi >> (8u * s_axis[q])) & 0xFFu) < sb;
-        active |= 1u << i;
-        side |= left ? (1u << i) : 0u;
-        my_left += left ? 1u : 0u;
-      }
-    }
-    uint32_t inc = my_left; // inclusive scan over the block's 256 lanes
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off);
-      if (lane >= (unsigned)off) inc += t;
-    }
-    if (lane == 63) s_w[w] = inc;
-    __syncthreads();
-    uint32_t lefts_before = inc - my_left; // low-side records of the level before this lane's first position
-    for (unsigned j = 0; j < w; j++) lefts_before += s_w[j];
-    // the lane that owns a node's first position publishes the count up to there
-    for (uint32_t q = 0; q < nq; q++) {
-      const uint32_t lq = s_l[tab][q];
-      if (lq >= p0 && lq < p0 + mine) s_base[q] = lefts_before + (uint32_t)__builtin_popcount(side & ((1u << (lq - p0)) - 1u));
-    }
-    __syncthreads();
-    // ---- pass 2: stable scatter into the other buffer + the children's bounds (runs of one (node, side) merged per lane) ----
-    {
-      uint32_t pkey = 0xFFFFFFFFu; // node * 2 + side of the pending run
-      T a_lo[3], a_hi[3], a_clo[3], a_chi[3];
-      auto flush_acc = [&]() {
-        const uint32_t q = pkey >> 1, sd = pkey & 1u;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          atomicMin(&s_acc[q][sd][k], Ord<T>::enc(a_lo[k]));
-          atomicMax(&s_acc[q][sd][3 + k], Ord<T>::enc(a_hi[k]));
-          atomicMin(&s_acc[q][sd][6 + k], Ord<T>::enc(a_clo[k]));
-          atomicMax(&s_acc[q][sd][9 + k], Ord<T>::enc(a_chi[k]));
-        }
-      };
-      uint32_t run_left = 0u; // low-side records among this lane's positions before the current one
-#pragma unroll 1
-      for (uint32_t h0 = 0; h0 < mine; h0 += kHold) {
-        PrimRec<T> rr[kHold];
-#pragma unroll
-        for (uint32_t j = 0; j < kHold; j++)
-          if (((active >> (h0 + j)) & 1u) != 0u) rr[j] = src[p0 + h0 + j];
-#pragma unroll
-        for (uint32_t j = 0; j < kHold; j++) {
-          if (((active >> (h0 + j)) & 1u) != 0u) {
-            const PrimRec<T> &r = rr[j];
-            const uint32_t q = s_bins[h0 + j][tid] >> 24, p = p0 + h0 + j;
-            const bool left = ((side >> (h0 + j)) & 1u) != 0u;
-            const uint32_t lq = s_l[tab][q];
-            const uint32_t lrank = lefts_before + run_left - s_base[q]; // low-side records of node q before p
-            const uint32_t d = left ? lq + lrank : lq + s_nleft[q] + ((p - lq) - lrank);
-            run_left += left ? 1u : 0u;
-            dst[d] = r;
-            const uint32_t key = 2u * q + (left ? 0u : 1u);
-            if (key != pkey) {
-              if (pkey != 0xFFFFFFFFu) flush_acc();
-              pkey = key;
-#pragma unroll
-              for (int k = 0; k < 3; k++) {
-                a_lo[k] = r.bmin[k];
-                a_hi[k] = r.bmax[k];
-                a_clo[k] = r.c[k];
-                a_chi[k] = r.c[k];
-              }
-            } else {
-#pragma unroll
-              for (int k = 0; k < 3; k++) {
-                a_lo[k] = tmin(a_lo[k], r.bmin[k]);
-                a_hi[k] = tmax(a_hi[k], r.bmax[k]);
-                a_clo[k] = tmin(a_clo[k], r.c[k]);
-                a_chi[k] = tmax(a_chi[k], r.c[k]);
-              }
-            }
-          }
-        }
-      }
-      if (pkey != 0xFFFFFFFFu) flush_acc();
-    }
-    __syncthreads();
-    // ---- the level's nodes become branches; their children (make_children's fields); the next level's table ----
-    if (tid < 64u) { // (one wave: the ballot below orders the children that go on)
-      const bool have = tid < 2u * nq;
-      const uint32_t q = tid >> 1, c = tid & 1u;
-      bool goes_on = false;
-      TopNode<T> t;
-      uint32_t ci = 0;
-      if (have) {
-        const uint32_t idx = s_idx[tab][q], lq = s_l[tab][q], rq = s_r[tab][q], nleft = s_nleft[q];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          t.bmin[k] = Ord<T>::dec(s_acc[q][c][k]);
-          t.bmax[k] = Ord<T>::dec(s_acc[q][c][3 + k]);
-          t.cmin[k] = Ord<T>::dec(s_acc[q][c][6 + k]);
-          t.cmax[k] = Ord<T>::dec(s_acc[q][c][9 + k]);
-        }
-        t.l = c == 0 ? lq : lq + nleft;
-        t.r = c == 0 ? lq + nleft : rq;
-        t.depth = top[idx].depth + 1;
-        LeafRule inner = rule;
-        inner.mid = 0; // (whatever is still large is split right here, on the next level)
-        t.kind = classify<T>(t.r - t.l, t.depth, inner);
-        t.axis = 0;
-        t.split_bin = kMedian;
-        t.nleft = 0;
-        t.child0 = 0;
-        t.size = 1;
-        t.dfs = 0;
-        t.buf = cur_buf ^ 1u;
-        t.chunk_base = 0;
-        t.nchunks = 0;
-        t.parent = idx | (c ? kHighChild : 0u);
-        ci = s_child_base + 2u * q + c;
-        top[ci] = t;
-        if (t.kind == KIND_SMALL) small_list[atomicAdd(&info->num_small, 1u)] = ci;
-        goes_on = t.kind == KIND_SPLIT;
-        if (c == 0) {
-          TopNode<T> &me = top[idx];
-          me.kind = KIND_SPLIT;
-          me.axis = (int32_t)s_axis[q];
-          me.split_bin = s_bin[q];
-          me.nleft = nleft;
-          me.child0 = s_child_base + 2u * q;
-        }
-      }
-      const unsigned long long on = __ballot(goes_on);
-      if (goes_on) { // children in (node, side) order == range order
-        const uint32_t at = (uint32_t)__builtin_popcountll(on & ((1ull << lane) - 1ull));
-        if (at < (uint32_t)NQ) {
-          const int K = node_bins(kpack, t.r - t.l);
-          s_idx[tab ^ 1][at] = ci;
-          s_l[tab ^ 1][at] = t.l;
-          s_r[tab ^ 1][at] = t.r;
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            s_lo[tab ^ 1][at][k] = t.cmin[k];
-            s_sc[tab ^ 1][at][k] = bin_scale<T>(t.cmin[k], t.cmax[k], K);
-          }
-        } else { // (cannot happen: the nodes of a level are disjoint and each holds more than kHandoff primitives)
-          info->error = 1;
-          s_abort = 1;
-        }
-      }
-      if (lane == 0) s_nq[tab ^ 1] = (uint32_t)__builtin_popcountll(on);
-    }
-    cur_buf ^= 1u;
-    __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------------------
 // subtree phase: one wave builds everything below a node of <= kSmall prims
 // ---------------------------------------------------------------------------
 #ifdef NRT_PROF // the one-node-per-step form lives in libnanort_hip_prof.so only: the cross-check of the row form (tests/test_gpu_build.py, tunable subtree_rows = 0)
@@ -1765,7 +1397,7 @@ struct SubPending {
 // parent's partition pass instead of a pass of its own; the bins are reset by the lanes that read them; wave
 // reductions and the winner's broadcast go through DPP and scalar registers.  Two barriers per inner node.
 template <typename T>
-__device__ void subtree_task(const uint32_t task_id, TopNode<T> *top, const uint32_t *__restrict__ small_list,
+__global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t *__restrict__ small_list,
                                                 const PrimRec<T> *__restrict__ recs0,
                                                 const PrimRec<T> *__restrict__ recs1, int K, uint32_t min_leaf,
                                                 uint32_t max_depth, typename Wire<T>::Node *scratch_nodes,
@@ -1785,7 +1417,8 @@ __device__ void subtree_task(const uint32_t task_id, TopNode<T> *top, const uint
   __shared__ U s_bmax[3][kSmallBins][3];
 
   const unsigned lane = threadIdx.x;
-  TopNode<T> &task = top[small_list[task_id]];
+  if (blockIdx.x >= info->num_small) return; // grid is an upper bound
+  TopNode<T> &task = top[small_list[blockIdx.x]];
   const uint32_t L = task.l, n_all = task.r - task.l;
   const PrimRec<T> *src = (task.buf ? recs1 : recs0) + L;
   for (uint32_t i = lane; i < n_all; i += 64u) {
@@ -2178,15 +1811,6 @@ __device__ void subtree_task(const uint32_t task_id, TopNode<T> *top, const uint
   }
 }
 #undef NRT_SUB_REC
-template <typename T>
-__global__ __launch_bounds__(64) void k_subtree(TopNode<T> *top, const uint32_t *__restrict__ small_list,
-                                                const PrimRec<T> *__restrict__ recs0, const PrimRec<T> *__restrict__ recs1, int K,
-                                                uint32_t min_leaf, uint32_t max_depth, typename Wire<T>::Node *scratch_nodes,
-                                                uint32_t *indices, LevelInfo *info) {
-  const uint32_t num = info->num_small;
-  for (uint32_t t = blockIdx.x; t < num; t += gridDim.x)
-    subtree_task<T>(t, top, small_list, recs0, recs1, K, min_leaf, max_depth, scratch_nodes, indices, info);
-}
 #endif // NRT_PROF
 
 // ---------------------------------------------------------------------------
@@ -2247,10 +1871,11 @@ __device__ __forceinline__ U group_allmax(U x, uint32_t shift) {
 }
 
 template <typename T>
-__device__ void subtree_rows_task(const uint32_t task_id, TopNode<T> *top, const uint32_t *__restrict__ small_list,
-                                  const PrimRec<T> *__restrict__ recs0, const PrimRec<T> *__restrict__ recs1, int K, uint32_t min_leaf,
-                                  uint32_t max_depth, typename Wire<T>::Node *scratch_nodes, uint16_t *premap, uint32_t *indices,
-                                  LevelInfo *info) {
+__global__ __launch_bounds__(64) void k_subtree_rows(TopNode<T> *top, const uint32_t *__restrict__ small_list,
+                                                     const PrimRec<T> *__restrict__ recs0,
+                                                     const PrimRec<T> *__restrict__ recs1, int K, uint32_t min_leaf,
+                                                     uint32_t max_depth, typename Wire<T>::Node *scratch_nodes,
+                                                     uint16_t *premap, uint32_t *indices, LevelInfo *info) {
   typedef typename Wire<T>::Node Node;
   typedef typename Ord<T>::U U;
   __shared__ uint16_t s_perm[2][kHandoff];
@@ -2262,7 +1887,8 @@ __device__ void subtree_rows_task(const uint32_t task_id, TopNode<T> *top, const
   static_assert(sizeof(U) * 4 * 3 * kSmallBins * 3 >= sizeof(uint32_t) * 2 * kHandoff, "sizes fit the bins");
 
   const unsigned lane = threadIdx.x;
-  TopNode<T> &task = top[small_list[task_id]];
+  if (blockIdx.x >= info->num_small) return; // grid is an upper bound
+  TopNode<T> &task = top[small_list[blockIdx.x]];
   const uint32_t L = task.l, n_all = task.r - task.l;
   const PrimRec<T> *src = (task.buf ? recs1 : recs0) + L;
   Node *out = scratch_nodes + 2 * (size_t)L;
@@ -2706,18 +2332,6 @@ __device__ void subtree_rows_task(const uint32_t task_id, TopNode<T> *top, const
     atomicMax(&info->max_leaf_count, biggest_leaf);
   }
 }
-// One wave per subtree task; a wave takes several when the grid is smaller than the task list (the list grows until the
-// mid phase has finished, so the host sizes the grid by an estimate: any grid works).
-template <typename T>
-__global__ __launch_bounds__(64) void k_subtree_rows(TopNode<T> *top, const uint32_t *__restrict__ small_list,
-                                                     const PrimRec<T> *__restrict__ recs0,
-                                                     const PrimRec<T> *__restrict__ recs1, int K, uint32_t min_leaf,
-                                                     uint32_t max_depth, typename Wire<T>::Node *scratch_nodes,
-                                                     uint16_t *premap, uint32_t *indices, LevelInfo *info) {
-  const uint32_t num = info->num_small;
-  for (uint32_t t = blockIdx.x; t < num; t += gridDim.x)
-    subtree_rows_task<T>(t, top, small_list, recs0, recs1, K, min_leaf, max_depth, scratch_nodes, premap, indices, info);
-}
 
 // ---------------------------------------------------------------------------
 // relayout: sizes bottom-up, DFS pre-order top-down (single block over the
@@ -2898,9 +2512,8 @@ __global__ __launch_bounds__(64) void k_emit_small(const TopNode<T> *__restrict_
                                                    const typename Wire<T>::Node *__restrict__ scratch_nodes,
                                                    const uint16_t *__restrict__ premap, typename Wire<T>::Node *nodes,
                                                    const LevelInfo *info) {
-  const uint32_t num = info->num_small;
-  for (uint32_t task = blockIdx.x; task < num; task += gridDim.x) { // (any grid: see k_subtree_rows)
-  const TopNode<T> &t = top[small_list[task]];
+  if (blockIdx.x >= info->num_small) return;
+  const TopNode<T> &t = top[small_list[blockIdx.x]];
   const typename Wire<T>::Node *src = scratch_nodes + 2 * (size_t)t.l;
   if (premap) { // creation index -> pre-order index inside the subtree (k_subtree_rows)
     const uint16_t *map = premap + 2 * (size_t)t.l;
@@ -2912,7 +2525,7 @@ __global__ __launch_bounds__(64) void k_emit_small(const TopNode<T> *__restrict_
       }
       nodes[t.dfs + map[i]] = nd;
     }
-    continue;
+    return;
   }
   for (uint32_t i = threadIdx.x; i < t.size; i += 64u) { // (k_subtree wrote its nodes in pre-order)
     typename Wire<T>::Node nd = src[i];
@@ -2921,7 +2534,6 @@ __global__ __launch_bounds__(64) void k_emit_small(const TopNode<T> *__restrict_
       nd.data[1] += t.dfs;
     }
     nodes[t.dfs + i] = nd;
-  }
   }
 }
 
@@ -2934,7 +2546,7 @@ template <typename T>
 struct BuildPlan { // carve-up of the build workspace for n primitives
   size_t max_top, max_active, max_chunks;
   size_t off_recs0, off_recs1, off_scratch, off_top, off_child_acc, off_active, off_chunk_base, off_gbins,
-      off_chunk_hist, off_chunk_left, off_small, off_mid, off_scene, off_info, off_sort, off_premap, sort_blocks, total;
+      off_chunk_hist, off_chunk_left, off_small, off_scene, off_info, off_sort, off_premap, sort_blocks, total;
   BuildPlan(uint32_t n, size_t top_scale, bool tiny_top = false) {
     typedef typename Wire<T>::Node Node;
     max_active = (size_t)n / kHandoff + 2;
@@ -2959,7 +2571,6 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
     off_chunk_hist = take(max_chunks * 3 * kMaxBins * sizeof(uint32_t));
     off_chunk_left = take(max_chunks * sizeof(uint32_t));
     off_small = take((max_top + 1) * sizeof(uint32_t));
-    off_mid = take((max_active + 1) * sizeof(uint32_t)); // (nodes handed to k_mid hold more than kHandoff primitives each and are disjoint)
     off_scene = take((1 + kSceneReplicas) * sizeof(BoundsAcc<T>));
     off_info = take(sizeof(LevelInfo));
     // Morton sort: keys/values ping-pong (4 x n u32) + digit-major block histograms
@@ -3064,7 +2675,6 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
   const bool subtree_rows = true; // (k_subtree is not in this library)
 #endif
   const bool morton_order = (build_flags & kBuildMorton) != 0;
-  const uint32_t mid = std::min<uint32_t>(build_flags >> 8, MidLimit<T>::max_prims); // nodes of at most this many primitives are finished by k_mid, one block each (0: the level-synchronous phase goes all the way down)
   static_assert(offsetof(LevelInfo, level_begin) <= kBuildPinnedBytes, "state block");
   const int K = (int)(bin_size < 2 ? 2 : (bin_size > (uint32_t)kMaxBins ? (uint32_t)kMaxBins : bin_size));
   const int Ks = K < kSmallBins ? K : kSmallBins;
@@ -3092,7 +2702,6 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     uint32_t *chunk_hist = (uint32_t *)(base + plan.off_chunk_hist);
     uint32_t *chunk_left = (uint32_t *)(base + plan.off_chunk_left);
     uint32_t *small_list = (uint32_t *)(base + plan.off_small);
-    uint32_t *mid_list = (uint32_t *)(base + plan.off_mid);
     BoundsAcc<T> *scene = (BoundsAcc<T> *)(base + plan.off_scene);
     LevelInfo *info = (LevelInfo *)(base + plan.off_info);
     uint32_t *indices = (uint32_t *)indices_buf->p;
@@ -3121,8 +2730,8 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
       hipLaunchKernelGGL((k_gather_records<T>), dim3((n + 255) / 256), dim3(256), 0, s, recs[0], vals[pp], n, recs[1]);
       cur = 1;
     }
-    const LeafRule rule = {max_depth, min_leaf > 1u ? min_leaf : 1u, mid > (uint32_t)kHandoff ? mid : 0u};
-    hipLaunchKernelGGL((k_make_root<T>), dim3(1), dim3(64), 0, s, scene, n, rule, (uint32_t)cur, top, small_list, mid_list,
+    const LeafRule rule = {max_depth, min_leaf > 1u ? min_leaf : 1u};
+    hipLaunchKernelGGL((k_make_root<T>), dim3(1), dim3(64), 0, s, scene, n, rule, (uint32_t)cur, top, small_list,
                        info);
     BCHK(hipGetLastError());
 
@@ -3130,11 +2739,10 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     // From the level at which the nodes could first all be small, the state block written by k_level_setup is read
     // back every level; the level's kernels are enqueued before the host waits for it.
     int expect = 0;
-    const size_t leave_at = rule.mid ? rule.mid : (size_t)kHandoff; // node size at which the level-synchronous phase lets go
-    for (size_t m = (size_t)n / leave_at; m > 0; m >>= 1) expect++;
-    const int first_check = (n <= leave_at) ? 0 : expect + 2;
+    for (size_t m = (size_t)n / kHandoff; m > 0; m >>= 1) expect++;
+    const int first_check = (n <= (uint32_t)kHandoff) ? 0 : expect + 2;
     bool overflow = false;
-    uint32_t num_small = 0, num_mid = 0;
+    uint32_t num_small = 0;
     for (int level = 0;; level++) {
       // children of the level partitioned last (their records are in recs[cur]): inside k_level_setup while a level
       // cannot have more than 1024 active nodes, by a grid of their own below that
@@ -3142,9 +2750,9 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
       const bool wide = prev_max > 1024;
       if (wide)
         hipLaunchKernelGGL((k_children<T>), dim3((unsigned)((prev_max + 255) / 256)), dim3(256), 0, s, top, active, child_acc,
-                           (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, mid_list, info);
+                           (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, info);
       hipLaunchKernelGGL((k_level_setup<T>), dim3(1), dim3(1024), 0, s, top, active, chunk_base, info, child_acc,
-                         (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, mid_list, wide ? 0 : 1);
+                         (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, wide ? 0 : 1);
       const bool check = level >= first_check;
       if (check) {
         BCHK(hipMemcpyAsync(pinned, info, state_bytes, hipMemcpyDeviceToHost, s));
@@ -3168,29 +2776,21 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
         }
         if (hp->num_active == 0) { // (the three launches above found nothing to do)
           num_small = hp->num_small;
-          num_mid = hp->num_mid;
           break;
         }
       }
     }
     if (overflow) continue; // lopsided splits outgrew the top array: retry with a larger one
 
-    // ---- middle phase: one block per node of at most `mid` primitives, down to the subtree tasks ----------------
-    if (num_mid)
-      hipLaunchKernelGGL((k_mid<T>), dim3(num_mid), dim3(256), 0, s, top, mid_list, recs[0], recs[1], K | (Ks << 8), rule, small_list, info);
     // ---- subtree phase + relayout + emission ---------------------------------------------------------
-    // (k_mid appends subtree tasks: their number is known on the device only.  The grid is an estimate — the tasks of the
-    // level-synchronous phase plus a node of kHandoff / 2 primitives for all that went to k_mid — and a wave takes several
-    // tasks where it falls short.)
-    const unsigned small_grid = (unsigned)std::min<size_t>((size_t)num_small + (num_mid ? (size_t)n / (kHandoff / 2) + 64 : 0), (size_t)1 << 20);
-    if (small_grid) {
+    if (num_small) {
 #ifdef NRT_PROF
       if (!subtree_rows) // (the one-node-per-step form: the cross-check of the row form, tunable subtree_rows = 0 of the profiling build)
-        hipLaunchKernelGGL((k_subtree<T>), dim3(small_grid), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
+        hipLaunchKernelGGL((k_subtree<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
                            min_leaf, max_depth, scratch, indices, info);
       else
 #endif
-        hipLaunchKernelGGL((k_subtree_rows<T>), dim3(small_grid), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
+        hipLaunchKernelGGL((k_subtree_rows<T>), dim3(num_small), dim3(64), 0, s, top, small_list, recs[0], recs[1], Ks,
                            min_leaf, max_depth, scratch, premap, indices, info);
     }
     BCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_layout<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3208,8 +2808,8 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     Node *nodes = (Node *)nodes_buf->p;
     hipLaunchKernelGGL((k_emit_top<T>), dim3((unsigned)((plan.max_top + 255) / 256)), dim3(256), 0, s, top, info, recs[0], recs[1],
                        nodes, indices);
-    if (small_grid)
-      hipLaunchKernelGGL((k_emit_small<T>), dim3(small_grid), dim3(64), 0, s, top, small_list, scratch,
+    if (num_small)
+      hipLaunchKernelGGL((k_emit_small<T>), dim3(num_small), dim3(64), 0, s, top, small_list, scratch,
                          subtree_rows ? premap : (uint16_t *)nullptr, nodes, info);
     BCHK(hipGetLastError());
     return hipSuccess;
@@ -3226,7 +2826,6 @@ hipError_t gpu_build_result(const void *pinned, hipEvent_t ev, BuildResult *res)
   res->num_leaves = hp->num_leaves;
   res->num_branches = hp->num_branches;
   res->max_leaf_count = hp->max_leaf_count;
-  res->error = hp->error;
   return hipSuccess;
 }
 

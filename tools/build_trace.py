@@ -10,7 +10,6 @@ if sys.argv[1] == 'run':
     gx, gy = (int(x) for x in os.environ.get('NRT_TRACE_GRID', '1000x500').split('x'))
     v, f = scenes.plane(gx, gy)
     a = BVHAccel(np.float32); m = TriangleMesh(v, f)
-    if os.environ.get('NRT_TRACE_MID'): a.SetTunable('build_mid', int(os.environ['NRT_TRACE_MID']))
     for _ in range(4):
         a.Build(m.num_faces, m)
     print("build ms", a.LastBuildMs())
