@@ -195,14 +195,49 @@ struct SceneInst {
   uint32_t id, pad2;          // instance id (== its index in the by-id table)
 };
 static_assert(sizeof(SceneInst) == 272, "SceneInst");
+// Does the ray enter an instance's world box, and over which interval?  First the BVH leaf's robust test (IntersectRayAABB,
+// nanort.h:2285-2325, hit_t == ray.max_t throughout ListNodeIntersections), then NodeBBoxIntersector::Intersect
+// (nanosg.h:603-639: plain reciprocal, no MaxMult, no clipping), whose near end the reference's list is sorted by.
+__device__ __forceinline__ bool scene_node_interval(const nrt_ray_f32 &r, const float xbmin[3], const float xbmax[3], float &t_min_out) {
+  float tmin = r.min_t, tmax = r.max_t;
+  float tn[3], tf[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float d = r.dir[k];
+    const bool neg = d < 0.0f;
+    float inv_safe;
+    if (__builtin_fabsf(d) < 1.1920928955078125e-07f)
+      inv_safe = __builtin_huge_valf() * (neg ? -1.0f : 1.0f);
+    else
+      inv_safe = 1.0f / d;
+    const float lo = neg ? xbmax[k] : xbmin[k], hi = neg ? xbmin[k] : xbmax[k];
+    const float t0 = (lo - r.org[k]) * inv_safe;
+    const float t1 = (hi - r.org[k]) * inv_safe * 1.00000024f;
+    tmin = (t0 > tmin) ? t0 : tmin;
+    tmax = (t1 < tmax) ? t1 : tmax;
+    const float inv = 1.0f / d;
+    tn[k] = (lo - r.org[k]) * inv;
+    tf[k] = (hi - r.org[k]) * inv;
+  }
+  if (!(tmin <= tmax)) return false;
+  float a = (tn[1] > tn[0]) ? tn[1] : tn[0];
+  a = (tn[2] > a) ? tn[2] : a;
+  float b = (tf[1] < tf[0]) ? tf[1] : tf[0];
+  b = (tf[2] < b) ? tf[2] : b;
+  if (!(a <= b)) return false;
+  t_min_out = a;
+  return true;
+}
 constexpr int kSceneLdsStack = 12; // per-lane stack entries of k_scene_trace kept in LDS; deeper ones go to the overflow arrays
 struct SceneTraceArgs {
   const nrt_ray_f32 *rays;
   uint32_t n;
   const SceneInst *insts;
-  const float *list_t;        // [cap][n]: entry distances of the instances a ray enters, nearest first (k_scene_list*)
-  const uint32_t *list_node;  // [cap][n]: their ids
-  const uint32_t *count;      // [n]: list lengths
+  float *list_t;              // [cap][n]: entry distances of the instances a ray enters, unsorted (k_scene_list*, or this kernel itself: scan_nodes)
+  uint32_t *list_node;        // [cap][n]: their ids
+  const uint32_t *count;      // [n]: list lengths (unused when scan_nodes != 0)
+  uint32_t scan_nodes;        // != 0: a scene of this many (a handful of) instances — the kernel lists a ray's instances itself when it
+                              // fetches the ray, by testing every world box (insts[k].xbmin/xbmax), and no listing kernel runs
   nrt_scene_hit_f32 *hits;    // [n] out
   uint8_t *mask;              // [n] out, may be null
   uint32_t *spill;            // overflow stack [spill_levels][spill_stride], may be null

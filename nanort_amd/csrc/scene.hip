@@ -72,42 +72,13 @@ __host__ __device__ inline void mult_v(float dst[3], const float m[4][4], const 
   dst[2] = t2;
 }
 
-// Does the ray enter node box `nd`, and over which interval?  First the BVH leaf's robust test
-// (IntersectRayAABB, nanort.h:2285-2325, hit_t == ray.max_t throughout ListNodeIntersections), then
-// NodeBBoxIntersector::Intersect (nanosg.h:603-639: plain reciprocal, no MaxMult, no clipping).
-__device__ inline bool node_interval_box(const nrt_ray_f32 &r, const float xbmin[3], const float xbmax[3], float &t_min_out);
-__device__ inline bool node_interval(const nrt_ray_f32 &r, const NodeDev &nd, float &t_min_out) {
-  return node_interval_box(r, nd.xbmin, nd.xbmax, t_min_out);
-}
+// Does the ray enter node box `nd`, and over which interval?  nrt::scene_node_interval (common.h): the BVH leaf's robust test, then
+// NodeBBoxIntersector::Intersect.
 __device__ inline bool node_interval_box(const nrt_ray_f32 &r, const float xbmin[3], const float xbmax[3], float &t_min_out) {
-  float tmin = r.min_t, tmax = r.max_t;
-  float tn[3], tf[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const float d = r.dir[k];
-    const bool neg = d < 0.0f;
-    float inv_safe;
-    if (__builtin_fabsf(d) < 1.1920928955078125e-07f)
-      inv_safe = __builtin_huge_valf() * (neg ? -1.0f : 1.0f);
-    else
-      inv_safe = 1.0f / d;
-    const float lo = neg ? xbmax[k] : xbmin[k], hi = neg ? xbmin[k] : xbmax[k];
-    const float t0 = (lo - r.org[k]) * inv_safe;
-    const float t1 = (hi - r.org[k]) * inv_safe * 1.00000024f;
-    tmin = (t0 > tmin) ? t0 : tmin;
-    tmax = (t1 < tmax) ? t1 : tmax;
-    const float inv = 1.0f / d;
-    tn[k] = (lo - r.org[k]) * inv;
-    tf[k] = (hi - r.org[k]) * inv;
-  }
-  if (!(tmin <= tmax)) return false;
-  float a = (tn[1] > tn[0]) ? tn[1] : tn[0];
-  a = (tn[2] > a) ? tn[2] : a;
-  float b = (tf[1] < tf[0]) ? tf[1] : tf[0];
-  b = (tf[2] < b) ? tf[2] : b;
-  if (!(a <= b)) return false;
-  t_min_out = a;
-  return true;
+  return nrt::scene_node_interval(r, xbmin, xbmax, t_min_out);
+}
+__device__ inline bool node_interval(const nrt_ray_f32 &r, const NodeDev &nd, float &t_min_out) {
+  return nrt::scene_node_interval(r, nd.xbmin, nd.xbmax, t_min_out);
 }
 
 // A ray's candidate list while it is being collected: UNSORTED, at most `cap` entries — the cap nearest by (entry distance,
@@ -465,6 +436,7 @@ struct nrt_scene {
   unsigned walk_backoff_pct = 25; // share of a batch handed to the listing path above which the next kWalkBackoff calls skip the walk (tunable)
   unsigned walk_min = kWalkMinNodes; // scenes of at least this many nodes are traced by the walk (tunable "walk_min")
   unsigned prune_min = 32768; // scenes of at least this many instances are listed by the pruning walk (k_scene_list_w4<true>)
+  unsigned fuse_scan = 1; // scenes of at most kScanMaxNodes nodes: k_scene_trace lists a ray's instances itself (one launch); 0: k_scene_list in a launch of its own (the A/B)
   unsigned trav_min = 8;
   unsigned cand_min = 1, cand_busy_max = 64; // batching of the per-instance steps of k_scene_trace (env NRT_SCENE_CAND / NRT_SCENE_CAND_BUSY; 1 / 64: none)
   unsigned trace_blocks_per_cu = 0, num_cus = 0, refill_min = 56; // persistent grid of k_scene_trace (env NRT_SCENE_REFILL; 16-48 measured slower on small scenes, 64 slower on 10 000 instances)
@@ -733,6 +705,7 @@ static nrt_status scene_list_and_trace(nrt_scene *s, const nrt_ray_f32 *d_rays, 
   }
   SCHK(s, hipMemsetAsync(s->d_cursor.p, 0, (size_t)nrt::kMaxParts * nrt::kCursorStrideWords * sizeof(uint32_t), s->stream));
   const NodeDev *d_nodes = (const NodeDev *)s->d_nodes.p;
+  const bool fused_scan = !s->use_top && s->fuse_scan && num_nodes <= (uint32_t)kMaxList; // (every entered box fits the list: no replacement logic needed in the trace kernel)
   if (s->use_top && s->top_view.wide4 && s->top_view.root_is_branch && s->top_view.tree_nested &&
       3u * (s->top_view.tree_depth / 2u + 1u) + 2u < (uint32_t)kTopStack)
   {
@@ -748,16 +721,18 @@ static nrt_status scene_list_and_trace(nrt_scene *s, const nrt_ray_f32 *d_rays, 
   else if (s->use_top)
     hipLaunchKernelGGL(k_scene_list_bvh, dim3(grid), dim3(256), 0, s->stream, d_rays, n, s->top_view.nodes, s->top_view.indices,
                        d_nodes, cap, (float *)s->d_list_t.p, (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p, subset);
-  else
+  else if (!fused_scan)
     hipLaunchKernelGGL(k_scene_list, dim3(grid), dim3(256), 0, s->stream, d_rays, n, d_nodes, num_nodes, cap,
                        (float *)s->d_list_t.p, (uint32_t *)s->d_list_node.p, (uint32_t *)s->d_count.p, subset);
+  // (else: a handful of nodes — k_scene_trace tests every world box itself as it fetches a ray: no listing launch)
   SCHK(s, hipGetLastError());
   nrt::SceneTraceArgs a;
+  a.scan_nodes = fused_scan ? num_nodes : 0u;
   a.rays = d_rays;
   a.n = n;
   a.insts = (const nrt::SceneInst *)s->d_insts.p;
-  a.list_t = (const float *)s->d_list_t.p;
-  a.list_node = (const uint32_t *)s->d_list_node.p;
+  a.list_t = (float *)s->d_list_t.p;
+  a.list_node = (uint32_t *)s->d_list_node.p;
   a.count = (const uint32_t *)s->d_count.p;
   a.hits = d_hits;
   a.mask = d_mask;
@@ -921,6 +896,7 @@ nrt_status nrtSceneSetTunable(nrt_scene *s, const char *name, int value) {
   else if (k == "walk_refill_min") s->walk_refill_min = lanes;
   else if (k == "cand_min") s->cand_min = lanes;
   else if (k == "cand_busy_max") s->cand_busy_max = (unsigned)std::min(65, std::max(1, value));
+  else if (k == "fuse_scan") s->fuse_scan = value != 0;
   else if (k == "prune_min") s->prune_min = (unsigned)std::max(0, value);
   else if (k == "walk_min") s->walk_min = (unsigned)std::max(2, value);
   else if (k == "walk_backoff_pct") s->walk_backoff_pct = (unsigned)std::min(100, std::max(0, value));

@@ -1619,7 +1619,11 @@ __device__ __forceinline__ void scene_mult_v(float dst[3], const float m[4][4], 
   dst[2] = t2;
 }
 
-template <int STACK>
+// SCAN: a scene of a handful of instances (a.scan_nodes of them): the lane lists the instances its ray enters ITSELF when it fetches
+// the ray — every world box tested in id order, exactly what the listing kernel of such scenes did in a launch of its own
+// (scene.hip k_scene_list) — into its own slots of the list arrays, which it alone reads back: one launch per batch, no second
+// pass over the rays.
+template <int STACK, bool SCAN>
 __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTraceArgs a) {
   typedef float T;
   typedef StackEntry<float> SE;
@@ -1683,7 +1687,18 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
             worg[k] = r.org[k];
             wdir[k] = r.dir[k];
           }
-          cnt = a.count[i];
+          if (SCAN) {
+            cnt = 0u;
+            for (uint32_t k = 0; k < a.scan_nodes; k++) { // (wave-uniform addresses: the boxes arrive through the scalar cache)
+              float t;
+              if (!scene_node_interval(r, a.insts[k].xbmin, a.insts[k].xbmax, t)) continue;
+              a.list_t[(size_t)cnt * a.n + i] = t;
+              a.list_node[(size_t)cnt * a.n + i] = k;
+              cnt++;
+            }
+          } else {
+            cnt = a.count[i];
+          }
           j = 0;
           last_t = 0.0f;
           last_id = 0u;
@@ -1850,12 +1865,17 @@ __global__ __launch_bounds__(kTraverseBlock) void k_scene_trace(const SceneTrace
 
 hipError_t launch_scene_trace(const SceneTraceArgs &args, unsigned grid, hipStream_t s) {
   if (args.n == 0) return hipSuccess;
-  hipLaunchKernelGGL((k_scene_trace<kSceneLdsStack>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+  if (args.scan_nodes)
+    hipLaunchKernelGGL((k_scene_trace<kSceneLdsStack, true>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
+  else
+    hipLaunchKernelGGL((k_scene_trace<kSceneLdsStack, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
   return hipGetLastError();
 }
 int scene_trace_blocks_per_cu() {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scene_trace<kSceneLdsStack>, kTraverseBlock, 0) != hipSuccess || n < 1) n = 4;
+  int n1 = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_scene_trace<kSceneLdsStack, false>, kTraverseBlock, 0) != hipSuccess || n < 1) n = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_scene_trace<kSceneLdsStack, true>, kTraverseBlock, 0) == hipSuccess && n1 >= 1 && n1 < n) n = n1;
   return n > 8 ? 8 : n;
 }
 

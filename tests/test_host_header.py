@@ -261,6 +261,31 @@ def test_nanosg_hip_addon_fits_the_unmodified_nanosg(tmp_path):
          "-I", os.path.join(REFERENCE, "examples", "nanosg"), str(tu)])
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "nanort.h")), reason="reference tree not present")
+def test_reference_nanosg_is_float_only(tmp_path):
+    """Why there are no nrtScene*_f64 entry points (DESIGN.md 7): nanosg::Node / Scene carry a template parameter T, but the
+    reference's own header only compiles for T = float — Node::Update builds nanort::TriangleMesh<float> /
+    TriangleSAHPred<float> from the mesh's vertices (nanosg.h:404-406) and Scene::Traverse's box intersector takes a
+    nanort::Ray<float> (nanosg.h:638).  Scene<double, M> is rejected by the compiler, against the reference's own nanort.h."""
+    tu = tmp_path / "sg64.cc"
+    tu.write_text(
+        '#include "nanort.h"\n#include "nanosg.h"\n#include <vector>\n'
+        "template <typename T> struct Mesh { std::vector<T> vertices; std::vector<unsigned int> faces; size_t stride;\n"
+        "  const T *GetVertices() const { return vertices.data(); } const unsigned int *GetFaces() const { return faces.data(); }\n"
+        "  size_t GetVertexStrideBytes() const { return stride; }\n"
+        "  void GetNormal(T Ng[3], T Ns[3], unsigned int, T, T) const { Ng[0]=Ns[0]=0; Ng[1]=Ns[1]=0; Ng[2]=Ns[2]=1; } };\n"
+        "template <typename T> int run() { Mesh<T> m; nanosg::Node<T, Mesh<T> > node(&m); nanosg::Scene<T, Mesh<T> > scene;\n"
+        "  scene.AddNode(node); scene.Commit(); nanort::Ray<T> ray; nanosg::Intersection<T> isect;\n"
+        "  return scene.template Traverse<nanosg::Intersection<T>, nanort::TriangleIntersector<T, nanosg::Intersection<T> > >(ray, &isect) ? 0 : 1; }\n"
+        "int main() { return run<REAL>(); }\n")
+    base = ["g++", "-std=c++11", "-fsyntax-only", "-w", "-I", REFERENCE, "-I", os.path.join(REFERENCE, "examples", "nanosg"), str(tu)]
+    ok = subprocess.run(base + ["-DREAL=float"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert ok.returncode == 0, ok.stdout[-2000:]
+    bad = subprocess.run(base + ["-DREAL=double"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert bad.returncode != 0, "the reference's nanosg.h now compiles for double: add the f64 scene entry points"
+    assert "TriangleMesh<float>" in bad.stdout and "Ray<float>" in bad.stdout
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "examples", "objrender", "cornellbox_suzanne.obj")), reason="reference tree not present")
 @pytest.mark.parametrize("example,outputs", [("objrender", ("render.exr", "render.png")), ("double_precision", ("render.exr", "render.data"))])
 def test_reference_renderers_write_the_same_images(tmp_path, example, outputs):
