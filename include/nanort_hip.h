@@ -455,7 +455,8 @@ NRT_API nrt_status nrtSceneTraverseBatch_f32(nrt_scene *scene, const nrt_ray_f32
 /* The same traversal with rays and results resident in HBM (device pointers; d_mask_out may be NULL): no PCIe traffic.
  * On the scene's own stream: scenes of 64 nodes or more — ONE launch of the single-pass walk (top-level tree and instance trees on
  * one per-lane stack, no per-ray list), a 4-byte read-back, and only if the walk handed rays over, the two launches below on
- * those; smaller scenes — two launches (the listing over the top-level BVH, then one trace kernel for the whole batch).  The call
+ * those; scenes of at most 8 nodes — ONE launch (the trace kernel tests every world box itself as it fetches a ray); 9 to 63
+ * nodes — two launches (the listing over the top-level BVH, then one trace kernel for the whole batch).  The call
  * is SYNCHRONOUS (the scene owns the per-ray scratch), and the caller makes sure `d_rays` is complete before calling. */
 NRT_API nrt_status nrtSceneTraverseBatchDevice_f32(nrt_scene *scene, const nrt_ray_f32 *d_rays, uint64_t num_rays,
                                                    nrt_scene_hit_f32 *d_hits_out, uint8_t *d_mask_out);
@@ -464,7 +465,9 @@ NRT_API nrt_status nrtSceneTraverseBatchDevice_f32(nrt_scene *scene, const nrt_r
  * are re-done by the listing path; 2: every scene of two nodes or more; 0: listing + trace for every ray), "trav_min", "refill_min"
  * (listing path), "walk_trav_min", "walk_refill_min" (the walk's), "cand_min",
  * "cand_busy_max" (lane-count thresholds of the phases), "prune_min" (instance count from which the listing prunes beyond a
- * full list), "walk_min" (instance count from which single_pass = 1 uses the walk; 64).  After a batch of which the walk had to
+ * full list), "walk_min" (instance count from which single_pass = 1 uses the walk; 64), "scan_max" (scenes of at most this many
+ * nodes get no top-level tree: every world box is tested per ray; 8, at most 64; takes effect at the next nrtSceneCommit),
+ * "fuse_scan" (1: such a scene is listed inside the trace kernel, one launch; 0: by a listing launch of its own).  After a batch of which the walk had to
  * hand more than a quarter ("walk_backoff_pct", 25) to the listing path (direction vectors far shorter than 1, where the reference's cull compares a
  * distance with a parameter) the next 15 calls use the listing path directly. */
 NRT_API nrt_status nrtSceneSetTunable(nrt_scene *scene, const char *name, int value);

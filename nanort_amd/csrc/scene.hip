@@ -436,6 +436,7 @@ struct nrt_scene {
   unsigned walk_backoff_pct = 25; // share of a batch handed to the listing path above which the next kWalkBackoff calls skip the walk (tunable)
   unsigned walk_min = kWalkMinNodes; // scenes of at least this many nodes are traced by the walk (tunable "walk_min")
   unsigned prune_min = 32768; // scenes of at least this many instances are listed by the pruning walk (k_scene_list_w4<true>)
+  unsigned scan_max = kScanMaxNodes; // scenes of at most this many nodes are listed by testing every world box (no top-level tree); tunable, <= kMaxList (next Commit)
   unsigned fuse_scan = 1; // scenes of at most kScanMaxNodes nodes: k_scene_trace lists a ray's instances itself (one launch); 0: k_scene_list in a launch of its own (the A/B)
   unsigned trav_min = 8;
   unsigned cand_min = 1, cand_busy_max = 64; // batching of the per-instance steps of k_scene_trace (env NRT_SCENE_CAND / NRT_SCENE_CAND_BUSY; 1 / 64: none)
@@ -577,7 +578,7 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
   // ... only where something reads it: the listing kernels of scenes of more than kScanMaxNodes nodes, the single-pass walk from
   // walk_min nodes (or forced, single_pass = 2).  A handful of nodes is scanned: no context, no build, no read-back for them
   // (a tunable that makes the walk eligible later commits the scene again: scene_traverse).
-  const bool want_top = s->insts.size() > kScanMaxNodes || (s->single_pass && (s->insts.size() >= s->walk_min || s->single_pass > 1));
+  const bool want_top = s->insts.size() > s->scan_max || (s->single_pass && (s->insts.size() >= s->walk_min || s->single_pass > 1));
   if (s->insts.size() >= 2 && want_top) {
     if (!s->top && nrtCreate(s->device, &s->top) != NRT_OK)
       return sfail(s, NRT_ERR_DEVICE, "nrtSceneCommit: top-level context: %s", nrtLastError(nullptr));
@@ -644,7 +645,7 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
       SCHK(s, hipMemcpy(s->d_meshes.p, mt.data(), mt.size() * sizeof(nrt::SceneMesh), hipMemcpyHostToDevice));
     }
     s->have_top = true;                                                                              // the single-pass walk's
-    s->use_top = s->insts.size() > kScanMaxNodes && s->top_view.tree_depth + 2 < (uint32_t)kTopStack; // the listing kernels' (else: the scan)
+    s->use_top = s->insts.size() > s->scan_max && s->top_view.tree_depth + 2 < (uint32_t)kTopStack; // the listing kernels' (else: the scan)
   }
   s->mesh_gens.clear();
   for (size_t m = 0; m < meshes.size(); m++) s->mesh_gens.push_back(std::make_pair(meshes[m].first, meshes[m].second.tv.generation));
@@ -789,7 +790,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     }
   }
   // the walk became eligible after Commit (nrtSceneSetTunable / the variables above) on a scene committed without its top-level tree
-  if (s->single_pass && !s->have_top && s->insts.size() >= 2 && s->insts.size() <= kScanMaxNodes &&
+  if (s->single_pass && !s->have_top && s->insts.size() >= 2 && s->insts.size() <= s->scan_max &&
       (s->insts.size() >= s->walk_min || s->single_pass > 1)) {
     const nrt_status st = nrtSceneCommit(s);
     if (st) return st;
@@ -897,6 +898,7 @@ nrt_status nrtSceneSetTunable(nrt_scene *s, const char *name, int value) {
   else if (k == "cand_min") s->cand_min = lanes;
   else if (k == "cand_busy_max") s->cand_busy_max = (unsigned)std::min(65, std::max(1, value));
   else if (k == "fuse_scan") s->fuse_scan = value != 0;
+  else if (k == "scan_max") s->scan_max = (unsigned)std::min(kMaxList, std::max(1, value));
   else if (k == "prune_min") s->prune_min = (unsigned)std::max(0, value);
   else if (k == "walk_min") s->walk_min = (unsigned)std::max(2, value);
   else if (k == "walk_backoff_pct") s->walk_backoff_pct = (unsigned)std::min(100, std::max(0, value));
