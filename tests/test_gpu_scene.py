@@ -7,7 +7,7 @@ import pytest
 
 from nanort_amd import BVHAccel, Scene, TriangleMesh, scenes
 from oracle import bindings as ob
-from scene_fixture import instances
+from scene_fixture import instances, xform
 
 pytestmark = pytest.mark.gpu
 
@@ -378,6 +378,41 @@ def test_single_pass_walk_equals_the_listing_path_and_the_restatement(oracle, di
         sc.SetTunable(name, value)
         h2, m2 = sc.TraverseBatch(rays)
         assert np.array_equal(m2, om) and fields_equal(h2, oh, ("t", "u", "v", "prim_id", "node_id")), (name, value)
+
+
+@pytest.mark.parametrize("count", [1, 3, 8, 20])
+def test_small_scenes_every_listing_form_gives_the_restatements_records(oracle, count):
+    """Scenes of a handful of nodes: the trace kernel lists a ray's instances itself (one launch; the default up to 8 nodes), a
+    listing launch of its own (fuse_scan = 0), the scan raised past the node count (scan_max = 64: no top-level tree at 20
+    nodes) and the tree listing (scan_max = 1: a top-level tree even for 3 nodes) — the same records, the restatement's, on the
+    same local trees (reference-built, adopted), overlapping instances, ragged batch size."""
+    rng = np.random.default_rng(300 + count)
+    sv, sf = scenes.sphere(32, 16)
+    sv = sv - np.array([0, 5, 0], dtype=np.float32)
+    nodes, idx, _ = oracle.build(sv, sf)
+    a = BVHAccel(np.float32)
+    a.SetMesh(TriangleMesh(sv, sf))
+    a.SetTree(nodes, idx)
+    xs = [xform(tuple(rng.uniform(0.15, 0.5, 3)), rng.uniform(0, 6.28), rng.uniform(0, 6.28), tuple(rng.uniform(-4, 4, 3) + np.array([0, 5, 0])))
+          for _ in range(count)]
+    O = ob.SceneOracle(oracle)
+    for x in xs:
+        O.add_node(sv, sf, x)
+    assert O.commit()
+    rays = scenes.camera_rays(331, 187)
+    rays["org"] += rng.uniform(-0.2, 0.2, size=(rays.shape[0], 3)).astype(np.float32)
+    oh, om = O.traverse(rays)
+    assert 0.02 < om.mean() < 0.98
+    for tun in ({}, {"fuse_scan": 0}, {"scan_max": 64}, {"scan_max": 1}, {"scan_max": 64, "fuse_scan": 0}):
+        sc = Scene()
+        for k, v in tun.items():
+            sc.SetTunable(k, v)
+        for x in xs:
+            sc.AddNode(a, x)
+        assert sc.Commit()
+        h, m = sc.TraverseBatch(rays)
+        assert np.array_equal(m, om), tun
+        assert fields_equal(h[om == 1], oh[om == 1], ("t", "u", "v", "prim_id", "node_id")), tun
 
 
 def test_walk_opens_one_leaf_meshes_too(oracle):
