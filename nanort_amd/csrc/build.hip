@@ -776,6 +776,8 @@ __device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *a
                                               uint32_t num_active, uint32_t max_active, LeafRule rule, uint32_t dst_buf,
                                               uint32_t *small_list, LevelInfo *info) {
   const TopNode<T> p = top[active[a]];
+  bool small[2];
+  uint32_t ci2[2];
   for (uint32_t c = 0; c < 2; c++) {
     TopNode<T> t;
     BoundsAcc<T> &acc = child_acc[2 * a + c];
@@ -804,12 +806,31 @@ __device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *a
     t.parent = active[a] | (c ? kHighChild : 0u);
     const uint32_t ci = p.child0 + c;
     top[ci] = t;
-    if (t.kind == KIND_SMALL) small_list[atomicAdd(&info->num_small, 1u)] = ci;
+    small[c] = t.kind == KIND_SMALL;
+    ci2[c] = ci;
+  }
+  // the subtree tasks of the wave's lanes are appended with ONE atomic (late levels hand over thousands of tasks: one
+  // device-scope atomic per task on one word was most of a narrow level's k_level_setup)
+  const unsigned long long m0 = __ballot(small[0]), m1 = __ballot(small[1]), live = __ballot(true);
+  const uint32_t n0 = (uint32_t)__builtin_popcountll(m0), total = n0 + (uint32_t)__builtin_popcountll(m1);
+  if (total) {
+    const int leader = __builtin_ctzll(live);
+    const unsigned lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&info->num_small, total);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (small[0]) small_list[base + (uint32_t)__builtin_popcountll(m0 & below)] = ci2[0];
+    if (small[1]) small_list[base + n0 + (uint32_t)__builtin_popcountll(m1 & below)] = ci2[1];
   }
 }
 
-// Wide levels (more active nodes than one block has threads) create their children with a grid of their own; narrow levels
+// Wide levels (more than kNarrowLevel active nodes) create their children with a grid of their own; narrow levels
 // do it at the head of k_level_setup and save the launch.
+#ifndef NRT_NARROW_LEVEL
+#define NRT_NARROW_LEVEL 256 // (1024 -> 256 with the wave-aggregated task append: 1 M 1.582 -> 1.557 ms, fp64 2.176 -> 2.142, 10 M 11.08 -> 10.94; profiles/r05j_build_children_variants.txt)
+#endif
+constexpr size_t kNarrowLevel = NRT_NARROW_LEVEL;
 template <typename T>
 __global__ __launch_bounds__(256) void k_children(TopNode<T> *top, const uint32_t *__restrict__ active, BoundsAcc<T> *child_acc,
                                                   uint32_t max_active, LeafRule rule, uint32_t dst_buf,
@@ -2745,9 +2766,9 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     uint32_t num_small = 0;
     for (int level = 0;; level++) {
       // children of the level partitioned last (their records are in recs[cur]): inside k_level_setup while a level
-      // cannot have more than 1024 active nodes, by a grid of their own below that
+      // cannot have more than kNarrowLevel active nodes, by a grid of their own beyond that
       const size_t prev_max = level == 0 ? 0 : (level - 1 < 31 ? std::min<size_t>((size_t)1 << (level - 1), plan.max_active) : plan.max_active);
-      const bool wide = prev_max > 1024;
+      const bool wide = prev_max > kNarrowLevel;
       if (wide)
         hipLaunchKernelGGL((k_children<T>), dim3((unsigned)((prev_max + 255) / 256)), dim3(256), 0, s, top, active, child_acc,
                            (uint32_t)plan.max_active, rule, (uint32_t)cur, small_list, info);
