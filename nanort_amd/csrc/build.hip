@@ -66,6 +66,9 @@ static_assert(kHandoff <= kSmall && kHandoff >= 64, "hand-off size");
 #ifndef NRT_SUBTREE_REC_LDS
 #define NRT_SUBTREE_REC_LDS 0 // 1: k_subtree copies its node's primitive records into LDS (10 KB per wave: 10 waves per CU instead of 22; measured slower, profiles/r02j_build_subtree_ab.txt)
 #endif
+#ifndef NRT_BIN_REPL
+#define NRT_BIN_REPL 4 // copies of k_bin's LDS bins (fp64: at most 2), neighbouring lanes on different copies: 1 M 1.418 -> 1.314 ms, fp64 2.13 -> 2.08 (1 / 2 / 4 / 8 copies: 1.414 / 1.343 / 1.312 / 1.330; profiles/r05l_bin_repl_variants.txt)
+#endif
 #ifndef NRT_BIN_PRELOAD
 #define NRT_BIN_PRELOAD 1 // k_bin requests a lane's records together instead of one by one (profiles/r03D_build_variants.txt: 10M-triangle build 14.5 -> 11.3 ms, 1M unchanged)
 #endif
@@ -1015,21 +1018,26 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
   if (blockIdx.x >= info->num_chunks) return; // grids are upper bounds
   const uint32_t num_active = info->num_active;
   typedef typename Ord<T>::U U;
-  __shared__ uint32_t s_cnt[3][kMaxBins];
-  __shared__ U s_min[3][kMaxBins][3];
-  __shared__ U s_max[3][kMaxBins][3];
+  // The bins are kept in R copies, neighbouring lanes on different ones (the copy index is the fastest-running one: the R
+  // copies of a word lie in R different banks): lanes of a wave that end in the same bin — the rule on coherent input —
+  // queue R ways less on one LDS word; the copies are folded into copy 0 before anything reads the bins.
+  constexpr int R = sizeof(T) == 4 ? NRT_BIN_REPL : (NRT_BIN_REPL > 2 ? 2 : NRT_BIN_REPL);
+  __shared__ uint32_t s_cnt[3][kMaxBins][R];
+  __shared__ U s_min[3][kMaxBins][3][R];
+  __shared__ U s_max[3][kMaxBins][3][R];
   __shared__ uint32_t s_task;
+  const unsigned rep = threadIdx.x & (unsigned)(R - 1);
   const uint32_t chunk = blockIdx.x;
   if (threadIdx.x < 64u) {
     const uint32_t t = find_task_wave(chunk_base, num_active, chunk, threadIdx.x);
     if (threadIdx.x == 0) s_task = t;
   }
-  for (int i = threadIdx.x; i < 3 * kMaxBins; i += 256) {
-    const int k = i / kMaxBins, b = i % kMaxBins;
-    s_cnt[k][b] = 0;
+  for (int i = threadIdx.x; i < 3 * kMaxBins * R; i += 256) {
+    const int k = i / (kMaxBins * R), b = (i / R) % kMaxBins, r = i % R;
+    s_cnt[k][b][r] = 0;
     for (int d = 0; d < 3; d++) {
-      s_min[k][b][d] = Ord<T>::highest();
-      s_max[k][b][d] = Ord<T>::lowest();
+      s_min[k][b][d][r] = Ord<T>::highest();
+      s_max[k][b][d][r] = Ord<T>::lowest();
     }
   }
   __syncthreads();
@@ -1060,11 +1068,11 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
     const uint32_t per = (end - begin + 255u) >> 8;
     const uint32_t p0 = begin + threadIdx.x * per;
     auto flush = [&](int k) {
-      atomicAdd(&s_cnt[k][pb[k]], pc[k]);
+      atomicAdd(&s_cnt[k][pb[k]][rep], pc[k]);
 #pragma unroll
       for (int d = 0; d < 3; d++) {
-        atomicMin(&s_min[k][pb[k]][d], pmin[k][d]);
-        atomicMax(&s_max[k][pb[k]][d], pmax[k][d]);
+        atomicMin(&s_min[k][pb[k]][d][rep], pmin[k][d]);
+        atomicMax(&s_max[k][pb[k]][d][rep], pmax[k][d]);
       }
     };
     auto bin_rec = [&](const PrimRec<T> &r) {
@@ -1123,6 +1131,28 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
       if (pb[k] >= 0) flush(k);
   }
   __syncthreads();
+  if (R > 1) { // fold the copies into copy 0
+    for (int i = threadIdx.x; i < 3 * kMaxBins; i += 256) {
+      const int k = i / kMaxBins, b = i % kMaxBins;
+      uint32_t c = s_cnt[k][b][0];
+#pragma unroll
+      for (int r = 1; r < R; r++) c += s_cnt[k][b][r];
+      s_cnt[k][b][0] = c;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        U mn = s_min[k][b][d][0], mx = s_max[k][b][d][0];
+#pragma unroll
+        for (int r = 1; r < R; r++) {
+          const U a_ = s_min[k][b][d][r], b_ = s_max[k][b][d][r];
+          mn = a_ < mn ? a_ : mn;
+          mx = b_ > mx ? b_ : mx;
+        }
+        s_min[k][b][d][0] = mn;
+        s_max[k][b][d][0] = mx;
+      }
+    }
+    __syncthreads();
+  }
   if (whole_node) { // the node's complete bins are in LDS: split it here (k_split skips it)
     if (threadIdx.x < 64u) {
       const unsigned lane = threadIdx.x;
@@ -1130,11 +1160,11 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
       U mn3[3][3], mx3[3][3];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        if ((int)lane < K) cnt3[k] = s_cnt[k][lane];
+        if ((int)lane < K) cnt3[k] = s_cnt[k][lane][0];
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          mn3[k][d] = s_min[k][lane][d];
-          mx3[k][d] = s_max[k][lane][d];
+          mn3[k][d] = s_min[k][lane][d][0];
+          mx3[k][d] = s_max[k][lane][d][0];
         }
       }
       int best_axis;
@@ -1157,13 +1187,13 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
   GBins<T> *g = &gbins[a];
   for (int i = threadIdx.x; i < 3 * kMaxBins; i += 256) {
     const int k = i / kMaxBins, b = i % kMaxBins;
-    const uint32_t c = s_cnt[k][b];
+    const uint32_t c = s_cnt[k][b][0];
     chunk_hist[(size_t)chunk * (3 * kMaxBins) + i] = c;
     if (c) {
       atomicAdd(&g->count[k][b], c);
       for (int d = 0; d < 3; d++) {
-        atomicMin(&g->bmin[k][b][d], s_min[k][b][d]);
-        atomicMax(&g->bmax[k][b][d], s_max[k][b][d]);
+        atomicMin(&g->bmin[k][b][d], s_min[k][b][d][0]);
+        atomicMax(&g->bmax[k][b][d], s_max[k][b][d][0]);
       }
     }
   }
