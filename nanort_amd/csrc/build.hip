@@ -546,8 +546,29 @@ __device__ __forceinline__ void clean_acc(BoundsAcc<T> *acc) {
   for (int j = 0; j < 12; j++) acc->v[j] = (j % 6 < 3) ? (U)Ord<T>::highest() : (U)Ord<T>::lowest();
 }
 
+// TOP LEVELS: a level of at most kRepNodes active nodes whose chunks all add into ONE node's bins and child accumulators sends
+// hundreds of blocks' atomics through the same few cache lines (level 0 of a 1 M-triangle build: 489 blocks on 84 lines of bins
+// and 2 of accumulators, ~75 requests per microsecond and line: +20 us on k_bin, +7 on k_partition).  Nodes of at least
+// kRepMinChunks chunks (131 072 primitives) on such a level therefore accumulate into kRep COPIES — chunk c of the node into copy c % kRep — kept
+// behind the regular slots (gbins[max_active ...], child_acc[2 max_active ...]); the consumer (k_split / make_children) folds
+// the copies and hands them on clean like the regular slots.  Sums, minima and maxima of integers: the result is the same.
+#ifndef NRT_TOP_REP
+#define NRT_TOP_REP 4
+#endif
+constexpr uint32_t kRep = NRT_TOP_REP, kRepNodes = 8, kRepMinChunks = 64;
+__device__ __forceinline__ bool rep_node(uint32_t num_active, uint32_t nchunks) {
+  return kRep > 1u && num_active <= kRepNodes && nchunks >= kRepMinChunks;
+}
+
 template <typename T>
-__global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info, uint32_t top_cap, GBins<T> *gbins, BoundsAcc<T> *child_acc) {
+__global__ void k_init_scene(BoundsAcc<T> *scene, LevelInfo *info, uint32_t top_cap, GBins<T> *gbins, BoundsAcc<T> *child_acc,
+                             uint32_t max_active) {
+  if (blockIdx.x > 0) { // blocks 1 .. kRepNodes * kRep: one copy of the top levels' bins each (+ its two child accumulators)
+    const uint32_t c = blockIdx.x - 1u;
+    for (int k = 0; k < 3; k++) clean_bins<T>(&gbins[max_active + c], k, threadIdx.x);
+    if (threadIdx.x < 2) clean_acc<T>(&child_acc[2u * max_active + 2u * c + threadIdx.x]);
+    return;
+  }
   if (threadIdx.x < 12)
     for (int r = 0; r <= kSceneReplicas; r++) scene[r].v[threadIdx.x] = (threadIdx.x % 6 < 3) ? Ord<T>::highest() : Ord<T>::lowest();
   for (int k = 0; k < 3; k++) clean_bins<T>(&gbins[0], k, threadIdx.x); // 64 threads == kMaxBins
@@ -781,15 +802,36 @@ __device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *a
   const TopNode<T> p = top[active[a]];
   bool small[2];
   uint32_t ci2[2];
+  const bool folded = rep_node(num_active, p.nchunks); // (a top level: the node's chunks reduced into kRep copies)
   for (uint32_t c = 0; c < 2; c++) {
     TopNode<T> t;
     BoundsAcc<T> &acc = child_acc[2 * a + c];
+    typename Ord<T>::U m[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) m[j] = acc.v[j];
+    if (folded) { // (two copies are requested together before they are used and cleaned only then: kRep / 2 round trips, not kRep)
+      static_assert(kRep % 2u == 0u || kRep == 1u, "copies are folded in pairs");
+      for (uint32_t r0 = 0; r0 < kRep; r0 += 2u) {
+        BoundsAcc<T> *ar = &child_acc[2u * max_active + 2u * (a * kRep + r0) + c]; // (copy r0 + 1 of this child: two records on)
+        typename Ord<T>::U x[2][12];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int j = 0; j < 12; j++) x[q][j] = ar[2 * q].v[j];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+          for (int j = 0; j < 12; j++) m[j] = (j % 6 < 3) ? (x[q][j] < m[j] ? x[q][j] : m[j]) : (x[q][j] > m[j] ? x[q][j] : m[j]);
+        clean_acc<T>(&ar[0]);
+        clean_acc<T>(&ar[2]);
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      t.bmin[k] = Ord<T>::dec(acc.v[k]);
-      t.bmax[k] = Ord<T>::dec(acc.v[3 + k]);
-      t.cmin[k] = Ord<T>::dec(acc.v[6 + k]);
-      t.cmax[k] = Ord<T>::dec(acc.v[9 + k]);
+      t.bmin[k] = Ord<T>::dec(m[k]);
+      t.bmax[k] = Ord<T>::dec(m[3 + k]);
+      t.cmin[k] = Ord<T>::dec(m[6 + k]);
+      t.cmax[k] = Ord<T>::dec(m[9 + k]);
     }
     clean_acc<T>(&acc);
     if (a + num_active < max_active) clean_acc<T>(&child_acc[2 * (a + num_active) + c]);
@@ -1184,7 +1226,7 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
     }
     return;
   }
-  GBins<T> *g = &gbins[a];
+  GBins<T> *g = rep_node(num_active, nd.nchunks) ? &gbins[max_active + a * kRep + ((chunk - chunk_base[a]) & (kRep - 1u))] : &gbins[a];
   for (int i = threadIdx.x; i < 3 * kMaxBins; i += 256) {
     const int k = i / kMaxBins, b = i % kMaxBins;
     const uint32_t c = s_cnt[k][b][0];
@@ -1234,6 +1276,46 @@ __global__ __launch_bounds__(64) void k_split(TopNode<T> *top, const uint32_t *_
         mx3[k][d] = g.bmax[k][lane][d];
       }
     }
+  }
+  if (rep_node(num_active, nch)) { // a top level: the node's chunks added into kRep copies (the regular slot stayed clean)
+    // (axis by axis: the kRep copies of an axis are requested together, folded, and cleaned only then — a store would pin the
+    // loads behind it)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      uint32_t rc[kRep];
+      U rmn[kRep][3], rmx[kRep][3];
+#pragma unroll
+      for (uint32_t r = 0; r < kRep; r++) {
+        const GBins<T> &gr = gbins[max_active + a * kRep + r];
+        rc[r] = 0;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          rmn[r][d] = Ord<T>::highest();
+          rmx[r][d] = Ord<T>::lowest();
+        }
+        if ((int)lane < K) {
+          rc[r] = gr.count[k][lane];
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            rmn[r][d] = gr.bmin[k][lane][d];
+            rmx[r][d] = gr.bmax[k][lane][d];
+          }
+        }
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < kRep; r++) {
+        cnt3[k] += rc[r];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          mn3[k][d] = rmn[r][d] < mn3[k][d] ? rmn[r][d] : mn3[k][d];
+          mx3[k][d] = rmx[r][d] > mx3[k][d] ? rmx[r][d] : mx3[k][d];
+        }
+      }
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < kRep; r++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) clean_bins<T>(&gbins[max_active + a * kRep + r], k, lane);
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -1293,7 +1375,7 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
                                                    const uint32_t *__restrict__ chunk_base, const LevelInfo *info,
                                                    const uint32_t *__restrict__ chunk_left_base,
                                                    const PrimRec<T> *__restrict__ src, PrimRec<T> *__restrict__ dst,
-                                                   int kpack, BoundsAcc<T> *child_acc) {
+                                                   int kpack, BoundsAcc<T> *child_acc, uint32_t max_active) {
   typedef typename Ord<T>::U U;
   __shared__ uint32_t s_task;
   __shared__ uint32_t s_w[2][4];
@@ -1417,10 +1499,13 @@ __global__ __launch_bounds__(256) void k_partition(const TopNode<T> *__restrict_
   __syncthreads();
   if (tid < 24) {
     const int s = tid / 12, j = tid % 12;
+    BoundsAcc<T> *acc = rep_node(num_active, nd.nchunks)
+                            ? &child_acc[2u * max_active + 2u * (a * kRep + ((chunk - chunk_base[a]) & (kRep - 1u))) + s]
+                            : &child_acc[2 * a + s];
     if (j % 6 < 3)
-      atomicMin(&child_acc[2 * a + s].v[j], s_acc[s][j]);
+      atomicMin(&acc->v[j], s_acc[s][j]);
     else
-      atomicMax(&child_acc[2 * a + s].v[j], s_acc[s][j]);
+      atomicMax(&acc->v[j], s_acc[s][j]);
   }
 }
 
@@ -2638,10 +2723,10 @@ struct BuildPlan { // carve-up of the build workspace for n primitives
     off_scratch = take(2 * (size_t)n * sizeof(Node));
     off_premap = take(2 * (size_t)n * sizeof(uint16_t));
     off_top = take(max_top * sizeof(TopNode<T>));
-    off_child_acc = take(2 * max_active * sizeof(BoundsAcc<T>));
+    off_child_acc = take(2 * (max_active + kRepNodes * kRep) * sizeof(BoundsAcc<T>)); // (+ the top levels' copies)
     off_active = take(max_active * sizeof(uint32_t));
     off_chunk_base = take(max_active * sizeof(uint32_t));
-    off_gbins = take(max_active * sizeof(GBins<T>));
+    off_gbins = take((max_active + kRepNodes * kRep) * sizeof(GBins<T>));
     off_chunk_hist = take(max_chunks * 3 * kMaxBins * sizeof(uint32_t));
     off_chunk_left = take(max_chunks * sizeof(uint32_t));
     off_small = take((max_top + 1) * sizeof(uint32_t));
@@ -2780,7 +2865,8 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     LevelInfo *info = (LevelInfo *)(base + plan.off_info);
     uint32_t *indices = (uint32_t *)indices_buf->p;
 
-    hipLaunchKernelGGL((k_init_scene<T>), dim3(1), dim3(64), 0, s, scene, info, (uint32_t)plan.max_top, gbins, child_acc);
+    hipLaunchKernelGGL((k_init_scene<T>), dim3(1 + kRepNodes * kRep), dim3(64), 0, s, scene, info, (uint32_t)plan.max_top, gbins, child_acc,
+                       (uint32_t)plan.max_active);
     {
       unsigned grid = (unsigned)std::min<size_t>(((size_t)n + 255) / 256, 2048);
       hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, d_radii, cylinders, n, d_prim_map, recs[0], scene);
@@ -2839,7 +2925,7 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
       hipLaunchKernelGGL((k_split<T>), dim3((unsigned)a_max), dim3(64), 0, s, top, active, gbins, K | (Ks << 8), chunk_hist,
                          chunk_left, info, (uint32_t)plan.max_active);
       hipLaunchKernelGGL((k_partition<T>), dim3((unsigned)c_max), dim3(256), 0, s, top, active, chunk_base, info,
-                         chunk_left, recs[cur], recs[1 - cur], K | (Ks << 8), child_acc);
+                         chunk_left, recs[cur], recs[1 - cur], K | (Ks << 8), child_acc, (uint32_t)plan.max_active);
       BCHK(hipGetLastError());
       cur = 1 - cur;
       if (check) {
