@@ -2503,9 +2503,28 @@ __global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, LevelInfo *inf
   __shared__ uint32_t s_nupper;
   const uint32_t total = info->top_count;
   uint32_t *s_size = s_dyn, *s_par = s_dyn + kLayoutLds;
+  uint32_t leaves = 0, branches = 0, deepest = 0, biggest = 0; // statistics of the top part + what the subtree tasks left (task_stats)
+  auto count_node = [&](uint32_t kind, uint32_t depth, uint32_t prims, uint32_t size, uint32_t nleft, uint32_t split_bin, uint32_t nchunks) {
+    if (kind == KIND_SPLIT) branches++;
+    if (kind == KIND_LEAF) {
+      leaves++;
+      deepest = depth > deepest ? depth : deepest;
+      biggest = prims > biggest ? prims : biggest;
+    }
+    if (kind == KIND_SMALL) {
+      leaves += nleft;
+      branches += size - nleft;
+      deepest = split_bin > deepest ? split_bin : deepest;
+      biggest = nchunks > biggest ? nchunks : biggest;
+    }
+  };
   if (total <= kLayoutLds) {
+    // ONE CU reads every top record here, and a scattered 4-byte load costs its L1 the address work of a whole line: the
+    // records' integer words are fetched as 8-byte pairs, once, and the statistics are taken in the same pass (a second sweep
+    // over the records was half of this kernel's time)
     uint32_t own[kLayoutOwn], dep[kLayoutOwn]; // contribution and depth of node threadIdx.x + 1024 j
-    uint32_t kid[kLayoutOwn];                  // its first child if it is a branch above the cut (else kNoParent): read once, here
+    uint32_t kid[kLayoutOwn];                  // its first child if it is a branch (else kNoParent)
+    uint32_t small_mask = 0;                   // bit j: node j of this thread is a subtree task (its size is final)
 #pragma unroll
     for (uint32_t j = 0; j < kLayoutOwn; j++) {
       const uint32_t i = threadIdx.x + 1024u * j;
@@ -2513,11 +2532,17 @@ __global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, LevelInfo *inf
       dep[j] = 0xFFFFFFFFu;
       kid[j] = kNoParent;
       if (i < total) {
-        own[j] = layout_contribution<T>(top[i]);
-        dep[j] = top[i].depth;
+        static_assert(offsetof(TopNode<T>, l) % 8 == 0 && sizeof(TopNode<T>) % 8 == 0 && offsetof(TopNode<T>, parent) == offsetof(TopNode<T>, l) + 52, "TopNode: 14 words from l");
+        const uint2 *w = reinterpret_cast<const uint2 *>(&top[i].l);
+        const uint2 lr = w[0], dk = w[1], as = w[2], nc = w[3], sd = w[4], np = w[6]; // (l, r) (depth, kind) (axis, split_bin) (nleft, child0) (size, dfs) (nchunks, parent)
+        const uint32_t kind = dk.y;
+        own[j] = kind == KIND_SMALL ? sd.x : 1u;
+        dep[j] = dk.x;
         s_size[i] = own[j];
-        s_par[i] = top[i].parent;
-        if (top[i].kind == KIND_SPLIT) kid[j] = top[i].child0;
+        s_par[i] = np.y;
+        if (kind == KIND_SPLIT) kid[j] = nc.y;
+        if (kind == KIND_SMALL) small_mask |= 1u << j;
+        count_node(kind, dk.x, lr.y - lr.x, sd.x, nc.x, as.y, np.x);
       }
     }
     __syncthreads();
@@ -2548,8 +2573,8 @@ __global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, LevelInfo *inf
         uint32_t dfs = 0;
         for (uint32_t x = i, pw = s_par[i]; (pw & ~kHighChild) != kNoParent; x = pw & ~kHighChild, pw = s_par[x])
           dfs += 1u + ((pw & kHighChild) ? s_size[x - 1u] : 0u); // (children are allocated in pairs: the low side is x - 1)
-        top[i].dfs = dfs;
-        if (top[i].kind != KIND_SMALL) top[i].size = s_size[i];
+        // (size, dfs) are neighbours: one 8-byte store (a subtree task's size is final: written back as it was read)
+        reinterpret_cast<uint2 *>(&top[i].l)[4] = make_uint2(((small_mask >> j) & 1u) ? own[j] : s_size[i], dfs);
       }
     }
     if (threadIdx.x == 0) info->num_nodes = s_size[0];
@@ -2568,22 +2593,9 @@ __global__ __launch_bounds__(1024) void k_layout(TopNode<T> *top, LevelInfo *inf
       __syncthreads();
     }
     if (threadIdx.x == 0) info->num_nodes = top[0].size;
-  }
-  // stats of the top part
-  uint32_t leaves = 0, branches = 0, deepest = 0, biggest = 0;
-  for (uint32_t i = threadIdx.x; i < total; i += 1024u) {
-    const TopNode<T> &t = top[i];
-    if (t.kind == KIND_SPLIT) branches++;
-    if (t.kind == KIND_LEAF) {
-      leaves++;
-      deepest = t.depth > deepest ? t.depth : deepest;
-      biggest = t.r - t.l > biggest ? t.r - t.l : biggest;
-    }
-    if (t.kind == KIND_SMALL) { // what its subtree task left there (task_stats)
-      leaves += t.nleft;
-      branches += t.size - t.nleft;
-      deepest = t.split_bin > deepest ? t.split_bin : deepest;
-      biggest = t.nchunks > biggest ? t.nchunks : biggest;
+    for (uint32_t i = threadIdx.x; i < total; i += 1024u) { // (this path's statistics: a sweep of their own)
+      const TopNode<T> &t = top[i];
+      count_node(t.kind, t.depth, t.r - t.l, t.size, t.nleft, t.split_bin, t.nchunks);
     }
   }
   // (one atomic per wave and counter: a thousand device-scope atomics on one word are ~10 us of a one-block kernel)
