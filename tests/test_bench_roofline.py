@@ -1,14 +1,24 @@
 """bench.py's roofline arithmetic on the CPU: counter means in, fractions of the stated peaks out (no GPU, no profiler)."""
-import importlib.util
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
 def load_bench():
-    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
-    m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
+    """the counter arithmetic lives in benchlib/ (bench.py re-exports what tools/ use)"""
+    import types
+
+    import benchlib
+    from benchlib import counters
+
+    m = types.SimpleNamespace()
+    for mod in (benchlib, counters):
+        for k, v in vars(mod).items():
+            if not k.startswith("_"):
+                setattr(m, k, v)
     return m
 
 
