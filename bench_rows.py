@@ -194,6 +194,11 @@ def wf_gpu_cmd():
             os.path.join(ROOT, "examples", "wavefront_path_tracer_gpu", "main.hip"), "-L", LIBDIR, "-lnanort_hip", "-Wl,-rpath," + LIBDIR]
 
 
+def build_host_cmd():
+    return ["g++", "-std=c++11", "-O2", "-I", INC, os.path.join(ROOT, "tools", "build_host.cc"), "-L", LIBDIR, "-lnanort_hip", "-lnrt_scenes",
+            "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+
+
 def embree_row():
     """rtcIntersect1M over 96-byte host RTCRay records (2 M triangles in 5 meshes, 1920x1080): the stream query of the Embree-2
     API.  Parity sample: the same scene through nrtScene* directly (identity transforms) on a strided sample of the rays."""

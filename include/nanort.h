@@ -18,8 +18,10 @@
 //   * NANORT_USE_HIP_BACKEND — when Build() is called with the built-in
 //     TriangleMesh<T> + TriangleSAHPred<T>, construction runs on the GPU through
 //     the C ABI of libnanort_hip.so (include/nanort_hip.h): the node array and
-//     index permutation are copied back into nodes_/indices_, so GetNodes(),
-//     Dump(), BoundingBox() and the per-ray Traverse() keep working.  The one
+//     index permutation stay on the device and are copied into nodes_/indices_
+//     by the first host access, so GetNodes(), Dump(), BoundingBox() and the
+//     per-ray Traverse() keep working while an application that only calls
+//     TraverseBatch() never pays the read-back.  The one
 //     API addition, TraverseBatch(), intersects N rays in one GPU launch; it
 //     does not exist without the backend (there is no CPU stand-in for it).
 //     Link with -lnanort_hip.
@@ -46,6 +48,8 @@
 #include <vector>
 
 #ifdef NANORT_USE_HIP_BACKEND
+#include <mutex>
+
 #include "nanort_hip.h"
 #endif
 #ifdef _OPENMP
@@ -960,6 +964,7 @@ struct HipApi<float> {
   static nrt_status SetMesh(nrt_ctx *c, const float *v, size_t s, const unsigned int *f, unsigned int n) { return nrtSetMesh_f32(c, v, s, f, n); }
   static nrt_status Build(nrt_ctx *c, const BuildPod *o, nrt_build_stats *st, uint64_t *nn) { return nrtBuild_f32(c, o, st, nn); }
   static nrt_status GetTree(nrt_ctx *c, NodePod *n, uint32_t *i) { return nrtGetTree_f32(c, n, i); }
+  static nrt_status TreeBounds(nrt_ctx *c, float *lo, float *hi) { return nrtGetTreeBounds_f32(c, lo, hi); }
   static nrt_status SetTree(nrt_ctx *c, const NodePod *n, uint64_t nn, const uint32_t *i, uint64_t ni) { return nrtSetTree_f32(c, n, nn, i, ni); }
   static nrt_status Traverse(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, HitPod *h, uint8_t *m) {
     return nrtTraverseBatch_f32(c, r, n, o, h, m);
@@ -992,6 +997,7 @@ struct HipApi<double> {
   static nrt_status SetMesh(nrt_ctx *c, const double *v, size_t s, const unsigned int *f, unsigned int n) { return nrtSetMesh_f64(c, v, s, f, n); }
   static nrt_status Build(nrt_ctx *c, const BuildPod *o, nrt_build_stats *st, uint64_t *nn) { return nrtBuild_f64(c, o, st, nn); }
   static nrt_status GetTree(nrt_ctx *c, NodePod *n, uint32_t *i) { return nrtGetTree_f64(c, n, i); }
+  static nrt_status TreeBounds(nrt_ctx *c, double *lo, double *hi) { return nrtGetTreeBounds_f64(c, lo, hi); }
   static nrt_status SetTree(nrt_ctx *c, const NodePod *n, uint64_t nn, const uint32_t *i, uint64_t ni) { return nrtSetTree_f64(c, n, nn, i, ni); }
   static nrt_status Traverse(nrt_ctx *c, const RayPod *r, uint64_t n, const nrt_trace_options *o, HitPod *h, uint8_t *m) {
     return nrtTraverseBatch_f64(c, r, n, o, h, m);
@@ -1018,6 +1024,11 @@ struct HipApi<double> {
 struct CtxDeleter {
   void operator()(nrt_ctx *c) const { nrtDestroy(c); }
 };
+// serialises the on-demand read-back of GPU-built trees (BVHAccel::EnsureHostTree); one per process is plenty
+inline std::mutex &HostTreeMutex() {
+  static std::mutex m;
+  return m;
+}
 #endif
 }  // namespace detail
 
@@ -1026,6 +1037,17 @@ class BVHAccel {
  public:
   BVHAccel() : pad0_(0) { (void)pad0_; }
   ~BVHAccel() {}
+#ifdef NANORT_USE_HIP_BACKEND
+  // A GPU Build() leaves the tree on the device: nodes_ / indices_ are fetched by the first host access (GetNodes(),
+  // GetIndices(), Traverse(), ListNodeIntersections(), Dump(), Debug()).  A copy shares the device context (shared_ptr), so
+  // it takes the host arrays with it: copying materialises them first — the copy then never depends on what the original's
+  // context holds later.
+  BVHAccel(const BVHAccel &o) : pad0_(0) { CopyFrom(o); }
+  BVHAccel &operator=(const BVHAccel &o) {
+    if (this != &o) CopyFrom(o);
+    return *this;
+  }
+#endif
 
   // Build a BVH over `num_primitives` primitives (ref nanort.h:716-718).
   // Returns false iff num_primitives == 0.
@@ -1046,6 +1068,7 @@ class BVHAccel {
     return ok;
   }
   bool Dump(FILE *fp) const {
+    EnsureHostTree();
     const size_t nn = nodes_.size(), ni = indices_.size();
     if (nn == 0) return false;
     bool ok = fwrite(&nn, sizeof(size_t), 1, fp) == 1;
@@ -1062,6 +1085,9 @@ class BVHAccel {
     return ok;
   }
   bool Load(FILE *fp) {
+#ifdef NANORT_USE_HIP_BACKEND
+    DropPendingHostTree();
+#endif
     size_t nn = 0, ni = 0;
     if (fread(&nn, sizeof(size_t), 1, fp) != 1 || nn == 0) return false;
     nodes_.resize(nn);
@@ -1077,6 +1103,7 @@ class BVHAccel {
 #endif
 
   void Debug() {
+    EnsureHostTree();
     for (size_t i = 0; i < indices_.size(); i++) printf("index[%d] = %d\n", int(i), int(indices_[i]));
     for (size_t i = 0; i < nodes_.size(); i++) {
       printf("node[%d] : bmin %f, %f, %f, bmax %f, %f, %f\n", int(i), double(nodes_[i].bmin[0]), double(nodes_[i].bmin[1]),
@@ -1087,6 +1114,7 @@ class BVHAccel {
   // Closest hit along one ray (ref nanort.h:757-759, 2487-2556).
   template <class I, class H>
   bool Traverse(const Ray<T> &ray, const I &intersector, H *isect, const BVHTraceOptions &options = BVHTraceOptions()) const {
+    EnsureHostTree();
     unsigned int todo[kNANORT_MAX_STACK_DEPTH];
     int top = 0;
     todo[0] = 0;
@@ -1139,6 +1167,7 @@ class BVHAccel {
   template <class I>
   bool ListNodeIntersections(const Ray<T> &ray, int max_intersections, const I &intersector,
                              StackVector<NodeHit<T>, 128> *hits) const {
+    EnsureHostTree();
     std::priority_queue<NodeHit<T>, std::vector<NodeHit<T> >, NodeHitComparator<T> > farthest_first;
     (*hits)->clear();
     unsigned int todo[kNANORT_MAX_STACK_DEPTH];
@@ -1460,17 +1489,56 @@ class BVHAccel {
  public:
 #endif
 
-  const std::vector<BVHNode<T> > &GetNodes() const { return nodes_; }
-  const std::vector<unsigned int> &GetIndices() const { return indices_; }
+  const std::vector<BVHNode<T> > &GetNodes() const {
+    EnsureHostTree();
+    return nodes_;
+  }
+  const std::vector<unsigned int> &GetIndices() const {
+    EnsureHostTree();
+    return indices_;
+  }
 
   void BoundingBox(T bmin[3], T bmax[3]) const {
+#ifdef NANORT_USE_HIP_BACKEND
+    if (HostTreePending()) {  // (the root's box came back with the build: no need for the whole array)
+      for (int k = 0; k < 3; k++) {
+        bmin[k] = root_bmin_[k];
+        bmax[k] = root_bmax_[k];
+      }
+      return;
+    }
+#endif
     for (int k = 0; k < 3; k++) {
       bmin[k] = nodes_.empty() ? std::numeric_limits<T>::max() : nodes_[0].bmin[k];
       bmax[k] = nodes_.empty() ? -std::numeric_limits<T>::max() : nodes_[0].bmax[k];
     }
   }
 
-  bool IsValid() const { return nodes_.size() > 0; }
+  bool IsValid() const { return HostTreePending() || nodes_.size() > 0; }
+
+#ifdef NANORT_USE_HIP_BACKEND
+  // The host copy of a GPU-built tree, on demand (thread-safe: Traverse() is const and may be called from many threads).
+  void EnsureHostTree() const {
+    if (!__atomic_load_n(&host_tree_pending_, __ATOMIC_ACQUIRE)) return;
+    std::lock_guard<std::mutex> lock(detail::HostTreeMutex());
+    if (!host_tree_pending_) return;
+    typedef detail::HipApi<T> Api;
+    nodes_.resize(static_cast<size_t>(pending_nodes_));
+    indices_.resize(static_cast<size_t>(pending_indices_));
+    if (!ctx_ || Api::GetTree(ctx_.get(), reinterpret_cast<typename Api::NodePod *>(&nodes_[0]), indices_.empty() ? NULL : &indices_[0]) != NRT_OK) {
+      backend_error_ = ctx_ ? nrtLastError(ctx_.get()) : "host tree requested without a GPU context";
+      fprintf(stderr, "[nanort] reading the tree back from the GPU failed: %s\n", backend_error_.c_str());
+      nodes_.clear();
+      indices_.clear();
+    }
+    __atomic_store_n(&host_tree_pending_, false, __ATOMIC_RELEASE);
+  }
+  bool HostTreePending() const { return __atomic_load_n(&host_tree_pending_, __ATOMIC_ACQUIRE); }
+  // Set NANORT_HIP_EAGER_READBACK=1 (environment) to make Build() fetch the arrays itself, as rounds 1-5 did.
+#else
+  void EnsureHostTree() const {}
+  bool HostTreePending() const { return false; }
+#endif
 
  private:
   // ---- generic host builder: binned SAH over all three axes, iterative, pre-order ----
@@ -1708,6 +1776,9 @@ class BVHAccel {
   bool BuildImpl(unsigned int n, const Prim &prim, const Pred &pred, const BVHBuildOptions<T> &options, detail::generic_tag) {
     options_ = options;
     stats_ = BVHBuildStatistics();
+#ifdef NANORT_USE_HIP_BACKEND
+    DropPendingHostTree();
+#endif
     nodes_.clear();
     indices_.clear();
     assert(options_.bin_size > 1);
@@ -1815,6 +1886,7 @@ class BVHAccel {
     static_assert(sizeof(BVHBuildStatistics) == sizeof(nrt_build_stats), "BVHBuildStatistics layout");
     options_ = options;
     stats_ = BVHBuildStatistics();
+    DropPendingHostTree();
     nodes_.clear();
     indices_.clear();
     assert(options_.bin_size > 1);
@@ -1869,13 +1941,19 @@ class BVHAccel {
     // its builder, which are named once per segment — the reference's Traverse takes such a tree as it is)
     uint64_t tree_nodes = num_nodes, tree_indices = n;
     if (nrtTreeSize(c, &tree_nodes, &tree_indices) != NRT_OK) tree_indices = n;
-    nodes_.resize(static_cast<size_t>(num_nodes));
-    indices_.resize(static_cast<size_t>(tree_indices));
-    if (Api::GetTree(c, reinterpret_cast<typename Api::NodePod *>(&nodes_[0]), &indices_[0]) != NRT_OK) {
+    // The arrays stay on the device until the host asks for them (EnsureHostTree): an application that only calls
+    // TraverseBatch() never pays the 27 MB read-back of a 1 M-triangle tree.  The root's box comes back now (24 / 48 bytes).
+    pending_nodes_ = num_nodes;
+    pending_indices_ = tree_indices;
+    if (Api::TreeBounds(c, root_bmin_, root_bmax_) != NRT_OK) {
       backend_error_ = nrtLastError(c);
-      nodes_.clear();
-      indices_.clear();
       return false;
+    }
+    __atomic_store_n(&host_tree_pending_, true, __ATOMIC_RELEASE);
+    static const bool eager = std::getenv("NANORT_HIP_EAGER_READBACK") != NULL && std::atoi(std::getenv("NANORT_HIP_EAGER_READBACK")) != 0;
+    if (eager) {
+      EnsureHostTree();
+      if (nodes_.empty()) return false;
     }
     stats_.max_tree_depth = st.max_tree_depth;
     stats_.num_leaf_nodes = st.num_leaf_nodes;
@@ -1898,12 +1976,45 @@ class BVHAccel {
   }
 #endif
 
+#ifdef NANORT_USE_HIP_BACKEND
+  mutable std::vector<BVHNode<T> > nodes_;  // (mutable: filled by EnsureHostTree() on the first host access after a GPU build)
+  mutable std::vector<unsigned int> indices_;
+#else
   std::vector<BVHNode<T> > nodes_;
   std::vector<unsigned int> indices_;
+#endif
   BVHBuildOptions<T> options_;
   BVHBuildStatistics stats_;
   unsigned int pad0_;
 #ifdef NANORT_USE_HIP_BACKEND
+  void DropPendingHostTree() { __atomic_store_n(&host_tree_pending_, false, __ATOMIC_RELEASE); }
+  void CopyFrom(const BVHAccel &o) {
+    o.EnsureHostTree();
+    nodes_ = o.nodes_;
+    indices_ = o.indices_;
+    options_ = o.options_;
+    stats_ = o.stats_;
+    ctx_ = o.ctx_;
+    peers_ = o.peers_;
+    batch_row_len_ = o.batch_row_len_;
+    device_tree_stale_ = o.device_tree_stale_;
+    device_prim_kind_ = o.device_prim_kind_;
+    cyl_endpoints_ = o.cyl_endpoints_;
+    cyl_radii_ = o.cyl_radii_;
+    cyl_count_ = o.cyl_count_;
+    cyl_test_cap_ = o.cyl_test_cap_;
+    host_tree_pending_ = false;
+    pending_nodes_ = pending_indices_ = 0;
+    for (int k = 0; k < 3; k++) {
+      root_bmin_[k] = o.root_bmin_[k];
+      root_bmax_[k] = o.root_bmax_[k];
+    }
+    backend_error_ = o.backend_error_;
+    // (the staging buffers stay with their owner: they are scratch, grown on the first TraverseBatch())
+  }
+  mutable bool host_tree_pending_ = false;  // the tree of the last GPU Build() has not been copied to nodes_ / indices_ yet
+  uint64_t pending_nodes_ = 0, pending_indices_ = 0;
+  T root_bmin_[3] = {T(0), T(0), T(0)}, root_bmax_[3] = {T(0), T(0), T(0)};
   std::shared_ptr<nrt_ctx> ctx_;
   std::vector<std::shared_ptr<nrt_ctx> > peers_;  // replicas on the other devices of NANORT_HIP_DEVICES
   size_t batch_row_len_ = 0;                      // rays per interleaved row of a multi-device TraverseBatch (0: 4096)

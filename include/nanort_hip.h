@@ -280,6 +280,10 @@ NRT_API nrt_status nrtBuild_f64(nrt_ctx *ctx, const nrt_build_options_f64 *optio
 NRT_API nrt_status nrtGetTree_f32(nrt_ctx *ctx, nrt_node_f32 *nodes_out, uint32_t *indices_out);
 NRT_API nrt_status nrtGetTree_f64(nrt_ctx *ctx, nrt_node_f64 *nodes_out, uint32_t *indices_out);
 NRT_API nrt_status nrtTreeSize(nrt_ctx *ctx, uint64_t *num_nodes_out, uint64_t *num_indices_out);
+/* The root node's box alone (24 / 48 bytes instead of the whole array): what BVHAccel::BoundingBox returns (nanort.h:786-799)
+ * while the header leaves the tree on the device until the host asks for it (include/nanort.h: EnsureHostTree). */
+NRT_API nrt_status nrtGetTreeBounds_f32(nrt_ctx *ctx, float bmin_out[3], float bmax_out[3]);
+NRT_API nrt_status nrtGetTreeBounds_f64(nrt_ctx *ctx, double bmin_out[3], double bmax_out[3]);
 
 /* Adopt a tree built elsewhere: BVHAccel<T>::Load (nanort.h:2219-2275) or a
  * CPU Build().  Validates child / slot bounds and measures the depth. */

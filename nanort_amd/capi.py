@@ -20,7 +20,7 @@ SYMBOLS = [
     "nrtSetMesh_f32", "nrtSetMesh_f64", "nrtSetSpheres_f32",
     "nrtSetCylinders_f32", "nrtTraverseBatchCylinders_f32", "nrtTraverseBatchCylindersDevice_f32",
     "nrtBuild_f32", "nrtBuild_f64",
-    "nrtGetTree_f32", "nrtGetTree_f64", "nrtTreeSize",
+    "nrtGetTree_f32", "nrtGetTree_f64", "nrtTreeSize", "nrtGetTreeBounds_f32", "nrtGetTreeBounds_f64",
     "nrtSetTree_f32", "nrtSetTree_f64",
     "nrtTraverseBatch_f32", "nrtTraverseBatch_f64",
     "nrtTraverseBatchDevice_f32", "nrtTraverseBatchDevice_f64", "nrtTraverseBatchesDevice_f32", "nrtTraverseBatchesDevice_f64", "nrtTraverseBatches_f32", "nrtTraverseBatches_f64",

@@ -719,6 +719,22 @@ static nrt_status get_tree(nrt_ctx *c, typename Wire<T>::Node *nodes_out, uint32
   return NRT_OK;
 }
 
+template <typename T>
+static nrt_status get_tree_bounds(nrt_ctx *c, T *bmin, T *bmax) {
+  if (!c || !bmin || !bmax) return NRT_ERR_INVALID;
+  if (c->prec != (int)sizeof(T)) return fail(c, NRT_ERR_PRECISION, "nrtGetTreeBounds: precision mismatch");
+  if (!c->d_nodes) return fail(c, NRT_ERR_INVALID, "nrtGetTreeBounds: no tree");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  T box[6]; // BVHNode<T> starts with bmin[3], bmax[3] (nanort.h:498-550)
+  HIPCHK(c, hipMemcpy(box, c->d_nodes, sizeof(box), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 3; k++) {
+    bmin[k] = box[k];
+    bmax[k] = box[3 + k];
+  }
+  return NRT_OK;
+}
+
 // ---------------------------------------------------------------------------
 // build
 // ---------------------------------------------------------------------------
@@ -1443,6 +1459,9 @@ nrt_status nrtBuild_f64(nrt_ctx *c, const nrt_build_options_f64 *o, nrt_build_st
 
 nrt_status nrtGetTree_f32(nrt_ctx *c, nrt_node_f32 *n, uint32_t *i) { return get_tree<float>(c, n, i); }
 nrt_status nrtGetTree_f64(nrt_ctx *c, nrt_node_f64 *n, uint32_t *i) { return get_tree<double>(c, n, i); }
+
+nrt_status nrtGetTreeBounds_f32(nrt_ctx *c, float *lo, float *hi) { return get_tree_bounds<float>(c, lo, hi); }
+nrt_status nrtGetTreeBounds_f64(nrt_ctx *c, double *lo, double *hi) { return get_tree_bounds<double>(c, lo, hi); }
 
 nrt_status nrtTreeSize(nrt_ctx *c, uint64_t *nn, uint64_t *ni) {
   if (!c) return NRT_ERR_INVALID;

@@ -324,7 +324,95 @@ static int cylinders(const char *scene_path, int W, int H, const char *out_path)
   return 0;
 }
 
+#ifdef NANORT_USE_HIP_BACKEND
+#include <thread>
+// The host copy of a GPU-built tree is fetched on demand (include/nanort.h: EnsureHostTree): Build() + TraverseBatch() never
+// read it back; the first GetNodes() / Traverse() does, also when eight threads make that first call at once; BoundingBox()
+// and IsValid() answer without it; a copy of the accel carries its own arrays.
+template <typename T>
+static int lazy(const char *mesh_path, const char *rays_path) {
+  FILE *fp = fopen(mesh_path, "rb");
+  if (!fp) return 2;
+  uint32_t nv = 0, nf = 0;
+  if (fread(&nv, 4, 1, fp) != 1 || fread(&nf, 4, 1, fp) != 1) return 2;
+  std::vector<T> verts(3 * (size_t)nv);
+  std::vector<unsigned int> faces(3 * (size_t)nf);
+  if (fread(verts.data(), sizeof(T), verts.size(), fp) != verts.size()) return 2;
+  if (fread(faces.data(), 4, faces.size(), fp) != faces.size()) return 2;
+  fclose(fp);
+  fp = fopen(rays_path, "rb");
+  if (!fp) return 2;
+  uint64_t n = 0;
+  if (fread(&n, 8, 1, fp) != 1) return 2;
+  std::vector<nanort::Ray<T> > rays(n);
+  if (fread(rays.data(), sizeof(nanort::Ray<T>), n, fp) != n) return 2;
+  fclose(fp);
+
+  nanort::TriangleMesh<T> mesh(verts.data(), faces.data(), sizeof(T) * 3);
+  nanort::TriangleSAHPred<T> pred(verts.data(), faces.data(), sizeof(T) * 3);
+  nanort::BVHAccel<T> accel;
+  if (!accel.Build(nf, mesh, pred)) return 3;
+  printf("pending_after_build %d valid %d\n", accel.HostTreePending() ? 1 : 0, accel.IsValid() ? 1 : 0);
+  T lo[3], hi[3];
+  accel.BoundingBox(lo, hi);
+  printf("pending_after_bounds %d\n", accel.HostTreePending() ? 1 : 0);
+  std::vector<nanort::TriangleIntersection<T> > bh(n);
+  std::vector<unsigned char> bm(n, 0);
+  for (uint64_t i = 0; i < n; i++) {
+    memset(&bh[i], 0, sizeof(bh[i]));
+    bh[i].t = rays[i].max_t;
+    bh[i].prim_id = 0xFFFFFFFFu;
+  }
+  if (!accel.TraverseBatch(rays.data(), n, bh.data(), bm.data())) return 4;
+  printf("pending_after_batch %d\n", accel.HostTreePending() ? 1 : 0);
+  // eight threads make the first per-ray call at the same time
+  std::vector<nanort::TriangleIntersection<T> > hits(n);
+  std::vector<unsigned char> mask(n, 0);
+  std::vector<std::thread> pool;
+  for (int w = 0; w < 8; w++)
+    pool.push_back(std::thread([&, w]() {
+      nanort::TriangleIntersector<T> isector(verts.data(), faces.data(), sizeof(T) * 3);
+      for (uint64_t i = w; i < n; i += 8) {
+        memset(&hits[i], 0, sizeof(hits[i]));
+        hits[i].t = rays[i].max_t;
+        hits[i].prim_id = 0xFFFFFFFFu;
+        mask[i] = accel.Traverse(rays[i], isector, &hits[i]) ? 1 : 0;
+      }
+    }));
+  for (size_t w = 0; w < pool.size(); w++) pool[w].join();
+  uint64_t bad = 0;
+  for (uint64_t i = 0; i < n; i++)
+    if (bm[i] != mask[i] || memcmp(&bh[i], &hits[i], sizeof(hits[i])) != 0) bad++;
+  printf("pending_after_traverse %d threads_vs_batch_mismatches %llu\n", accel.HostTreePending() ? 1 : 0, (unsigned long long)bad);
+  const std::vector<nanort::BVHNode<T> > &nodes = accel.GetNodes();
+  int box_ok = !nodes.empty();
+  for (int k = 0; k < 3 && box_ok; k++) box_ok = nodes[0].bmin[k] == lo[k] && nodes[0].bmax[k] == hi[k];
+  printf("bounds_match_root %d nodes %zu indices %zu\n", box_ok, nodes.size(), accel.GetIndices().size());
+  // a rebuild leaves the tree on the device again; a copy taken now carries the arrays, and so does the original afterwards
+  if (!accel.Build(nf, mesh, pred)) return 3;
+  const int pend = accel.HostTreePending() ? 1 : 0;
+  nanort::BVHAccel<T> copy(accel);
+  nanort::BVHAccel<T> assigned;
+  assigned = accel;
+  printf("pending_after_rebuild %d copy_pending %d copy_nodes %zu assigned_nodes %zu same_bytes %d\n", pend, copy.HostTreePending() ? 1 : 0,
+         copy.GetNodes().size(), assigned.GetNodes().size(),
+         copy.GetNodes().size() == nodes.size() && memcmp(copy.GetNodes().data(), accel.GetNodes().data(), nodes.size() * sizeof(nanort::BVHNode<T>)) == 0 ? 1 : 0);
+  // the copy traces through the shared device context as before
+  std::vector<nanort::TriangleIntersection<T> > ch(bh);
+  std::vector<unsigned char> cm(n, 0);
+  if (!copy.TraverseBatch(rays.data(), n, ch.data(), cm.data())) return 4;
+  bad = 0;
+  for (uint64_t i = 0; i < n; i++)
+    if (bm[i] != cm[i] || (cm[i] && memcmp(&bh[i], &ch[i], sizeof(ch[i])) != 0)) bad++;
+  printf("copy_batch_mismatches %llu\n", (unsigned long long)bad);
+  return 0;
+}
+#endif
+
 int main(int argc, char **argv) {
+#ifdef NANORT_USE_HIP_BACKEND
+  if (argc == 5 && !strcmp(argv[1], "lazy")) return !strcmp(argv[2], "f64") ? lazy<double>(argv[3], argv[4]) : lazy<float>(argv[3], argv[4]);
+#endif
   if (argc >= 2 && !strcmp(argv[1], "regress30")) return regress30(argc > 2);
   if (argc == 6 && !strcmp(argv[1], "cylinders")) return cylinders(argv[2], atoi(argv[3]), atoi(argv[4]), argv[5]);
   if (argc == 6 && !strcmp(argv[1], "spheres")) return spheres(argv[2], atoi(argv[3]), atoi(argv[4]), argv[5]);

@@ -403,6 +403,32 @@ def test_hip_backend_build_and_traverse_batch(tmp_path, oracle, f64):
     assert_hits_match(oh, om, hits, mask, oracle, onodes, oidx, v, f, rays, max_ties=200)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("f64", [False, True])
+def test_hip_backend_leaves_the_tree_on_the_device_until_the_host_asks(tmp_path, f64):
+    """Build() no longer reads the tree back (the application-visible build time): BoundingBox(), IsValid()
+    and TraverseBatch() work without the host arrays; the first Traverse() — from eight threads at once — fetches them and gives
+    TraverseBatch()'s records bit for bit; copies carry their own arrays."""
+    exe = tmp_path / "host_check_hip"
+    cxx(["-std=c++11", "-O2", "-Wall", "-Wextra", "-pthread", "-DNANORT_USE_HIP_BACKEND", "-D__HIP_PLATFORM_AMD__", "-I", INC, "-isystem", "/opt/rocm/include",
+         os.path.join(ROOT, "tests", "cpp", "host_check.cc"), "-o", str(exe),
+         "-L", LIBDIR, "-lnanort_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
+    v, f = scenes.sphere(128, 64)
+    rays = scenes.camera_rays(160, 90)
+    if f64:
+        v, rays = v.astype(np.float64), widen_rays(rays)
+    mesh, rp = write_inputs(str(tmp_path), v, f, rays)
+    r = subprocess.run([str(exe), "lazy", "f64" if f64 else "f32", mesh, rp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    for want in ("pending_after_build 1 valid 1", "pending_after_bounds 1", "pending_after_batch 1", "pending_after_traverse 0 threads_vs_batch_mismatches 0",
+                 "bounds_match_root 1", "pending_after_rebuild 1 copy_pending 0", "same_bytes 1", "copy_batch_mismatches 0"):
+        assert want in r.stdout, (want, r.stdout)
+    # NANORT_HIP_EAGER_READBACK=1: Build() fetches the arrays itself, as before
+    r = subprocess.run([str(exe), "lazy", "f64" if f64 else "f32", mesh, rp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       env=dict(os.environ, NANORT_HIP_EAGER_READBACK="1"))
+    assert r.returncode == 0 and "pending_after_build 0 valid 1" in r.stdout and "threads_vs_batch_mismatches 0" in r.stdout, r.stdout
+
+
 def test_wavefront_path_tracer_example_host_path(tmp_path):
     """the wavefront restructuring of the reference's path tracer; host path (per-ray Traverse)."""
     exe = tmp_path / "wf"
