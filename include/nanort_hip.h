@@ -365,6 +365,46 @@ NRT_API nrt_status nrtTraverseBatchMulti_f64(nrt_ctx *const *ctxs, uint32_t num_
 /* HIP devices visible to this process (0 when there is none or the runtime cannot be initialised). */
 NRT_API int nrtDeviceCount(void);
 
+/* ---- multi-GPU with DEVICE-RESIDENT rays: tiles traced where they live, hit records gathered to one GPU by RCCL ----------
+ * replicated BVH, image-tile split, RCCL gather of the 16 / 32-byte records over xGMI.  (No reference
+ * counterpart: examples/path_tracer/main.cc:785-806 is the reference's only parallel loop.)  A frame of `total_rays` rays is
+ * cut into rows of `row_len` rays (0 = 4096); tile t of N owns the interleaved rows t, t + N, t + 2N, ... in that order
+ * (nrtGroupTileRays gives its size) — the split of nrtTraverseBatchMulti.  Every tile belongs to one context holding a replica
+ * of the tree (nrtBuild is deterministic: the same mesh gives bit-identical replicas).
+ *   nrtGroupCreate        ONE process drives all N contexts, normally one per GPU (several on one GPU work: their records are
+ *                         read in place); one RCCL rank per distinct device.
+ *   nrtGroupCreateRanked  one process per GPU: this process owns tile `rank` of `nranks`; `unique_id` = the 128 bytes rank 0
+ *                         got from nrtGroupUniqueId, handed round by the host program.
+ * RCCL is bound at run time (librccl.so.1 — the process's own copy when a framework has loaded one); when it cannot be, a
+ * single-process group moves the records with hipMemcpyPeerAsync instead and nrtGroupLastError(group) says so.
+ * nrtGroupTraverseGather_*: d_rays[k] / counts[k] describe this process's k-th tile (device pointers on that tile's GPU,
+ * complete before the call).  Every tile is traced on a stream of the group (nrtTraverseBatchDevice_* semantics: every record
+ * written, a miss = {0, 0, max_t, ~0}); tiles on other GPUs than the root tile's send their records (ncclSend / ncclRecv in one
+ * group call); a kernel on the root GPU writes them to d_frame_hits[total_rays] (and flags to d_frame_mask, optional) in FRAME
+ * order.  Only the process owning `root_tile` passes frame pointers (memory of the root tile's GPU); the others pass NULL.  The
+ * call returns once everything is enqueued: nrtGroupSynchronize before reading the frame or reusing the ray buffers.  Frames
+ * are byte-identical to nrtTraverseBatchDevice_* over the whole ray array on one context.
+ * Tunables: "transport" (0 RCCL, 1 peer copies; single-process groups), "self_send" (1: the root tile's own records take the
+ * send / receive path too — lets a one-GPU box execute the exchange). */
+typedef struct nrt_group nrt_group;
+NRT_API nrt_status nrtGroupUniqueId(void *id_out, size_t bytes /* >= 128 */);
+NRT_API nrt_status nrtGroupCreate(nrt_ctx *const *ctxs, uint32_t num_ctx, nrt_group **out);
+NRT_API nrt_status nrtGroupCreateRanked(nrt_ctx *ctx, const void *unique_id, int rank, int nranks, nrt_group **out);
+NRT_API void nrtGroupDestroy(nrt_group *group);
+NRT_API const char *nrtGroupLastError(const nrt_group *group); /* NULL: the calling thread's last creation error */
+NRT_API nrt_status nrtGroupSetTunable(nrt_group *group, const char *name, long long value);
+NRT_API nrt_status nrtGroupInfo(const nrt_group *group, uint32_t *num_tiles_out, uint32_t *num_local_out, int *nranks_out, int *rccl_bound_out);
+NRT_API uint64_t nrtGroupTileRays(uint64_t total_rays, uint64_t row_len, uint32_t tile, uint32_t num_tiles);
+NRT_API nrt_status nrtGroupTraverseGather_f32(nrt_group *group, const nrt_ray_f32 *const *d_rays, const uint64_t *counts, uint64_t total_rays,
+                                              uint64_t row_len, const nrt_trace_options *options, uint32_t root_tile, nrt_hit_f32 *d_frame_hits,
+                                              uint8_t *d_frame_mask);
+NRT_API nrt_status nrtGroupTraverseGather_f64(nrt_group *group, const nrt_ray_f64 *const *d_rays, const uint64_t *counts, uint64_t total_rays,
+                                              uint64_t row_len, const nrt_trace_options *options, uint32_t root_tile, nrt_hit_f64 *d_frame_hits,
+                                              uint8_t *d_frame_mask);
+NRT_API nrt_status nrtGroupSynchronize(nrt_group *group);
+/* bytes the last gather moved by RCCL / by peer copies / read in place on the root GPU */
+NRT_API nrt_status nrtGroupLastTraffic(const nrt_group *group, uint64_t *bytes_rccl, uint64_t *bytes_peer, uint64_t *bytes_in_place);
+
 /* Measurement aid: run the batch once on HBM-resident rays with the work
  * counters on (synchronous; results are not written).  Used by bench.py to
  * turn kernel time into algorithmic bytes per SURVEY.md §8(d). */

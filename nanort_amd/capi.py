@@ -28,6 +28,8 @@ SYMBOLS = [
     "nrtTraverseCountDevice_f32", "nrtTraverseCountDevice_f64",
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
     "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtHostAlloc", "nrtHostFree",
+    "nrtGroupUniqueId", "nrtGroupCreate", "nrtGroupCreateRanked", "nrtGroupDestroy", "nrtGroupLastError", "nrtGroupSetTunable", "nrtGroupInfo",
+    "nrtGroupTileRays", "nrtGroupTraverseGather_f32", "nrtGroupTraverseGather_f64", "nrtGroupSynchronize", "nrtGroupLastTraffic",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
     "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32", "nrtSceneSetTunable", "nrtSceneLastRedone", "nrtSceneLastPath",
 ]

@@ -456,6 +456,7 @@ static nrt_status set_mesh(nrt_ctx *c, const T *vertices, size_t stride, const u
   if (num_faces && (!vertices || !faces)) return fail(c, NRT_ERR_INVALID, "nrtSetMesh: NULL mesh pointer");
   if (stride < 3 * sizeof(T) && num_faces)
     return fail(c, NRT_ERR_INVALID, "nrtSetMesh: vertex stride %zu < %zu", stride, 3 * sizeof(T));
+  NRT_RANGE("nrtSetMesh (compaction + upload)");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, wait_for_launches(c));
   free_tree(c);
@@ -710,6 +711,7 @@ static nrt_status get_tree(nrt_ctx *c, typename Wire<T>::Node *nodes_out, uint32
   if (!c) return NRT_ERR_INVALID;
   if (c->prec != (int)sizeof(T)) return fail(c, NRT_ERR_PRECISION, "nrtGetTree: precision mismatch");
   if (!c->d_nodes) return fail(c, NRT_ERR_INVALID, "nrtGetTree: no tree");
+  NRT_RANGE("nrtGetTree (read-back)");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (nodes_out)
@@ -751,6 +753,7 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
     bin_size = opt->bin_size;
   }
   if (bin_size < 2) return fail(c, NRT_ERR_INVALID, "nrtBuild: bin_size must be > 1 (nanort.h:1905)");
+  NRT_RANGE("nrtBuild");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, wait_for_launches(c));
   free_tree(c);
@@ -769,7 +772,9 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   c->d_nodes = c->b_nodes.p;
   c->d_indices = (uint32_t *)c->b_indices.p;
   c->num_indices = build_n;
+  NRT_RANGE_PUSH("build: leaf-ordered primitive records");
   nrt_status fst = finish_leaf_records<T>(c);
+  NRT_RANGE_POP();
   if (fst) {
     free_tree(c); // (no half-built tree is left behind: a later traversal call then reports "no tree")
     return fst;
@@ -785,7 +790,9 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   c->root_is_branch = res.num_nodes > 1 ? 1u : 0u;
   c->min_leaf_count = 1; // the GPU builder never emits an empty leaf
   c->tree_nested = 1;    // a branch's box is the exact union of its children's
+  NRT_RANGE_PUSH("build: WideNode / Wide4Node records");
   fst = finish_wide<T>(c); // WideNode arrays: part of the build
+  NRT_RANGE_POP();
   if (fst) {
     free_tree(c);
     return fst;
@@ -827,6 +834,7 @@ nrt_status nrt_internal_tree_view(nrt_ctx *c, nrt::TreeViewF32 *out) {
   return NRT_OK;
 }
 uint64_t nrt_internal_generation(const nrt_ctx *c) { return c ? c->generation : 0; }
+int nrt_internal_device(const nrt_ctx *c) { return c ? c->device : 0; } // group.hip
 
 // ---------------------------------------------------------------------------
 // traverse

@@ -2877,14 +2877,17 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     LevelInfo *info = (LevelInfo *)(base + plan.off_info);
     uint32_t *indices = (uint32_t *)indices_buf->p;
 
+    NRT_RANGE_PUSH("build: primitive records (per-prim AABB + centroid, scene bounds)");
     hipLaunchKernelGGL((k_init_scene<T>), dim3(1 + kRepNodes * kRep), dim3(64), 0, s, scene, info, (uint32_t)plan.max_top, gbins, child_acc,
                        (uint32_t)plan.max_active);
     {
       unsigned grid = (unsigned)std::min<size_t>(((size_t)n + 255) / 256, 2048);
       hipLaunchKernelGGL((k_prim_records<T>), dim3(grid), dim3(256), 0, s, d_verts, d_faces, d_radii, cylinders, n, d_prim_map, recs[0], scene);
     }
+    NRT_RANGE_POP();
     int cur = 0; // buffer holding the ranges of the nodes being split
     if (morton_order && n > 1) {
+      NRT_RANGE("build: Morton keys + radix sort");
       uint32_t *keys[2] = {(uint32_t *)(base + plan.off_sort), (uint32_t *)(base + plan.off_sort) + (size_t)n};
       uint32_t *vals[2] = {keys[1] + (size_t)n, keys[1] + 2 * (size_t)n};
       uint32_t *block_hist = keys[1] + 3 * (size_t)n;
@@ -2915,6 +2918,7 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
     const int first_check = (n <= (uint32_t)kHandoff) ? 0 : expect + 2;
     bool overflow = false;
     uint32_t num_small = 0;
+    NRT_RANGE_PUSH("build: top phase (level setup / bin / split / partition per level)");
     for (int level = 0;; level++) {
       // children of the level partitioned last (their records are in recs[cur]): inside k_level_setup while a level
       // cannot have more than kNarrowLevel active nodes, by a grid of their own beyond that
@@ -2952,7 +2956,9 @@ hipError_t gpu_build(hipStream_t s, const T *d_verts, const uint32_t *d_faces, c
         }
       }
     }
+    NRT_RANGE_POP();
     if (overflow) continue; // lopsided splits outgrew the top array: retry with a larger one
+    NRT_RANGE("build: subtree phase + layout + emission");
 
     // ---- subtree phase + relayout + emission ---------------------------------------------------------
     if (num_small) {

@@ -13,6 +13,28 @@
 
 #include "../../include/nanort_hip.h"
 
+// roctx ranges: compiled into the PROFILING library only (-DNRT_PROF -DNRT_ROCTX, nanort_amd/csrc/Makefile), so that a
+// `rocprofv3 --marker-trace --kernel-trace` run of tools/ names the build phases and every traversal launch; the product
+// library carries no marker calls.  Ranges bracket the host-side enqueue of a phase (the kernels run asynchronously).
+#ifdef NRT_ROCTX
+#include <rocprofiler-sdk-roctx/roctx.h>
+namespace nrt {
+struct RoctxRange {
+  explicit RoctxRange(const char *msg) { roctxRangePushA(msg); }
+  ~RoctxRange() { roctxRangePop(); }
+};
+} // namespace nrt
+#define NRT_RANGE_CAT2(a, b) a##b
+#define NRT_RANGE_CAT(a, b) NRT_RANGE_CAT2(a, b)
+#define NRT_RANGE(msg) ::nrt::RoctxRange NRT_RANGE_CAT(nrt_range_, __LINE__)(msg)
+#define NRT_RANGE_PUSH(msg) roctxRangePushA(msg)
+#define NRT_RANGE_POP() roctxRangePop()
+#else
+#define NRT_RANGE(msg) do { } while (0)
+#define NRT_RANGE_PUSH(msg) do { } while (0)
+#define NRT_RANGE_POP() do { } while (0)
+#endif
+
 namespace nrt {
 
 // NRT_<NAME> environment overrides are a debugging aid: the profiling library always honours them, the product library only

@@ -2248,6 +2248,7 @@ hipError_t launch_scene_walk(const SceneWalkArgs &args, unsigned grid, hipStream
     return hipGetLastError();
   }
 #endif
+  NRT_RANGE("scene walk launch (k_scene_walk)");
   hipLaunchKernelGGL((k_scene_walk<kSceneWalkLdsStack, false>), dim3(grid), dim3(kTraverseBlock), 0, s, args);
   return hipGetLastError();
 }
@@ -2504,9 +2505,12 @@ static const char *variant_name(bool f32, int stack, bool stats, int kind, bool 
 }
 #define NRT_LAUNCH_WIDE_O(STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_, ORDER_)                                          \
   do {                                                                                                                  \
+    const char *vn_ = variant_name(sizeof(T) == 4, STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_, ORDER_);              \
+    NRT_RANGE_PUSH(vn_); /* (profiling library: a marker range per traversal launch, named like the kernel) */          \
     hipLaunchKernelGGL((k_traverse_wide<T, STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_, ORDER_>), dim3(grid),         \
                        dim3(kTraverseBlock), 0, s, args);                                                               \
-    if (name_out) *name_out = variant_name(sizeof(T) == 4, STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_, ORDER_);      \
+    NRT_RANGE_POP();                                                                                                    \
+    if (name_out) *name_out = vn_;                                                                                      \
   } while (0)
 #define NRT_LAUNCH_WIDE(STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_) NRT_LAUNCH_WIDE_O(STACK_, STATS_, KIND_, PLAIN_, CLOCK_, WIDTH_, 0)
 
