@@ -18,7 +18,8 @@ extern "C" {
  * instantiated, slower kernel).  out16[0..7] = inner-node-phase wave iterations, sum of active lanes, idle lanes at leaf-phase
  * entry, leaf-phase trips, sum of lanes testing a (first) record, refill events, lanes refilled, leaf-phase entries;
  * [8..10] = shader-clock ticks the waves spent refilling / in the inner-node phase / in the leaf phase; [11] = lanes
- * with a second record in a leaf trip.  Returns 0 on success. */
+ * with a second record in a leaf trip; [12..15] = inner iterations, their active lanes, leaf trips and records tested counted only
+ * while rays were still being handed out (the steady part of a launch: the rest is its drain).  Returns 0 on success. */
 NRT_API int nrtDebugCounters(nrt_ctx *ctx, unsigned long long *out, int capacity /* >= 16 */);
 /* Profiling aid: with NRT_DEBUG bit 8192 every wave of a traversal launch records when it started, ran out of rays and
  * finished (100 MHz realtime ticks, 3 x u64 per wave).  Copies up to `cap` records of the most recent launch; returns

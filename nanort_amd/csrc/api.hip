@@ -169,6 +169,7 @@ struct nrt_ctx {
   int last_timed_slot = -1; // slot of the most recent timed traversal launch (nrtLastTraverseMs)
   int launch_timing = 0;    // 1: bracket every traversal launch with timing events and follow it with a completion event (nrtSetLaunchTiming); 0: completion records
   bool have_build_time = false;
+  float segment_ms = 0.f; // cylinders: wall time nrtSetCylinders spent cutting them into segments (counted into the next build's time)
   const char *last_kernel = ""; // variant of the most recent traversal launch (nrtLastKernelName)
 };
 
@@ -544,7 +545,13 @@ static nrt_status set_cylinders(nrt_ctx *c, const float *endpoints, const float 
   // Segments for the builder (build.hip, k_cylinder_segments): a cylinder many radii long is handed over as several pieces
   // with their own tight boxes and the cylinder's id.  Counts on the host (the arrays are here anyway), pieces on the device.
   c->num_segs = 0;
-  if (c->cyl_split > 1) {
+  c->segment_ms = 0.f;
+  // (zero-radius "cylinders" are boxes — the top-level tree of a scene is built over them — and cyl_split = 1 asks for the
+  // example's own boxes: neither needs the counting pass or its array)
+  bool any_radius = false;
+  for (size_t i = 0; i < 2 * (size_t)n && !any_radius; i++) any_radius = radii[i] > 0.0f;
+  if (c->cyl_split > 1 && any_radius) {
+    const auto seg_t0 = std::chrono::steady_clock::now();
     std::vector<uint32_t> off((size_t)n + 1);
     uint64_t total = 0;
     for (int pass = 0; pass < 2 && total == 0; pass++) {
@@ -578,6 +585,8 @@ static nrt_status set_cylinders(nrt_ctx *c, const float *endpoints, const float 
       HIPCHK(c, hipStreamSynchronize(c->stream)); // (`off` is pageable host memory)
       c->num_segs = (uint32_t)total;
     }
+    // the segmentation is part of building this tree: its wall time is added to the build's (nrtLastBuildMs, build_secs)
+    c->segment_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - seg_t0).count();
   }
   return NRT_OK;
 }
@@ -805,7 +814,7 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
   c->stats.max_tree_depth = res.max_depth;
   c->stats.num_leaf_nodes = res.num_leaves;
   c->stats.num_branch_nodes = res.num_branches;
-  c->stats.build_secs = ms * 1e-3f;
+  c->stats.build_secs = (ms + (segs ? c->segment_ms : 0.f)) * 1e-3f; // (cylinder trees: + the segmentation nrtSetCylinders did for this build)
   if (stats_out) *stats_out = c->stats;
   if (num_nodes_out) *num_nodes_out = c->num_nodes;
   return NRT_OK;
@@ -1265,11 +1274,18 @@ static nrt_status traverse_batches_device(nrt_ctx *c, uint32_t nb, const typenam
                                           uint8_t *const *d_masks, const uint32_t *flags, hipStream_t s) {
   if (!c) return NRT_ERR_INVALID;
   if (nb == 0) return NRT_OK;
-  if (!d_rays || !counts || !d_hits) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchesDevice: NULL argument");
+  if (!d_rays || !counts) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchesDevice: NULL argument");
   for (uint32_t k = 0; k < nb; k++)
     if (flags && (flags[k] & NRT_BATCH_OCCLUSION) && counts[k] && !(d_masks && d_masks[k]))
       return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchesDevice: occlusion batch %u has no flag array", k);
-  for (uint32_t k = 0; k < nb; k++) // as nrtTraverseBatchDevice: a closest-hit batch needs its record array
+  // as nrtTraverseBatchDevice: a closest-hit batch needs its record array — an occlusion batch does not, and a call made of
+  // occlusion batches only may pass no record table at all
+  std::vector<typename Wire<T>::Hit *> no_hits;
+  if (!d_hits) {
+    no_hits.assign(nb, nullptr);
+    d_hits = no_hits.data();
+  }
+  for (uint32_t k = 0; k < nb; k++)
     if (counts[k] && !(flags && (flags[k] & NRT_BATCH_OCCLUSION)) && !d_hits[k])
       return fail(c, NRT_ERR_INVALID, "nrtTraverseBatchesDevice: batch %u has no hit array", k);
   TraverseBatches<T> mb;
@@ -1325,31 +1341,37 @@ static nrt_status traverse_batches_host(nrt_ctx *c, uint32_t nb, const typename 
   typedef typename Wire<T>::Hit Hit;
   if (!c) return NRT_ERR_INVALID;
   if (nb == 0) return NRT_OK;
-  if (!rays || !counts || !hits) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: NULL argument");
-  uint64_t total = 0;
+  if (!rays || !counts) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: NULL argument");
+  uint64_t total = 0, total_closest = 0; // (record staging is sized over the closest-hit batches only)
   for (uint32_t k = 0; k < nb; k++) {
     if (!counts[k]) continue;
     const bool occ = flags && (flags[k] & NRT_BATCH_OCCLUSION);
     if (!rays[k]) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: batch %u has no rays", k);
     if (occ && !(masks && masks[k])) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: occlusion batch %u has no flag array", k);
-    if (!occ && !hits[k]) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: batch %u has no hit array", k);
+    if (!occ && !(hits && hits[k])) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: batch %u has no hit array", k);
     total += counts[k];
+    if (!occ) total_closest += counts[k];
   }
   if (total == 0) return NRT_OK;
   if (total > (1ull << 26)) return fail(c, NRT_ERR_INVALID, "nrtTraverseBatches: more than 2^26 rays in one call");
   std::lock_guard<std::mutex> host_lock(c->host_mutex);
   HIPCHK(c, hipSetDevice(c->device));
   nrt_status st;
-  if ((st = ensure(c, c->st_rays, total * sizeof(Ray))) || (st = ensure(c, c->st_hits, total * sizeof(Hit))) || (st = ensure(c, c->st_mask, total)))
+  if ((st = ensure(c, c->st_rays, total * sizeof(Ray))) || (st = ensure(c, c->st_hits, std::max<uint64_t>(1, total_closest) * sizeof(Hit))) ||
+      (st = ensure(c, c->st_mask, total)))
     return st;
   std::vector<const Ray *> d_r(nb, nullptr);
   std::vector<Hit *> d_h(nb, nullptr);
   std::vector<uint8_t *> d_m(nb, nullptr);
-  uint64_t off = 0;
+  uint64_t off = 0, off_closest = 0;
   for (uint32_t k = 0; k < nb; k++) {
     if (!counts[k]) continue;
+    const bool occ = flags && (flags[k] & NRT_BATCH_OCCLUSION);
     d_r[k] = (const Ray *)c->st_rays.p + off;
-    d_h[k] = (Hit *)c->st_hits.p + off;
+    if (!occ) {
+      d_h[k] = (Hit *)c->st_hits.p + off_closest;
+      off_closest += counts[k];
+    }
     d_m[k] = (uint8_t *)c->st_mask.p + off;
     HIPCHK(c, hipMemcpyAsync((void *)d_r[k], rays[k], counts[k] * sizeof(Ray), hipMemcpyHostToDevice, c->stream));
     off += counts[k];

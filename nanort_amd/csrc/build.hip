@@ -811,6 +811,7 @@ __device__ __forceinline__ void make_children(TopNode<T> *top, const uint32_t *a
     for (int j = 0; j < 12; j++) m[j] = acc.v[j];
     if (folded) { // (two copies are requested together before they are used and cleaned only then: kRep / 2 round trips, not kRep)
       static_assert(kRep % 2u == 0u || kRep == 1u, "copies are folded in pairs");
+      static_assert((kRep & (kRep - 1u)) == 0u, "a copy is selected with & (kRep - 1): NRT_TOP_REP must be a power of two");
       for (uint32_t r0 = 0; r0 < kRep; r0 += 2u) {
         BoundsAcc<T> *ar = &child_acc[2u * max_active + 2u * (a * kRep + r0) + c]; // (copy r0 + 1 of this child: two records on)
         typename Ord<T>::U x[2][12];
@@ -1064,6 +1065,7 @@ __global__ __launch_bounds__(256) void k_bin(TopNode<T> *top, const uint32_t *__
   // copies of a word lie in R different banks): lanes of a wave that end in the same bin — the rule on coherent input —
   // queue R ways less on one LDS word; the copies are folded into copy 0 before anything reads the bins.
   constexpr int R = sizeof(T) == 4 ? NRT_BIN_REPL : (NRT_BIN_REPL > 2 ? 2 : NRT_BIN_REPL);
+  static_assert(R >= 1 && (R & (R - 1)) == 0, "a lane's copy is threadIdx.x & (R - 1): NRT_BIN_REPL must be a power of two");
   __shared__ uint32_t s_cnt[3][kMaxBins][R];
   __shared__ U s_min[3][kMaxBins][3][R];
   __shared__ U s_max[3][kMaxBins][3][R];
@@ -2801,13 +2803,15 @@ __global__ __launch_bounds__(256) void k_cylinder_segments(const float *__restri
   const float rr = r0 > r1 ? r0 : r1; // std::max<float>(r0, r1), main.cc:256
   const float invK = 1.0f / (float)K;
   float a[3] = {p0[0], p0[1], p0[2]};
+  // The interior end points p0 + (p1 - p0) * s are rounded: p1 - p0 alone carries an error of the order of an ulp of the
+  // CYLINDER's end points, whatever the size of the interior point itself (a long cylinder spanning the origin has interior
+  // points near 0 whose error is that of its far ends).  So the slack the radius carries is sized once, from the end points.
+  const float mag = fmaxf(fmaxf(fabsf(p0[0]), fabsf(p0[1])), fabsf(p0[2])) + fmaxf(fmaxf(fabsf(p1[0]), fabsf(p1[1])), fabsf(p1[2])) + rr;
+  const float rs = rr + 1.0e-6f * mag;
   for (uint32_t j = 0; j < K; j++) {
     float b[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) b[k] = (j + 1u == K) ? p1[k] : p0[k] + (p1[k] - p0[k]) * ((float)(j + 1u) * invK);
-    // the interior end points are rounded (a few ulps of their coordinates): the radius carries that slack
-    const float mag = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fabsf(a[2])) + fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fabsf(b[2])) + rr;
-    const float rs = rr + 1.0e-6f * mag;
     const size_t o = (size_t)first + j;
 #pragma unroll
     for (int k = 0; k < 3; k++) {

@@ -1279,6 +1279,9 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
   uint32_t st_steps = 0, st_tris = 0; // per ray; with debug flag 64 they replace u, v of the hit record
   // ... and where the wave's time goes (shader-clock ticks): refill (claim, result stores, ray loads, lane set-up), inner-node phase, leaf phase
   unsigned long long st_t_refill = 0, st_t_p1 = 0, st_t_p2 = 0, st_act2b = 0, st_stamp = 0;
+  // ... and the same occupancy counts restricted to the STEADY part of the launch (rays still to be handed out), so that the
+  // drain (every wave finishing what it holds) can be told from the steady state: counters[12..15]
+  unsigned long long st_it1_s = 0, st_act1_s = 0, st_it2_s = 0, st_act2_s = 0;
 
   // PostTraversal (nanort.h:1205-1211) with the strict final predicate (:2552).  Finished lanes keep
   // their result in registers until the lane is refilled (or the wave runs out of rays), so the
@@ -1397,6 +1400,10 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
       if (STATS) {
         st_it1++;
         st_act1 += (unsigned)__builtin_popcountll(__ballot(true));
+        if (!ck.exhausted) {
+          st_it1_s++;
+          st_act1_s += (unsigned)__builtin_popcountll(__ballot(true));
+        }
       }
       // a lane that must pop does so first and, if the popped entry survives, steps into it in the same iteration
 #pragma unroll
@@ -1508,6 +1515,10 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
             st_it2++;
             st_act2 += (unsigned)__builtin_popcountll(__ballot(i < cnt));
             st_act2b += (unsigned)__builtin_popcountll(__ballot(i + 1u < cnt));
+            if (!ck.exhausted) {
+              st_it2_s++;
+              st_act2_s += (unsigned)__builtin_popcountll(__ballot(i < cnt)) + (unsigned)__builtin_popcountll(__ballot(i + 1u < cnt));
+            }
             if (i < cnt) st_tris += (i + 1u < cnt) ? 2u : 1u;
           }
 #pragma unroll
@@ -1568,6 +1579,10 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
     atomicAdd(&a.counters[9], st_t_p1);
     atomicAdd(&a.counters[10], st_t_p2);
     atomicAdd(&a.counters[11], st_act2b);   // leaf loop, two records per trip: lanes with a second record
+    atomicAdd(&a.counters[12], st_it1_s);   // [12..15]: inner iterations / their active lanes / leaf trips / records tested while rays were still being handed out
+    atomicAdd(&a.counters[13], st_act1_s);
+    atomicAdd(&a.counters[14], st_it2_s);
+    atomicAdd(&a.counters[15], st_act2_s);
   }
 }
 

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include <string>
 #include <vector>
 
 #include "nanort.h"
@@ -308,6 +309,32 @@ static int cylinders(const char *scene_path, int W, int H, const char *out_path)
     if (bmask[i] != mask[i] || memcmp(&bhits[i], &hits[i], sizeof(hits[i])) != 0) bad++;
   printf("batch_vs_per_ray_mismatches %llu\n", (unsigned long long)bad);
   if (bad) return 5;
+#ifdef NANORT_ENABLE_SERIALIZATION
+  {
+    // Dump() / Load() of a SEGMENTED cylinder tree (its index array names a cylinder once per segment, so it is longer than
+    // the primitive count): the file round-trips both arrays at their own lengths and the re-sent tree gives the same records
+    const std::string path = std::string(out_path) + ".bvh";
+    const size_t nn0 = accel.GetNodes().size(), ni0 = accel.GetIndices().size();
+    if (!accel.Dump(path.c_str()) || !accel.Load(path.c_str())) return 6;
+    printf("dump_load nodes %zu/%zu indices %zu/%zu primitives %u\n", accel.GetNodes().size(), nn0, accel.GetIndices().size(), ni0, n);
+    std::vector<nanort::CylinderIntersection> lhits(bhits.size());
+    std::vector<unsigned char> lmask(nr, 0);
+    for (uint64_t i = 0; i < nr; i++) {
+      memset(static_cast<void *>(&lhits[i]), 0, sizeof(lhits[i]));
+      lhits[i].t = rays[i].max_t;
+      lhits[i].prim_id = 0xFFFFFFFFu;
+    }
+    if (!accel.TraverseBatch(rays.data(), nr, lhits.data(), lmask.data())) {
+      fprintf(stderr, "TraverseBatch after Load failed: %s\n", accel.LastBackendError().c_str());
+      return 7;
+    }
+    uint64_t lbad = 0;
+    for (uint64_t i = 0; i < nr; i++)
+      if (lmask[i] != mask[i] || memcmp(&lhits[i], &hits[i], sizeof(hits[i])) != 0) lbad++;
+    printf("after_dump_load_mismatches %llu\n", (unsigned long long)lbad);
+    if (lbad || accel.GetNodes().size() != nn0 || accel.GetIndices().size() != ni0) return 8;
+  }
+#endif
 #endif
   fp = fopen(out_path, "wb");
   if (!fp) return 2;

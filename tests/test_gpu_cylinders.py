@@ -111,6 +111,68 @@ def test_gpu_built_tree(n, split, golden_dir):
             assert np.array_equal(h[f][:cam][same], gh[f][same]), f
 
 
+def test_long_needles_far_from_the_origin_keep_every_hit():
+    """the slack of a segment's box must cover the rounding of its interior end points, which scales with the
+    CYLINDER's end points (p1 - p0 is rounded at their magnitude), not with the interior point.  Long thin needles through and
+    far from the origin, large coordinates: the segmented tree (default) gives, ray for ray, what the whole-cylinder boxes give
+    (cyl_split = 1) — a box that fell short of its tube would lose grazing hits — and both are the restated example's records
+    on their own arrays.  The covering property is checked on EVERY node."""
+    rng = np.random.default_rng(20260930)
+    n = 3000
+    v = np.zeros((n, 2, 3), dtype=np.float32)
+    r = np.zeros((n, 2), dtype=np.float32)
+    c = rng.uniform(-50.0, 50.0, size=(n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    half = rng.uniform(400.0, 1200.0, size=(n, 1))
+    off = np.where(rng.random((n, 1)) < 0.5, 0.0, 5000.0)  # half of them pass near the origin, half sit 5000 units away
+    v[:, 0] = (c + off - d * half).astype(np.float32)
+    v[:, 1] = (c + off + d * half).astype(np.float32)
+    # (axis-aligned ones too: their boxes are the thinnest)
+    for k in range(3):
+        sel = slice(k * 100, (k + 1) * 100)
+        e = np.zeros(3)
+        e[k] = 1.0
+        v[sel, 0] = (c[sel] - e * half[sel]).astype(np.float32)
+        v[sel, 1] = (c[sel] + e * half[sel]).astype(np.float32)
+    r[:] = rng.uniform(0.05, 0.4, size=(n, 1)).astype(np.float32)
+    # rays: from a shell around the origin towards points ON the needles (near their tubes' silhouettes), and the same far away
+    m = 60000
+    pick = rng.integers(0, n, size=m)
+    s = rng.random((m, 1))
+    on_axis = v[pick, 0] + (v[pick, 1] - v[pick, 0]) * s
+    side = rng.normal(size=(m, 3))
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    target = on_axis + side * r[pick, :1] * rng.uniform(0.9, 1.1, size=(m, 1))  # grazing: just inside / outside the tube
+    org = target + rng.normal(size=(m, 3)) * 300.0
+    dirs = target - org
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    from nanort_amd.wire import RAY_F32
+
+    rays = np.zeros(m, dtype=RAY_F32)
+    rays["org"], rays["dir"] = org.astype(np.float32), dirs.astype(np.float32)
+    rays["min_t"], rays["max_t"] = 0.0, 1.0e30
+    res = {}
+    for split in (1, 32):
+        a = BVHAccel(np.float32)
+        a.SetTunable("cyl_split", split)
+        assert a.Build(n, CylinderGeometry(v, r))
+        nodes, idx = a.GetTree()
+        if split > 1:
+            assert idx.shape[0] > 4 * n
+            leaf_segments_cover(nodes, idx, v, r, n_check=nodes.shape[0])
+        h, msk = a.TraverseBatch(rays)
+        oh, om = ob.CylinderOracle().traverse(nodes, idx, v, r, rays)
+        check(h, msk, oh, om)
+        res[split] = (h, msk)
+    (hw, mw), (hs, ms) = res[1], res[32]
+    assert int(mw.sum()) > m // 4
+    # unit directions: the intersector's answer does not depend on the tree (see test_gpu_built_tree) except where two tubes
+    # cross at the same t — none here
+    assert np.array_equal(mw, ms), int((mw != ms).sum())
+    assert hw["t"].tobytes() == hs["t"].tobytes() and hw["prim_id"].tobytes() == hs["prim_id"].tobytes()
+
+
 def test_device_entry_point_and_errors():
     import torch
 

@@ -529,3 +529,24 @@ def test_host_batches_in_one_launch_equal_separate_host_calls(real):
         fl = (ctypes.c_uint32 * nb)(1)
         hh = (ctypes.c_void_p * nb)(None)
         a._check(getattr(a._L, "nrtTraverseBatches_" + a._s)(a._h, nb, r, n, None, hh, None, fl))
+    # ... but no record table at all when every batch is an occlusion query: host and device entry points
+    import ctypes
+
+    import torch
+
+    occ = [sets[0], sets[0][::3].copy()]
+    r = (ctypes.c_void_p * 2)(*[x.ctypes.data for x in occ])
+    n = (ctypes.c_uint64 * 2)(*[x.shape[0] for x in occ])
+    fl = (ctypes.c_uint32 * 2)(1, 1)
+    outs = [np.full(x.shape[0], 0xCD, dtype=np.uint8) for x in occ]
+    mm = (ctypes.c_void_p * 2)(*[x.ctypes.data for x in outs])
+    a._check(getattr(a._L, "nrtTraverseBatches_" + a._s)(a._h, 2, r, n, None, None, mm, fl))
+    want = [a.OccludedBatch(x) for x in occ]
+    assert np.array_equal(outs[0], want[0]) and np.array_equal(outs[1], want[1])
+    d_r = [torch.from_numpy(x.view(np.uint8).reshape(-1)).cuda() for x in occ]
+    d_m = [torch.full((x.shape[0],), 0xCD, dtype=torch.uint8, device="cuda") for x in occ]
+    r = (ctypes.c_void_p * 2)(*[x.data_ptr() for x in d_r])
+    mm = (ctypes.c_void_p * 2)(*[x.data_ptr() for x in d_m])
+    a._check(getattr(a._L, "nrtTraverseBatchesDevice_" + a._s)(a._h, 2, r, n, None, None, mm, fl, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_m[0].cpu().numpy(), want[0]) and np.array_equal(d_m[1].cpu().numpy(), want[1])

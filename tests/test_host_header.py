@@ -140,8 +140,8 @@ def test_builtin_cylinder_primitive_hip_backend(tmp_path):
     from oracle.bindings import CylinderOracle
 
     exe = tmp_path / "host_check_hip"
-    cxx(["-std=c++11", "-O2", "-Wall", "-Wextra", "-DNANORT_USE_HIP_BACKEND", "-D__HIP_PLATFORM_AMD__", "-I", INC, "-isystem", "/opt/rocm/include",
-         os.path.join(ROOT, "tests", "cpp", "host_check.cc"), "-o", str(exe),
+    cxx(["-std=c++11", "-O2", "-Wall", "-Wextra", "-DNANORT_USE_HIP_BACKEND", "-DNANORT_ENABLE_SERIALIZATION", "-D__HIP_PLATFORM_AMD__", "-I", INC,
+         "-isystem", "/opt/rocm/include", os.path.join(ROOT, "tests", "cpp", "host_check.cc"), "-o", str(exe),
          "-L", LIBDIR, "-lnanort_hip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64"])
     v, r = scenes.random_cylinders(20000)
     out = os.path.join(str(tmp_path), "out.bin")
@@ -150,6 +150,12 @@ def test_builtin_cylinder_primitive_hip_backend(tmp_path):
                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert rr.returncode == 0, rr.stdout
     assert "batch_vs_per_ray_mismatches 0" in rr.stdout
+    # the default cylinder tree is SEGMENTED (indices longer than the primitive count): Dump() / Load() through the
+    # header keep both arrays at their own lengths and the re-sent tree gives the same records
+    assert "after_dump_load_mismatches 0" in rr.stdout, rr.stdout
+    dl = [ln for ln in rr.stdout.splitlines() if ln.startswith("dump_load ")][0].split()
+    nn, ni = dl[2].split("/"), dl[4].split("/")
+    assert nn[0] == nn[1] and ni[0] == ni[1] and int(ni[0]) > 20000 == int(dl[6])
     hits, mask, nodes, idx = read_cyl_output(out, W * H, 20000)
     oh, om = CylinderOracle().traverse(nodes, idx, v, r, scenes.particle_camera_rays(W, H))
     assert np.array_equal(mask, om) and hits.tobytes() == oh.tobytes()

@@ -39,12 +39,17 @@ for name in cfg:
         c = np.zeros(16, dtype=np.uint64)
         L.nrtDebugCounters(a._h, c.ctypes.data_as(ctypes.c_void_p), 16)
         it1, act1, idle2, it2, act2, refills, refilled, ent2, t_ref, t_p1, t_p2, act2b = [int(x) for x in c[:12]]
+        it1_s, act1_s, it2_s, act2_s = [int(x) for x in c[12:16]]
         g = n / 64.0
         tt = max(1, t_ref + t_p1 + t_p2)
         print("%s %-8s %s  production %.4f ms (profiling variant %.4f ms, %s)" % (name, wave, tun, float(np.median(ts)), ms_stats, a.LastKernelName()))
         print("    inner-node phase: %.1f wave-iterations per 64 rays, %.1f lanes active | leaf phase: %.1f trips per 64 rays, %.1f lanes with a "
               "first record, %.1f with a second; entered %.2f times per 64 rays with %.1f lanes idle | refills %.2f per 64 rays, %.1f lanes each"
               % (it1 / g, act1 / max(1, it1), it2 / g, act2 / max(1, it2), act2b / max(1, it2), ent2 / g, idle2 / max(1, ent2), refills / g, refilled / max(1, refills)))
+        # steady state (rays still being handed out) against the drain (every wave finishing what it holds)
+        d_it1, d_act1, d_it2, d_act2 = it1 - it1_s, act1 - act1_s, it2 - it2_s, (act2 + act2b) - act2_s
+        print("    steady: %.1f %% of the inner iterations at %.1f lanes, %.1f %% of the leaf trips at %.1f records (of 128) | drain: inner %.1f lanes, leaf %.1f records"
+              % (100.0 * it1_s / max(1, it1), act1_s / max(1, it1_s), 100.0 * it2_s / max(1, it2), act2_s / max(1, it2_s), d_act1 / max(1, d_it1), d_act2 / max(1, d_it2)))
         print("    wave time: refill %.1f %%, inner-node phase %.1f %%, leaf phase %.1f %%  (ticks per 64 rays: %.0f / %.0f / %.0f; per refill %.0f, per inner iteration %.0f, per leaf trip %.0f)"
               % (100.0 * t_ref / tt, 100.0 * t_p1 / tt, 100.0 * t_p2 / tt, t_ref / g, t_p1 / g, t_p2 / g, t_ref / max(1, refills), t_p1 / max(1, it1), t_p2 / max(1, it2)), flush=True)
     del wl
