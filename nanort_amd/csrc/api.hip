@@ -159,6 +159,7 @@ struct nrt_ctx {
   // 1 (opt-in): by entry distance, +2...5 % — the closest t is the reference's except where a leaf box's entry distance rounds
   // above a hit inside it, and among primitives at exactly the same t another one may be named (contract-level parity)
   int order4 = 0;
+  int leaf_compact = 0; // EXPERIMENT r06 (traverse.hip "leaf items"): the two-level walk's leaf phase spreads the waiting lanes' records over the wave
   int wide_scramble = 0; // probe (tunable wide_scramble): the private node records in a pseudo-random order instead of pre-order
   unsigned wide4_blocks_per_cu = 0;
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
@@ -298,6 +299,7 @@ static const TunableDesc kTunables[] = {
 #endif
     NRT_TUNABLE("wide", 0, 1, wide, int),                         // 0: the literal BVHNode loop
     NRT_TUNABLE("wide4", 0, 1, wide4, int),                       // two tree levels per step (next build / set_tree)
+    NRT_TUNABLE("leaf_compact", 0, 1, leaf_compact, int),         // two-level walk, triangle trees with leaves of <= 4 records: leaf phase over items (records bit-identical)
     NRT_TUNABLE("order4", 0, 1, order4, int),                     // two-level walk: 0 (default) = the reference's order, every field bit-identical; 1 = slots by entry distance (faster; contract-level parity at ties)
     NRT_TUNABLE("launch_timing", 0, 1, launch_timing, int),       // == nrtSetLaunchTiming
     NRT_TUNABLE("host_pipeline", 0, 1, host_pipeline, int),       // pipelined host entry point
@@ -1016,6 +1018,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.plain_options = plain_options ? 1u : 0u;
   a.root_test = c->tree_nested ? 0u : 1u;
   a.order4 = (c->order4 && use_wide4 && !spheres && !any_hit && !(dbg & (32u | 8192u))) ? 1u : 0u;
+  a.leaf_items = (c->leaf_compact && use_wide4 && c->prim_kind == kPrimTriangles && c->max_leaf_count <= 4u && !(dbg & (32u | 8192u))) ? 1u : 0u;
   a.spill = (uint32_t *)slot->spill.p;
   a.spill_stride = total_threads;
   a.spill_levels = levels;

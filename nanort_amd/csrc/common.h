@@ -374,6 +374,7 @@ struct TraverseArgs {
   uint32_t any_hit;       // occlusion query (opt-in extension): a ray stops at the first primitive it accepts
   uint32_t plain_options; // the options above cannot reject any primitive of this tree (host-checked)
   uint32_t root_test;     // node 0's box must be tested before its children (an adopted tree whose child boxes may stick out)
+  uint32_t leaf_items;    // two-level walk: the leaf phase hands the waiting lanes' records out over the whole wave (tunable leaf_compact; leaves of <= 4 records)
   uint32_t order4;        // two-level walk: enter the four slots of a record by entry distance instead of the binary loop's order (tunable order4)
   uint32_t *spill;        // [spill_levels][spill_stride] overflow stack, may be null
   T *spill_tmin;          // same shape, entry t_min (wide kernel)

@@ -1241,11 +1241,17 @@ do {                                                                            
 #endif
 // CLOCK: profiling instantiation that stamps when each wave starts, runs dry and finishes (tools/drain_probe.py).
 // WIDTH: 2 = one WideNode (two boxes) per step, 4 = one Wide4Node (two levels, four boxes) per step.
-// ORDER (WIDTH = 4 only): 0 = the four slots in the binary loop's order (same leaf sequence as the reference), 1 = by entry distance.
+// ORDER (WIDTH = 4 only), two bits: bit 0: 0 = the four slots in the binary loop's order (same leaf sequence as the reference), 1 = by
+// entry distance.  Bit 1 (tunable leaf_compact): the LEAF PHASE hands the records of all the lanes waiting at a leaf out over the
+// whole wave, one record per lane and trip (see "leaf items" below) — same tests on the same operands, accepted in the same order.
 template <typename T, int STACK, bool STATS, int KIND, bool PLAIN = false, bool CLOCK = false, int WIDTH = 2, int ORDER = 0>
 __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NRT_W4_WAVES : 1) void k_traverse_wide(const TraverseArgs<T> a) {
   static_assert(WIDTH == 2 || WIDTH == 4, "one or two tree levels per step");
-  static_assert(ORDER == 0 || (WIDTH == 4 && sizeof(T) == 4), "distance order is a variant of the fp32 two-level step");
+  static_assert(ORDER == 0 || (WIDTH == 4 && sizeof(T) == 4), "distance order / leaf items are variants of the fp32 two-level step");
+  static_assert((ORDER & 2) == 0 || (KIND == kPrimTriangles && !STATS), "leaf items: triangle records, production instantiations");
+  constexpr bool LEAFC = (ORDER & 2) != 0;
+  // leaf items (LEAFC): which lane owns the record a lane tests, and which of the owner's records it is (lane | k << 6)
+  __shared__ uint8_t s_item_owner[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? 4 * kWave : 1];
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
 
@@ -1418,7 +1424,7 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
             const uint32_t rec_ = cur << 7; // (api.hip keeps Wide4Node<float> arrays below 4 GiB)
             const Slab4<float> sl = slab4_presel(L, wb_, rec_);
             const Wide4Tail w = *reinterpret_cast<const Wide4Tail *>(wb_ + (size_t)rec_ + 96);
-            if constexpr (ORDER == 1)
+            if constexpr ((ORDER & 1) == 1)
               NRT_STEP_NODE4_DIST(sl, w);
             else
               NRT_STEP_NODE4_SL(sl, w);
@@ -1505,7 +1511,107 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
         st_entries2++;
         st_idle2 += (unsigned)__builtin_popcountll(__ballot(state == W_IDLE));
       }
-      if constexpr (KIND == kPrimTriangles && (WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL) > 1) {
+      if constexpr (LEAFC) {
+        // ---- leaf items: the records of every waiting lane, spread over the wave --------------------------------------------
+        // In the steady state fewer than half of the lanes wait at a leaf when this phase runs (tools/loop_stats.py: 30 of 64
+        // on C3's primaries, 20 on its bounce rays) and a lane's 1-4 records used to be tested two per trip by their OWNER, the
+        // other lanes idling.  Here record k of owner o becomes ITEM base(o) + k, item j is tested by lane j % 64 in trip j / 64
+        // with the owner's ray constants (fetched by ds_bpermute: org, Sx Sy Sz, the packed axes), and the owner then takes its
+        // items' results IN RECORD ORDER through the reference's own accept rule (`tt > t` / `tt < min_t` reject, equality
+        // and NaN accepted, nanort.h:1133-1139): the same tests on the same operands, accepted in the same sequence, so the lane
+        // state after the leaf is bit for bit what the owner's own loop leaves (tests/test_gpu_leaf_items.py).  Trees whose
+        // leaves hold more than four records do not take this variant (api.hip).
+        const unsigned long long b0_ = __ballot((cnt & 1u) != 0u), b1_ = __ballot((cnt & 2u) != 0u), b2_ = __ballot((cnt & 4u) != 0u);
+        const unsigned long long below_ = (1ull << lane) - 1ull;
+        const uint32_t base_ = (uint32_t)__builtin_popcountll(b0_ & below_) + 2u * (uint32_t)__builtin_popcountll(b1_ & below_) +
+                               4u * (uint32_t)__builtin_popcountll(b2_ & below_);
+        const uint32_t items_ = (uint32_t)__builtin_popcountll(b0_) + 2u * (uint32_t)__builtin_popcountll(b1_) + 4u * (uint32_t)__builtin_popcountll(b2_);
+        const uint32_t kmax_ = b2_ ? 4u : ((b1_ & b0_) ? 3u : (b1_ ? 2u : 1u)); // most records any lane holds (wave-uniform)
+        volatile uint8_t *own_ = s_item_owner[tid / kWave];
+#pragma unroll
+        for (uint32_t k_ = 0; k_ < 4u; k_++)
+          if (k_ < cnt) own_[base_ + k_] = (uint8_t)(lane | (k_ << 6));
+        // (LDS operations of one wave are performed in issue order and the accesses are volatile: the reads below see the writes)
+        const int f_org0 = __float_as_int(L.org0), f_org1 = __float_as_int(L.org1), f_org2 = __float_as_int(L.org2);
+        const int f_sx = __float_as_int(L.Sx), f_sy = __float_as_int(L.Sy), f_sz = __float_as_int(L.Sz);
+        for (uint32_t t0_ = 0; t0_ < items_; t0_ += (uint32_t)kWave) {
+          const uint32_t j_ = t0_ + lane;
+          const bool item_ = j_ < items_;
+          const uint32_t oc_ = item_ ? (uint32_t)own_[j_] : 0u;
+          const int oa_ = (int)((oc_ & 63u) << 2); // the owner lane's byte address for ds_bpermute
+          const uint32_t k_ = oc_ >> 6;
+          const uint32_t first_o = (uint32_t)__builtin_amdgcn_ds_bpermute(oa_, (int)first);
+          const LeafTri<T> tri = a.tris[first_o + k_];
+          const float o0 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_org0)), o1 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_org1)),
+                      o2 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_org2));
+          const float sx = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_sx)), sy = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_sy)),
+                      sz = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_sz));
+          const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute(oa_, (int)L.pk);
+          const int ikx = (int)(pk & 3u), iky = (int)((pk >> 2) & 3u), ikz = (int)((pk >> 4) & 3u);
+          // TriangleIntersector::Intersect (nanort.h:1054-1150) up to the hit distance: tri_test's own operations on the owner's constants
+          const uint32_t prim_i = tri.prim_id;
+          bool ok = PLAIN ? item_ : (item_ & (prim_i >= a.range0) & (prim_i < a.range1) & (prim_i != a.skip_prim));
+          const bool cull_i = PLAIN ? false : cull;
+          const T A0 = tri.p0[0] - o0, A1 = tri.p0[1] - o1, A2 = tri.p0[2] - o2;
+          const T B0 = tri.p1[0] - o0, B1 = tri.p1[1] - o1, B2 = tri.p1[2] - o2;
+          const T C0 = tri.p2[0] - o0, C1 = tri.p2[1] - o1, C2 = tri.p2[2] - o2;
+          const T Akz = sel3(A0, A1, A2, ikz), Bkz = sel3(B0, B1, B2, ikz), Ckz = sel3(C0, C1, C2, ikz);
+          const T Ax = sel3(A0, A1, A2, ikx) - sx * Akz;
+          const T Ay = sel3(A0, A1, A2, iky) - sy * Akz;
+          const T Bx = sel3(B0, B1, B2, ikx) - sx * Bkz;
+          const T By = sel3(B0, B1, B2, iky) - sy * Bkz;
+          const T Cx = sel3(C0, C1, C2, ikx) - sx * Ckz;
+          const T Cy = sel3(C0, C1, C2, iky) - sy * Ckz;
+          T U = Cx * By - Cy * Bx;
+          T V = Ax * Cy - Ay * Cx;
+          T W = Bx * Ay - By * Ax;
+          if (ok && (U == T(0) || V == T(0) || W == T(0))) { // nanort.h:1094-1107
+            const double CxBy = double(Cx) * double(By), CyBx = double(Cy) * double(Bx);
+            const double AxCy = double(Ax) * double(Cy), AyCx = double(Ay) * double(Cx);
+            const double BxAy = double(Bx) * double(Ay), ByAx = double(By) * double(Ax);
+            U = T(CxBy - CyBx);
+            V = T(AxCy - AyCx);
+            W = T(BxAy - ByAx);
+          }
+          const bool neg = (U < T(0)) | (V < T(0)) | (W < T(0));
+          const bool pos = (U > T(0)) | (V > T(0)) | (W > T(0));
+          ok = ok & !(neg & (cull_i | pos));
+          const T det = U + V + W;
+          ok = ok & !(det == T(0));
+          T tt_i = T(0), uu_i = T(0), vv_i = T(0);
+          if (ok) {
+            const T Az = sz * Akz, Bz = sz * Bkz, Cz = sz * Ckz;
+            const T D = U * Az + V * Bz + W * Cz;
+            const T rcp = T(1.0) / det;
+            tt_i = D * rcp;
+            uu_i = V * rcp;
+            vv_i = W * rcp;
+          }
+          // ... and back to the owners, record by record
+          const unsigned long long okm_ = __ballot(ok);
+          bool got_ = false;
+          int win_ = 0;
+          for (uint32_t k2_ = 0; k2_ < kmax_; k2_++) {
+            const int src_ = (int)(base_ + k2_) - (int)t0_;
+            const bool mine_ = (k2_ < cnt) & (src_ >= 0) & (src_ < kWave);
+            const T ttk = __int_as_float(__builtin_amdgcn_ds_bpermute((src_ & 63) << 2, __float_as_int(tt_i)));
+            const bool okk = mine_ & (((okm_ >> (src_ & 63)) & 1ull) != 0ull);
+            const bool acc = okk & !(ttk > L.hit_t) & !(ttk < L.min_t); // nanort.h:1133-1139: equality and NaN accepted
+            L.hit_t = acc ? ttk : L.hit_t;
+            win_ = acc ? src_ : win_;
+            got_ = got_ | acc;
+          }
+          if (__ballot(got_) != 0ull) {
+            const int wa_ = (win_ & 63) << 2;
+            const T uw = __int_as_float(__builtin_amdgcn_ds_bpermute(wa_, __float_as_int(uu_i)));
+            const T vw = __int_as_float(__builtin_amdgcn_ds_bpermute(wa_, __float_as_int(vv_i)));
+            const uint32_t pw = (uint32_t)__builtin_amdgcn_ds_bpermute(wa_, (int)prim_i);
+            L.u = got_ ? uw : L.u;
+            L.v = got_ ? vw : L.v;
+            L.prim = got_ ? pw : L.prim;
+          }
+        }
+      } else if constexpr (KIND == kPrimTriangles && (WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL) > 1) {
         // several records per trip, all fetched before any is tested (same tests in the same order; fewer dependent
         // round trips per leaf — this variant has the registers for it)
         constexpr uint32_t U_ = WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL;
@@ -2566,7 +2672,15 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
         NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, true, 4); // per-wave time stamps (default trace options only)
       else
 #endif
-      if (args.order4 && args.plain_options) // slots entered by entry distance (tunable order4; contract-level parity: see NRT_STEP_NODE4_DIST)
+      if (args.leaf_items && !args.order4 && args.plain_options) // leaf phase over items (tunable leaf_compact): the reference's walk, records bit-identical
+        NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, true, false, 4, 2);
+      else if (args.leaf_items && !args.order4)
+        NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, false, false, 4, 2);
+      else if (args.leaf_items && args.plain_options)
+        NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, true, false, 4, 3);
+      else if (args.leaf_items)
+        NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, false, false, 4, 3);
+      else if (args.order4 && args.plain_options) // slots entered by entry distance (tunable order4; contract-level parity: see NRT_STEP_NODE4_DIST)
         NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, true, false, 4, 1);
       else if (args.order4)
         NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, false, false, 4, 1);

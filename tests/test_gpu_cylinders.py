@@ -167,10 +167,15 @@ def test_long_needles_far_from_the_origin_keep_every_hit():
         res[split] = (h, msk)
     (hw, mw), (hs, ms) = res[1], res[32]
     assert int(mw.sum()) > m // 4
-    # unit directions: the intersector's answer does not depend on the tree (see test_gpu_built_tree) except where two tubes
-    # cross at the same t — none here
-    assert np.array_equal(mw, ms), int((mw != ms).sum())
-    assert hw["t"].tobytes() == hs["t"].tobytes() and hw["prim_id"].tobytes() == hs["prim_id"].tobytes()
+    # The example's intersector is not a pure closest-hit function (its cap test measures in distance, its side test in ray
+    # parameter, and a tube is rejected against the CURRENT t: main.cc:272-343), so across two trees a few grazing rays may be
+    # answered differently (test_gpu_built_tree allows 3 of 40 000 camera rays).  What a box that fell short of its tube would
+    # do is different: it LOSES hits, one-sidedly and by the hundred on these grazing rays.
+    lost, gained = int((mw & ~ms.astype(bool)).sum()), int((ms & ~mw.astype(bool)).sum())
+    both = (mw == 1) & (ms == 1)
+    moved = int((both & ((hw["t"] != hs["t"]) | (hw["prim_id"] != hs["prim_id"]))).sum())
+    assert lost + gained + moved <= m // 2000, (lost, gained, moved)
+    assert lost <= max(3, 2 * gained + 3), (lost, gained, moved)
 
 
 def test_device_entry_point_and_errors():
