@@ -159,7 +159,7 @@ struct nrt_ctx {
   // 1 (opt-in): by entry distance, +2...5 % — the closest t is the reference's except where a leaf box's entry distance rounds
   // above a hit inside it, and among primitives at exactly the same t another one may be named (contract-level parity)
   int order4 = 0;
-  int leaf_compact = 0; // EXPERIMENT r06 (traverse.hip "leaf items"): the two-level walk's leaf phase spreads the waiting lanes' records over the wave
+  int leaf_compact = 1; // traverse.hip "leaf items" (round 6): when the records of all the lanes waiting at a leaf fit one trip of the wave, they are tested one per lane with the owner's ray constants and accepted by the owner in record order — records bit-identical, C3 +2 %, C4 tile +2.8 %; 0: every owner tests its own records
   int wide_scramble = 0; // probe (tunable wide_scramble): the private node records in a pseudo-random order instead of pre-order
   unsigned wide4_blocks_per_cu = 0;
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;

@@ -1251,7 +1251,8 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
   static_assert((ORDER & 2) == 0 || (KIND == kPrimTriangles && !STATS), "leaf items: triangle records, production instantiations");
   constexpr bool LEAFC = (ORDER & 2) != 0;
   // leaf items (LEAFC): which lane owns the record a lane tests, and which of the owner's records it is (lane | k << 6)
-  __shared__ uint8_t s_item_owner[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? 4 * kWave : 1];
+  __shared__ uint8_t s_item_owner[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1];
+  __shared__ uint32_t s_item_rec[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1]; // ... and that record's slot in the leaf-ordered array
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
 
@@ -1511,41 +1512,43 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
         st_entries2++;
         st_idle2 += (unsigned)__builtin_popcountll(__ballot(state == W_IDLE));
       }
+      bool items_done_ = false; // (wave-uniform)
       if constexpr (LEAFC) {
         // ---- leaf items: the records of every waiting lane, spread over the wave --------------------------------------------
         // In the steady state fewer than half of the lanes wait at a leaf when this phase runs (tools/loop_stats.py: 30 of 64
-        // on C3's primaries, 20 on its bounce rays) and a lane's 1-4 records used to be tested two per trip by their OWNER, the
-        // other lanes idling.  Here record k of owner o becomes ITEM base(o) + k, item j is tested by lane j % 64 in trip j / 64
-        // with the owner's ray constants (fetched by ds_bpermute: org, Sx Sy Sz, the packed axes), and the owner then takes its
-        // items' results IN RECORD ORDER through the reference's own accept rule (`tt > t` / `tt < min_t` reject, equality
-        // and NaN accepted, nanort.h:1133-1139): the same tests on the same operands, accepted in the same sequence, so the lane
-        // state after the leaf is bit for bit what the owner's own loop leaves (tests/test_gpu_leaf_items.py).  Trees whose
-        // leaves hold more than four records do not take this variant (api.hip).
+        // on C3's primaries, 20 on its bounce rays) and a lane's 1-4 records are tested two per trip by their OWNER, the other
+        // lanes idling.  When all the waiting lanes' records together fit ONE trip of the wave (<= 64: the rule on incoherent
+        // waves), record k of owner o becomes ITEM base(o) + k, item j is tested by lane j with the owner's ray constants (fetched
+        // by ds_bpermute: org, Sx Sy Sz, the packed axes), and the owner then takes its items' results IN RECORD ORDER through
+        // the reference's own accept rule (`tt > t` / `tt < min_t` reject, equality and NaN accepted, nanort.h:1133-1139): the
+        // same tests on the same operands, accepted in the same sequence, so the lane state after the leaf is bit for bit what
+        // the owner's own loop leaves (tests/test_gpu_leaf_items.py).  More records than lanes: the owners' loop below.  Trees
+        // whose leaves hold more than four records do not take this variant at all (api.hip).
         const unsigned long long b0_ = __ballot((cnt & 1u) != 0u), b1_ = __ballot((cnt & 2u) != 0u), b2_ = __ballot((cnt & 4u) != 0u);
-        const unsigned long long below_ = (1ull << lane) - 1ull;
-        const uint32_t base_ = (uint32_t)__builtin_popcountll(b0_ & below_) + 2u * (uint32_t)__builtin_popcountll(b1_ & below_) +
-                               4u * (uint32_t)__builtin_popcountll(b2_ & below_);
         const uint32_t items_ = (uint32_t)__builtin_popcountll(b0_) + 2u * (uint32_t)__builtin_popcountll(b1_) + 4u * (uint32_t)__builtin_popcountll(b2_);
-        const uint32_t kmax_ = b2_ ? 4u : ((b1_ & b0_) ? 3u : (b1_ ? 2u : 1u)); // most records any lane holds (wave-uniform)
-        volatile uint8_t *own_ = s_item_owner[tid / kWave];
+        if (items_ <= (uint32_t)kWave) {
+          items_done_ = true;
+          const unsigned long long below_ = (1ull << lane) - 1ull;
+          const uint32_t base_ = (uint32_t)__builtin_popcountll(b0_ & below_) + 2u * (uint32_t)__builtin_popcountll(b1_ & below_) +
+                                 4u * (uint32_t)__builtin_popcountll(b2_ & below_);
+          const uint32_t kmax_ = b2_ ? 4u : ((b1_ & b0_) ? 3u : (b1_ ? 2u : 1u)); // most records any lane holds (wave-uniform)
+          volatile uint8_t *own_ = s_item_owner[tid / kWave];
+          volatile uint32_t *rec_ = s_item_rec[tid / kWave];
 #pragma unroll
-        for (uint32_t k_ = 0; k_ < 4u; k_++)
-          if (k_ < cnt) own_[base_ + k_] = (uint8_t)(lane | (k_ << 6));
-        // (LDS operations of one wave are performed in issue order and the accesses are volatile: the reads below see the writes)
-        const int f_org0 = __float_as_int(L.org0), f_org1 = __float_as_int(L.org1), f_org2 = __float_as_int(L.org2);
-        const int f_sx = __float_as_int(L.Sx), f_sy = __float_as_int(L.Sy), f_sz = __float_as_int(L.Sz);
-        for (uint32_t t0_ = 0; t0_ < items_; t0_ += (uint32_t)kWave) {
-          const uint32_t j_ = t0_ + lane;
-          const bool item_ = j_ < items_;
-          const uint32_t oc_ = item_ ? (uint32_t)own_[j_] : 0u;
-          const int oa_ = (int)((oc_ & 63u) << 2); // the owner lane's byte address for ds_bpermute
-          const uint32_t k_ = oc_ >> 6;
-          const uint32_t first_o = (uint32_t)__builtin_amdgcn_ds_bpermute(oa_, (int)first);
-          const LeafTri<T> tri = a.tris[first_o + k_];
-          const float o0 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_org0)), o1 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_org1)),
-                      o2 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_org2));
-          const float sx = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_sx)), sy = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_sy)),
-                      sz = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, f_sz));
+          for (uint32_t k_ = 0; k_ < 4u; k_++)
+            if (k_ < cnt) {
+              own_[base_ + k_] = (uint8_t)lane;
+              rec_[base_ + k_] = first + k_;
+            }
+          // (LDS operations of one wave are performed in issue order and the accesses are volatile: the reads below see the writes)
+          const bool item_ = lane < items_;
+          const uint32_t slot_ = item_ ? rec_[lane] : 0u;
+          const int oa_ = item_ ? (int)((uint32_t)own_[lane] << 2) : 0; // the owner lane's byte address for ds_bpermute
+          const LeafTri<T> tri = a.tris[slot_]; // (issued before the constants are fetched: the two latencies overlap)
+          const float o0 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org0))), o1 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org1))),
+                      o2 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org2)));
+          const float sx = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sx))), sy = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sy))),
+                      sz = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sz)));
           const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute(oa_, (int)L.pk);
           const int ikx = (int)(pk & 3u), iky = (int)((pk >> 2) & 3u), ikz = (int)((pk >> 4) & 3u);
           // TriangleIntersector::Intersect (nanort.h:1054-1150) up to the hit distance: tri_test's own operations on the owner's constants
@@ -1590,19 +1593,18 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
           // ... and back to the owners, record by record
           const unsigned long long okm_ = __ballot(ok);
           bool got_ = false;
-          int win_ = 0;
+          uint32_t win_ = 0;
           for (uint32_t k2_ = 0; k2_ < kmax_; k2_++) {
-            const int src_ = (int)(base_ + k2_) - (int)t0_;
-            const bool mine_ = (k2_ < cnt) & (src_ >= 0) & (src_ < kWave);
-            const T ttk = __int_as_float(__builtin_amdgcn_ds_bpermute((src_ & 63) << 2, __float_as_int(tt_i)));
-            const bool okk = mine_ & (((okm_ >> (src_ & 63)) & 1ull) != 0ull);
+            const uint32_t src_ = (base_ + k2_) & 63u;
+            const T ttk = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_ << 2), __float_as_int(tt_i)));
+            const bool okk = (k2_ < cnt) & (((okm_ >> src_) & 1ull) != 0ull);
             const bool acc = okk & !(ttk > L.hit_t) & !(ttk < L.min_t); // nanort.h:1133-1139: equality and NaN accepted
             L.hit_t = acc ? ttk : L.hit_t;
             win_ = acc ? src_ : win_;
             got_ = got_ | acc;
           }
           if (__ballot(got_) != 0ull) {
-            const int wa_ = (win_ & 63) << 2;
+            const int wa_ = (int)(win_ << 2);
             const T uw = __int_as_float(__builtin_amdgcn_ds_bpermute(wa_, __float_as_int(uu_i)));
             const T vw = __int_as_float(__builtin_amdgcn_ds_bpermute(wa_, __float_as_int(vv_i)));
             const uint32_t pw = (uint32_t)__builtin_amdgcn_ds_bpermute(wa_, (int)prim_i);
@@ -1611,6 +1613,9 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
             L.prim = got_ ? pw : L.prim;
           }
         }
+      }
+      if (items_done_) {
+        // (the waiting lanes' records were tested as items)
       } else if constexpr (KIND == kPrimTriangles && (WIDTH == 4 ? NRT_W4_TRI_UNROLL : NRT_W2_TRI_UNROLL) > 1) {
         // several records per trip, all fetched before any is tested (same tests in the same order; fewer dependent
         // round trips per leaf — this variant has the registers for it)

@@ -66,3 +66,21 @@ def assert_hits_match(ref_hits, ref_mask, hits, mask, oracle, onodes, oindices, 
         assert m1[0] == 1 and _fields_equal(h1, hits[i:i + 1]), \
             "ray %d: reported prim %d is not an exact tie of the reference's prim %d" % (i, p, ref_hits["prim_id"][i])
     return int(diff.size)
+
+
+def walk_order_bits(kernel_name):
+    """Template arguments of k_traverse_wide: <T, STACK, STATS, KIND, PLAIN, CLOCK, WIDTH, ORDER> -> (WIDTH, ORDER).  ORDER bit 0:
+    slots entered by entry distance (opt-in, tunable order4); bit 1: the leaf phase over items (tunable leaf_compact, default on —
+    records bit-identical either way)."""
+    args = kernel_name.split("<", 1)[1].rstrip(">").split(", ")
+    return int(args[6]), int(args[7])
+
+
+def is_reference_order_two_level_walk(kernel_name):
+    w, o = walk_order_bits(kernel_name)
+    return w == 4 and (o & 1) == 0
+
+
+def is_distance_order_two_level_walk(kernel_name):
+    w, o = walk_order_bits(kernel_name)
+    return w == 4 and (o & 1) == 1

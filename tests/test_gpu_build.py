@@ -16,7 +16,7 @@ def validate_bvh(*args, **kw):  # every tree in this file comes from the GPU bui
     kw.setdefault("low_side_first", True)
     return _validate_bvh(*args, **kw)
 
-from helpers import assert_hits_identical, assert_hits_match
+from helpers import assert_hits_identical, assert_hits_match, is_distance_order_two_level_walk, is_reference_order_two_level_walk
 from nanort_amd import BVHAccel, TriangleMesh, scenes
 from nanort_amd.wire import default_build_options, widen_rays
 
@@ -40,7 +40,7 @@ def check_opt_in_distance_order(a, rays, h0, m0, oracle, nodes, idx, v, f, max_t
     a.SetTunable("order4", 1)
     try:
         h1, m1 = a.TraverseBatch(rays)
-        assert ", 4, 1>" in a.LastKernelName(), a.LastKernelName()
+        assert is_distance_order_two_level_walk(a.LastKernelName()), a.LastKernelName()
     finally:
         a.SetTunable("order4", 0)
     return assert_hits_match(h0, m0, h1, m1, oracle, nodes, idx, v, f, rays, max_ties=max_ties)
@@ -174,7 +174,7 @@ def test_c2_sphere_full_frame_vs_reference_sample(oracle, golden_dir):
     onodes, oidx, _ = oracle.build(v, f)
     assert_hits_match(s["hits"], s["mask"], h[::st], mk[::st], oracle, onodes, oidx, v, f, rays[::st], max_ties=200)
     # the default walk is the reference's leaf sequence: every field identical to the restatement on the GPU-built tree
-    assert ", 4, 0>" in a.LastKernelName(), a.LastKernelName()
+    assert is_reference_order_two_level_walk(a.LastKernelName()), a.LastKernelName()
     sub = slice(None, None, 5)
     oh, om = oracle.traverse(nodes, idx, v, f, rays[sub])
     assert_hits_identical(oh, om, h[sub], mk[sub])
@@ -200,7 +200,7 @@ def test_c3_plane_1m_full_frame(oracle, golden_dir):
     onodes, oidx, _ = oracle.build(v, f)
     ties = assert_hits_match(s["hits"], s["mask"], h[::st], mk[::st], oracle, onodes, oidx, v, f, rays[::st], max_ties=2000)
     # the GPU traversal and the CPU restatement agree bit-for-bit on the GPU-built tree (subsample)
-    assert ", 4, 0>" in a.LastKernelName(), a.LastKernelName()  # the shipped default: the reference's slot order
+    assert is_reference_order_two_level_walk(a.LastKernelName()), a.LastKernelName()  # the shipped default: the reference's slot order
     sub = rays[::7]
     oh, om = oracle.traverse(nodes, idx, v, f, sub)
     assert_hits_identical(oh, om, h[::7], mk[::7])
@@ -292,7 +292,7 @@ def test_c4_10m_triangles_4k_tile(oracle):
     rays = scenes.camera_rays(4096, 4096, 1792, 2304)  # the central tile
     h, mk = a.TraverseBatch(rays)
     assert int(mk.sum()) > rays.shape[0] // 2
-    assert ", 4, 0>" in a.LastKernelName(), a.LastKernelName()
+    assert is_reference_order_two_level_walk(a.LastKernelName()), a.LastKernelName()
     sub = slice(None, None, 53)
     oh, om = oracle.traverse(nodes, idx, v, f, rays[sub])
     assert_hits_identical(oh, om, h[sub], mk[sub])

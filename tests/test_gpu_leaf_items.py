@@ -1,4 +1,4 @@
-"""Tunable leaf_compact (traverse.hip "leaf items", template bit ORDER & 2): the two-level walk's leaf phase hands the records of
+"""Tunable leaf_compact (traverse.hip "leaf items", template bit ORDER & 2; the default since round 6): the two-level walk's leaf phase hands the records of
 all lanes waiting at a leaf out over the whole wave (one record per lane and trip, the owner's ray constants fetched by
 ds_bpermute) and the owners accept their items' results in record order through the reference's own rule.  Same tests on the same
 operands in the same sequence: every field of every record must be BIT-IDENTICAL to the default walk's and to the restated
@@ -21,7 +21,6 @@ def both_walks(a, rays, opt=None):
     a.SetTunable("leaf_compact", 1)
     h1, m1 = a.TraverseBatch(rays, opt)
     k1 = a.LastKernelName()
-    a.SetTunable("leaf_compact", 0)
     return (h0, m0, k0), (h1, m1, k1)
 
 
@@ -85,6 +84,7 @@ def test_occlusion_and_batches_and_big_leaves():
     h, m = a.TraverseBatch(rays1)
     shadow = scenes.secondary_rays("shadow", v, f, rays1, h, m)
     bounce = scenes.secondary_rays("bounce", v, f, rays1, h, m)
+    a.SetTunable("leaf_compact", 0)
     want_occ = a.OccludedBatch(shadow)
     want = a.TraverseBatches([(shadow, "occlusion"), bounce, rays1[:999]])
     a.SetTunable("leaf_compact", 1)
