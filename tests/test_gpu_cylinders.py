@@ -111,14 +111,37 @@ def test_gpu_built_tree(n, split, golden_dir):
             assert np.array_equal(h[f][:cam][same], gh[f][same]), f
 
 
-def test_long_needles_far_from_the_origin_keep_every_hit():
+def union_of_leaf_boxes_covers_the_tubes(nodes, idx, v, r, samples=257):
+    """Exact, in fp64: every sampled point of every cylinder's axis, grown by the tube radius, lies inside a leaf box that names the
+    cylinder — the segments' boxes together cover the whole tube.  A box that fell short by any amount fails this."""
+    rr = np.maximum(r[:, 0], r[:, 1]).astype(np.float64)
+    leaves = np.nonzero(nodes["flag"] == 1)[0]
+    boxes = {}
+    for i in leaves:
+        cnt, first = int(nodes["data"][i][0]), int(nodes["data"][i][1])
+        for p in idx[first:first + cnt]:
+            boxes.setdefault(int(p), []).append(i)
+    s_ = np.linspace(0.0, 1.0, samples)[:, None]
+    worst = 0.0
+    for p in range(v.shape[0]):
+        assert p in boxes, p
+        lo = nodes["bmin"][boxes[p]].astype(np.float64)  # (k, 3)
+        hi = nodes["bmax"][boxes[p]].astype(np.float64)
+        p0, p1 = v[p, 0].astype(np.float64), v[p, 1].astype(np.float64)
+        pts = p0 + (p1 - p0) * s_  # (samples, 3)
+        short = np.maximum(lo[None] - (pts[:, None] - rr[p]), (pts[:, None] + rr[p]) - hi[None]).max(axis=2)  # (samples, k): > 0 where box k falls short
+        worst = max(worst, float(short.min(axis=1).max()))
+    return worst
+
+
+def test_long_needles_through_and_far_from_the_origin_are_covered_by_their_segments():
     """the slack of a segment's box must cover the rounding of its interior end points, which scales with the
-    CYLINDER's end points (p1 - p0 is rounded at their magnitude), not with the interior point.  Long thin needles through and
-    far from the origin, large coordinates: the segmented tree (default) gives, ray for ray, what the whole-cylinder boxes give
-    (cyl_split = 1) — a box that fell short of its tube would lose grazing hits — and both are the restated example's records
-    on their own arrays.  The covering property is checked on EVERY node."""
+    CYLINDER's end points (p1 - p0 is rounded at their magnitude), not with the interior point: a needle from -1000 to +1000 has
+    interior points near 0 whose error is an ulp of 1000.  Long thin needles through and far from the origin, axis-aligned ones
+    included: the union of the leaf boxes naming a cylinder covers its whole tube, exactly, in fp64 (a shortfall of 1e-4, what
+    the old per-segment slack left near the origin, fails); and the GPU's records on that tree are the restated example's."""
     rng = np.random.default_rng(20260930)
-    n = 3000
+    n = 1500
     v = np.zeros((n, 2, 3), dtype=np.float32)
     r = np.zeros((n, 2), dtype=np.float32)
     c = rng.uniform(-50.0, 50.0, size=(n, 3))
@@ -128,54 +151,35 @@ def test_long_needles_far_from_the_origin_keep_every_hit():
     off = np.where(rng.random((n, 1)) < 0.5, 0.0, 5000.0)  # half of them pass near the origin, half sit 5000 units away
     v[:, 0] = (c + off - d * half).astype(np.float32)
     v[:, 1] = (c + off + d * half).astype(np.float32)
-    # (axis-aligned ones too: their boxes are the thinnest)
-    for k in range(3):
+    for k in range(3):  # (axis-aligned ones: their boxes are the thinnest)
         sel = slice(k * 100, (k + 1) * 100)
         e = np.zeros(3)
         e[k] = 1.0
         v[sel, 0] = (c[sel] - e * half[sel]).astype(np.float32)
         v[sel, 1] = (c[sel] + e * half[sel]).astype(np.float32)
     r[:] = rng.uniform(0.05, 0.4, size=(n, 1)).astype(np.float32)
-    # rays: from a shell around the origin towards points ON the needles (near their tubes' silhouettes), and the same far away
-    m = 60000
+    a = BVHAccel(np.float32)
+    assert a.Build(n, CylinderGeometry(v, r))
+    nodes, idx = a.GetTree()
+    assert idx.shape[0] > 4 * n
+    worst = union_of_leaf_boxes_covers_the_tubes(nodes, idx, v, r)
+    assert worst <= 0.0, worst
+    # rays at the tubes (the example's intersector is numerically rough on needles this long: only the same-arrays comparison is exact)
+    m = 20000
     pick = rng.integers(0, n, size=m)
-    s = rng.random((m, 1))
-    on_axis = v[pick, 0] + (v[pick, 1] - v[pick, 0]) * s
-    side = rng.normal(size=(m, 3))
-    side /= np.linalg.norm(side, axis=1, keepdims=True)
-    target = on_axis + side * r[pick, :1] * rng.uniform(0.9, 1.1, size=(m, 1))  # grazing: just inside / outside the tube
-    org = target + rng.normal(size=(m, 3)) * 300.0
-    dirs = target - org
+    on_axis = v[pick, 0] + (v[pick, 1] - v[pick, 0]) * rng.random((m, 1))
+    org = on_axis + rng.normal(size=(m, 3)) * 30.0
+    dirs = on_axis - org
     dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
     from nanort_amd.wire import RAY_F32
 
     rays = np.zeros(m, dtype=RAY_F32)
     rays["org"], rays["dir"] = org.astype(np.float32), dirs.astype(np.float32)
     rays["min_t"], rays["max_t"] = 0.0, 1.0e30
-    res = {}
-    for split in (1, 32):
-        a = BVHAccel(np.float32)
-        a.SetTunable("cyl_split", split)
-        assert a.Build(n, CylinderGeometry(v, r))
-        nodes, idx = a.GetTree()
-        if split > 1:
-            assert idx.shape[0] > 4 * n
-            leaf_segments_cover(nodes, idx, v, r, n_check=nodes.shape[0])
-        h, msk = a.TraverseBatch(rays)
-        oh, om = ob.CylinderOracle().traverse(nodes, idx, v, r, rays)
-        check(h, msk, oh, om)
-        res[split] = (h, msk)
-    (hw, mw), (hs, ms) = res[1], res[32]
-    assert int(mw.sum()) > m // 4
-    # The example's intersector is not a pure closest-hit function (its cap test measures in distance, its side test in ray
-    # parameter, and a tube is rejected against the CURRENT t: main.cc:272-343), so across two trees a few grazing rays may be
-    # answered differently (test_gpu_built_tree allows 3 of 40 000 camera rays).  What a box that fell short of its tube would
-    # do is different: it LOSES hits, one-sidedly and by the hundred on these grazing rays.
-    lost, gained = int((mw & ~ms.astype(bool)).sum()), int((ms & ~mw.astype(bool)).sum())
-    both = (mw == 1) & (ms == 1)
-    moved = int((both & ((hw["t"] != hs["t"]) | (hw["prim_id"] != hs["prim_id"]))).sum())
-    assert lost + gained + moved <= m // 2000, (lost, gained, moved)
-    assert lost <= max(3, 2 * gained + 3), (lost, gained, moved)
+    h, msk = a.TraverseBatch(rays)
+    oh, om = ob.CylinderOracle().traverse(nodes, idx, v, r, rays)
+    check(h, msk, oh, om)
+    assert int(msk.sum()) > m // 4
 
 
 def test_device_entry_point_and_errors():
