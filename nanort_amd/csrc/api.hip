@@ -841,6 +841,7 @@ nrt_status nrt_internal_tree_view(nrt_ctx *c, nrt::TreeViewF32 *out) {
   out->tree_nested = c->tree_nested;
   out->prim_kind = (uint32_t)c->prim_kind;
   out->tree_depth = c->tree_depth;
+  out->max_leaf_count = c->max_leaf_count;
   out->generation = c->generation;
   return NRT_OK;
 }

@@ -199,6 +199,7 @@ struct TreeViewF32 {
   const void *prims;             // leaf-ordered primitive records (LeafTri<float> for triangle contexts)
   uint32_t num_nodes, num_indices;
   uint32_t packed_leaves, root_is_branch, tree_nested, prim_kind, tree_depth;
+  uint32_t max_leaf_count;       // most records a leaf of the tree holds
   uint64_t generation;           // counts the context's rebuilds: a view is stale once the context's generation has moved on
 };
 
@@ -314,6 +315,7 @@ struct SceneWalkArgs {
   uint32_t *cursor;
   uint32_t num_parts;
   uint32_t refill_min, trav_min, cand_min, cand_busy_max;
+  uint32_t leaf_items;  // the leaf phase may hand the waiting lanes' records out over the wave (every mesh's leaves hold <= 4 records; tunable walk_leaf_items)
   uint32_t *redo;       // [n]: rays left to the listing path
   uint32_t *redo_count; // zero at launch
   unsigned long long *counters; // profiling build only (libnanort_hip_prof.so): 13 loop counters of the launch, or null

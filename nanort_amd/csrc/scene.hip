@@ -431,6 +431,8 @@ struct nrt_scene {
   unsigned single_pass = 1;   // scenes of kWalkMinNodes nodes or more are traced by k_scene_walk (no per-ray list); 0: always listing +
                               // k_scene_trace; 2: k_scene_walk for every scene of two nodes or more
   unsigned walk_blocks_per_cu = 0;
+  unsigned walk_leaf_items = 1; // the walk's leaf phase over items (traverse.hip leaf_items_one_trip; records bit-identical) when every mesh's leaves hold <= 4 records
+  unsigned max_mesh_leaf = 0;   // most records a leaf of any instanced mesh holds (set by commit)
   unsigned walk_trav_min = 24, walk_refill_min = 24; // the walk's own phase thresholds (profiles/r04t_scene_walk_thresholds.txt: 8 / 56, the listing path's, cost it 10-13 %)
   unsigned walk_backoff = 0;  // calls left that skip the walk (see scene_traverse)
   unsigned walk_backoff_pct = 25; // share of a batch handed to the listing path above which the next kWalkBackoff calls skip the walk (tunable)
@@ -524,6 +526,7 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
     nrt_node_f32 root;
   };
   std::vector<std::pair<nrt_ctx *, MeshInfo> > meshes;
+  s->max_mesh_leaf = 0;
   std::unordered_map<nrt_ctx *, uint32_t> mesh_index;
   std::vector<uint32_t> mesh_of(s->insts.size());
   for (size_t i = 0; i < s->insts.size(); i++) {
@@ -535,6 +538,7 @@ nrt_status nrtSceneCommit(nrt_scene *s) {
       if (nrt_internal_tree_view(s->insts[i].mesh, &mi.tv) != NRT_OK || mi.tv.prim_kind != (uint32_t)nrt::kPrimTriangles)
         return sfail(s, NRT_ERR_PRECISION, "nrtSceneCommit: node %zu is not a built f32 triangle mesh: %s", i, nrtLastError(s->insts[i].mesh));
       SCHK(s, hipMemcpy(&mi.root, mi.tv.nodes, sizeof(mi.root), hipMemcpyDeviceToHost));
+      s->max_mesh_leaf = std::max(s->max_mesh_leaf, (unsigned)mi.tv.max_leaf_count);
       meshes.push_back(std::make_pair(s->insts[i].mesh, mi));
     }
     mesh_of[i] = m;
@@ -843,6 +847,7 @@ static nrt_status scene_traverse(nrt_scene *s, const nrt_ray_f32 *rays, uint64_t
     w.trav_min = s->walk_trav_min;
     w.cand_min = s->cand_min;
     w.cand_busy_max = s->cand_busy_max;
+    w.leaf_items = (s->walk_leaf_items && s->max_mesh_leaf <= 4u) ? 1u : 0u;
     w.redo = (uint32_t *)s->d_redo.p;
     w.redo_count = (uint32_t *)s->d_redo_count.p;
     w.counters = nullptr;
@@ -894,6 +899,7 @@ nrt_status nrtSceneSetTunable(nrt_scene *s, const char *name, int value) {
   else if (k == "trav_min") s->trav_min = lanes;
   else if (k == "refill_min") s->refill_min = lanes;
   else if (k == "walk_trav_min") s->walk_trav_min = lanes;
+  else if (k == "walk_leaf_items") s->walk_leaf_items = value ? 1u : 0u;
   else if (k == "walk_refill_min") s->walk_refill_min = lanes;
   else if (k == "cand_min") s->cand_min = lanes;
   else if (k == "cand_busy_max") s->cand_busy_max = (unsigned)std::min(65, std::max(1, value));

@@ -1241,6 +1241,108 @@ do {                                                                            
 #endif
 // CLOCK: profiling instantiation that stamps when each wave starts, runs dry and finishes (tools/drain_probe.py).
 // WIDTH: 2 = one WideNode (two boxes) per step, 4 = one Wide4Node (two levels, four boxes) per step.
+// Leaf items (k_traverse_wide with ORDER bit 1, k_scene_walk): the records of all the lanes of a wave that wait at a leaf, tested
+// ONE PER LANE in one trip when they are at most 64 together.  `cnt` (0 for a lane that does not wait, at most 4) and `first` (the
+// lane's first record) describe the leaves; record k of owner o becomes item base(o) + k (prefix sums of the counts by three
+// ballots), item j is tested by lane j with its OWNER's ray constants (org, Sx Sy Sz and the packed axes, fetched by ds_bpermute;
+// the record's address and the owner's lane through two small LDS arrays), and every owner then takes its items' results IN RECORD
+// ORDER through the reference's own accept rule (`tt > t` / `tt < min_t` reject, equality and NaN accepted, nanort.h:1133-1139).
+// The same tests on the same operands (tri_test's operations, one for one), accepted in the same sequence: the lane state after
+// the leaf is bit for bit what the owner's own loop leaves (tests/test_gpu_leaf_items.py, tests/test_gpu_scene.py).  Returns false
+// — nothing done — when the records do not fit one trip: the caller's owner loop then runs.  Wave-uniform control flow only.
+template <bool PLAIN>
+__device__ __forceinline__ bool leaf_items_one_trip(Lane<float> &L, uint32_t cnt, const LeafTri<float> *first, unsigned lane, volatile uint8_t *own_,
+                                                    const LeafTri<float> *volatile *rec_, uint32_t range0, uint32_t range1, uint32_t skip_prim, bool cull) {
+  typedef float T;
+  const unsigned long long b0_ = __ballot((cnt & 1u) != 0u), b1_ = __ballot((cnt & 2u) != 0u), b2_ = __ballot((cnt & 4u) != 0u);
+  const uint32_t items_ = (uint32_t)__builtin_popcountll(b0_) + 2u * (uint32_t)__builtin_popcountll(b1_) + 4u * (uint32_t)__builtin_popcountll(b2_);
+  if (items_ > (uint32_t)kWave || items_ == 0u) return false;
+  const unsigned long long below_ = (1ull << lane) - 1ull;
+  const uint32_t base_ = (uint32_t)__builtin_popcountll(b0_ & below_) + 2u * (uint32_t)__builtin_popcountll(b1_ & below_) +
+                         4u * (uint32_t)__builtin_popcountll(b2_ & below_);
+  const uint32_t kmax_ = b2_ ? 4u : ((b1_ & b0_) ? 3u : (b1_ ? 2u : 1u)); // most records any lane holds (wave-uniform)
+#pragma unroll
+  for (uint32_t k_ = 0; k_ < 4u; k_++)
+    if (k_ < cnt) {
+      own_[base_ + k_] = (uint8_t)lane;
+      rec_[base_ + k_] = first + k_;
+    }
+  // (LDS operations of one wave are performed in issue order and the accesses are volatile: the reads below see the writes)
+  const bool item_ = lane < items_;
+  const uint32_t me_ = item_ ? lane : 0u; // (a lane without an item repeats item 0 — there is one: the callers come here with a lane waiting — and drops the result)
+  const LeafTri<float> *slot_ = rec_[me_];
+  const int oa_ = (int)((uint32_t)own_[me_] << 2); // the owner lane's byte address for ds_bpermute
+  const LeafTri<T> tri = *slot_; // (issued before the constants are fetched: the two latencies overlap)
+  const float o0 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org0))), o1 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org1))),
+              o2 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org2)));
+  const float sx = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sx))), sy = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sy))),
+              sz = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sz)));
+  const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute(oa_, (int)L.pk);
+  const int ikx = (int)(pk & 3u), iky = (int)((pk >> 2) & 3u), ikz = (int)((pk >> 4) & 3u);
+  // TriangleIntersector::Intersect (nanort.h:1054-1150) up to the hit distance: tri_test's own operations on the owner's constants
+  const uint32_t prim_i = tri.prim_id;
+  bool ok = PLAIN ? item_ : (item_ & (prim_i >= range0) & (prim_i < range1) & (prim_i != skip_prim));
+  const bool cull_i = PLAIN ? false : cull;
+  const T A0 = tri.p0[0] - o0, A1 = tri.p0[1] - o1, A2 = tri.p0[2] - o2;
+  const T B0 = tri.p1[0] - o0, B1 = tri.p1[1] - o1, B2 = tri.p1[2] - o2;
+  const T C0 = tri.p2[0] - o0, C1 = tri.p2[1] - o1, C2 = tri.p2[2] - o2;
+  const T Akz = sel3(A0, A1, A2, ikz), Bkz = sel3(B0, B1, B2, ikz), Ckz = sel3(C0, C1, C2, ikz);
+  const T Ax = sel3(A0, A1, A2, ikx) - sx * Akz;
+  const T Ay = sel3(A0, A1, A2, iky) - sy * Akz;
+  const T Bx = sel3(B0, B1, B2, ikx) - sx * Bkz;
+  const T By = sel3(B0, B1, B2, iky) - sy * Bkz;
+  const T Cx = sel3(C0, C1, C2, ikx) - sx * Ckz;
+  const T Cy = sel3(C0, C1, C2, iky) - sy * Ckz;
+  T U = Cx * By - Cy * Bx;
+  T V = Ax * Cy - Ay * Cx;
+  T W = Bx * Ay - By * Ax;
+  if (ok && (U == T(0) || V == T(0) || W == T(0))) { // nanort.h:1094-1107
+    const double CxBy = double(Cx) * double(By), CyBx = double(Cy) * double(Bx);
+    const double AxCy = double(Ax) * double(Cy), AyCx = double(Ay) * double(Cx);
+    const double BxAy = double(Bx) * double(Ay), ByAx = double(By) * double(Ax);
+    U = T(CxBy - CyBx);
+    V = T(AxCy - AyCx);
+    W = T(BxAy - ByAx);
+  }
+  const bool neg = (U < T(0)) | (V < T(0)) | (W < T(0));
+  const bool pos = (U > T(0)) | (V > T(0)) | (W > T(0));
+  ok = ok & !(neg & (cull_i | pos));
+  const T det = U + V + W;
+  ok = ok & !(det == T(0));
+  T tt_i = T(0), uu_i = T(0), vv_i = T(0);
+  if (ok) {
+    const T Az = sz * Akz, Bz = sz * Bkz, Cz = sz * Ckz;
+    const T D = U * Az + V * Bz + W * Cz;
+    const T rcp = T(1.0) / det;
+    tt_i = D * rcp;
+    uu_i = V * rcp;
+    vv_i = W * rcp;
+  }
+  // ... and back to the owners, record by record
+  const unsigned long long okm_ = __ballot(ok);
+  bool got_ = false;
+  uint32_t win_ = 0;
+  for (uint32_t k2_ = 0; k2_ < kmax_; k2_++) {
+    const uint32_t src_ = (base_ + k2_) & 63u;
+    const T ttk = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_ << 2), __float_as_int(tt_i)));
+    const bool okk = (k2_ < cnt) & (((okm_ >> src_) & 1ull) != 0ull);
+    const bool acc = okk & !(ttk > L.hit_t) & !(ttk < L.min_t); // nanort.h:1133-1139: equality and NaN accepted
+    L.hit_t = acc ? ttk : L.hit_t;
+    win_ = acc ? src_ : win_;
+    got_ = got_ | acc;
+  }
+  if (__ballot(got_) != 0ull) {
+    const int wa_ = (int)(win_ << 2);
+    const T uw = __int_as_float(__builtin_amdgcn_ds_bpermute(wa_, __float_as_int(uu_i)));
+    const T vw = __int_as_float(__builtin_amdgcn_ds_bpermute(wa_, __float_as_int(vv_i)));
+    const uint32_t pw = (uint32_t)__builtin_amdgcn_ds_bpermute(wa_, (int)prim_i);
+    L.u = got_ ? uw : L.u;
+    L.v = got_ ? vw : L.v;
+    L.prim = got_ ? pw : L.prim;
+  }
+  return true;
+}
+
 // ORDER (WIDTH = 4 only), two bits: bit 0: 0 = the four slots in the binary loop's order (same leaf sequence as the reference), 1 = by
 // entry distance.  Bit 1 (tunable leaf_compact): the LEAF PHASE hands the records of all the lanes waiting at a leaf out over the
 // whole wave, one record per lane and trip (see "leaf items" below) — same tests on the same operands, accepted in the same order.
@@ -1252,7 +1354,7 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
   constexpr bool LEAFC = (ORDER & 2) != 0;
   // leaf items (LEAFC): which lane owns the record a lane tests, and which of the owner's records it is (lane | k << 6)
   __shared__ uint8_t s_item_owner[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1];
-  __shared__ uint32_t s_item_rec[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1]; // ... and that record's slot in the leaf-ordered array
+  __shared__ const LeafTri<float> *s_item_rec[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1]; // ... and where that record is
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
 
@@ -1524,95 +1626,8 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
         // same tests on the same operands, accepted in the same sequence, so the lane state after the leaf is bit for bit what
         // the owner's own loop leaves (tests/test_gpu_leaf_items.py).  More records than lanes: the owners' loop below.  Trees
         // whose leaves hold more than four records do not take this variant at all (api.hip).
-        const unsigned long long b0_ = __ballot((cnt & 1u) != 0u), b1_ = __ballot((cnt & 2u) != 0u), b2_ = __ballot((cnt & 4u) != 0u);
-        const uint32_t items_ = (uint32_t)__builtin_popcountll(b0_) + 2u * (uint32_t)__builtin_popcountll(b1_) + 4u * (uint32_t)__builtin_popcountll(b2_);
-        if (items_ <= (uint32_t)kWave) {
-          items_done_ = true;
-          const unsigned long long below_ = (1ull << lane) - 1ull;
-          const uint32_t base_ = (uint32_t)__builtin_popcountll(b0_ & below_) + 2u * (uint32_t)__builtin_popcountll(b1_ & below_) +
-                                 4u * (uint32_t)__builtin_popcountll(b2_ & below_);
-          const uint32_t kmax_ = b2_ ? 4u : ((b1_ & b0_) ? 3u : (b1_ ? 2u : 1u)); // most records any lane holds (wave-uniform)
-          volatile uint8_t *own_ = s_item_owner[tid / kWave];
-          volatile uint32_t *rec_ = s_item_rec[tid / kWave];
-#pragma unroll
-          for (uint32_t k_ = 0; k_ < 4u; k_++)
-            if (k_ < cnt) {
-              own_[base_ + k_] = (uint8_t)lane;
-              rec_[base_ + k_] = first + k_;
-            }
-          // (LDS operations of one wave are performed in issue order and the accesses are volatile: the reads below see the writes)
-          const bool item_ = lane < items_;
-          const uint32_t slot_ = item_ ? rec_[lane] : 0u;
-          const int oa_ = item_ ? (int)((uint32_t)own_[lane] << 2) : 0; // the owner lane's byte address for ds_bpermute
-          const LeafTri<T> tri = a.tris[slot_]; // (issued before the constants are fetched: the two latencies overlap)
-          const float o0 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org0))), o1 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org1))),
-                      o2 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org2)));
-          const float sx = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sx))), sy = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sy))),
-                      sz = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sz)));
-          const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute(oa_, (int)L.pk);
-          const int ikx = (int)(pk & 3u), iky = (int)((pk >> 2) & 3u), ikz = (int)((pk >> 4) & 3u);
-          // TriangleIntersector::Intersect (nanort.h:1054-1150) up to the hit distance: tri_test's own operations on the owner's constants
-          const uint32_t prim_i = tri.prim_id;
-          bool ok = PLAIN ? item_ : (item_ & (prim_i >= a.range0) & (prim_i < a.range1) & (prim_i != a.skip_prim));
-          const bool cull_i = PLAIN ? false : cull;
-          const T A0 = tri.p0[0] - o0, A1 = tri.p0[1] - o1, A2 = tri.p0[2] - o2;
-          const T B0 = tri.p1[0] - o0, B1 = tri.p1[1] - o1, B2 = tri.p1[2] - o2;
-          const T C0 = tri.p2[0] - o0, C1 = tri.p2[1] - o1, C2 = tri.p2[2] - o2;
-          const T Akz = sel3(A0, A1, A2, ikz), Bkz = sel3(B0, B1, B2, ikz), Ckz = sel3(C0, C1, C2, ikz);
-          const T Ax = sel3(A0, A1, A2, ikx) - sx * Akz;
-          const T Ay = sel3(A0, A1, A2, iky) - sy * Akz;
-          const T Bx = sel3(B0, B1, B2, ikx) - sx * Bkz;
-          const T By = sel3(B0, B1, B2, iky) - sy * Bkz;
-          const T Cx = sel3(C0, C1, C2, ikx) - sx * Ckz;
-          const T Cy = sel3(C0, C1, C2, iky) - sy * Ckz;
-          T U = Cx * By - Cy * Bx;
-          T V = Ax * Cy - Ay * Cx;
-          T W = Bx * Ay - By * Ax;
-          if (ok && (U == T(0) || V == T(0) || W == T(0))) { // nanort.h:1094-1107
-            const double CxBy = double(Cx) * double(By), CyBx = double(Cy) * double(Bx);
-            const double AxCy = double(Ax) * double(Cy), AyCx = double(Ay) * double(Cx);
-            const double BxAy = double(Bx) * double(Ay), ByAx = double(By) * double(Ax);
-            U = T(CxBy - CyBx);
-            V = T(AxCy - AyCx);
-            W = T(BxAy - ByAx);
-          }
-          const bool neg = (U < T(0)) | (V < T(0)) | (W < T(0));
-          const bool pos = (U > T(0)) | (V > T(0)) | (W > T(0));
-          ok = ok & !(neg & (cull_i | pos));
-          const T det = U + V + W;
-          ok = ok & !(det == T(0));
-          T tt_i = T(0), uu_i = T(0), vv_i = T(0);
-          if (ok) {
-            const T Az = sz * Akz, Bz = sz * Bkz, Cz = sz * Ckz;
-            const T D = U * Az + V * Bz + W * Cz;
-            const T rcp = T(1.0) / det;
-            tt_i = D * rcp;
-            uu_i = V * rcp;
-            vv_i = W * rcp;
-          }
-          // ... and back to the owners, record by record
-          const unsigned long long okm_ = __ballot(ok);
-          bool got_ = false;
-          uint32_t win_ = 0;
-          for (uint32_t k2_ = 0; k2_ < kmax_; k2_++) {
-            const uint32_t src_ = (base_ + k2_) & 63u;
-            const T ttk = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_ << 2), __float_as_int(tt_i)));
-            const bool okk = (k2_ < cnt) & (((okm_ >> src_) & 1ull) != 0ull);
-            const bool acc = okk & !(ttk > L.hit_t) & !(ttk < L.min_t); // nanort.h:1133-1139: equality and NaN accepted
-            L.hit_t = acc ? ttk : L.hit_t;
-            win_ = acc ? src_ : win_;
-            got_ = got_ | acc;
-          }
-          if (__ballot(got_) != 0ull) {
-            const int wa_ = (int)(win_ << 2);
-            const T uw = __int_as_float(__builtin_amdgcn_ds_bpermute(wa_, __float_as_int(uu_i)));
-            const T vw = __int_as_float(__builtin_amdgcn_ds_bpermute(wa_, __float_as_int(vv_i)));
-            const uint32_t pw = (uint32_t)__builtin_amdgcn_ds_bpermute(wa_, (int)prim_i);
-            L.u = got_ ? uw : L.u;
-            L.v = got_ ? vw : L.v;
-            L.prim = got_ ? pw : L.prim;
-          }
-        }
+        items_done_ = leaf_items_one_trip<PLAIN>(L, cnt, a.tris + first, lane, s_item_owner[tid / kWave], s_item_rec[tid / kWave], a.range0, a.range1,
+                                                 a.skip_prim, cull);
       }
       if (items_done_) {
         // (the waiting lanes' records were tested as items)
@@ -2061,6 +2076,8 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
   typedef float T;
   typedef StackEntry<float> SE;
   __shared__ SE::type s_stack[STACK][kTraverseBlock];
+  __shared__ uint8_t s_item_owner[kTraverseBlock / kWave][kWave]; // leaf items (leaf_items_one_trip)
+  __shared__ const LeafTri<float> *s_item_rec[kTraverseBlock / kWave][kWave];
   // (profiling build only) per wave: [0] outer trips, [1..2] level-change blocks run / lanes served, [3..4] inner-phase trips / lane
   // steps, [5] of those steps in the top-level tree, [6..7] leaf-phase trips / lanes with a first record, [8] instances opened,
   // [9] top-level leaves reached, [10..12] shader-clock ticks in level changes / the inner phase / the leaf phase
@@ -2343,6 +2360,10 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
         lcnt = (cur >> kPackedFirstBits) + 1u;
         first = cur & kPackedFirstMask;
       }
+      // (few lanes wait at a leaf in this kernel — 10 of 64 on the instanced scenes: their records nearly always fit one trip)
+      const bool items_done_ = !STATS && a.leaf_items != 0u &&
+                               leaf_items_one_trip<true>(L, lcnt, tris + first, lane, s_item_owner[tid / kWave], s_item_rec[tid / kWave], 0u, 0u, 0u, false);
+      if (!items_done_)
       for (uint32_t k = 0; __ballot(k < lcnt) != 0ull; k += 2u) {
         if (STATS) {
           st[6]++;

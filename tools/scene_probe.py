@@ -41,6 +41,16 @@ for N in COUNTS:
     t0 = time.perf_counter(); sc.Commit(); tc = (time.perf_counter() - t0) * 1e3
     ms = timed(lambda: sc.TraverseBatchDevice(d, o, m), reps=5)
     print("%d instances of a %d-triangle mesh: commit %.1f ms, scene %.3f ms = %.1f Mrays/s, hit fraction %.3f, re-done by the listing path %d" % (N, sf.shape[0], tc, ms, len(rays) / ms / 1e3, float(m.float().mean()), sc.LastRedone()), flush=True)
+    for kv in [x for x in sys.argv[1:] if "=" in x]:  # name=v0,v1,...: the same query under each value of a scene tunable, records compared with the first
+        name, vals = kv.split("=")
+        ref = None
+        for v in vals.split(","):
+            sc.SetTunable(name, int(v))
+            msv = timed(lambda: sc.TraverseBatchDevice(d, o, m), reps=7)
+            rec = (o.clone(), m.clone())
+            same = True if ref is None else bool(torch.equal(rec[0], ref[0]) and torch.equal(rec[1], ref[1]))
+            ref = ref or rec
+            print("    %s = %s: %.3f ms = %.1f Mrays/s  records identical to the first: %s" % (name, v, msv, len(rays) / msv / 1e3, same), flush=True)
     if "--ab" in sys.argv:
         sc.SetTunable("single_pass", 0)
         ms0 = timed(lambda: sc.TraverseBatchDevice(d, o, m), reps=5)
