@@ -1251,7 +1251,7 @@ do {                                                                            
 // the leaf is bit for bit what the owner's own loop leaves (tests/test_gpu_leaf_items.py, tests/test_gpu_scene.py).  Returns false
 // — nothing done — when the records do not fit one trip: the caller's owner loop then runs.  Wave-uniform control flow only.
 template <bool PLAIN>
-__device__ __forceinline__ bool leaf_items_one_trip(Lane<float> &L, uint32_t cnt, const LeafTri<float> *first, unsigned lane, volatile uint8_t *own_,
+__device__ __forceinline__ bool leaf_items_one_trip(Lane<float> &L, uint32_t cnt, const LeafTri<float> *first, unsigned lane, volatile uint32_t *own_,
                                                     const LeafTri<float> *volatile *rec_, uint32_t range0, uint32_t range1, uint32_t skip_prim, bool cull) {
   typedef float T;
   const unsigned long long b0_ = __ballot((cnt & 1u) != 0u), b1_ = __ballot((cnt & 2u) != 0u), b2_ = __ballot((cnt & 4u) != 0u);
@@ -1264,14 +1264,14 @@ __device__ __forceinline__ bool leaf_items_one_trip(Lane<float> &L, uint32_t cnt
 #pragma unroll
   for (uint32_t k_ = 0; k_ < 4u; k_++)
     if (k_ < cnt) {
-      own_[base_ + k_] = (uint8_t)lane;
+      own_[base_ + k_] = lane; // (a word per item: sub-word stores of neighbouring lanes into one word would queue)
       rec_[base_ + k_] = first + k_;
     }
   // (LDS operations of one wave are performed in issue order and the accesses are volatile: the reads below see the writes)
   const bool item_ = lane < items_;
   const uint32_t me_ = item_ ? lane : 0u; // (a lane without an item repeats item 0 — there is one: the callers come here with a lane waiting — and drops the result)
   const LeafTri<float> *slot_ = rec_[me_];
-  const int oa_ = (int)((uint32_t)own_[me_] << 2); // the owner lane's byte address for ds_bpermute
+  const int oa_ = (int)(own_[me_] << 2); // the owner lane's byte address for ds_bpermute
   const LeafTri<T> tri = *slot_; // (issued before the constants are fetched: the two latencies overlap)
   const float o0 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org0))), o1 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org1))),
               o2 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org2)));
@@ -1353,7 +1353,7 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
   static_assert((ORDER & 2) == 0 || (KIND == kPrimTriangles && !STATS), "leaf items: triangle records, production instantiations");
   constexpr bool LEAFC = (ORDER & 2) != 0;
   // leaf items (LEAFC): which lane owns the record a lane tests, and which of the owner's records it is (lane | k << 6)
-  __shared__ uint8_t s_item_owner[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1];
+  __shared__ uint32_t s_item_owner[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1];
   __shared__ const LeafTri<float> *s_item_rec[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1]; // ... and where that record is
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
@@ -2076,7 +2076,7 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
   typedef float T;
   typedef StackEntry<float> SE;
   __shared__ SE::type s_stack[STACK][kTraverseBlock];
-  __shared__ uint8_t s_item_owner[kTraverseBlock / kWave][kWave]; // leaf items (leaf_items_one_trip)
+  __shared__ uint32_t s_item_owner[kTraverseBlock / kWave][kWave]; // leaf items (leaf_items_one_trip)
   __shared__ const LeafTri<float> *s_item_rec[kTraverseBlock / kWave][kWave];
   // (profiling build only) per wave: [0] outer trips, [1..2] level-change blocks run / lanes served, [3..4] inner-phase trips / lane
   // steps, [5] of those steps in the top-level tree, [6..7] leaf-phase trips / lanes with a first record, [8] instances opened,
