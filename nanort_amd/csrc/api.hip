@@ -159,10 +159,6 @@ struct nrt_ctx {
   // 1 (opt-in): by entry distance, +2...5 % — the closest t is the reference's except where a leaf box's entry distance rounds
   // above a hit inside it, and among primitives at exactly the same t another one may be named (contract-level parity)
   int order4 = 0;
-  // node 0's box on the host (page-locked: it comes back with a build, nrtGetTreeBounds answers from it) and the early test built on it
-  void *h_root_box = nullptr;  // 6 x T, written by the build's own stream / by nrtSetTree
-  bool root_box_valid = false;
-  unsigned root_early = 16;    // tunable root_early: 0 = off; else node 0's box is tested as a ray is fetched (traverse.hip) and the refill goes round again for at least this many freed lanes
   int leaf_compact = 1; // traverse.hip "leaf items" (round 6): when the records of all the lanes waiting at a leaf fit one trip of the wave, they are tested one per lane with the owner's ray constants and accepted by the owner in record order — records bit-identical, C3 +2 %, C4 tile +2.8 %; 0: every owner tests its own records
   int wide_scramble = 0; // probe (tunable wide_scramble): the private node records in a pseudo-random order instead of pre-order
   unsigned wide4_blocks_per_cu = 0;
@@ -252,7 +248,6 @@ static hipError_t wait_for_launches(nrt_ctx *c) {
 
 // Forget the current tree (the buffers stay allocated for the next one).
 static void free_tree(nrt_ctx *c) {
-  c->root_box_valid = false;
   c->generation++; // whoever cached device addresses / flags of the old tree (a committed nrt_scene) can tell
   c->d_wide = nullptr;
   c->d_wide4 = nullptr;
@@ -304,7 +299,6 @@ static const TunableDesc kTunables[] = {
 #endif
     NRT_TUNABLE("wide", 0, 1, wide, int),                         // 0: the literal BVHNode loop
     NRT_TUNABLE("wide4", 0, 1, wide4, int),                       // two tree levels per step (next build / set_tree)
-    NRT_TUNABLE("root_early", 0, 64, root_early, unsigned),      // nested trees with a branch root: node 0's box tested as a ray is fetched (0: off; else the refill's second-round threshold); records unaffected
     NRT_TUNABLE("leaf_compact", 0, 1, leaf_compact, int),         // two-level walk, triangle trees with leaves of <= 4 records: leaf phase over items (records bit-identical)
     NRT_TUNABLE("order4", 0, 1, order4, int),                     // two-level walk: 0 (default) = the reference's order, every field bit-identical; 1 = slots by entry distance (faster; contract-level parity at ties)
     NRT_TUNABLE("launch_timing", 0, 1, launch_timing, int),       // == nrtSetLaunchTiming
@@ -372,7 +366,6 @@ nrt_status nrtCreate(int device, nrt_ctx **out) {
       (e = hipEventCreate(&c->ev_b0)) != hipSuccess || (e = hipEventCreate(&c->ev_b1)) != hipSuccess ||
       (e = hipEventCreateWithFlags(&c->ev_build_state, hipEventDisableTiming)) != hipSuccess ||
       (e = hipHostMalloc(&c->build_state, kBuildPinnedBytes, hipHostMallocDefault)) != hipSuccess ||
-      (e = hipHostMalloc(&c->h_root_box, 64, hipHostMallocDefault)) != hipSuccess ||
       (e = hipMalloc((void **)&c->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess) {
     fail(nullptr, NRT_ERR_DEVICE, "nrtCreate: %s", hipGetErrorString(e));
     nrtDestroy(c);
@@ -436,7 +429,6 @@ void nrtDestroy(nrt_ctx *c) {
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->d_counters) (void)hipFree(c->d_counters);
-  if (c->h_root_box) (void)hipHostFree(c->h_root_box);
   if (c->build_state) (void)hipHostFree(c->build_state);
   hipEvent_t evs[] = {c->ev_b0, c->ev_b1, c->ev_build_state};
   for (hipEvent_t ev : evs)
@@ -719,8 +711,6 @@ static nrt_status set_tree(nrt_ctx *c, const typename Wire<T>::Node *nodes, uint
   c->d_nodes = c->b_nodes.p;
   c->d_indices = (uint32_t *)c->b_indices.p;
   HIPCHK(c, hipMemcpy(c->d_nodes, nodes, num_nodes * sizeof(typename Wire<T>::Node), hipMemcpyHostToDevice));
-  memcpy(c->h_root_box, &nodes[0], 6 * sizeof(T)); // bmin, bmax of node 0
-  c->root_box_valid = true;
   HIPCHK(c, hipMemcpy(c->d_indices, indices, num_indices * sizeof(uint32_t), hipMemcpyHostToDevice));
   if ((st = finish_tree<T>(c))) return st;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -747,14 +737,10 @@ static nrt_status get_tree_bounds(nrt_ctx *c, T *bmin, T *bmax) {
   if (!c || !bmin || !bmax) return NRT_ERR_INVALID;
   if (c->prec != (int)sizeof(T)) return fail(c, NRT_ERR_PRECISION, "nrtGetTreeBounds: precision mismatch");
   if (!c->d_nodes) return fail(c, NRT_ERR_INVALID, "nrtGetTreeBounds: no tree");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   T box[6]; // BVHNode<T> starts with bmin[3], bmax[3] (nanort.h:498-550)
-  if (c->root_box_valid) { // (it came back with the build / nrtSetTree)
-    memcpy(box, c->h_root_box, sizeof(box));
-  } else {
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(box, c->d_nodes, sizeof(box), hipMemcpyDeviceToHost));
-  }
+  HIPCHK(c, hipMemcpy(box, c->d_nodes, sizeof(box), hipMemcpyDeviceToHost));
   for (int k = 0; k < 3; k++) {
     bmin[k] = box[k];
     bmax[k] = box[3 + k];
@@ -822,10 +808,8 @@ static nrt_status build(nrt_ctx *c, const typename Wire<T>::BuildOptions *opt, n
     free_tree(c);
     return fst;
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_root_box, c->d_nodes, 6 * sizeof(T), hipMemcpyDeviceToHost, c->stream)); // node 0's bmin, bmax (nanort.h:498-550)
   HIPCHK(c, hipEventRecord(c->ev_b1, c->stream));
   HIPCHK(c, hipEventSynchronize(c->ev_b1));
-  c->root_box_valid = true;
   c->have_build_time = true;
   float ms = 0.f;
   HIPCHK(c, hipEventElapsedTime(&ms, c->ev_b0, c->ev_b1));
@@ -1034,8 +1018,6 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.any_hit = any_hit ? 1u : 0u;
   a.plain_options = plain_options ? 1u : 0u;
   a.root_test = c->tree_nested ? 0u : 1u;
-  a.root_early = (c->root_early && c->root_box_valid && c->tree_nested && c->root_is_branch) ? c->root_early : 0u;
-  memcpy(a.root_box, c->h_root_box, sizeof(a.root_box));
   a.order4 = (c->order4 && use_wide4 && !spheres && !any_hit && !(dbg & (32u | 8192u))) ? 1u : 0u;
   a.leaf_items = (c->leaf_compact && use_wide4 && c->prim_kind == kPrimTriangles && c->max_leaf_count <= 4u && !(dbg & (32u | 8192u))) ? 1u : 0u;
   a.spill = (uint32_t *)slot->spill.p;

@@ -376,8 +376,6 @@ struct TraverseArgs {
   uint32_t any_hit;       // occlusion query (opt-in extension): a ray stops at the first primitive it accepts
   uint32_t plain_options; // the options above cannot reject any primitive of this tree (host-checked)
   uint32_t root_test;     // node 0's box must be tested before its children (an adopted tree whose child boxes may stick out)
-  uint32_t root_early;    // > 0 (tunable root_early): node 0's box — root_box below, kernel arguments — is tested as a ray is fetched (the reference's own first test, nanort.h:2526-2533); a ray that misses it is finished on the spot and, when at least this many lanes of the wave are free again, the refill goes round once more
-  T root_box[6];          // node 0's bmin, bmax (valid when root_early != 0)
   uint32_t leaf_items;    // two-level walk: the leaf phase hands the waiting lanes' records out over the whole wave (tunable leaf_compact; leaves of <= 4 records)
   uint32_t order4;        // two-level walk: enter the four slots of a record by entry distance instead of the binary loop's order (tunable order4)
   uint32_t *spill;        // [spill_levels][spill_stride] overflow stack, may be null

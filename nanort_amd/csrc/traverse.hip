@@ -1467,15 +1467,7 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
           // The reference pops and tests the root first (nanort.h:2526-2533).  For a branch root that test is implied by
           // the first step: a ray that misses the root's box misses both children's boxes (each lies inside it and the
           // slab arithmetic is monotone), so the step on record 0 ends in W_POP with an empty stack — the same miss.
-          if (a.root_is_branch && !a.root_test && a.root_early) {
-            // ... but a frame full of background pays for it: a ray that misses the whole scene would walk one record (a 128-byte
-            // fetch, ~200 instructions) and then hold its lane until the wave's next refill.  With the root's box in the kernel
-            // arguments the reference's own first test costs ~20 instructions here, the lane is free again at once — its miss
-            // record is written by the next round of this loop, which takes another ray for it (C2: 58 % of the primaries).
-            cur = 0u;
-            const T rlo_[3] = {a.root_box[0], a.root_box[1], a.root_box[2]}, rhi_[3] = {a.root_box[3], a.root_box[4], a.root_box[5]};
-            state = slab_test<T>(L, rlo_, rhi_) ? W_TRAV : W_IDLE; // (W_IDLE with rid valid: finished, not yet written)
-          } else if (a.root_is_branch && !a.root_test) {
+          if (a.root_is_branch && !a.root_test) {
             cur = 0u;
             state = W_TRAV;
           } else if (a.root_is_branch) { // adopted tree whose child boxes may stick out of node 0's box: test it, as the reference does
@@ -1496,8 +1488,6 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
         }
         ck.next += take;
         fresh = __ballot(state == W_IDLE);
-        // (lanes whose new ray missed the root's box are free again: another round only for a worthwhile number of them)
-        if (a.root_early && take == want && (unsigned)__builtin_popcountll(fresh) < a.root_early) break;
       }
       idle = __ballot(state == W_IDLE);
     }
