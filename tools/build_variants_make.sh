@@ -9,11 +9,11 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=
 mkdir -p tools/bin/variants
 (cd nanort_amd/csrc && make -s >/dev/null)
 src=${VARIANT_SRC:-build}
-others=$(for o in api traverse build scene; do [ $o != $src ] && echo -n "$o.o "; done)
+others=$(for o in api traverse build scene group; do [ $o != $src ] && echo -n "$o.o "; done)
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   (cd nanort_amd/csrc && /opt/rocm/bin/hipcc $F $flags -c $src.hip -o /tmp/${src}_variant_$name.o &&
-   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/variants/$name.so $others /tmp/${src}_variant_$name.o) &
+   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/variants/$name.so $others /tmp/${src}_variant_$name.o -ldl) &
 done
 wait
 ls -la tools/bin/variants
