@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1: run the N > 1 code path anyway — torch.distributed over RCCL (backend nccl, world size 1), the asynchronous "
                          "double-buffered gather of both waves' records on device tensors — so that the exchange executes on a one-GPU box")
+    ap.add_argument("--gather", default="torch", choices=("torch", "cabi"),
+                    help="with a process group: how the records reach rank 0 — torch.distributed.gather over RCCL (default), or the C ABI's own "
+                         "nrtGroupCreateRanked / nrtGroupTraverseGather (RCCL send / recv from the library: what a C++ host runs)")
     ap.add_argument("--check-gather", action="store_true", help="with a process group: compare the frame the root assembled from the gathers with the ranks' own records")
     ap.add_argument("--pmc-dir", default=None, help="keep the raw rocprofv3 counter CSVs here")
     ap.add_argument("--extras-file", default=None, help="where the full result object goes (default gpurun_out/bench_extras.json)")
@@ -170,7 +173,12 @@ def main():
     c1, c2 = wl.counters()
     bytes1, bytes2 = algorithmic_bytes(c1, wl.rb), algorithmic_bytes(c2, wl.rb)
 
-    T = Timed(wl, args.steps, args.warmup, world, rank, dist, shared, check_gather=args.check_gather)
+    if args.gather == "cabi" and dist is not None and not shared:
+        from benchlib.timed import TimedCAbi
+
+        T = TimedCAbi(wl, args.steps, args.warmup, world, rank, dist, check_gather=args.check_gather)
+    else:
+        T = Timed(wl, args.steps, args.warmup, world, rank, dist, shared, check_gather=args.check_gather)
     k_ms1, k_ms2, kernel_name, region_ms = T.k_ms1, T.k_ms2, T.kernel_name, T.region_ms
     launch_ms = region_ms / (2 * args.steps)
     if rank == 0:
@@ -267,7 +275,7 @@ def main():
             "roofline": roof,
         }
         if dist is not None:
-            out["multi_gpu"] = dict(T.per_rank, rccl_ranks=world, backend="gloo (test hook)" if shared else "nccl (RCCL)",
+            out["multi_gpu"] = dict(T.per_rank, rccl_ranks=world, backend="gloo (test hook)" if shared else ("RCCL through the C ABI (nrtGroup*)" if args.gather == "cabi" else "nccl (RCCL)"),
                                     gathered_bytes_per_step=T.gathered_bytes_per_step)
             if T.gather_check is not None:
                 out["multi_gpu"]["gather_check"] = T.gather_check

@@ -401,6 +401,15 @@ NRT_API nrt_status nrtGroupTraverseGather_f32(nrt_group *group, const nrt_ray_f3
 NRT_API nrt_status nrtGroupTraverseGather_f64(nrt_group *group, const nrt_ray_f64 *const *d_rays, const uint64_t *counts, uint64_t total_rays,
                                               uint64_t row_len, const nrt_trace_options *options, uint32_t root_tile, nrt_hit_f64 *d_frame_hits,
                                               uint8_t *d_frame_mask);
+/* Ragged waves (secondary rays: every tile has its own number of them) — TILE-MAJOR gather: tile t traces counts[k] <= slot_rays
+ * rays and the root receives the tile's whole slot at d_tiles_hits + t * slot_rays (and d_tiles_mask + t * slot_rays, optional);
+ * records past a tile's count are undefined.  No frame order to restore: RCCL receives straight into the caller's array. */
+NRT_API nrt_status nrtGroupTraverseGatherTiles_f32(nrt_group *group, const nrt_ray_f32 *const *d_rays, const uint64_t *counts, uint64_t slot_rays,
+                                                   const nrt_trace_options *options, uint32_t root_tile, nrt_hit_f32 *d_tiles_hits,
+                                                   uint8_t *d_tiles_mask);
+NRT_API nrt_status nrtGroupTraverseGatherTiles_f64(nrt_group *group, const nrt_ray_f64 *const *d_rays, const uint64_t *counts, uint64_t slot_rays,
+                                                   const nrt_trace_options *options, uint32_t root_tile, nrt_hit_f64 *d_tiles_hits,
+                                                   uint8_t *d_tiles_mask);
 NRT_API nrt_status nrtGroupSynchronize(nrt_group *group);
 /* bytes the last gather moved by RCCL / by peer copies / read in place on the root GPU */
 NRT_API nrt_status nrtGroupLastTraffic(const nrt_group *group, uint64_t *bytes_rccl, uint64_t *bytes_peer, uint64_t *bytes_in_place);

@@ -29,7 +29,7 @@ SYMBOLS = [
     "nrtOccludedBatch_f32", "nrtOccludedBatch_f64", "nrtOccludedBatchDevice_f32", "nrtOccludedBatchDevice_f64",
     "nrtLastTraverseMs", "nrtSetLaunchTiming", "nrtSetTunable", "nrtGetTunable", "nrtLastBuildMs", "nrtLastKernelName", "nrtHostAlloc", "nrtHostFree",
     "nrtGroupUniqueId", "nrtGroupCreate", "nrtGroupCreateRanked", "nrtGroupDestroy", "nrtGroupLastError", "nrtGroupSetTunable", "nrtGroupInfo",
-    "nrtGroupTileRays", "nrtGroupTraverseGather_f32", "nrtGroupTraverseGather_f64", "nrtGroupSynchronize", "nrtGroupLastTraffic",
+    "nrtGroupTileRays", "nrtGroupTraverseGather_f32", "nrtGroupTraverseGather_f64", "nrtGroupTraverseGatherTiles_f32", "nrtGroupTraverseGatherTiles_f64", "nrtGroupSynchronize", "nrtGroupLastTraffic",
     "nrtSceneCreate", "nrtSceneDestroy", "nrtSceneLastError", "nrtSceneAddNode_f32", "nrtSceneCommit", "nrtSceneNodeState_f32",
     "nrtSceneBounds_f32", "nrtSceneTraverseBatch_f32", "nrtSceneTraverseBatchDevice_f32", "nrtSceneSetTunable", "nrtSceneLastRedone", "nrtSceneLastPath",
 ]

@@ -501,6 +501,126 @@ static nrt_status group_traverse_gather(nrt_group *g, const void *const *d_rays,
   return NRT_OK;
 }
 
+// Ragged waves (secondary rays: every tile has its own number of them): tile-major gather.  Tile t traces counts[k] <= slot_rays
+// rays into a buffer of slot_rays records; the root receives every tile's WHOLE slot at d_out + t * slot_rays (records past a
+// tile's count are undefined) — no frame order to restore, so records arrive where they stay: RCCL receives straight into the
+// caller's array, tiles on the root's own device are copied device to device.
+template <int HIT_BYTES>
+static nrt_status group_traverse_gather_tiles(nrt_group *g, const void *const *d_rays, const uint64_t *counts, uint64_t slot_rays,
+                                              const nrt_trace_options *opt, uint32_t root_tile, void *d_tiles_hits, uint8_t *d_tiles_mask) {
+  if (!g) return NRT_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(g->mu);
+  const uint32_t N = g->num_tiles;
+  if (root_tile >= N) return gfail(g, NRT_ERR_INVALID, "root tile out of range");
+  if (!d_rays || !counts || slot_rays == 0) return gfail(g, NRT_ERR_INVALID, "NULL ray table / empty slot");
+  int root_local = -1;
+  for (size_t k = 0; k < g->local.size(); k++) {
+    const nrt_group::Local &l = g->local[k];
+    if (counts[k] > slot_rays) return gfail(g, NRT_ERR_INVALID, "tile " + std::to_string(l.tile) + ": " + std::to_string(counts[k]) + " rays do not fit its slot of " + std::to_string(slot_rays));
+    if (counts[k] && !d_rays[k]) return gfail(g, NRT_ERR_INVALID, "tile " + std::to_string(l.tile) + ": NULL rays");
+    if (l.tile == root_tile) root_local = (int)k;
+  }
+  const bool i_am_root = root_local >= 0;
+  if (i_am_root && !d_tiles_hits) return gfail(g, NRT_ERR_INVALID, "the root needs an output buffer");
+  const bool send_mask = g->ranked ? true : d_tiles_mask != nullptr;
+  g->last_bytes_rccl = g->last_bytes_peer = g->last_bytes_in_place = 0;
+  const size_t slot_b = (size_t)slot_rays * HIT_BYTES;
+  for (size_t k = 0; k < g->local.size(); k++) {
+    nrt_group::Local &l = g->local[k];
+    GHIP(g, hipSetDevice(l.device));
+    if (g->frame_done_device >= 0) GHIP(g, hipStreamWaitEvent(l.stream, g->frame_done, 0));
+    GHIP(g, devbuf_ensure(&l.hits, slot_b));
+    GHIP(g, devbuf_ensure(&l.mask, slot_rays));
+    if (!counts[k]) continue;
+    nrt_status st = HIT_BYTES == 16
+                        ? nrtTraverseBatchDevice_f32(l.ctx, (const nrt_ray_f32 *)d_rays[k], counts[k], opt, (nrt_hit_f32 *)l.hits.p, (uint8_t *)l.mask.p, l.stream)
+                        : nrtTraverseBatchDevice_f64(l.ctx, (const nrt_ray_f64 *)d_rays[k], counts[k], opt, (nrt_hit_f64 *)l.hits.p, (uint8_t *)l.mask.p, l.stream);
+    if (st) return gfail(g, st, "tile " + std::to_string(l.tile) + ": " + nrtLastError(l.ctx));
+  }
+  const int root_dev = i_am_root ? g->local[root_local].device : -1;
+  hipStream_t root_stream = i_am_root ? g->local[root_local].stream : nullptr;
+  auto local_of = [&](uint32_t t) {
+    for (size_t k = 0; k < g->local.size(); k++)
+      if (g->local[k].tile == t) return (int)k;
+    return -1;
+  };
+  auto in_place = [&](uint32_t t) { // the tile's records are on the root's device already: a device-to-device copy
+    const int lk = local_of(t);
+    return i_am_root && lk >= 0 && g->local[lk].device == root_dev && !(g->self_send && t == root_tile);
+  };
+  auto travels = [&](const nrt_group::Local &l) {
+    if (g->ranked) return l.tile != root_tile || g->self_send != 0;
+    return i_am_root && (l.device != root_dev || (g->self_send && l.tile == root_tile));
+  };
+  if (g->transport == 0 && !g->comms.empty()) {
+    Rccl &r = rccl();
+    bool any = false;
+    for (size_t k = 0; k < g->local.size(); k++) any = any || travels(g->local[k]);
+    if (i_am_root)
+      for (uint32_t t = 0; t < N; t++) any = any || !in_place(t);
+    if (any) {
+      GNCCL(g, r.GroupStart());
+      for (size_t k = 0; k < g->local.size(); k++) {
+        nrt_group::Local &l = g->local[k];
+        if (!travels(l)) continue;
+        GHIP(g, hipSetDevice(l.device));
+        GNCCL(g, r.Send(l.hits.p, slot_b, ncclUint8, g->tile_rank[root_tile], g->comms[l.comm], l.stream));
+        if (send_mask) GNCCL(g, r.Send(l.mask.p, slot_rays, ncclUint8, g->tile_rank[root_tile], g->comms[l.comm], l.stream));
+        g->last_bytes_rccl += slot_b + (send_mask ? slot_rays : 0);
+      }
+      if (i_am_root) {
+        GHIP(g, hipSetDevice(root_dev));
+        for (uint32_t t = 0; t < N; t++) {
+          if (in_place(t)) continue;
+          GNCCL(g, r.Recv((char *)d_tiles_hits + (size_t)t * slot_b, slot_b, ncclUint8, g->tile_rank[t], g->comms[g->local[root_local].comm], root_stream));
+          if (send_mask) {
+            // (the flags travel even when the root does not want them: a sender cannot know; they land in the tile's staging then)
+            uint8_t *dst = d_tiles_mask ? d_tiles_mask + (size_t)t * slot_rays : nullptr;
+            if (!dst) {
+              GHIP(g, devbuf_ensure(&g->stage_mask[t], slot_rays));
+              dst = (uint8_t *)g->stage_mask[t].p;
+            }
+            GNCCL(g, r.Recv(dst, slot_rays, ncclUint8, g->tile_rank[t], g->comms[g->local[root_local].comm], root_stream));
+          }
+        }
+      }
+      GNCCL(g, r.GroupEnd());
+    }
+  } else if (i_am_root) {
+    for (size_t k = 0; k < g->local.size(); k++) {
+      nrt_group::Local &l = g->local[k];
+      if (!travels(l)) continue;
+      GHIP(g, hipSetDevice(l.device));
+      GHIP(g, hipMemcpyPeerAsync((char *)d_tiles_hits + (size_t)l.tile * slot_b, root_dev, l.hits.p, l.device, slot_b, l.stream));
+      if (d_tiles_mask) GHIP(g, hipMemcpyPeerAsync(d_tiles_mask + (size_t)l.tile * slot_rays, root_dev, l.mask.p, l.device, slot_rays, l.stream));
+      g->last_bytes_peer += slot_b + (d_tiles_mask ? slot_rays : 0);
+    }
+  } else if (g->ranked) {
+    return gfail(g, NRT_ERR_INVALID, "a ranked group needs RCCL");
+  }
+  if (i_am_root) {
+    for (size_t k = 0; k < g->local.size(); k++) { // tiles on the root's own device: copied on their own streams, which the root's then waits for
+      nrt_group::Local &l = g->local[k];
+      if (in_place(l.tile)) {
+        GHIP(g, hipSetDevice(l.device));
+        GHIP(g, hipMemcpyAsync((char *)d_tiles_hits + (size_t)l.tile * slot_b, l.hits.p, slot_b, hipMemcpyDeviceToDevice, l.stream));
+        if (d_tiles_mask) GHIP(g, hipMemcpyAsync(d_tiles_mask + (size_t)l.tile * slot_rays, l.mask.p, slot_rays, hipMemcpyDeviceToDevice, l.stream));
+        g->last_bytes_in_place += slot_b;
+      }
+      if ((int)k == root_local) continue;
+      GHIP(g, hipSetDevice(l.device));
+      GHIP(g, hipEventRecord(l.done, l.stream));
+      GHIP(g, hipSetDevice(root_dev));
+      GHIP(g, hipStreamWaitEvent(root_stream, l.done, 0));
+    }
+    GHIP(g, hipSetDevice(root_dev));
+    if (!g->frame_done) GHIP(g, hipEventCreateWithFlags(&g->frame_done, hipEventDisableTiming));
+    GHIP(g, hipEventRecord(g->frame_done, root_stream));
+    g->frame_done_device = root_dev;
+  }
+  return NRT_OK;
+}
+
 extern "C" {
 
 nrt_status nrtGroupTraverseGather_f32(nrt_group *g, const nrt_ray_f32 *const *d_rays, const uint64_t *counts, uint64_t total_rays, uint64_t row_len,
@@ -510,6 +630,14 @@ nrt_status nrtGroupTraverseGather_f32(nrt_group *g, const nrt_ray_f32 *const *d_
 nrt_status nrtGroupTraverseGather_f64(nrt_group *g, const nrt_ray_f64 *const *d_rays, const uint64_t *counts, uint64_t total_rays, uint64_t row_len,
                                       const nrt_trace_options *opt, uint32_t root_tile, nrt_hit_f64 *d_frame_hits, uint8_t *d_frame_mask) {
   return group_traverse_gather<32>(g, (const void *const *)d_rays, counts, total_rays, row_len, opt, root_tile, d_frame_hits, d_frame_mask);
+}
+nrt_status nrtGroupTraverseGatherTiles_f32(nrt_group *g, const nrt_ray_f32 *const *d_rays, const uint64_t *counts, uint64_t slot_rays,
+                                           const nrt_trace_options *opt, uint32_t root_tile, nrt_hit_f32 *d_tiles_hits, uint8_t *d_tiles_mask) {
+  return group_traverse_gather_tiles<16>(g, (const void *const *)d_rays, counts, slot_rays, opt, root_tile, d_tiles_hits, d_tiles_mask);
+}
+nrt_status nrtGroupTraverseGatherTiles_f64(nrt_group *g, const nrt_ray_f64 *const *d_rays, const uint64_t *counts, uint64_t slot_rays,
+                                           const nrt_trace_options *opt, uint32_t root_tile, nrt_hit_f64 *d_tiles_hits, uint8_t *d_tiles_mask) {
+  return group_traverse_gather_tiles<32>(g, (const void *const *)d_rays, counts, slot_rays, opt, root_tile, d_tiles_hits, d_tiles_mask);
 }
 
 } // extern "C"

@@ -55,6 +55,30 @@ def test_bench_runs_its_multi_gpu_path_over_rccl_on_one_gpu():
     _child_ok["ran"] = True
 
 
+def test_bench_runs_its_multi_gpu_path_through_the_c_abi_group():
+    """`--gather cabi`: the same timed region with the exchange done by the library itself — nrtGroupCreateRanked (the RCCL id is all
+    torch hands round), wave 1 gathered in frame order, the ragged wave 2 in tile slots; a world of one sends to itself so that
+    ncclSend / ncclRecv execute.  The root's frame and slots equal the rank's own records."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--gather", "cabi", "--check-gather", "--steps", "4",
+                        "--warmup", "1", "--builds", "1", "--no-cpu-baseline", "--no-extras", "--no-pmc", "--no-configs"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 8192, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["value"] > 500.0
+    mg = out["multi_gpu"]
+    assert mg["backend"].startswith("RCCL through the C ABI") and mg["rccl_ranks"] == 1
+    assert mg["gathered_bytes_per_step"] == 2 * 1920 * 1080 * 16
+    assert mg["last_gather_bytes"]["rccl"] == 1920 * 1080 * 17 and mg["last_gather_bytes"]["peer"] == 0  # records + flags of the root's own tile, sent to itself
+    gc = mg["gather_check"]
+    assert gc["frame_identical_to_the_ranks_records"] is True and gc["tile_slots_identical_to_the_ranks_records"] is True
+    assert gc["records"] == 1920 * 1080
+
+
 def test_rccl_gather_of_device_hit_records_in_this_process(oracle, c1_mesh):
     if not _child_ok["ran"]:
         pytest.skip("the child-process run of the same exchange did not pass (or was deselected): not risking this process")
