@@ -38,6 +38,9 @@ struct Api<float> {
   static nrt_status Gather(nrt_group *g, const Ray *const *r, const uint64_t *cnt, uint64_t total, uint64_t row, uint32_t root, Hit *h, uint8_t *m) {
     return nrtGroupTraverseGather_f32(g, r, cnt, total, row, NULL, root, h, m);
   }
+  static nrt_status GatherTiles(nrt_group *g, const Ray *const *r, const uint64_t *cnt, uint64_t slot, uint32_t root, Hit *h, uint8_t *m) {
+    return nrtGroupTraverseGatherTiles_f32(g, r, cnt, slot, NULL, root, h, m);
+  }
 };
 template <>
 struct Api<double> {
@@ -48,6 +51,9 @@ struct Api<double> {
   static nrt_status Trace(nrt_ctx *c, const Ray *r, uint64_t n, Hit *h, uint8_t *m) { return nrtTraverseBatchDevice_f64(c, r, n, NULL, h, m, NULL); }
   static nrt_status Gather(nrt_group *g, const Ray *const *r, const uint64_t *cnt, uint64_t total, uint64_t row, uint32_t root, Hit *h, uint8_t *m) {
     return nrtGroupTraverseGather_f64(g, r, cnt, total, row, NULL, root, h, m);
+  }
+  static nrt_status GatherTiles(nrt_group *g, const Ray *const *r, const uint64_t *cnt, uint64_t slot, uint32_t root, Hit *h, uint8_t *m) {
+    return nrtGroupTraverseGatherTiles_f64(g, r, cnt, slot, NULL, root, h, m);
   }
 };
 
@@ -179,6 +185,42 @@ static int run(int argc, char **argv) {
   for (uint64_t i = 0; i < n; i++) hits += refm[i];
   printf("rays %llu hits %llu frame_mismatches %llu bytes_rccl %llu bytes_peer %llu bytes_in_place %llu\n", (unsigned long long)n, hits, bad_total,
          (unsigned long long)b_rccl, (unsigned long long)b_peer, (unsigned long long)b_place);
+  // ragged waves (secondary rays): tile t traces only its first cnt[t] - 13 * t rays; the root receives every tile's slot, tile-major
+  {
+    uint64_t slot = 0;
+    for (uint32_t t = 0; t < N; t++) slot = cnt[t] > slot ? cnt[t] : slot;
+    std::vector<uint64_t> rag(N);
+    for (uint32_t t = 0; t < N; t++) rag[t] = cnt[t] > 13ull * t ? cnt[t] - 13ull * t : 0;
+    Hit *d_slots = NULL;
+    uint8_t *d_smask = NULL;
+    HIP(hipSetDevice(root_dev));
+    HIP(hipMalloc((void **)&d_slots, (size_t)N * slot * sizeof(Hit)));
+    HIP(hipMalloc((void **)&d_smask, (size_t)N * slot));
+    unsigned long long tbad = 0;
+    for (int round = 0; round < 2; round++) {
+      HIP(hipMemset(d_slots, 0xCD, (size_t)N * slot * sizeof(Hit)));
+      HIP(hipDeviceSynchronize());
+      if (Api<T>::GatherTiles(g, (const Ray *const *)d_tile.data(), rag.data(), slot, root, d_slots, d_smask) != NRT_OK || nrtGroupSynchronize(g) != NRT_OK) {
+        fprintf(stderr, "gather tiles: %s\n", nrtGroupLastError(g));
+        return 12;
+      }
+      std::vector<Hit> slots((size_t)N * slot);
+      std::vector<uint8_t> smask((size_t)N * slot);
+      HIP(hipMemcpy(slots.data(), d_slots, slots.size() * sizeof(Hit), hipMemcpyDeviceToHost));
+      HIP(hipMemcpy(smask.data(), d_smask, smask.size(), hipMemcpyDeviceToHost));
+      for (uint32_t t = 0; t < N; t++) {
+        uint64_t i = 0;  // the tile's i-th ray is the frame's ray of row t + (i / row_len) * N, column i % row_len
+        for (uint64_t r = t; r < rows && i < rag[t]; r += N)
+          for (uint64_t x = r * row_len; x < (r + 1) * row_len && x < n && i < rag[t]; x++, i++)
+            if (memcmp(&slots[(size_t)t * slot + i], &ref[x], kFieldBytes) != 0 || smask[(size_t)t * slot + i] != refm[x]) tbad++;
+      }
+    }
+    printf("tile_slot_mismatches %llu slot %llu\n", tbad, (unsigned long long)slot);
+    bad_total += tbad;
+    std::vector<uint64_t> too_many(rag);
+    too_many[0] = slot + 1;
+    printf("slot_overflow_status %d\n", (int)Api<T>::GatherTiles(g, (const Ray *const *)d_tile.data(), too_many.data(), slot, root, d_slots, d_smask));
+  }
   // misuse is reported, not executed
   std::vector<uint64_t> wrong(cnt);
   wrong[0] += 1;

@@ -65,7 +65,7 @@ def test_cpp_host_gathers_the_frame_of_row_interleaved_tiles(group_check, f64):
     for tiles, row_len, extra in ((2, W, []), (3, 1000, []), (8, W, ["root=5"]), (1, W, []), (2, W, ["transport=1"]),
                                   (2, W, ["self_send=1"]), (3, W, ["self_send=1", "root=2"]), (2, W, ["transport=1", "self_send=1"])):
         rc, out = run(exe, [real, mesh, rp, tiles, row_len] + extra)
-        assert rc == 0 and "frame_mismatches 0 " in out, (tiles, row_len, extra, out)
+        assert rc == 0 and "frame_mismatches 0 " in out and "tile_slot_mismatches 0 " in out and "slot_overflow_status 1" in out, (tiles, row_len, extra, out)
         assert "rays %d " % n in out and "wrong_count_status 1 " in out and "interleaved rows hold" in out, out
         line = [ln for ln in out.splitlines() if ln.startswith("rays ")][0].split()
         moved = {line[i]: int(line[i + 1]) for i in range(0, len(line), 2)}
@@ -90,7 +90,7 @@ def test_ranked_group_of_one_sends_to_itself(group_check):
     mesh, rp = write_inputs(d, v, f, rays, "ranked")
     for extra in (["ranked=1"], ["ranked=1", "self_send=1"]):
         rc, out = run(exe, ["f32", mesh, rp, 1, 200] + extra)
-        assert rc == 0 and "frame_mismatches 0 " in out and "tiles 1 local 1 ranks 1 rccl_bound 1" in out, out
+        assert rc == 0 and "frame_mismatches 0 " in out and "tile_slot_mismatches 0 " in out and "tiles 1 local 1 ranks 1 rccl_bound 1" in out, out
     assert "bytes_rccl %d " % (rays.shape[0] * 17) in out, out
 
 
