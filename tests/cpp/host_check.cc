@@ -409,7 +409,7 @@ static int lazy(const char *mesh_path, const char *rays_path) {
   for (size_t w = 0; w < pool.size(); w++) pool[w].join();
   uint64_t bad = 0;
   for (uint64_t i = 0; i < n; i++)
-    if (bm[i] != mask[i] || memcmp(&bh[i], &hits[i], sizeof(hits[i])) != 0) bad++;
+    if (bm[i] != mask[i] || bh[i].t != hits[i].t || bh[i].u != hits[i].u || bh[i].v != hits[i].v || bh[i].prim_id != hits[i].prim_id) bad++;  // (fields: the fp64 record ends in padding)
   printf("pending_after_traverse %d threads_vs_batch_mismatches %llu\n", accel.HostTreePending() ? 1 : 0, (unsigned long long)bad);
   const std::vector<nanort::BVHNode<T> > &nodes = accel.GetNodes();
   int box_ok = !nodes.empty();
@@ -430,7 +430,7 @@ static int lazy(const char *mesh_path, const char *rays_path) {
   if (!copy.TraverseBatch(rays.data(), n, ch.data(), cm.data())) return 4;
   bad = 0;
   for (uint64_t i = 0; i < n; i++)
-    if (bm[i] != cm[i] || (cm[i] && memcmp(&bh[i], &ch[i], sizeof(ch[i])) != 0)) bad++;
+    if (bm[i] != cm[i] || (cm[i] && (bh[i].t != ch[i].t || bh[i].u != ch[i].u || bh[i].v != ch[i].v || bh[i].prim_id != ch[i].prim_id))) bad++;
   printf("copy_batch_mismatches %llu\n", (unsigned long long)bad);
   return 0;
 }
