@@ -161,6 +161,15 @@ static nrt_status gfail(nrt_group *g, nrt_status st, const std::string &msg) {
     hipError_t e_ = (call);                                                                                    \
     if (e_ != hipSuccess) return gfail(g, NRT_ERR_DEVICE, std::string(#call ": ") + hipGetErrorString(e_));    \
   } while (0)
+// ... inside an open ncclGroupStart: the group is closed before the error is reported, so that the communicator stays usable
+#define GNCCL_IN_GROUP(g, call)                                                                                           \
+  do {                                                                                                                     \
+    int r_ = (call);                                                                                                       \
+    if (r_ != ncclSuccess) {                                                                                               \
+      (void)rccl().GroupEnd();                                                                                             \
+      return gfail(g, NRT_ERR_DEVICE, std::string(#call ": ") + rccl().GetErrorString(r_));                                \
+    }                                                                                                                      \
+  } while (0)
 #define GNCCL(g, call)                                                                                                     \
   do {                                                                                                                     \
     int r_ = (call);                                                                                                       \
@@ -442,8 +451,8 @@ static nrt_status group_traverse_gather(nrt_group *g, const void *const *d_rays,
         nrt_group::Local &l = g->local[k];
         if (!counts[k] || !travels(l)) continue;
         GHIP(g, hipSetDevice(l.device));
-        GNCCL(g, r.Send(l.hits.p, counts[k] * HIT_BYTES, ncclUint8, g->tile_rank[root_tile], g->comms[l.comm], l.stream));
-        if (send_mask) GNCCL(g, r.Send(l.mask.p, counts[k], ncclUint8, g->tile_rank[root_tile], g->comms[l.comm], l.stream));
+        GNCCL_IN_GROUP(g, r.Send(l.hits.p, counts[k] * HIT_BYTES, ncclUint8, g->tile_rank[root_tile], g->comms[l.comm], l.stream));
+        if (send_mask) GNCCL_IN_GROUP(g, r.Send(l.mask.p, counts[k], ncclUint8, g->tile_rank[root_tile], g->comms[l.comm], l.stream));
         g->last_bytes_rccl += counts[k] * HIT_BYTES + (send_mask ? counts[k] : 0);
       }
       if (i_am_root) {
@@ -451,8 +460,8 @@ static nrt_status group_traverse_gather(nrt_group *g, const void *const *d_rays,
         for (uint32_t t = 0; t < N; t++) {
           if (!src_hits[t] || src_hits[t] != g->stage_hits[t].p) continue;
           const uint64_t cnt = tile_share(total_rays, row_len, t, N);
-          GNCCL(g, r.Recv(g->stage_hits[t].p, cnt * HIT_BYTES, ncclUint8, g->tile_rank[t], g->comms[g->local[root_local].comm], root_stream));
-          if (send_mask) GNCCL(g, r.Recv(g->stage_mask[t].p, cnt, ncclUint8, g->tile_rank[t], g->comms[g->local[root_local].comm], root_stream));
+          GNCCL_IN_GROUP(g, r.Recv(g->stage_hits[t].p, cnt * HIT_BYTES, ncclUint8, g->tile_rank[t], g->comms[g->local[root_local].comm], root_stream));
+          if (send_mask) GNCCL_IN_GROUP(g, r.Recv(g->stage_mask[t].p, cnt, ncclUint8, g->tile_rank[t], g->comms[g->local[root_local].comm], root_stream));
         }
       }
       GNCCL(g, r.GroupEnd());
@@ -564,15 +573,15 @@ static nrt_status group_traverse_gather_tiles(nrt_group *g, const void *const *d
         nrt_group::Local &l = g->local[k];
         if (!travels(l)) continue;
         GHIP(g, hipSetDevice(l.device));
-        GNCCL(g, r.Send(l.hits.p, slot_b, ncclUint8, g->tile_rank[root_tile], g->comms[l.comm], l.stream));
-        if (send_mask) GNCCL(g, r.Send(l.mask.p, slot_rays, ncclUint8, g->tile_rank[root_tile], g->comms[l.comm], l.stream));
+        GNCCL_IN_GROUP(g, r.Send(l.hits.p, slot_b, ncclUint8, g->tile_rank[root_tile], g->comms[l.comm], l.stream));
+        if (send_mask) GNCCL_IN_GROUP(g, r.Send(l.mask.p, slot_rays, ncclUint8, g->tile_rank[root_tile], g->comms[l.comm], l.stream));
         g->last_bytes_rccl += slot_b + (send_mask ? slot_rays : 0);
       }
       if (i_am_root) {
         GHIP(g, hipSetDevice(root_dev));
         for (uint32_t t = 0; t < N; t++) {
           if (in_place(t)) continue;
-          GNCCL(g, r.Recv((char *)d_tiles_hits + (size_t)t * slot_b, slot_b, ncclUint8, g->tile_rank[t], g->comms[g->local[root_local].comm], root_stream));
+          GNCCL_IN_GROUP(g, r.Recv((char *)d_tiles_hits + (size_t)t * slot_b, slot_b, ncclUint8, g->tile_rank[t], g->comms[g->local[root_local].comm], root_stream));
           if (send_mask) {
             // (the flags travel even when the root does not want them: a sender cannot know; they land in the tile's staging then)
             uint8_t *dst = d_tiles_mask ? d_tiles_mask + (size_t)t * slot_rays : nullptr;
@@ -580,7 +589,7 @@ static nrt_status group_traverse_gather_tiles(nrt_group *g, const void *const *d
               GHIP(g, devbuf_ensure(&g->stage_mask[t], slot_rays));
               dst = (uint8_t *)g->stage_mask[t].p;
             }
-            GNCCL(g, r.Recv(dst, slot_rays, ncclUint8, g->tile_rank[t], g->comms[g->local[root_local].comm], root_stream));
+            GNCCL_IN_GROUP(g, r.Recv(dst, slot_rays, ncclUint8, g->tile_rank[t], g->comms[g->local[root_local].comm], root_stream));
           }
         }
       }

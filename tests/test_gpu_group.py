@@ -81,6 +81,21 @@ def test_cpp_host_gathers_the_frame_of_row_interleaved_tiles(group_check, f64):
             assert moved["bytes_rccl"] == 0 and moved["bytes_peer"] == 0 and moved["bytes_in_place"] == n * hit_b, moved
 
 
+def test_more_tiles_than_rows_and_a_single_ray(group_check):
+    """Edge cases of the split: tiles that own no row at all (8 tiles, 5 rows), a frame of one ray, a frame of one short row."""
+    exe, d = group_check
+    v, f = scenes.sphere(32, 16)
+    for tag, (w, h), tiles, row_len in (("few_rows", (40, 5), 8, 40), ("one_ray", (1, 1), 3, 7), ("short_row", (13, 1), 2, 64)):
+        rays = scenes.camera_rays(w, h)
+        mesh, rp = write_inputs(d, v, f, rays, tag)
+        for extra in ([], ["self_send=1", "root=%d" % (tiles - 1)] if tag == "few_rows" else ["self_send=1"]):
+            rc, out = run(exe, ["f32", mesh, rp, tiles, row_len] + extra)
+            if tag == "few_rows" and extra:  # (the root tile owns no rays: nothing to send to itself, everything read in place)
+                assert rc == 0 and "frame_mismatches 0 " in out and "bytes_rccl 0 " in out, out
+            else:
+                assert rc == 0 and "frame_mismatches 0 " in out and "tile_slot_mismatches 0 " in out, (tag, extra, out)
+
+
 def test_ranked_group_of_one_sends_to_itself(group_check):
     """nrtGroupCreateRanked (one process per GPU — bench.py's launch model) with a world of one: ncclGetUniqueId, ncclCommInitRank and,
     with self_send, a grouped ncclSend / ncclRecv of the records and flags on that communicator."""
