@@ -269,7 +269,8 @@ def main():
             "vs_baseline": None,
             "dtype": cfg["real"],
             "data": "synthetic" if not wl.mesh_note else "user mesh, synthetic rays",
-            "config": {"name": args.config, "workload": wl.describe(), "parallelism": par, "rays_per_step": int(T.total_rays)},
+            "config": {"name": args.config, "workload": wl.describe(), "parallelism": par, "rays_per_step": int(T.total_rays),
+                       "untimed_clock_ramp_steps": int(T.prewarm_steps)},
             "build_ms": round(build_ms, 4),
             "bvh": {"nodes": wl.num_nodes, "max_depth": int(wl.stats["max_tree_depth"])},
             "roofline": roof,

@@ -143,15 +143,18 @@ def end_to_end(wl, reps=5):
             "unit": "Mrays/s end to end (never `value`)", **res}
 
 
-def measure_config(name, mesh_path=None, reps=5, parity_rays=200_000):
+def measure_config(name, mesh_path=None, reps=20, parity_rays=200_000, ramp=60):
     """{Mrays/s, build_ms, parity} for one config on GPU 0, with the reference's answer on a bounded sample.  The counters of
     the config are attached by the caller (one profiled sub-run serves all configs)."""
     import torch
 
     wl = Workload(name, builds=3, mesh_path=mesh_path)
     a = wl.accel
+    for _ in range(ramp):  # (untimed: the device's clocks ramp over some tens of milliseconds of work, as in the headline's region)
+        a.TraverseBatchDevice(wl.d_rays1, wl.d_hits1, wl.d_mask1)
+        a.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)
     t1, t2 = [], []
-    for _ in range(reps):
+    for _ in range(5):
         a.TraverseBatchDevice(wl.d_rays1, wl.d_hits1, wl.d_mask1)
         t1.append(a.LastTraverseMs())
         a.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)

@@ -3,6 +3,9 @@ import time
 
 import numpy as np
 
+PREWARM_STEPS = 150  # untimed clock ramp before the warm-up steps (see Timed; a COUNT, the same on every rank: the steps of an N > 1 run carry collectives)
+
+
 class Timed:
     """The timed region of one workload on this rank's GPU: W warm-up steps, a short pass with an event pair around every
     launch (per-wave kernel times, outside the timed region), then exactly K steps bracketed by barrier + synchronize —
@@ -60,6 +63,15 @@ class Timed:
                         pending[w][b].wait()
                         pending[w][b] = None
 
+        # Clock ramp, untimed and before the W warm-up steps: the device reaches its sustained clocks only after some tens of
+        # milliseconds of traversal work (measured: K = 20 / W = 3 reads 2.3 % lower than K = 200 / W = 50 or K = 1000 / W = 100 on
+        # the same box, profiles/r06s_steps_sensitivity.txt), so PREWARM_STEPS of the same steps (~0.1 s on C3) run first — whatever
+        # K and W the caller asked for, the timed region then measures the steady state a renderer runs in.
+        self.prewarm_steps = PREWARM_STEPS
+        for _ in range(PREWARM_STEPS):
+            step()
+        drain()
+        torch.cuda.synchronize()
         for _ in range(warmup):
             step()
         drain()
@@ -166,7 +178,8 @@ class TimedCAbi(Timed):
             grp.traverse_gather(wl.d_rays1, n1, world * n1, W, root=0, frame_hits=frame1[b])
             grp.traverse_gather_tiles(wl.d_rays2, n2, n1, root=0, tiles_hits=tiles2[b])
 
-        for _ in range(warmup):
+        self.prewarm_steps = PREWARM_STEPS
+        for _ in range(PREWARM_STEPS + warmup):  # (the clock ramp of Timed, then the W warm-up steps)
             step()
         grp.synchronize()
         # per-wave kernel times: the same two launches without the exchange, an event pair around each (outside the timed region)

@@ -154,6 +154,7 @@ struct nrt_ctx {
   // Two tree levels per step (Wide4Node records, traverse.hip NRT_STEP_NODE4): the production walk of fp32 triangle trees
   // whose child boxes lie inside their parents'.  env NRT_WIDE4=0 goes back to one level per step.
   int wide4 = 1;
+  int wide4_big_ok = 1; // ... also when the record array reaches 4 GiB (tunable wide4_big; 0: such trees walk one level per step, as until round 6)
   // two-level walk, order of a record's four slots.  0 (default since round 5): the binary loop's order — the same leaves in the
   // same order as nanort.h:2526-2548, every field of every record bit-identical to the reference on the same node array.
   // 1 (opt-in): by entry distance, +2...5 % — the closest t is the reference's except where a leaf box's entry distance rounds
@@ -298,6 +299,7 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("subtree_rows", 0, 1, subtree_rows, int),         // 0: the builder's one-node-per-step subtree kernel (next build; same tree) — libnanort_hip_prof.so only
 #endif
     NRT_TUNABLE("wide", 0, 1, wide, int),                         // 0: the literal BVHNode loop
+    NRT_TUNABLE("wide4_big", 0, 2, wide4_big_ok, int),            // ... also for record arrays of 4 GiB and more (64-bit offsets; next build / set_tree); 2: 64-bit offsets whatever the size (tests)
     NRT_TUNABLE("wide4", 0, 1, wide4, int),                       // two tree levels per step (next build / set_tree)
     NRT_TUNABLE("leaf_compact", 0, 1, leaf_compact, int),         // two-level walk, triangle trees with leaves of <= 4 records: leaf phase over items (records bit-identical)
     NRT_TUNABLE("order4", 0, 1, order4, int),                     // two-level walk: 0 (default) = the reference's order, every field bit-identical; 1 = slots by entry distance (faster; contract-level parity at ties)
@@ -632,7 +634,9 @@ static nrt_status finish_wide(nrt_ctx *c) {
   const size_t tiles = (c->num_nodes + 1023) / 1024;
   if ((st = ensure(c, c->b_wide_scratch, (tiles + c->num_nodes + 1) * sizeof(uint32_t)))) return st;
   c->d_wide4 = nullptr;
-  if (c->wide4 && sizeof(T) == 4 && c->num_branch_records < (1ull << 25)) { // (every primitive kind: the step does not look at the leaves; the walk addresses the records with 32-bit byte offsets: below 4 GiB)
+  // (every primitive kind: the step does not look at the leaves.  Below 4 GiB — 2^25 records — the walk addresses the records with
+  // 32-bit byte offsets; triangle trees beyond that, ~110 M triangles and more, get the array too and 64-bit offsets)
+  if (c->wide4 && sizeof(T) == 4 && (c->num_branch_records < (1ull << 25) || (c->prim_kind == kPrimTriangles && c->wide4_big_ok))) {
     if ((st = ensure(c, c->b_wide4, std::max<size_t>(1, c->num_branch_records) * sizeof(Wide4Node<T>)))) return st;
     c->d_wide4 = c->b_wide4.p;
   }
@@ -929,7 +933,11 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   // (the profiling instantiations of the two-level walk are built for the default trace options only: with options that can
   // reject a primitive a profiled launch walks one level per step, whose profiling variant honours them)
   const bool prof_needs_w2 = (dbg & (32u | 8192u)) && !plain_options && !spheres;
-  const bool use_wide4 = use_wide && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch && !prof_needs_w2;
+  // (a record array of 4 GiB or more is walked two levels per step by the default walk of triangle trees only: closest hits in the
+  // reference's order, outside the profiling instantiations)
+  const bool wide4_big = c->num_branch_records >= (1ull << 25) || (c->wide4_big_ok == 2 && c->prim_kind == kPrimTriangles); // (2: forced, for the tests)
+  const bool use_wide4 = use_wide && c->d_wide4 && c->wide_stack == 10 && c->tree_nested && c->root_is_branch && !prof_needs_w2 &&
+                         (!wide4_big || (!spheres && !c->order4 && !(dbg & (32u | 8192u))));
   if (c->wide_blocks_per_cu == 0) c->wide_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(c->wide_stack, kPrimTriangles, false);
   if (use_wide4 && !spheres && c->wide4_blocks_per_cu == 0) c->wide4_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(kWide4LdsStack, kPrimTriangles, true);
   if (spheres && c->sphere_blocks_per_cu == 0) c->sphere_blocks_per_cu = (unsigned)traverse_wide_blocks_per_cu<T>(10, c->prim_kind, use_wide4); // (one kind and one walk per context)
@@ -976,6 +984,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.wide = (const WideNode<T> *)c->d_wide;
   a.wide4 = use_wide4 ? (const Wide4Node<T> *)c->d_wide4 : nullptr;
   a.packed_leaves = c->packed_leaves;
+  a.wide4_big = (use_wide4 && wide4_big) ? 1u : 0u;
   a.wide_below_4g = (c->f64_row_fetch && (uint64_t)c->num_branch_records * sizeof(WideNode<T>) < (1ull << 32)) ? 1u : 0u;
   a.root_is_branch = c->root_is_branch;
   a.debug_flags = dbg;

@@ -360,6 +360,7 @@ struct TraverseArgs {
   const WideNode<T> *wide; // may be null (binary kernel only)
   const Wide4Node<T> *wide4; // may be null: two tree levels per record (the WIDTH = 4 variants)
   uint32_t packed_leaves;  // leaf references of `wide` are PACKED (see WideNode)
+  uint32_t wide4_big;      // the Wide4Node array is 4 GiB or larger: the walk addresses its records with 64-bit offsets (template bit ORDER & 4)
   uint32_t wide_below_4g;  // the WideNode array is smaller than 4 GiB: the fp64 walk may address it with 32-bit byte offsets (slab_pair_presel)
   uint32_t root_is_branch; // node 0 is a branch (every tree of more than one node)
   uint32_t debug_flags;    // profiling only (env NRT_DEBUG): 1 = skip triangle tests, 2 = skip traversal

@@ -956,12 +956,14 @@ struct Wide4Tail { // bytes 96..127 of a Wide4Node<float>
   int32_t axis0, axis1, axis2;
   uint32_t pad;
 };
-__device__ __forceinline__ Slab4<float> slab4_presel(const Lane<float> &L, const char *base, uint32_t rec) {
+// (OFF = uint32_t for arrays below 4 GiB — scalar base + 32-bit lane offset —, uint64_t for larger ones: template bit ORDER & 4)
+template <typename OFF>
+__device__ __forceinline__ Slab4<float> slab4_presel(const Lane<float> &L, const char *base, OFF rec) {
   typedef float f2 __attribute__((ext_vector_type(2)));
   typedef float f4 __attribute__((ext_vector_type(4)));
   const f2 mm = {Const<float>::maxmult(), Const<float>::maxmult()};
   float tmin[4] = {L.min_t, L.min_t, L.min_t, L.min_t}, tmax[4] = {L.hit_t, L.hit_t, L.hit_t, L.hit_t};
-  const uint32_t rec48 = rec + 48u;
+  const OFF rec48 = rec + (OFF)48u;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const uint32_t so = k == 0 ? L.so0 : (k == 1 ? L.so1 : L.so2);
@@ -1351,7 +1353,10 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
   static_assert(WIDTH == 2 || WIDTH == 4, "one or two tree levels per step");
   static_assert(ORDER == 0 || (WIDTH == 4 && sizeof(T) == 4), "distance order / leaf items are variants of the fp32 two-level step");
   static_assert((ORDER & 2) == 0 || (KIND == kPrimTriangles && !STATS), "leaf items: triangle records, production instantiations");
+  static_assert((ORDER & 4) == 0 || ((ORDER & 1) == 0 && KIND == kPrimTriangles && !STATS && !CLOCK), "records addressed by 64-bit offsets: the default walk of triangle trees");
   constexpr bool LEAFC = (ORDER & 2) != 0;
+  constexpr bool BIG = (ORDER & 4) != 0; // a Wide4Node array of 4 GiB or more (trees beyond ~110 M triangles): 64-bit record offsets
+  typedef typename std::conditional<BIG, uint64_t, uint32_t>::type RecOff;
   // leaf items (LEAFC): which lane owns the record a lane tests, and which of the owner's records it is (lane | k << 6)
   __shared__ uint32_t s_item_owner[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1];
   __shared__ const LeafTri<float> *s_item_rec[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1]; // ... and where that record is
@@ -1524,8 +1529,8 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
 #if NRT_W4_PRESEL
           if constexpr (sizeof(T) == 4) {
             const char *wb_ = reinterpret_cast<const char *>(a.wide4);
-            const uint32_t rec_ = cur << 7; // (api.hip keeps Wide4Node<float> arrays below 4 GiB)
-            const Slab4<float> sl = slab4_presel(L, wb_, rec_);
+            const RecOff rec_ = (RecOff)cur << 7; // (32 bits: api.hip sends arrays of 4 GiB and more to the ORDER & 4 instantiations)
+            const Slab4<float> sl = slab4_presel<RecOff>(L, wb_, rec_);
             const Wide4Tail w = *reinterpret_cast<const Wide4Tail *>(wb_ + (size_t)rec_ + 96);
             if constexpr ((ORDER & 1) == 1)
               NRT_STEP_NODE4_DIST(sl, w);
@@ -2698,7 +2703,16 @@ hipError_t launch_traverse_wide(const TraverseArgs<T> &args, unsigned grid, int 
         NRT_LAUNCH_WIDE(kWide4LdsStack, false, kPrimTriangles, true, true, 4); // per-wave time stamps (default trace options only)
       else
 #endif
-      if (args.leaf_items && !args.order4 && args.plain_options) // leaf phase over items (tunable leaf_compact): the reference's walk, records bit-identical
+      if (args.wide4_big) { // a record array of 4 GiB or more: the default walk with 64-bit record offsets (api.hip sends nothing else here)
+        if (args.leaf_items && args.plain_options)
+          NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, true, false, 4, 6);
+        else if (args.leaf_items)
+          NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, false, false, 4, 6);
+        else if (args.plain_options)
+          NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, true, false, 4, 4);
+        else
+          NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, false, false, 4, 4);
+      } else if (args.leaf_items && !args.order4 && args.plain_options) // leaf phase over items (tunable leaf_compact): the reference's walk, records bit-identical
         NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, true, false, 4, 2);
       else if (args.leaf_items && !args.order4)
         NRT_LAUNCH_WIDE_O(kWide4LdsStack, false, kPrimTriangles, false, false, 4, 2);

@@ -158,3 +158,52 @@ def test_trees_with_boxes_sticking_out_walk_one_level_per_step(oracle):
     assert width(a.LastKernelName()) == 2
     oh, om = oracle.traverse(nodes, idx, v, f, rays)
     assert_hits_identical(oh, om, h, m)
+
+
+def test_64_bit_record_offsets_give_the_same_records(oracle):
+    """Record arrays of 4 GiB and more (trees beyond ~110 M triangles) are walked by instantiations that address the records with
+    64-bit offsets (template bit ORDER & 4; tools/big_mesh_probe.py runs a real one).  Forced here on an ordinary tree (tunable
+    wide4_big = 2): every field of every record equals the 32-bit walk's and the restatement's, with and without leaf items, with
+    rejecting trace options, for occlusion queries and several batches per launch."""
+    from helpers import assert_hits_identical
+    from nanort_amd.wire import default_trace_options
+
+    v, f = scenes.plane(200, 150)
+    a = BVHAccel(np.float32)
+    assert a.Build(f.shape[0], TriangleMesh(v, f))
+    rays1 = scenes.camera_rays(512, 288)
+    h0, m0 = a.TraverseBatch(rays1)
+    assert a.LastKernelName().endswith(", 4, 2>")
+    bounce = scenes.secondary_rays("bounce", v, f, rays1, h0, m0)
+    shadow = scenes.secondary_rays("shadow", v, f, rays1, h0, m0)
+    b0, bm0 = a.TraverseBatch(bounce)
+    o = default_trace_options()
+    o["prim_ids_range"] = (500, 50000)
+    o["skip_prim_id"] = 7000
+    o["cull_back_face"] = 1
+    c0, cm0 = a.TraverseBatch(bounce, o)
+    occ0 = a.OccludedBatch(shadow)
+    mb0 = a.TraverseBatches([(shadow, "occlusion"), bounce, rays1[:777]])
+    a.SetTunable("wide4_big", 2)
+    for leaf_compact, tail in ((1, ", 4, 6>"), (0, ", 4, 4>")):
+        a.SetTunable("leaf_compact", leaf_compact)
+        h1, m1 = a.TraverseBatch(rays1)
+        assert a.LastKernelName().endswith("true, false" + tail), a.LastKernelName()
+        assert_hits_identical(h0, m0, h1, m1)
+        b1, bm1 = a.TraverseBatch(bounce)
+        assert_hits_identical(b0, bm0, b1, bm1)
+        c1, cm1 = a.TraverseBatch(bounce, o)
+        assert a.LastKernelName().endswith("false, false" + tail), a.LastKernelName()
+        assert_hits_identical(c0, cm0, c1, cm1)
+        assert np.array_equal(a.OccludedBatch(shadow), occ0)
+        mb1 = a.TraverseBatches([(shadow, "occlusion"), bounce, rays1[:777]])
+        assert np.array_equal(mb0[0][1], mb1[0][1])
+        for k in (1, 2):
+            assert_hits_identical(mb0[k][0], mb0[k][1], mb1[k][0], mb1[k][1])
+    nodes, idx = a.GetTree()
+    oh, om = oracle.traverse(nodes, idx, v, f, bounce[::7])
+    assert_hits_identical(oh, om, b1[::7], bm1[::7])
+    # what the big arrays do not take: the opt-in distance order walks them one level per step
+    a.SetTunable("order4", 1)
+    a.TraverseBatch(rays1)
+    assert ", 2, 0>" in a.LastKernelName(), a.LastKernelName()
