@@ -78,7 +78,7 @@ struct Lane {
   // (floats and integers alternate on purpose: as neighbours, Sx Sy Sz u v get merged into overlapping two- and
   // four-float vector accesses by the vectoriser, which then pins all five in scratch memory instead of registers)
   T Sx;
-  uint32_t pk; // kx | ky << 2 | kz << 4 | (dir < 0 per axis) << 6..8: six small integers in one register (the kernel sits at
+  uint32_t pk; // (dir < 0 per axis) << 0..2 | kx << 3 | ky << 5 | kz << 7: six small integers in one register — the signs lowest, so that sign(axis) is one bit-field extract at `axis` with nothing added to it (three instructions per step) — (the kernel sits at
                // the 80-register edge of six waves per SIMD; the loops turn the fields into lane masks once, on entry)
   T Sy;
   uint32_t prim;
@@ -88,10 +88,10 @@ struct Lane {
   uint32_t so1;
   T v;
   uint32_t so2;
-  __device__ __forceinline__ int kx() const { return (int)(pk & 3u); }
-  __device__ __forceinline__ int ky() const { return (int)((pk >> 2) & 3u); }
-  __device__ __forceinline__ int kz() const { return (int)((pk >> 4) & 3u); }
-  __device__ __forceinline__ int sign(int k) const { return (int)((pk >> (6 + k)) & 1u); }
+  __device__ __forceinline__ int kx() const { return (int)((pk >> 3) & 3u); }
+  __device__ __forceinline__ int ky() const { return (int)((pk >> 5) & 3u); }
+  __device__ __forceinline__ int kz() const { return (int)((pk >> 7) & 3u); }
+  __device__ __forceinline__ int sign(int k) const { return (int)((pk >> k) & 1u); }
 };
 
 template <typename T>
@@ -131,12 +131,12 @@ __device__ __forceinline__ void lane_init(Lane<T> &L, const typename Wire<T>::Ra
     kx = ky;
     ky = t;
   }
-  uint32_t pk = (uint32_t)kx | ((uint32_t)ky << 2) | ((uint32_t)kz << 4);
+  uint32_t pk = ((uint32_t)kx << 3) | ((uint32_t)ky << 5) | ((uint32_t)kz << 7);
   L.Sx = sel3(d0, d1, d2, kx) / dz;
   L.Sy = sel3(d0, d1, d2, ky) / dz;
   L.Sz = T(1.0) / dz;
   // Traverse prologue (nanort.h:2505-2516)
-  pk |= (d0 < T(0) ? 64u : 0u) | (d1 < T(0) ? 128u : 0u) | (d2 < T(0) ? 256u : 0u);
+  pk |= (d0 < T(0) ? 1u : 0u) | (d1 < T(0) ? 2u : 0u) | (d2 < T(0) ? 4u : 0u);
   L.pk = pk;
   L.so0 = d0 < T(0) ? 48u : 0u;
   L.so1 = d1 < T(0) ? 48u : 0u;
@@ -1034,8 +1034,10 @@ struct StackEntry<double> {
 // slab test at pop time (see the comment above the kernel); an empty stack finishes the ray.
 #define NRT_POP_ENTRY()                                                                                \
 do {                                                                                                 \
-  const int s1_ = sp > 0 ? sp - 1 : 0;                                                               \
-  typename SE::type e_ = s_stack[s1_ < STACK ? s1_ : STACK - 1][tid];                                \
+  int s1_ = sp - 1;                                                                                  \
+  s1_ = s1_ < 0 ? 0 : s1_;                                                                           \
+  const int sl_ = s1_ > STACK - 1 ? STACK - 1 : s1_; /* (max then min: one v_med3_i32) */            \
+  typename SE::type e_ = s_stack[sl_][tid];                                                          \
   if (s1_ >= STACK) { /* rare: the entry lives in the global overflow stack */                       \
     const size_t o_ = (size_t)(s1_ - STACK) * a.spill_stride + gslot;                                \
     e_ = SE::make(a.spill[o_], a.spill_tmin[o_]);                                                    \
@@ -1280,7 +1282,7 @@ __device__ __forceinline__ bool leaf_items_one_trip(Lane<float> &L, uint32_t cnt
   const float sx = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sx))), sy = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sy))),
               sz = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.Sz)));
   const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute(oa_, (int)L.pk);
-  const int ikx = (int)(pk & 3u), iky = (int)((pk >> 2) & 3u), ikz = (int)((pk >> 4) & 3u);
+  const int ikx = (int)((pk >> 3) & 3u), iky = (int)((pk >> 5) & 3u), ikz = (int)((pk >> 7) & 3u);
   // TriangleIntersector::Intersect (nanort.h:1054-1150) up to the hit distance: tri_test's own operations on the owner's constants
   const uint32_t prim_i = tri.prim_id;
   bool ok = PLAIN ? item_ : (item_ & (prim_i >= range0) & (prim_i < range1) & (prim_i != skip_prim));
@@ -2120,7 +2122,7 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
     L.min_t = wmin_t;
     L.hit_t = wmax_t;
     L.max_t = wmax_t;
-    L.pk = (wdir[0] < 0.0f ? 64u : 0u) | (wdir[1] < 0.0f ? 128u : 0u) | (wdir[2] < 0.0f ? 256u : 0u);
+    L.pk = (wdir[0] < 0.0f ? 1u : 0u) | (wdir[1] < 0.0f ? 2u : 0u) | (wdir[2] < 0.0f ? 4u : 0u);
     wide4 = a.top_wide4;
     in_top = true;
     base = 0;
