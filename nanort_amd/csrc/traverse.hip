@@ -1254,9 +1254,11 @@ do {                                                                            
 // The same tests on the same operands (tri_test's operations, one for one), accepted in the same sequence: the lane state after
 // the leaf is bit for bit what the owner's own loop leaves (tests/test_gpu_leaf_items.py, tests/test_gpu_scene.py).  Returns false
 // — nothing done — when the records do not fit one trip: the caller's owner loop then runs.  Wave-uniform control flow only.
-template <bool PLAIN>
-__device__ __forceinline__ bool leaf_items_one_trip(Lane<float> &L, uint32_t cnt, const LeafTri<float> *first, unsigned lane, volatile uint32_t *own_,
-                                                    const LeafTri<float> *volatile *rec_, uint32_t range0, uint32_t range1, uint32_t skip_prim, bool cull) {
+// (SLOT: how an item names its record in LDS — a 32-bit index into `base` (k_traverse_wide: one array per launch; 4 bytes per item
+// keep the block's LDS below a sixth of the CU's) or the record's address (k_scene_walk: every owner's mesh has its own array))
+template <bool PLAIN, typename SLOT>
+__device__ __forceinline__ bool leaf_items_one_trip(Lane<float> &L, uint32_t cnt, const LeafTri<float> *base, SLOT first, unsigned lane, volatile uint32_t *own_,
+                                                    volatile SLOT *rec_, uint32_t range0, uint32_t range1, uint32_t skip_prim, bool cull) {
   typedef float T;
   const unsigned long long b0_ = __ballot((cnt & 1u) != 0u), b1_ = __ballot((cnt & 2u) != 0u), b2_ = __ballot((cnt & 4u) != 0u);
   const uint32_t items_ = (uint32_t)__builtin_popcountll(b0_) + 2u * (uint32_t)__builtin_popcountll(b1_) + 4u * (uint32_t)__builtin_popcountll(b2_);
@@ -1274,7 +1276,12 @@ __device__ __forceinline__ bool leaf_items_one_trip(Lane<float> &L, uint32_t cnt
   // (LDS operations of one wave are performed in issue order and the accesses are volatile: the reads below see the writes)
   const bool item_ = lane < items_;
   const uint32_t me_ = item_ ? lane : 0u; // (a lane without an item repeats item 0 — there is one: the callers come here with a lane waiting — and drops the result)
-  const LeafTri<float> *slot_ = rec_[me_];
+  const SLOT sv_ = rec_[me_];
+  const LeafTri<float> *slot_;
+  if constexpr (sizeof(SLOT) == 4)
+    slot_ = base + sv_;
+  else
+    slot_ = sv_;
   const int oa_ = (int)(own_[me_] << 2); // the owner lane's byte address for ds_bpermute
   const LeafTri<T> tri = *slot_; // (issued before the constants are fetched: the two latencies overlap)
   const float o0 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org0))), o1 = __int_as_float(__builtin_amdgcn_ds_bpermute(oa_, __float_as_int(L.org1))),
@@ -1361,7 +1368,7 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
   typedef typename std::conditional<BIG, uint64_t, uint32_t>::type RecOff;
   // leaf items (LEAFC): which lane owns the record a lane tests, and which of the owner's records it is (lane | k << 6)
   __shared__ uint32_t s_item_owner[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1];
-  __shared__ const LeafTri<float> *s_item_rec[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1]; // ... and where that record is
+  __shared__ uint32_t s_item_rec[LEAFC ? kTraverseBlock / kWave : 1][LEAFC ? kWave : 1]; // ... and which record of a.tris that is
   typedef StackEntry<T> SE;
   __shared__ typename SE::type s_stack[STACK][kTraverseBlock];
 
@@ -1633,7 +1640,7 @@ __global__ __launch_bounds__(kTraverseBlock, (WIDTH == 4 && sizeof(T) == 4) ? NR
         // same tests on the same operands, accepted in the same sequence, so the lane state after the leaf is bit for bit what
         // the owner's own loop leaves (tests/test_gpu_leaf_items.py).  More records than lanes: the owners' loop below.  Trees
         // whose leaves hold more than four records do not take this variant at all (api.hip).
-        items_done_ = leaf_items_one_trip<PLAIN>(L, cnt, a.tris + first, lane, s_item_owner[tid / kWave], s_item_rec[tid / kWave], a.range0, a.range1,
+        items_done_ = leaf_items_one_trip<PLAIN, uint32_t>(L, cnt, a.tris, first, lane, s_item_owner[tid / kWave], s_item_rec[tid / kWave], a.range0, a.range1,
                                                  a.skip_prim, cull);
       }
       if (items_done_) {
@@ -2369,7 +2376,7 @@ __global__ __launch_bounds__(kTraverseBlock, STATS ? 1 : NRT_SCENE_WALK_WAVES) v
       }
       // (few lanes wait at a leaf in this kernel — 10 of 64 on the instanced scenes: their records nearly always fit one trip)
       const bool items_done_ = !STATS && a.leaf_items != 0u &&
-                               leaf_items_one_trip<true>(L, lcnt, tris + first, lane, s_item_owner[tid / kWave], s_item_rec[tid / kWave], 0u, 0u, 0u, false);
+                               leaf_items_one_trip<true, const LeafTri<float> *>(L, lcnt, nullptr, tris + first, lane, s_item_owner[tid / kWave], s_item_rec[tid / kWave], 0u, 0u, 0u, false);
       if (!items_done_)
       for (uint32_t k = 0; __ballot(k < lcnt) != 0ull; k += 2u) {
         if (STATS) {
