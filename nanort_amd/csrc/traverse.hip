@@ -78,8 +78,10 @@ struct Lane {
   // (floats and integers alternate on purpose: as neighbours, Sx Sy Sz u v get merged into overlapping two- and
   // four-float vector accesses by the vectoriser, which then pins all five in scratch memory instead of registers)
   T Sx;
-  uint32_t pk; // (dir < 0 per axis) << 0..2 | kx << 3 | ky << 5 | kz << 7: six small integers in one register — the signs lowest, so that sign(axis) is one bit-field extract at `axis` with nothing added to it (three instructions per step) — (the kernel sits at
-               // the 80-register edge of six waves per SIMD; the loops turn the fields into lane masks once, on entry)
+  uint32_t pk; // (dir < 0 per axis) << 0..2 | kx << 3 | ky << 5 | kz << 7: six small integers in one register (the kernel sits near
+               // the 80-register edge of six waves per SIMD; the loops turn the fields into lane masks once, on entry).  The signs
+               // are the lowest bits so that sign(axis) is ONE bit-field extract at `axis` — three instructions fewer per step
+               // than with the signs above the axes (round 6)
   T Sy;
   uint32_t prim;
   T Sz;
