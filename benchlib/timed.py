@@ -67,8 +67,8 @@ class Timed:
         # milliseconds of traversal work (measured: K = 20 / W = 3 reads 2.3 % lower than K = 200 / W = 50 or K = 1000 / W = 100 on
         # the same box, profiles/r06s_steps_sensitivity.txt), so PREWARM_STEPS of the same steps (~0.1 s on C3) run first — whatever
         # K and W the caller asked for, the timed region then measures the steady state a renderer runs in.
-        self.prewarm_steps = PREWARM_STEPS
-        for _ in range(PREWARM_STEPS):
+        self.prewarm_steps = 0 if shared else PREWARM_STEPS  # (the test hook stages every step's records through the host: nothing to ramp)
+        for _ in range(self.prewarm_steps):
             step()
         drain()
         torch.cuda.synchronize()
