@@ -14,6 +14,17 @@ CONFIGS = {
            "text": "C4: Plane(2500,2000) = 10,000,000 triangles fp32, fixed 4096x4096 frame"},
     "C4tile": {"mesh": ("plane", 2500, 2000), "real": "f32", "w": 4096, "h": 4096, "scaling": "weak", "tile_of": 8,
                "text": "C4 tile: Plane(2500,2000) = 10,000,000 triangles fp32, one GPU's 4096x512 share (rows y = 0 mod 8) of the 4096x4096 frame"},
+    # (probe sizes between the tile and the frame: work-distribution sweeps, tools/tune_probe.py)
+    "C3a": {"mesh": ("plane", 1000, 500), "real": "f32", "w": 1600, "h": 960, "scaling": "weak", "text": "C3 mesh, 1600x960 (1.5 M rays)"},
+    "C3b": {"mesh": ("plane", 1000, 500), "real": "f32", "w": 2048, "h": 1184, "scaling": "weak", "text": "C3 mesh, 2048x1184 (2.4 M rays)"},
+    "C3c": {"mesh": ("plane", 1000, 500), "real": "f32", "w": 2560, "h": 1440, "scaling": "weak", "text": "C3 mesh, 2560x1440 (3.7 M rays)"},
+    "C2c": {"mesh": "sphere", "real": "f32", "w": 2560, "h": 1440, "scaling": "weak", "text": "C2 stand-in, 2560x1440 (3.7 M rays)"},
+    "C4sixth": {"mesh": ("plane", 2500, 2000), "real": "f32", "w": 4096, "h": 4096, "scaling": "weak", "tile_of": 6,
+                "text": "C4 sixth: Plane(2500,2000) = 10,000,000 triangles fp32, 4096x682 rows (y = 0 mod 6) of the 4096x4096 frame"},
+    "C4quarter": {"mesh": ("plane", 2500, 2000), "real": "f32", "w": 4096, "h": 4096, "scaling": "weak", "tile_of": 4,
+                  "text": "C4 quarter: Plane(2500,2000) = 10,000,000 triangles fp32, 4096x1024 rows (y = 0 mod 4) of the 4096x4096 frame"},
+    "C4half": {"mesh": ("plane", 2500, 2000), "real": "f32", "w": 4096, "h": 4096, "scaling": "weak", "tile_of": 2,
+               "text": "C4 half: Plane(2500,2000) = 10,000,000 triangles fp32, 4096x2048 rows (y = 0 mod 2) of the 4096x4096 frame"},
     "C5": {"mesh": ("plane", 1000, 500), "real": "f64", "w": 1920, "h": 1080, "scaling": "weak",
            "text": "C5: Plane(1000,500) = 1,000,000 triangles, fp64 build + traversal"},
 }

@@ -146,7 +146,13 @@ struct nrt_ctx {
   unsigned debug_flags = 0;
   int subtree_rows = 1; // builder: subtree phase in row form (up to four nodes per step); 0 (profiling build only): one node per step — same tree, the cross-check (tests/test_gpu_build.py)
   int morton = 0; // Morton-order the primitive records before the build (env NRT_MORTON=1): measured +0.4 ms at 1M tris for an identical tree, so off by default
-  unsigned static_pct = 75; // share of a batch handed out statically, percent (env NRT_STATIC_PCT)
+  // share of a batch handed out statically, percent (tunable static_pct).  75 until the end of round 6; 16 since: with ~400 rays per
+  // wave (a 1080p wave on this grid) a wave's static share was 256 of them, and whenever the cost per ray is uneven over the image
+  // (C2: 40 % sky) the waves with cheap slices drained the dynamic rest while the others were still on rays nobody could take from
+  // them.  One 64-ray group per wave there (it starts every wave without an atomic) and the rest claimed in chunks:
+  // C3 +2.8 %, C2 +7 %, C4 tile +2.9 %, C5 +0.9 %, a 2560x1440 view of C2's mesh +17 %; balanced frames of other sizes -3.3 ... +1 %
+  // (profiles/r06y_distribution_*.txt)
+  unsigned static_pct = 16;
   unsigned static_bands = 8; // ... as up to this many slices per wave, one in each band of the batch
   unsigned static_slice_groups = 2; // ... each of at least this many 64-ray groups
   unsigned max_blocks_per_cu = 0; // env NRT_BLOCKS_PER_CU caps the persistent grid
@@ -953,6 +959,8 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   // Work distribution (traverse.hip, Claim).  Static share: c->static_pct percent of the batch, in whole 64-ray groups per
   // wave, cut into up to `static_bands` slices — one at the head of each of as many equal bands of the batch; the rest of
   // each band (a whole number of chunks) and the tail behind the last band are claimed dynamically.
+  // (less than one group per wave: none — a batch of fewer than ~400 rays per wave is claimed in chunks from its first ray; a forced
+  // group per wave measured -2.7 % on a 1600x960 wave, profiles/r06y_distribution10.txt)
   const uint32_t static_share = (uint32_t)(((uint64_t)n * c->static_pct / 100) / total_waves / 64); // 64-ray groups per wave
   // (a slice shorter than two 64-ray groups makes the waves of an XCD drift apart over the bands within one refill, and its
   // L2 then holds several strips of the scene at once: measured on C3, 64-ray slices in 4 bands cost 3 %; two bands of 128
