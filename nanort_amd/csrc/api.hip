@@ -167,6 +167,7 @@ struct nrt_ctx {
   // above a hit inside it, and among primitives at exactly the same t another one may be named (contract-level parity)
   int order4 = 0;
   int leaf_compact = 1; // traverse.hip "leaf items" (round 6): when the records of all the lanes waiting at a leaf fit one trip of the wave, they are tested one per lane with the owner's ray constants and accepted by the owner in record order — records bit-identical, C3 +2 %, C4 tile +2.8 %; 0: every owner tests its own records
+  int dyn_head = 1; // batches too small for a static group per wave: every wave's first chunk is its own (traverse.hip claim_init; tunable dyn_head)
   int wide_scramble = 0; // probe (tunable wide_scramble): the private node records in a pseudo-random order instead of pre-order
   unsigned wide4_blocks_per_cu = 0;
   unsigned wide_blocks_per_cu = 0, sphere_blocks_per_cu = 0;
@@ -308,6 +309,7 @@ static const TunableDesc kTunables[] = {
     NRT_TUNABLE("wide4_big", 0, 2, wide4_big_ok, int),            // ... also for record arrays of 4 GiB and more (64-bit offsets; next build / set_tree); 2: 64-bit offsets whatever the size (tests)
     NRT_TUNABLE("wide4", 0, 1, wide4, int),                       // two tree levels per step (next build / set_tree)
     NRT_TUNABLE("leaf_compact", 0, 1, leaf_compact, int),         // two-level walk, triangle trees with leaves of <= 4 records: leaf phase over items (records bit-identical)
+    NRT_TUNABLE("dyn_head", 0, 1, dyn_head, int),                 // a batch without a static share: a wave's first chunk without an atomic
     NRT_TUNABLE("order4", 0, 1, order4, int),                     // two-level walk: 0 (default) = the reference's order, every field bit-identical; 1 = slots by entry distance (faster; contract-level parity at ties)
     NRT_TUNABLE("launch_timing", 0, 1, launch_timing, int),       // == nrtSetLaunchTiming
     NRT_TUNABLE("host_pipeline", 0, 1, host_pipeline, int),       // pipelined host entry point
@@ -1053,6 +1055,7 @@ static nrt_status traverse_device(nrt_ctx *c, const typename Wire<T>::Ray *d_ray
   a.dyn_total = a.dyn_banded + ((uint32_t)n - a.tail_begin);
   a.dyn_per_part = (a.dyn_total / parts / c->chunk) * c->chunk;
   a.blocks_per_part = grid / parts;
+  a.dyn_head = c->dyn_head ? 1u : 0u;
   a.counters = c->d_counters;
   a.wave_clock = nullptr;
 #ifdef NRT_PROF

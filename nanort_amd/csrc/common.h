@@ -397,6 +397,7 @@ struct TraverseArgs {
   uint32_t dyn_total;                // all dynamic rays = dyn_banded + num_rays - tail_begin
   uint32_t dyn_per_part;             // virtual dynamic rays per partition cursor (whole chunks; the last partition takes the rest)
   uint32_t blocks_per_part;          // gridDim.x / num_parts
+  uint32_t dyn_head;                 // a batch without a static share: the first chunk of a wave is chunk `wave index` of its home range, without an atomic (tunable dyn_head)
   unsigned long long *counters;      // 4 x u64 when counting
   unsigned long long *wave_clock;    // profiling (NRT_DEBUG bit 8192): 3 x u64 per wave {start, out of rays, done}, 100 MHz ticks; else null
   uint32_t chunk;                    // rays claimed per atomic (a multiple of 32)

@@ -417,13 +417,43 @@ __device__ __forceinline__ uint32_t batch_of(const TraverseArgs<T> &a, uint32_t 
 //    whole batch, not its cheapest corner.
 //    (Device-scope atomics on one word saturate near 100 per microsecond on this part, hence the static share and the modest
 //    chunk count.  Round 2 re-measured static share 0-75 %, chunks of 16-128 rays, claims issued one chunk ahead of need:
-//    nothing beats 75 % / 128; profiles/r02d_scheduling_sweep.txt.)
+//    nothing beats 75 % / 128; profiles/r02d_scheduling_sweep.txt.  Round 6, with finer steps: the static share is 16 % — ONE
+//    64-ray group per wave at 1080p, enough to start every wave without an atomic — because whatever a wave owns nobody can take
+//    from it when the cost per ray is uneven over the image: C2 +7 %, C3 +2.8 %, profiles/r06y_distribution_static_share.txt.)
+//  * A batch too small for a static group per wave has no static share at all; its waves then own the FIRST chunk of their home
+//    range (chunk `wave index`, no atomic: claim_init) and the cursors count from the range's wave count.
 struct Claim {
   uint32_t next, end; // claimed, not yet handed out: [next, end)
   uint32_t part, tried;
   uint32_t rank, band; // static share: this wave's rank, the band its current slice lies in
   bool exhausted;
 };
+
+// Chunk `idx` of cursor range `part`: where it starts in the virtual array of dynamic rays and how many rays it holds (false: past
+// the range's end).  The cursor counts CHUNKS: the first `main_chunks` are whole ones, the rest of the range goes out in half chunks
+// (tunable chunk_tail_pct) — the last rays of a launch in finer portions; half chunks subdivide whole ones, so no chunk straddles two
+// bands.
+template <typename T>
+__device__ __forceinline__ bool chunk_of(const TraverseArgs<T> &a, uint32_t part, uint32_t idx, uint32_t &v, uint32_t &cnt) {
+  const uint32_t lo = part * a.dyn_per_part; // range of this part in the virtual array of dynamic rays
+  const uint32_t len = (part + 1u == a.num_parts) ? a.dyn_total - lo : a.dyn_per_part;
+  const uint32_t main_chunks = (uint32_t)(((unsigned long long)(len / a.chunk) * (100u - a.chunk_tail_pct)) / 100u), half = a.chunk >> 1;
+  const uint32_t base = idx < main_chunks ? idx * a.chunk : main_chunks * a.chunk + (idx - main_chunks) * half;
+  const uint32_t want = idx < main_chunks ? a.chunk : half;
+  if (!(idx < 0x1000000u && base < len)) return false;
+  v = lo + base;
+  cnt = (len - base < want) ? len - base : want;
+  return true;
+}
+// ... and where those rays lie in the batch
+template <typename T>
+__device__ __forceinline__ uint32_t dyn_to_real(const TraverseArgs<T> &a, uint32_t v) {
+  if (v < a.dyn_banded) { // inside band b's dynamic part
+    const uint32_t b = v / a.dyn_per_band;
+    return b * a.band_len + a.band_static + (v - b * a.dyn_per_band);
+  }
+  return a.tail_begin + (v - a.dyn_banded); // the tail behind the last band
+}
 
 template <typename T>
 __device__ __forceinline__ void claim_init(const TraverseArgs<T> &a, Claim &c) {
@@ -439,6 +469,21 @@ __device__ __forceinline__ void claim_init(const TraverseArgs<T> &a, Claim &c) {
   c.part = part;
   c.tried = 0;
   c.exhausted = false;
+  if (a.dyn_head != 0u && a.static_per_wave == 0u) {
+    // A batch too small for a static group per wave (fewer than ~400 rays per wave at the default share): no static share, but no
+    // start-up burst on the cursors either — chunk `wi` of the wave's HOME range belongs to wave `wi` of that partition without an
+    // atomic (the cursors then count from the partition's wave count: claim_chunk), so the launch starts inside every XCD's own
+    // strip of the batch and everything after a wave's first chunk is balanced dynamically.  (C3's mesh at 1600x960 +3 %, C2 +2.5 %
+    // through its 1.24 M-ray bounce wave: profiles/r06z_dyn_head_small.txt.)
+    const uint32_t wi = rank - part * a.blocks_per_part * (uint32_t)(kTraverseBlock / kWave);
+    uint32_t v, cnt;
+    if (chunk_of<T>(a, part, wi, v, cnt)) {
+      c.next = dyn_to_real<T>(a, v);
+      c.end = c.next + cnt;
+    } else {
+      c.next = c.end = 0u;
+    }
+  }
 }
 
 // All lanes of the wave call this (uniform control flow); `leader` is any active lane index.
@@ -451,28 +496,14 @@ __device__ __forceinline__ bool claim_chunk(const TraverseArgs<T> &a, Claim &c, 
     return true;
   }
   while (c.tried < a.num_parts) {
-    const uint32_t lo = c.part * a.dyn_per_part; // range of this part in the virtual array of dynamic rays
-    const uint32_t len = (c.part + 1u == a.num_parts) ? a.dyn_total - lo : a.dyn_per_part;
-    // The cursor counts CHUNKS: the first `main_chunks` are whole ones, the rest of the range goes out in half chunks — the
-    // last rays of a launch in finer portions, so that the waves run dry closer together (half chunks subdivide whole ones:
-    // still no chunk straddles two bands).
     uint32_t idx = 0;
     if (lane == (unsigned)leader) idx = atomicAdd(a.ray_cursor + kCursorStrideWords * c.part, 1u);
     idx = __builtin_amdgcn_readfirstlane(__shfl(idx, leader));
-    const uint32_t main_chunks = (uint32_t)(((unsigned long long)(len / a.chunk) * (100u - a.chunk_tail_pct)) / 100u), half = a.chunk >> 1;
-    const uint32_t base = idx < main_chunks ? idx * a.chunk : main_chunks * a.chunk + (idx - main_chunks) * half;
-    const uint32_t want = idx < main_chunks ? a.chunk : half;
-    if (idx < 0x1000000u && base < len) {
-      const uint32_t v = lo + base, cnt = (len - base < want) ? len - base : want;
-      uint32_t real;
-      if (v < a.dyn_banded) { // inside band b's dynamic part
-        const uint32_t b = v / a.dyn_per_band;
-        real = b * a.band_len + a.band_static + (v - b * a.dyn_per_band);
-      } else { // the tail behind the last band
-        real = a.tail_begin + (v - a.dyn_banded);
-      }
-      c.next = real;
-      c.end = real + cnt;
+    if (a.dyn_head != 0u && a.static_per_wave == 0u) idx += a.blocks_per_part * (uint32_t)(kTraverseBlock / kWave); // (the first chunks of every range have owners: claim_init)
+    uint32_t v, cnt;
+    if (chunk_of<T>(a, c.part, idx, v, cnt)) {
+      c.next = dyn_to_real<T>(a, v);
+      c.end = c.next + cnt;
       return true;
     }
     c.part = (c.part + 1 == a.num_parts) ? 0 : c.part + 1;

@@ -23,7 +23,7 @@ rng = np.random.default_rng(seed)
 MESHES = [(2, 1), (3, 3), (20, 10), (100, 60), (300, 200), (700, 400)]  # Plane(nx, ny): 4 ... 560 000 triangles
 SIZES = [1, 63, 64, 65, 1000, 4097, 60000, 250000]
 TUN = {"static_pct": (0, 16, 16, 40, 75, 100), "static_bands": (1, 2, 8), "chunk": (32, 64, 128), "parts": (1, 3, 8), "refill_min": (1, 24, 44, 64),
-       "trav_min4": (1, 12, 24, 48), "leaf_min": (1, 32), "leaf_compact": (0, 1), "wide4_big": (1, 2), "launch_timing": (0, 1)}
+       "trav_min4": (1, 12, 24, 48), "leaf_min": (1, 32), "leaf_compact": (0, 1), "wide4_big": (1, 2), "launch_timing": (0, 1), "dyn_head": (0, 1), "chunk_tail_pct": (0, 25)}
 streams = [torch.cuda.Stream() for _ in range(6)]
 all_rays = scenes.camera_rays(640, 400)
 

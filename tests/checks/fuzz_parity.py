@@ -66,7 +66,7 @@ while time.time() < t_end:
     # size, ray partitions, refill / phase thresholds, one or two tree levels per step
     for k, choices in (("static_pct", (0, 16, 16, 40, 75, 100)), ("static_bands", (1, 2, 8)), ("static_slice_groups", (1, 2)), ("chunk", (16, 64, 128)),
                        ("parts", (1, 3, 8)), ("refill_min", (1, 24, 48, 64)), ("trav_min", (1, 8, 32)), ("trav_min4", (1, 12, 24, 48)), ("leaf_min", (1, 32)), ("wide4", (0, 1)),
-                       ("leaf_compact", (0, 1, 1)), ("wide4_big", (1, 1, 2))):  # (wide4_big = 2: the 64-bit-offset instantiations on an ordinary tree)
+                       ("leaf_compact", (0, 1, 1)), ("wide4_big", (1, 1, 2)), ("dyn_head", (0, 1, 1)), ("chunk_tail_pct", (0, 0, 30))):  # (wide4_big = 2: the 64-bit-offset instantiations on an ordinary tree)
         a.SetTunable(k, int(rng.choice(choices)))
     assert a.GetTunable("order4") == 0  # the library default: the reference's slot order
     if default_walk:
