@@ -27,6 +27,10 @@ for name in names:
             if k not in defaults:
                 defaults[k] = a.GetTunable(k)
     res = [dict(t1=[], t2=[], step=[], hsh=None) for _ in combos]
+    for _ in range(60):  # (round 6: the first combination of a run read ~2 % low — the device's clocks ramp over some tens of milliseconds of work)
+        a.TraverseBatchDevice(wl.d_rays1, wl.d_hits1, wl.d_mask1)
+        a.TraverseBatchDevice(wl.d_rays2, wl.d_hits2, wl.d_mask2)
+    torch.cuda.synchronize()
     for rnd in range(ROUNDS):
         for ci, combo in enumerate(combos):
             for k, v in defaults.items():
